@@ -1,0 +1,159 @@
+/* vqk -- C-ABI of the MI355X (gfx950) VQ-VAE / VQ-GAN train-step kernels.
+ *
+ * Boundary rules:
+ *   - plain C: raw device pointers + sizes + scalars, no torch types;
+ *   - the CALLER owns every buffer (outputs, workspaces); nothing is allocated, nothing is
+ *     synchronised, no global mutable state is kept inside the library;
+ *   - every launch goes to the `stream` argument (a hipStream_t passed as void*; NULL = the
+ *     null stream);
+ *   - return value: 0 = ok, negative = vqk_status (see vqk_status_str).  There is NO fallback
+ *     path: an unsupported shape/dtype is an error, never a silent detour.
+ *
+ * Layouts: activations are NHWC (pixel-major, channels contiguous); conv weights are
+ * [Cout][kh][kw][Cin] ("KRSC" = the physical layout of a channels_last OIHW torch tensor).
+ * dtype codes: VQK_F32 = 0 (parity mode), VQK_BF16 = 1 (throughput mode, fp32 accumulate).
+ *
+ * What each entry point replaces in the reference (paths relative to the reference checkout):
+ *   vqk_bias_act / vqk_upfirdn2d : the reference's own native plugin ABI,
+ *        vqvae/modules/loss/stylegan2_discriminator/utils/ops/bias_act.cpp:32-90 and
+ *        .../upfirdn2d.cpp:16-94 (pybind functions `bias_act`, `upfirdn2d`);
+ *   everything else: ATen/cuDNN calls made from
+ *        vqvae/modules/autoencoder.py:25-39 (GroupNorm), :63-77 (ResBlock), :89-91, :104-106,
+ *        vqvae/modules/vector_quantizers.py:23-61, :128-180, :290-356 (quantizers),
+ *        vqvae/model.py:272 (MSE), :428 (AdamW).
+ */
+#ifndef VQK_H_
+#define VQK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQK_F32 0
+#define VQK_BF16 1
+
+enum vqk_status {
+    VQK_OK = 0,
+    VQK_ERR_SHAPE = -1,       /* unsupported / inconsistent shape */
+    VQK_ERR_DTYPE = -2,       /* unsupported dtype code */
+    VQK_ERR_ALIGN = -3,       /* pointer not 16-byte aligned */
+    VQK_ERR_LAUNCH = -4,      /* hipGetLastError() after launch */
+    VQK_ERR_ARG = -5,         /* NULL / out-of-range argument */
+    VQK_ERR_WORKSPACE = -6    /* workspace too small */
+};
+
+const char* vqk_status_str(int status);
+int vqk_version(void);
+/* name of the code-object architecture this library was built for ("gfx950") */
+const char* vqk_arch(void);
+
+/* ---------------------------------------------------------------- vector quantizer ---------
+ * vector_quantizers.py:33-44 / :337-343.  z[N][D], e[K][D] fp32 row-major, D % 8 == 0.
+ * assoc 0: d = (|z|^2 + |e|^2) - 2 z.e (Standard/EMA); assoc 1: d = (|z|^2 - 2 z.e) + |e|^2 (Entropy).
+ * Products are exact fp32 (v_mfma_f32_32x32x2_f32), first minimum wins. */
+int vqk_row_sqnorm_f32(const float* x, int64_t rows, int d, float* out, void* stream);
+int vqk_vq_assign_f32(const float* z, const float* e, const float* z2, const float* e2,
+                      int64_t n, int k, int d, int assoc, int64_t* idx, void* stream);
+/* q = e[idx] (written as fp32 and, if q_lo != NULL, also as bf16), sse[0] += sum (q - z)^2,
+ * hist[idx] += 1 (int32, optional).  sse must be zeroed by the caller. */
+int vqk_vq_gather_f32(const float* z, const float* e, const int64_t* idx, int64_t n, int k, int d,
+                      float* q, void* q_lo, float* sse, int32_t* hist, void* stream);
+/* dz = dq + s*cz * (z - q)   ;   de[idx] += s*ce * (q - z)   (de optional, pre-zeroed by caller)
+ * s = *gscale_dev (a device scalar: the upstream gradient of the loss; NULL = 1), dq optional (NULL = 0),
+ * fp32 or bf16 (dq_dtype).  vector_quantizers.py:52-56 differentiated. */
+int vqk_vq_backward_f32(const float* z, const float* e, const int64_t* idx, const void* dq, int dq_dtype,
+                        int64_t n, int k, int d, float cz, float ce, const float* gscale_dev, float* dz, float* de,
+                        void* stream);
+/* EMA statistics (vector_quantizers.py:159-169): counts[k] += 1, dw[idx] += z (both pre-zeroed) ... */
+int vqk_ema_stats_f32(const float* z, const int64_t* idx, int64_t n, int k, int d,
+                      float* counts, float* dw, void* stream);
+/* ... and the update: count' = smooth(decay*count + (1-decay)*n_k), weight' = decay*weight + (1-decay)*dw,
+ * codebook = weight'/count'.  `batch` is the smoothing constant b (global image batch). */
+int vqk_ema_update_f32(float* ema_count, float* ema_weight, float* codebook, const float* counts, const float* dw,
+                       int k, int d, float decay, float eps, float batch, void* stream);
+
+/* ---------------------------------------------------------------- convolution --------------
+ * Implicit-GEMM conv, stride 1, 'same' zero padding, ksize in {1,3}.
+ *   x [N][Hin][Win][Cin], w [Cout][ks][ks][Cin], y [N][H][W][Cout]; (H,W) = (Hin,Win) << ups.
+ *   ups = 1 fuses a nearest x2 upsample of x into the input addressing (autoencoder.py:104-106).
+ *   bias (fp32, optional), residual (same dtype/shape as y, optional) are fused into the epilogue;
+ *   act: 0 none, 1 tanh.  in/w dtype = `dtype`; y/residual dtype = out_dtype.
+ *   Cin must be a multiple of 16 bytes worth of elements (4 fp32 / 8 bf16).
+ * dgrad is the same entry point with weights repacked by vqk_conv_pack_dgrad. */
+int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                     int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int act,
+                     const void* zeros, void* stream);
+/* w [Cout][ks][ks][Cin] -> wt [Cin][ks][ks][Cout] with both taps flipped; src fp32, dst `dtype`. */
+int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, int ksize, void* stream);
+/* dw[Cout][ks][ks][Cin] (fp32) += sum_pix dy[pix][co] * x[pix (+) tap][ci].  dw must be pre-zeroed
+ * (split-K partials are combined with fp32 atomics). */
+int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
+                     int cout, int ksize, int ups, const void* zeros, void* stream);
+/* out[c] (+)= sum over rows of x[rows][c]  (bias gradients); out pre-zeroed. */
+int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream);
+/* elementwise fp32 -> dtype cast (weight shadow copies) */
+int vqk_cast(const float* src, void* dst, int dtype, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- GroupNorm + SiLU ----------
+ * autoencoder.py:25-39: per (sample, group) mean and UNBIASED variance; y = (x-mu)*rstd*w + b,
+ * optionally followed by SiLU.  stats[n][g] = {mean, rstd} fp32.  acc = N*G*2 doubles scratch (zeroed
+ * by the caller). */
+int vqk_gn_stats(int dtype, const void* x, int n, int64_t hw, int c, int groups, float eps,
+                 double* acc, float* stats, void* stream);
+int vqk_gn_apply(int dtype, const void* x, const float* stats, const float* w, const float* b, void* y,
+                 int n, int64_t hw, int c, int groups, int silu, void* stream);
+/* backward of y = act(GN(x)): needs x, stats, w, b and dy.  red = N*G*2 doubles scratch, dw/db [C] fp32;
+ * all three pre-zeroed.  dx may alias nothing; if accumulate != 0, dx += result. */
+int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
+                    void* dx, float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu,
+                    int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- pooling / pointwise -------
+ * 2x2 stride-2 pooling with a scale: scale = 0.25 is avg_pool2d (autoencoder.py:89-91), scale = 1 is the
+ * backward of the nearest x2 upsample.  x [N][H][W][C] -> y [N][H/2][W/2][C]. */
+int vqk_pool2x2(int dtype, const void* x, void* y, int n, int h, int w, int c, float scale, void* stream);
+/* y[N][2H][2W][C] = scale * x[N][H][W][C] replicated (backward of avg-pool with scale = 0.25). */
+int vqk_unpool2x2(int dtype, const void* x, void* y, int n, int h, int w, int c, float scale, void* stream);
+/* images [N][3][H][W] fp32 in [0,1] (NCHW) -> clamp, (x-0.5)/0.5, NHWC with C padded to cpad (zeros),
+ * written as `dtype` and (optionally) as an fp32 NHWC-3 target for the loss.  base_autoencoder.py:31-50. */
+int vqk_preprocess(const float* images, void* x_pad, int dtype, float* target, int n, int h, int w, int cpad,
+                   void* stream);
+/* loss[0] += sum (recon - target)^2 over n elements (recon dtype given; target fp32). */
+int vqk_sse(int dtype, const void* recon, const float* target, int64_t n, float* loss, void* stream);
+/* d = s * gscale * 2 (recon - target) * (through_tanh ? 1 - recon^2 : 1), s = *gscale_dev (NULL = 1)
+ * (MSE backward, optionally through the decoder's tanh head; model.py:272, autoencoder.py:179) */
+int vqk_mse_tanh_backward(int dtype, const void* recon, const float* target, int64_t n, float gscale,
+                          const float* gscale_dev, int through_tanh, void* d, void* stream);
+/* dx = dy * (1 - y^2) */
+int vqk_tanh_backward(int dtype, const void* dy, const void* y, void* dx, int64_t n, void* stream);
+/* generic elementwise: y = a*x + b*y2 (y2 optional) -- residual adds in backward */
+int vqk_axpby(int dtype, const void* x, const void* y2, void* y, float a, float b, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- optimizer ----------------
+ * AdamW over a flat fp32 arena (model.py:428; torch.optim.AdamW semantics, decoupled decay).
+ * seg_end[i] (exclusive, element index) / seg_wd[i]: weight decay per contiguous segment;
+ * grad_scale multiplies g first (1/world after a sum all-reduce).  If shadow != NULL a bf16 copy of the
+ * updated parameters is written in the same pass. */
+int vqk_adamw(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end, const float* seg_wd,
+              int nseg, float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* shadow,
+              void* stream);
+
+/* ---------------------------------------------------------------- StyleGAN2 plugin ops ------
+ * Same argument meaning as the reference's pybind functions (bias_act.cpp:32, upfirdn2d.cpp:16), with raw
+ * pointers instead of tensors; NULL encodes the reference's "empty tensor".  x is contiguous NCHW fp32
+ * with `inner` = elements per channel step (H*W) and `channels` = size of `dim`.
+ * act: 1 linear, 3 lrelu (the reference's cuda_idx).  grad: 0 forward, 1 first-order backward. */
+int vqk_bias_act(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* y,
+                 int64_t numel, int64_t inner, int channels, int grad, int act, float alpha, float gain, float clamp,
+                 void* stream);
+int vqk_upfirdn2d(const float* x, const float* f, float* y, int n, int c, int in_h, int in_w, int fh, int fw,
+                  int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip,
+                  float gain, int out_h, int out_w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQK_H_ */

@@ -1,0 +1,107 @@
+"""Loader of the native boundary: ``libvqk.so`` (C-ABI declared in ``include/vqk.h``).
+
+Counterpart of the reference's plugin loader ``custom_ops.get_plugin``
+(vqvae/modules/loss/stylegan2_discriminator/utils/custom_ops.py:49-129): there the two CUDA
+plugins are JIT-built with ninja/nvcc and a *silent fallback* to a PyTorch implementation exists;
+here the library is built ahead of time, in-tree, with plain ``hipcc --offload-arch=gfx950``
+(one builder at a time, file lock), loaded with ``ctypes`` and there is NO fallback: a missing or
+broken library raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import fcntl
+import os
+import subprocess
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, 'csrc')
+_SO = os.path.join(_HERE, 'libvqk.so')
+_lib = None
+
+P = c_void_p
+I, L, F = c_int, c_int64, c_float
+
+# name -> argtypes ; every function returns int (status) unless listed in _SPECIAL
+_PROTOS = {
+    'vqk_row_sqnorm_f32': [P, L, I, P, P],
+    'vqk_vq_assign_f32': [P, P, P, P, L, I, I, I, P, P],
+    'vqk_vq_gather_f32': [P, P, P, L, I, I, P, P, P, P, P],
+    'vqk_vq_backward_f32': [P, P, P, P, I, L, I, I, F, F, P, P, P, P],
+    'vqk_ema_stats_f32': [P, P, L, I, I, P, P, P],
+    'vqk_ema_update_f32': [P, P, P, P, P, I, I, F, F, F, P],
+    'vqk_conv2d_fprop': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, P],
+    'vqk_conv_pack_dgrad': [P, P, I, I, I, I, P],
+    'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
+    'vqk_colsum': [I, P, L, I, P, P],
+    'vqk_cast': [P, P, I, L, P],
+    'vqk_gn_stats': [I, P, I, L, I, I, F, P, P, P],
+    'vqk_gn_apply': [I, P, P, P, P, P, I, L, I, I, I, P],
+    'vqk_gn_backward': [I, P, P, P, P, P, P, P, P, P, I, L, I, I, I, I, P],
+    'vqk_pool2x2': [I, P, P, I, I, I, I, F, P],
+    'vqk_unpool2x2': [I, P, P, I, I, I, I, F, P],
+    'vqk_preprocess': [P, P, I, P, I, I, I, I, P],
+    'vqk_sse': [I, P, P, L, P, P],
+    'vqk_mse_tanh_backward': [I, P, P, L, F, P, I, P, P],
+    'vqk_tanh_backward': [I, P, P, P, L, P],
+    'vqk_axpby': [I, P, P, P, F, F, L, P],
+    'vqk_adamw': [P, P, P, P, L, P, P, I, F, F, F, F, I, F, P, P],
+    'vqk_bias_act': [P, P, P, P, P, P, L, L, I, I, I, F, F, F, P],
+    'vqk_upfirdn2d': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, I, P],
+}
+_SPECIAL = {'vqk_status_str': (c_char_p, [I]), 'vqk_version': (I, []), 'vqk_arch': (c_char_p, [])}
+EXPORTS = sorted(list(_PROTOS) + list(_SPECIAL))
+
+
+def library_path() -> str:
+    return _SO
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``libvqk.so`` (cross-compiles without a GPU).
+
+    Serialised across processes with a file lock (the reference serialises its JIT build with a
+    FileBaton, custom_ops.py:100-110)."""
+    lock_path = os.path.join(_CSRC, '.build.lock')
+    with open(lock_path, 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(('.hip', '.cpp', '.h'))]
+            srcs.append(os.path.join(_HERE, '..', 'include', 'vqk.h'))
+            stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+            if force or stale:
+                cmd = ['make', '-C', _CSRC, '-j8'] + ([] if verbose else ['-s'])
+                if force:
+                    subprocess.check_call(['make', '-C', _CSRC, '-s', 'clean'])
+                subprocess.check_call(cmd)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return _SO
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  -- loads the HIP runtime (libamdhip64.so.7) the library binds to
+    if not os.path.exists(_SO):
+        raise RuntimeError(f'vqk: native library {_SO} is missing -- run `python -c "import __graft_entry__ as g; '
+                           f'g.build()"` (hipcc --offload-arch=gfx950). There is no fallback path.')
+    cdll = ctypes.CDLL(_SO, mode=ctypes.RTLD_GLOBAL)
+    for name, args in _PROTOS.items():
+        fn = getattr(cdll, name)
+        fn.restype = c_int
+        fn.argtypes = args
+    for name, (res, args) in _SPECIAL.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = cdll
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f'vqk: {what} failed: {lib().vqk_status_str(status).decode()} ({status})')

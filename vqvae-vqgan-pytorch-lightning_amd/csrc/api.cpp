@@ -1,0 +1,22 @@
+// Status strings / version of the vqk C-ABI (include/vqk.h).
+#include "../../include/vqk.h"
+
+extern "C" {
+
+const char* vqk_status_str(int status) {
+    switch (status) {
+        case VQK_OK: return "ok";
+        case VQK_ERR_SHAPE: return "unsupported or inconsistent shape";
+        case VQK_ERR_DTYPE: return "unsupported dtype";
+        case VQK_ERR_ALIGN: return "pointer is not 16-byte aligned";
+        case VQK_ERR_LAUNCH: return "kernel launch failed";
+        case VQK_ERR_ARG: return "bad argument";
+        case VQK_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown status";
+    }
+}
+
+int vqk_version(void) { return 1; }
+const char* vqk_arch(void) { return "gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// Shared device helpers for the vqk kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vqk.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef unsigned short bf16_raw;
+
+#define VQK_LDS __attribute__((address_space(3)))
+#define VQK_GLB __attribute__((address_space(1)))
+
+__device__ __forceinline__ float bf16_to_f32(bf16_raw v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_raw)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_raw)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kPer16B = 4;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_raw> {
+    static constexpr int kPer16B = 8;
+    __device__ static __forceinline__ float ld(const bf16_raw* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_raw* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 16-byte vector of T <-> float array
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void load(const float* p, float (&o)[4]) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+    __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
+        f32x4 v = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(p) = v;
+    }
+};
+template <> struct Vec16<bf16_raw> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void load(const bf16_raw* p, float (&o)[8]) {
+        u16x8 v = *reinterpret_cast<const u16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(v[i]);
+    }
+    __device__ static __forceinline__ void store(bf16_raw* p, const float (&o)[8]) {
+        u16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = f32_to_bf16(o[i]);
+        *reinterpret_cast<u16x8*>(p) = v;
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+#define VQK_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH; } while (0)
+#define VQK_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
+static inline bool vqk_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline hipStream_t vqk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int vqk_grid_1d(int64_t work_items, int per_block, int cap = 256 * 8) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}

@@ -1,0 +1,556 @@
+// Implicit-GEMM convolution for gfx950: fprop (= dgrad with repacked weights) and wgrad, NHWC,
+// bf16 (v_mfma_f32_32x32x16_bf16) and exact fp32 (v_mfma_f32_32x32x2_f32) with fp32 accumulation.
+// Replaces the F.conv2d calls of vqvae/modules/autoencoder.py:57-60, :102-105, :114, :132, :153, :170
+// (3x3 / 1x1, stride 1, 'same' padding) including the nearest x2 upsample of :104-106, which is folded
+// into the input addressing.
+//
+// fprop:  C[M = N*H*W pixels][Cout] = im2col(x)[M][ks*ks*Cin] . W[Cout][ks*ks*Cin]^T
+//   block 256 threads = 2x2 waves, tile 128 pixels x 128 couts, K-step = 8 chunks of 16 bytes
+//   (64 bf16 / 32 fp32 channels).  Both tiles are [128 rows][128 B] in LDS, filled by
+//   global_load_lds (16 B per lane, the im2col gather is done by the per-lane SOURCE address; padding
+//   rows read a caller-provided zero page), XOR-swizzled on the source side so that the ds_read_b128
+//   fragment reads are bank-conflict-free.
+// wgrad:  dW[co][tap][ci] = sum_pix dy[pix][co] * x[pix (+) tap][ci]; contraction over pixels, so
+//   both operands are pixel-major in LDS and the bf16 fragments come from ds_read_b64_tr_b16
+//   (hardware transpose read); fp32 fragments are plain ds_read_b32.  Split-K over pixel ranges,
+//   partials combined with fp32 atomics.
+#include "common.h"
+
+namespace {
+
+struct ConvGeom {
+    int n, h_in, w_in, h, w, cin, cout, ks, ups;
+    int m;          // n*h*w output pixels
+    int cpt;        // 16-byte chunks per tap  (cin / elems-per-16B)
+    int kchunks;    // ks*ks*cpt
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+    // contiguous chunk of tiles per XCD (block b runs on XCD b % 8); bijective for any total
+    const int q = total >> 3, r = total & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_raw> {
+    static constexpr int EPC = 8;     // elements per 16-byte chunk
+    __device__ static __forceinline__ void run(const char* pa, const char* pb, f32x16& acc) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(pa);
+        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(pb);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int EPC = 4;
+    __device__ static __forceinline__ void run(const char* pa, const char* pb, f32x16& acc) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pa);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pb);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const VQK_GLB void*)src, (VQK_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fprop / dgrad
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TO, bool FASTK>
+__global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict__ x, const T* __restrict__ wgt,
+                                                            const float* __restrict__ bias, const TO* __restrict__ res,
+                                                            TO* __restrict__ y, const char* __restrict__ zeros,
+                                                            ConvGeom g, int act) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_a = smem;              // [128][128 B]
+    char* lds_b = smem + 16384;      // [128][128 B]
+    constexpr int EPC = Mma<T>::EPC;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    const int mt = tile / g.tiles_n, nt = tile - mt * g.tiles_n;
+    const int m0 = mt * 128, n0 = nt * 128;
+    const int pad = g.ks >> 1;
+
+    // ---- per-lane load slots: 4 A rows + 4 B rows (row = 8*(4*wave+t) + lane/8), fixed over K
+    int a_oh[4], a_ow[4];
+    const T* a_img[4];
+    const char* b_row[4];
+    bool b_ok[4];
+    int lchunk[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = 8 * (4 * wave + t) + (lane >> 3);
+        const int m = m0 + r;
+        if (m < g.m) {
+            const int hw = g.h * g.w;
+            const int img = m / hw, rem = m - img * hw;
+            a_oh[t] = rem / g.w;
+            a_ow[t] = rem - a_oh[t] * g.w;
+            a_img[t] = x + (int64_t)img * g.h_in * g.w_in * g.cin;
+        } else {
+            a_oh[t] = -100000; a_ow[t] = 0; a_img[t] = x;
+        }
+        const int co = n0 + r;
+        b_ok[t] = co < g.cout;
+        b_row[t] = reinterpret_cast<const char*>(wgt) + (int64_t)(b_ok[t] ? co : 0) * g.kchunks * 16;
+    }
+    // logical chunk held by this lane's physical LDS slot (swizzle: phys = logical ^ ((row>>1)&7))
+    lchunk[0] = (lane & 7) ^ ((lane >> 4) & 7);
+    lchunk[1] = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment read offsets (bytes): row*128 + ((2*ks + kg) ^ ((row>>1)&7))*16
+    const int frow = lane & 31, kg = lane >> 5;
+    int fa[2], fb[2], fsw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
+        fa[i] = ra * 128; fb[i] = rb * 128;
+        fsw[i] = 0;
+    }
+    const int swz = (frow >> 1) & 7;   // identical for A and B rows (tile bases are multiples of 32)
+    (void)fsw;
+
+    const int ksteps = (g.kchunks + 7) >> 3;
+    const int steps_per_tap = FASTK ? (g.cpt >> 3) : 1;
+
+    for (int s = 0; s < ksteps; ++s) {
+        // ---------------- stage: 4 A + 4 B 16-byte pieces per lane
+        int tap_u = 0, kh_u = 0, kw_u = 0, cbase_u = 0;
+        if (FASTK) {
+            tap_u = s / steps_per_tap;
+            kh_u = tap_u / g.ks; kw_u = tap_u - kh_u * g.ks;
+            cbase_u = (s - tap_u * steps_per_tap) * 8;     // chunk offset inside the tap
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int lc = lchunk[t & 1];
+            const int gch = s * 8 + lc;                      // global chunk index along K
+            int kh, kw, coff;
+            bool ok = true;
+            if (FASTK) { kh = kh_u; kw = kw_u; coff = cbase_u + lc; }
+            else {
+                ok = gch < g.kchunks;
+                const int tap = gch / g.cpt;
+                coff = gch - tap * g.cpt;
+                kh = tap / g.ks; kw = tap - kh * g.ks;
+            }
+            const int ih = a_oh[t] + kh - pad, iw = a_ow[t] + kw - pad;
+            ok = ok && ih >= 0 && ih < g.h && iw >= 0 && iw < g.w;
+            const T* src = a_img[t] + ((int64_t)(ih >> g.ups) * g.w_in + (iw >> g.ups)) * g.cin + coff * EPC;
+            const void* sa = ok ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(zeros);
+            glds16(sa, lds_a + (4 * wave + t) * 1024);
+            const bool okb = b_ok[t] && gch < g.kchunks;
+            const void* sb = okb ? reinterpret_cast<const void*>(b_row[t] + (int64_t)gch * 16)
+                                 : reinterpret_cast<const void*>(zeros);
+            glds16(sb, lds_b + (4 * wave + t) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---------------- compute: 4 k-substeps of two 16-byte chunks
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int poff = ((2 * ks + kg) ^ swz) * 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    Mma<T>::run(lds_a + fa[i] + poff, lds_b + fb[j] + poff, acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: bias, residual, activation, store
+    const int ocol = lane & 31, orow = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + j * 32 + ocol;
+        if (co >= g.cout) continue;
+        const float bv = bias ? bias[co] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + orow;
+                if (m < g.m) {
+                    const int64_t o = (int64_t)m * g.cout + co;
+                    float v = acc[i][j][r] + bv;
+                    if (res) v += Elem<TO>::ld(res + o);
+                    if (act == 1) v = tanhf(v);
+                    Elem<TO>::st(y + o, v);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad.  grid = (co tiles * ci tiles, taps, splits).  Tile 128 co x 128 ci, K-step KP pixels.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct WgradFrag;
+
+// bf16: LDS rows are pixels, 256 B (128 channels) each, 16-B chunk index XORed with (row&3)<<2.
+template <> struct WgradFrag<bf16_raw> {
+    static constexpr int KP = 64;           // pixels per K-step
+    static constexpr int ROWB = 256;        // bytes per LDS row
+    static constexpr int EPC = 8;
+    // one 32x32x16 step: 16 pixels starting at row k0; operand columns [cbase, cbase+32)
+    __device__ static __forceinline__ bf16x8_t frag(const char* tile, int k0, int cbase, int lane) {
+        const int i = lane & 15, grp = (lane >> 4) & 1, kgrp = lane >> 5;
+        const int col = cbase + 16 * grp + 4 * (i & 3);
+        const int row = k0 + 8 * kgrp + (i >> 2);
+        const int lc = col >> 3;
+        const char* p0 = tile + row * ROWB + ((lc ^ ((row & 3) << 2)) << 4) + ((col & 7) << 1);
+        const char* p1 = p0 + 4 * ROWB;     // rows +4: same (row&3) -> same swizzle
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VQK_LDS s16x4*)p0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VQK_LDS s16x4*)p1);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, v);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            float* __restrict__ dw, const char* __restrict__ zeros,
+                                                            ConvGeom g, int pix_per_split);
+
+template <>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16_raw* __restrict__ x,
+                                                                      const bf16_raw* __restrict__ dy,
+                                                                      float* __restrict__ dw,
+                                                                      const char* __restrict__ zeros, ConvGeom g,
+                                                                      int pix_per_split) {
+    typedef WgradFrag<bf16_raw> F;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_a = smem;                       // dy tile  [64 pix][128 co]
+    char* lds_b = smem + F::KP * F::ROWB;     // x tile   [64 pix][128 ci]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_ci = (g.cin + 127) >> 7;
+    const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
+    const int co0 = tco * 128, ci0 = tci * 128;
+    const int tap = blockIdx.y, kh = tap / g.ks, kw = tap - kh * g.ks, pad = g.ks >> 1;
+    const int p_begin = blockIdx.z * pix_per_split;
+    const int p_end = min(g.m, p_begin + pix_per_split);
+
+    // load slots: one wave instruction = 4 rows x 16 chunks; 16 instructions per tile, 4 per wave
+    const int pc = lane & 15, rsub = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int hw = g.h * g.w;
+    for (int p0 = p_begin; p0 < p_end; p0 += F::KP) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 4 * (4 * wave + t) + rsub;          // (row & 3) == rsub
+            const int lc = pc ^ (rsub << 2);
+            const int p = p0 + row;
+            const bool pv = p < p_end;
+            // A: dy[p][co0 + lc*8 ..]
+            const bool oka = pv && (co0 + lc * 8) < g.cout;
+            const void* sa = oka ? (const void*)(dy + (int64_t)p * g.cout + co0 + lc * 8) : (const void*)zeros;
+            glds16(sa, lds_a + (4 * wave + t) * 1024);
+            // B: x[p (+) tap][ci0 + lc*8 ..]
+            bool okb = pv && (ci0 + lc * 8) < g.cin;
+            const void* sb = zeros;
+            if (okb) {
+                const int img = p / hw, rem = p - img * hw;
+                const int oh = rem / g.w, ow = rem - oh * g.w;
+                const int ih = oh + kh - pad, iw = ow + kw - pad;
+                if (ih >= 0 && ih < g.h && iw >= 0 && iw < g.w)
+                    sb = x + (((int64_t)img * g.h_in + (ih >> g.ups)) * g.w_in + (iw >> g.ups)) * g.cin + ci0 + lc * 8;
+            }
+            glds16(sb, lds_b + (4 * wave + t) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < F::KP; k0 += 16) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = F::frag(lds_a, k0, wm * 64 + i * 32, lane);
+                b[i] = F::frag(lds_b, k0, wn * 64 + i * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int taps = g.ks * g.ks;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+        if (ci >= g.cin) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < g.cout) atomicAdd(dw + ((int64_t)co * taps + tap) * g.cin + ci, acc[i][j][r]);
+            }
+    }
+}
+
+// fp32: LDS rows are pixels, 512 B (128 fp32 channels) each, no swizzle; fragments are ds_read_b32.
+template <>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<float>(const float* __restrict__ x,
+                                                                   const float* __restrict__ dy,
+                                                                   float* __restrict__ dw,
+                                                                   const char* __restrict__ zeros, ConvGeom g,
+                                                                   int pix_per_split) {
+    constexpr int KP = 32, ROWB = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_a = smem;
+    char* lds_b = smem + KP * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_ci = (g.cin + 127) >> 7;
+    const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
+    const int co0 = tco * 128, ci0 = tci * 128;
+    const int tap = blockIdx.y, kh = tap / g.ks, kw = tap - kh * g.ks, pad = g.ks >> 1;
+    const int p_begin = blockIdx.z * pix_per_split;
+    const int p_end = min(g.m, p_begin + pix_per_split);
+
+    const int pc = lane & 31, rsub = lane >> 5;     // one wave instruction = 2 rows x 32 chunks
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int hw = g.h * g.w;
+    for (int p0 = p_begin; p0 < p_end; p0 += KP) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 2 * (4 * wave + t) + rsub;
+            const int p = p0 + row;
+            const bool pv = p < p_end;
+            const bool oka = pv && (co0 + pc * 4) < g.cout;
+            const void* sa = oka ? (const void*)(dy + (int64_t)p * g.cout + co0 + pc * 4) : (const void*)zeros;
+            glds16(sa, lds_a + (4 * wave + t) * 1024);
+            bool okb = pv && (ci0 + pc * 4) < g.cin;
+            const void* sb = zeros;
+            if (okb) {
+                const int img = p / hw, rem = p - img * hw;
+                const int oh = rem / g.w, ow = rem - oh * g.w;
+                const int ih = oh + kh - pad, iw = ow + kw - pad;
+                if (ih >= 0 && ih < g.h && iw >= 0 && iw < g.w)
+                    sb = x + (((int64_t)img * g.h_in + (ih >> g.ups)) * g.w_in + (iw >> g.ups)) * g.cin + ci0 + pc * 4;
+            }
+            glds16(sb, lds_b + (4 * wave + t) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kslot = lane >> 5, c = lane & 31;
+#pragma unroll 4
+        for (int k0 = 0; k0 < KP; k0 += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float*>(lds_a + (k0 + kslot) * ROWB + (wm * 64 + i * 32 + c) * 4);
+                b[i] = *reinterpret_cast<const float*>(lds_b + (k0 + kslot) * ROWB + (wn * 64 + i * 32 + c) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int taps = g.ks * g.ks;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+        if (ci >= g.cin) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < g.cout) atomicAdd(dw + ((int64_t)co * taps + tap) * g.cin + ci, acc[i][j][r]);
+            }
+    }
+}
+
+// w [Cout][taps][Cin] fp32 -> wt [Cin][taps (flipped)][Cout] as TD
+template <typename TD>
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, TD* __restrict__ wt, int cout, int cin, int taps) {
+    const int64_t total = (int64_t)cout * taps * cin;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        // o indexes the destination [ci][tap][co]
+        const int co = (int)(o % cout);
+        const int64_t r = o / cout;
+        const int tap = (int)(r % taps), ci = (int)(r / taps);
+        Elem<TD>::st(wt + o, w[((int64_t)co * taps + (taps - 1 - tap)) * cin + ci]);
+    }
+}
+
+template <typename TD>
+__global__ void cast_kernel(const float* __restrict__ s, TD* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<TD>::st(d + i, s[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t rows, int c, float* __restrict__ out) {
+    // thread owns a column (grid.x covers columns), grid.y strides over rows
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rlane = threadIdx.x >> 6;
+    __shared__ float part[4][64];
+    float acc = 0.0f;
+    if (col < c)
+        for (int64_t r = (int64_t)blockIdx.y * 4 + rlane; r < rows; r += (int64_t)gridDim.y * 4)
+            acc += Elem<T>::ld(x + r * c + col);
+    part[rlane][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rlane == 0 && col < c)
+        atomicAdd(out + col, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+template <typename T, typename TO>
+int launch_fprop(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
+                 const ConvGeom& g, int act, hipStream_t st) {
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    const bool fastk = (g.cpt % 8) == 0;
+    if (fastk)
+        hipLaunchKernelGGL((conv_fprop_kernel<T, TO, true>), grid, dim3(256), 32768, st, (const T*)x, (const T*)w, bias,
+                           (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+    else
+        hipLaunchKernelGGL((conv_fprop_kernel<T, TO, false>), grid, dim3(256), 32768, st, (const T*)x, (const T*)w, bias,
+                           (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+    if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+    return VQK_OK;
+}
+
+int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups) {
+    if (dtype != VQK_F32 && dtype != VQK_BF16) return VQK_ERR_DTYPE;
+    const int epc = dtype == VQK_F32 ? 4 : 8;
+    if (n <= 0 || h_in <= 0 || w_in <= 0 || cin <= 0 || cout <= 0) return VQK_ERR_SHAPE;
+    if (ksize != 1 && ksize != 3) return VQK_ERR_SHAPE;
+    if (ups != 0 && ups != 1) return VQK_ERR_ARG;
+    if (cin % epc) return VQK_ERR_SHAPE;
+    g.n = n; g.h_in = h_in; g.w_in = w_in; g.h = h_in << ups; g.w = w_in << ups;
+    g.cin = cin; g.cout = cout; g.ks = ksize; g.ups = ups;
+    const int64_t m = (int64_t)n * g.h * g.w;
+    if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
+    g.m = (int)m;
+    g.cpt = cin / epc;
+    g.kchunks = ksize * ksize * g.cpt;
+    g.tiles_m = (g.m + 127) / 128;
+    g.tiles_n = (cout + 127) / 128;
+    return VQK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                     int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int act,
+                     const void* zeros, void* stream) {
+    VQK_REQUIRE(x && w && y && zeros, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
+    VQK_REQUIRE(act == 0 || act == 1, VQK_ERR_ARG);
+    ConvGeom g;
+    const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
+    if (rc) return rc;
+    hipStream_t st = vqk_stream(stream);
+    if (dtype == VQK_F32 && out_dtype == VQK_F32) return launch_fprop<float, float>(x, w, bias, residual, y, zeros, g, act, st);
+    if (dtype == VQK_BF16 && out_dtype == VQK_BF16) return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, act, st);
+    if (dtype == VQK_BF16 && out_dtype == VQK_F32) return launch_fprop<bf16_raw, float>(x, w, bias, residual, y, zeros, g, act, st);
+    return VQK_ERR_DTYPE;
+}
+
+int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, int ksize, void* stream) {
+    VQK_REQUIRE(w && wt, VQK_ERR_ARG);
+    VQK_REQUIRE(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), VQK_ERR_SHAPE);
+    const int64_t total = (int64_t)cout * cin * ksize * ksize;
+    const dim3 grid(vqk_grid_1d(total, 256));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(pack_dgrad_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), w, (float*)wt, cout, cin, ksize * ksize);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(pack_dgrad_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), w, (bf16_raw*)wt, cout, cin, ksize * ksize);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin, int cout,
+                     int ksize, int ups, const void* zeros, void* stream) {
+    VQK_REQUIRE(x && dy && dw && zeros, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
+    ConvGeom g;
+    const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
+    if (rc) return rc;
+    const int epc = dtype == VQK_F32 ? 4 : 8;
+    VQK_REQUIRE(cout % epc == 0, VQK_ERR_SHAPE);
+    const int kp = dtype == VQK_F32 ? 32 : 64;
+    const int tiles = ((cout + 127) / 128) * ((cin + 127) / 128) * ksize * ksize;
+    // split the pixel range so that ~2048 blocks are in flight, each with >= 4 K-steps
+    int splits = (2048 + tiles - 1) / tiles;
+    const int max_splits = (g.m + 4 * kp - 1) / (4 * kp);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int pps = (g.m + splits - 1) / splits;
+    pps = ((pps + kp - 1) / kp) * kp;
+    splits = (g.m + pps - 1) / pps;
+    const dim3 grid((unsigned)(((cout + 127) / 128) * ((cin + 127) / 128)), (unsigned)(ksize * ksize), (unsigned)splits);
+    if (dtype == VQK_F32)
+        hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 32768, vqk_stream(stream), (const float*)x, (const float*)dy, dw, (const char*)zeros, g, pps);
+    else
+        hipLaunchKernelGGL(conv_wgrad_kernel<bf16_raw>, grid, dim3(256), 32768, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream) {
+    VQK_REQUIRE(x && out, VQK_ERR_ARG);
+    VQK_REQUIRE(rows >= 0 && c > 0, VQK_ERR_SHAPE);
+    if (rows == 0) return VQK_OK;
+    int gy = (int)((rows + 255) / 256); if (gy > 1024) gy = 1024; if (gy < 1) gy = 1;
+    const dim3 grid((unsigned)((c + 63) / 64), (unsigned)gy);
+    if (dtype == VQK_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, rows, c, out);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)x, rows, c, out);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_cast(const float* src, void* dst, int dtype, int64_t n, void* stream) {
+    VQK_REQUIRE(src && dst, VQK_ERR_ARG);
+    if (n <= 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(n, 256));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(cast_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), src, (float*)dst, n);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(cast_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), src, (bf16_raw*)dst, n);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+// GroupNorm (unbiased variance) + SiLU, NHWC.  Restates vqvae/modules/autoencoder.py:25-39 and the SiLU
+// that follows every norm (:65,:68,:139-140,:176-177); backward per SURVEY Appendix B:
+//   dxhat = dy_pre * w_c ;  dx = (dxhat - mean(dxhat) - xhat * sum(dxhat*xhat)/(M-1)) * rstd
+// (mean over M, the xhat term over M-1 because the variance is the unbiased one).
+// Thread mapping: a thread owns one 16-byte channel vector slot (fixed channels) and strides over pixels,
+// so per-channel affine terms / partial sums live in registers.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int64_t hw, int c, int groups,
+                                                       int pix_per_block, double* __restrict__ acc) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sh = reinterpret_cast<double*>(smem);          // [2][c]
+    const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * c; i += 256) sh[i] = 0.0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = min(hw, p0 + pix_per_block);
+    float s[V], ss[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s[i] = 0.f; ss[i] = 0.f; }
+    const T* base = x + (int64_t)n * hw * c + slot * V;
+    for (int64_t p = p0 + prow; p < p1; p += pstep) {
+        float v[V];
+        Vec16<T>::load(base + p * c, v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) { s[i] += v[i]; ss[i] = __fmaf_rn(v[i], v[i], ss[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        atomicAdd(&sh[slot * V + i], (double)s[i]);
+        atomicAdd(&sh[c + slot * V + i], (double)ss[i]);
+    }
+    __syncthreads();
+    const int cpg = c / groups;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < cpg; ++i) { a += sh[g * cpg + i]; b += sh[c + g * cpg + i]; }
+        atomicAdd(&acc[((int64_t)n * groups + g) * 2 + 0], a);
+        atomicAdd(&acc[((int64_t)n * groups + g) * 2 + 1], b);
+    }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ acc, float* __restrict__ stats, int total, double m,
+                                   float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double s = acc[2 * i], ss = acc[2 * i + 1];
+    const double mean = s / m;
+    double var = (ss - s * mean) / (m - 1.0);          // unbiased (torch.var default)
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       T* __restrict__ y, int64_t hw, int c, int groups, int silu,
+                                                       int pix_per_block) {
+    constexpr int V = Vec16<T>::N;
+    const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
+    const int n = blockIdx.y, cpg = c / groups;
+    float scale[V], shift[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = slot * V + i, g = ch / cpg;
+        const float mean = stats[((int64_t)n * groups + g) * 2], rstd = stats[((int64_t)n * groups + g) * 2 + 1];
+        scale[i] = rstd * w[ch];
+        shift[i] = __fmaf_rn(-mean, scale[i], b[ch]);
+    }
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = min(hw, p0 + pix_per_block);
+    const int64_t off = (int64_t)n * hw * c + slot * V;
+    for (int64_t p = p0 + prow; p < p1; p += pstep) {
+        float v[V];
+        Vec16<T>::load(x + off + p * c, v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float t = __fmaf_rn(v[i], scale[i], shift[i]);
+            v[i] = silu ? silu_f(t) : t;
+        }
+        Vec16<T>::store(y + off + p * c, v);
+    }
+}
+
+// pass 1 of the backward: per-channel sums of dy_pre and dy_pre*xhat (-> dw, db) and the per-group
+// sums of dxhat and dxhat*xhat (-> red[n][g][2], double).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const T* __restrict__ dy, float* __restrict__ dw,
+                                                            float* __restrict__ db, double* __restrict__ red,
+                                                            int64_t hw, int c, int groups, int silu,
+                                                            int pix_per_block) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sh = reinterpret_cast<float*>(smem);            // [2][c]
+    const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
+    const int n = blockIdx.y, cpg = c / groups;
+    for (int i = threadIdx.x; i < 2 * c; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    float mean[V], rstd[V], wv[V], bv[V], a[V], bb[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = slot * V + i, g = ch / cpg;
+        mean[i] = stats[((int64_t)n * groups + g) * 2]; rstd[i] = stats[((int64_t)n * groups + g) * 2 + 1];
+        wv[i] = w[ch]; bv[i] = b[ch]; a[i] = 0.f; bb[i] = 0.f;
+    }
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = min(hw, p0 + pix_per_block);
+    const int64_t off = (int64_t)n * hw * c + slot * V;
+    for (int64_t p = p0 + prow; p < p1; p += pstep) {
+        float xv[V], gv[V];
+        Vec16<T>::load(x + off + p * c, xv);
+        Vec16<T>::load(dy + off + p * c, gv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float xh = (xv[i] - mean[i]) * rstd[i];
+            float g = gv[i];
+            if (silu) {
+                const float yv = __fmaf_rn(xh, wv[i], bv[i]);
+                const float sg = 1.0f / (1.0f + __expf(-yv));
+                g *= sg * (1.0f + yv * (1.0f - sg));
+            }
+            a[i] += g;
+            bb[i] = __fmaf_rn(g, xh, bb[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        atomicAdd(&sh[slot * V + i], a[i]);
+        atomicAdd(&sh[c + slot * V + i], bb[i]);
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        atomicAdd(db + ch, sh[ch]);
+        atomicAdd(dw + ch, sh[c + ch]);
+    }
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < cpg; ++i) {
+            const int ch = g * cpg + i;
+            s1 += (double)sh[ch] * (double)w[ch];
+            s2 += (double)sh[c + ch] * (double)w[ch];
+        }
+        atomicAdd(&red[((int64_t)n * groups + g) * 2 + 0], s1);
+        atomicAdd(&red[((int64_t)n * groups + g) * 2 + 1], s2);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           const T* __restrict__ dy, T* __restrict__ dx,
+                                                           const double* __restrict__ red, int64_t hw, int c,
+                                                           int groups, int silu, int accumulate, int pix_per_block) {
+    constexpr int V = Vec16<T>::N;
+    const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
+    const int n = blockIdx.y, cpg = c / groups;
+    const double m = (double)hw * cpg;
+    float mean[V], rstd[V], wv[V], bv[V], k1[V], k2[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = slot * V + i, g = ch / cpg;
+        mean[i] = stats[((int64_t)n * groups + g) * 2]; rstd[i] = stats[((int64_t)n * groups + g) * 2 + 1];
+        wv[i] = w[ch]; bv[i] = b[ch];
+        k1[i] = (float)(red[((int64_t)n * groups + g) * 2] / m);
+        k2[i] = (float)(red[((int64_t)n * groups + g) * 2 + 1] / (m - 1.0));
+    }
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = min(hw, p0 + pix_per_block);
+    const int64_t off = (int64_t)n * hw * c + slot * V;
+    for (int64_t p = p0 + prow; p < p1; p += pstep) {
+        float xv[V], gv[V], ov[V];
+        Vec16<T>::load(x + off + p * c, xv);
+        Vec16<T>::load(dy + off + p * c, gv);
+        if (accumulate) Vec16<T>::load(dx + off + p * c, ov);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float xh = (xv[i] - mean[i]) * rstd[i];
+            float g = gv[i];
+            if (silu) {
+                const float yv = __fmaf_rn(xh, wv[i], bv[i]);
+                const float sg = 1.0f / (1.0f + __expf(-yv));
+                g *= sg * (1.0f + yv * (1.0f - sg));
+            }
+            const float r = (g * wv[i] - k1[i] - xh * k2[i]) * rstd[i];
+            ov[i] = accumulate ? ov[i] + r : r;
+        }
+        Vec16<T>::store(dx + off + p * c, ov);
+    }
+}
+
+int check_gn(int dtype, int c, int groups) {
+    if (dtype != VQK_F32 && dtype != VQK_BF16) return VQK_ERR_DTYPE;
+    const int v = dtype == VQK_F32 ? 4 : 8;
+    if (c <= 0 || groups <= 0 || c % groups || c % v) return VQK_ERR_SHAPE;
+    const int vpp = c / v;
+    if (vpp > 256 || 256 % vpp) return VQK_ERR_SHAPE;
+    return VQK_OK;
+}
+
+inline int pick_ppb(int n, int64_t hw) {
+    // ~2048 blocks in total, at least 64 pixels per block
+    int64_t blocks_per_sample = (2048 + n - 1) / n;
+    int64_t ppb = (hw + blocks_per_sample - 1) / blocks_per_sample;
+    if (ppb < 64) ppb = 64;
+    return (int)ppb;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqk_gn_stats(int dtype, const void* x, int n, int64_t hw, int c, int groups, float eps, double* acc, float* stats,
+                 void* stream) {
+    VQK_REQUIRE(x && acc && stats, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
+    const int rc = check_gn(dtype, c, groups);
+    if (rc) return rc;
+    VQK_REQUIRE(vqk_aligned16(x), VQK_ERR_ALIGN);
+    const int ppb = pick_ppb(n, hw);
+    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
+    const size_t lds = (size_t)2 * c * sizeof(double);
+    hipStream_t st = vqk_stream(stream);
+    if (dtype == VQK_F32) hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), lds, st, (const float*)x, hw, c, groups, ppb, acc);
+    else hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, grid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, ppb, acc);
+    const int total = n * groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, acc, stats, total,
+                       (double)hw * (c / groups), eps);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_gn_apply(int dtype, const void* x, const float* stats, const float* w, const float* b, void* y, int n, int64_t hw,
+                 int c, int groups, int silu, void* stream) {
+    VQK_REQUIRE(x && stats && w && b && y, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
+    const int rc = check_gn(dtype, c, groups);
+    if (rc) return rc;
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    const int ppb = pick_ppb(n, hw);
+    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
+    hipStream_t st = vqk_stream(stream);
+    if (dtype == VQK_F32) hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (float*)y, hw, c, groups, silu, ppb);
+    else hipLaunchKernelGGL(gn_apply_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy, void* dx,
+                    float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu, int accumulate,
+                    void* stream) {
+    VQK_REQUIRE(x && stats && w && b && dy && dx && dw && db && red, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
+    const int rc = check_gn(dtype, c, groups);
+    if (rc) return rc;
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(dx), VQK_ERR_ALIGN);
+    const int ppb = pick_ppb(n, hw);
+    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
+    const size_t lds = (size_t)2 * c * sizeof(float);
+    hipStream_t st = vqk_stream(stream);
+    if (dtype == VQK_F32) {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, ppb);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, red, hw, c, groups, silu, accumulate, ppb);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_raw>, grid, dim3(256), lds, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, dw, db, red, hw, c, groups, silu, ppb);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, red, hw, c, groups, silu, accumulate, ppb);
+    }
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+// Memory-bound pointwise / pooling kernels of the train step (NHWC, 16 bytes per lane):
+//   avg-pool 2x2 and its backward       vqvae/modules/autoencoder.py:89-91
+//   backward of the nearest x2 upsample  vqvae/modules/autoencoder.py:104-106
+//   clamp + normalise + NCHW->NHWC       vqvae/modules/abstract_modules/base_autoencoder.py:31-50
+//   MSE loss and its backward through the decoder's tanh   vqvae/model.py:272, autoencoder.py:179
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w,
+                                                      int c, float scale) {
+    constexpr int V = Vec16<T>::N;
+    const int oh = h >> 1, ow = w >> 1, vpp = c / V;
+    const int64_t total = (int64_t)n * oh * ow * vpp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpp);
+        int64_t p = i / vpp;
+        const int ox = (int)(p % ow); p /= ow;
+        const int oy = (int)(p % oh);
+        const int img = (int)(p / oh);
+        const T* s = x + (((int64_t)img * h + 2 * oy) * w + 2 * ox) * c + v * V;
+        float a[V], b[V], d[V], e[V], o[V];
+        Vec16<T>::load(s, a); Vec16<T>::load(s + c, b);
+        Vec16<T>::load(s + (int64_t)w * c, d); Vec16<T>::load(s + (int64_t)w * c + c, e);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = ((a[k] + b[k]) + (d[k] + e[k])) * scale;
+        Vec16<T>::store(y + i * V, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w,
+                                                        int c, float scale) {
+    constexpr int V = Vec16<T>::N;
+    const int oh = h * 2, ow = w * 2, vpp = c / V;
+    const int64_t total = (int64_t)n * oh * ow * vpp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpp);
+        int64_t p = i / vpp;
+        const int ox = (int)(p % ow); p /= ow;
+        const int oy = (int)(p % oh);
+        const int img = (int)(p / oh);
+        float a[V];
+        Vec16<T>::load(x + (((int64_t)img * h + (oy >> 1)) * w + (ox >> 1)) * c + v * V, a);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a[k] *= scale;
+        Vec16<T>::store(y + i * V, a);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ img, T* __restrict__ xp,
+                                                         float* __restrict__ target, int n, int h, int w, int cpad) {
+    const int64_t hw = (int64_t)h * w, total = (int64_t)n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / hw, p = i - b * hw;
+        for (int ch = 0; ch < cpad; ++ch) {
+            float v = 0.0f;
+            if (ch < 3) {
+                v = img[(b * 3 + ch) * hw + p];
+                v = fminf(fmaxf(v, 0.0f), 1.0f);
+                v = (v - 0.5f) / 0.5f;
+            }
+            Elem<T>::st(xp + i * cpad + ch, v);
+            if (target) target[i * cpad + ch] = v;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sse_kernel(const T* __restrict__ r, const float* __restrict__ t, int64_t n,
+                                                  float* __restrict__ loss) {
+    __shared__ float part[4];
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = Elem<T>::ld(r + i) - t[i];
+        acc = __fmaf_rn(d, d, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mse_tanh_bwd_kernel(const T* __restrict__ r, const float* __restrict__ t,
+                                                           int64_t n, float gscale, const float* __restrict__ gs,
+                                                           int through_tanh, T* __restrict__ d) {
+    if (gs) gscale *= *gs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float y = Elem<T>::ld(r + i);
+        float g = gscale * 2.0f * (y - t[i]);
+        if (through_tanh) g *= 1.0f - y * y;
+        Elem<T>::st(d + i, g);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                       int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float yv = Elem<T>::ld(y + i);
+        Elem<T>::st(dx + i, Elem<T>::ld(dy + i) * (1.0f - yv * yv));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y2, T* __restrict__ y,
+                                                    float a, float b, int64_t nvec) {
+    constexpr int V = Vec16<T>::N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float u[V], w[V];
+        Vec16<T>::load(x + i * V, u);
+        if (y2) {
+            Vec16<T>::load(y2 + i * V, w);
+#pragma unroll
+            for (int k = 0; k < V; ++k) u[k] = a * u[k] + b * w[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) u[k] = a * u[k];
+        }
+        Vec16<T>::store(y + i * V, u);
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, KERNEL, grid, lds, st, ...)                                                      \
+    do {                                                                                                   \
+        if ((dtype) == VQK_F32) hipLaunchKernelGGL(KERNEL<float>, grid, dim3(256), lds, st, __VA_ARGS__);   \
+        else if ((dtype) == VQK_BF16) hipLaunchKernelGGL(KERNEL<bf16_raw>, grid, dim3(256), lds, st, __VA_ARGS__); \
+        else return VQK_ERR_DTYPE;                                                                         \
+    } while (0)
+
+extern "C" {
+
+int vqk_pool2x2(int dtype, const void* x, void* y, int n, int h, int w, int c, float scale, void* stream) {
+    VQK_REQUIRE(x && y, VQK_ERR_ARG);
+    const int v = dtype == VQK_F32 ? 4 : 8;
+    VQK_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && !(h & 1) && !(w & 1) && c % v == 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    const int64_t total = (int64_t)n * (h / 2) * (w / 2) * (c / v);
+    const dim3 grid(vqk_grid_1d(total, 256, 256 * 16));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(pool2x2_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, (float*)y, n, h, w, c, scale);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(pool2x2_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)x, (bf16_raw*)y, n, h, w, c, scale);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_unpool2x2(int dtype, const void* x, void* y, int n, int h, int w, int c, float scale, void* stream) {
+    VQK_REQUIRE(x && y, VQK_ERR_ARG);
+    const int v = dtype == VQK_F32 ? 4 : 8;
+    VQK_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % v == 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    const int64_t total = (int64_t)n * (h * 2) * (w * 2) * (c / v);
+    const dim3 grid(vqk_grid_1d(total, 256, 256 * 16));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(unpool2x2_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, (float*)y, n, h, w, c, scale);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(unpool2x2_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)x, (bf16_raw*)y, n, h, w, c, scale);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_preprocess(const float* images, void* x_pad, int dtype, float* target, int n, int h, int w, int cpad, void* stream) {
+    VQK_REQUIRE(images && x_pad, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && h > 0 && w > 0 && cpad >= 3, VQK_ERR_SHAPE);
+    const dim3 grid(vqk_grid_1d((int64_t)n * h * w, 256, 256 * 16));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), images, (float*)x_pad, target, n, h, w, cpad);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(preprocess_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), images, (bf16_raw*)x_pad, target, n, h, w, cpad);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_sse(int dtype, const void* recon, const float* target, int64_t n, float* loss, void* stream) {
+    VQK_REQUIRE(recon && target && loss, VQK_ERR_ARG);
+    if (n <= 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(n, 256 * 8));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(sse_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)recon, target, n, loss);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(sse_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)recon, target, n, loss);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_tanh_backward(int dtype, const void* dy, const void* y, void* dx, int64_t n, void* stream) {
+    VQK_REQUIRE(dy && y && dx, VQK_ERR_ARG);
+    if (n <= 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(n, 256 * 4));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(tanh_bwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)dy, (const float*)y, (float*)dx, n);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(tanh_bwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)dy, (const bf16_raw*)y, (bf16_raw*)dx, n);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_mse_tanh_backward(int dtype, const void* recon, const float* target, int64_t n, float gscale, const float* gscale_dev,
+                          int through_tanh, void* d_pre, void* stream) {
+    VQK_REQUIRE(recon && target && d_pre, VQK_ERR_ARG);
+    if (n <= 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(n, 256 * 4));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(mse_tanh_bwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)recon, target, n, gscale, gscale_dev, through_tanh, (float*)d_pre);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(mse_tanh_bwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)recon, target, n, gscale, gscale_dev, through_tanh, (bf16_raw*)d_pre);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_axpby(int dtype, const void* x, const void* y2, void* y, float a, float b, int64_t n, void* stream) {
+    VQK_REQUIRE(x && y, VQK_ERR_ARG);
+    const int v = dtype == VQK_F32 ? 4 : 8;
+    VQK_REQUIRE(n >= 0 && n % v == 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y) && vqk_aligned16(y2), VQK_ERR_ALIGN);
+    if (n == 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(n / v, 256, 256 * 16));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(axpby_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, (const float*)y2, (float*)y, a, b, n / v);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(axpby_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)y2, (bf16_raw*)y, a, b, n / v);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+// Vector-quantizer kernels: nearest-codeword assignment on exact-fp32 MFMA, gather/loss, backward,
+// EMA statistics and update.  Restates vqvae/modules/vector_quantizers.py:33-56, :142-172, :337-350
+// of the reference (see include/vqk.h); the arithmetic order of the assignment is the canonical one
+// documented in oracle/vq_oracle.c, so indices are bit-exact against the oracle by construction.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// |row|^2 : one wavefront per row.  lane l: fma chain over l, l+64, ...; then xor butterfly 32..1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x, int64_t rows, int d,
+                                                         float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = x + row * d;
+    float acc = 0.0f;
+    for (int k = lane; k < d; k += 64) acc = __fmaf_rn(p[k], p[k], acc);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc = __fadd_rn(acc, __shfl_xor(acc, off, 64));
+    if (lane == 0) out[row] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Assignment.  Block = 4 waves = 32 z rows x all K codes; the z rows sit in LDS (row stride D+4
+// floats: conflict-free ds_read_b128), every wave walks a contiguous quarter of the 32-code tiles.
+// MFMA roles: A = codes (rows i), B = z rows (cols j)  ->  each lane owns one z row (j = lane&31)
+// and 16 codes of the tile, so the running (min, argmin) is lane-local; k is consumed in the order
+// 8m+{0,4,1,5,2,6,3,7} because lane (., half) holds the float4 at k = 8m + 4*half.
+// ------------------------------------------------------------------------------------------------
+template <int ASSOC>
+__global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict__ z, const float* __restrict__ e,
+                                                        const float* __restrict__ z2, const float* __restrict__ e2,
+                                                        int64_t n, int k, int d, int64_t* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* zt = reinterpret_cast<float*>(smem);                 // [32][d + 4]
+    const int ld = d + 4;
+    float* red_d = zt + 32 * ld;                                // [4][32]
+    int* red_i = reinterpret_cast<int*>(red_d + 128);           // [4][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * 32;
+
+    // stage the 32 z rows (rows past n are clamped: computed, never stored)
+    const int vec_per_row = d >> 2;
+    for (int v = tid; v < 32 * vec_per_row; v += 256) {
+        const int r = v / vec_per_row, c = v - r * vec_per_row;
+        int64_t src = n0 + r; if (src >= n) src = n - 1;
+        *reinterpret_cast<f32x4*>(zt + r * ld + 4 * c) = *reinterpret_cast<const f32x4*>(z + src * d + 4 * c);
+    }
+    __syncthreads();
+
+    const int j = lane & 31, half = lane >> 5;
+    int64_t zrow = n0 + j; if (zrow >= n) zrow = n - 1;
+    const float zz = z2[zrow];
+    const float* zb = zt + j * ld + 4 * half;
+
+    const int tiles = (k + 31) >> 5;
+    const int per_wave = (tiles + 3) >> 2;
+    const int t_begin = wave * per_wave;
+    const int t_end = min(tiles, t_begin + per_wave);
+
+    float best = INFINITY;
+    int best_i = 0x7fffffff;
+    for (int t = t_begin; t < t_end; ++t) {
+        int code_row = t * 32 + j; if (code_row >= k) code_row = k - 1;       // A row i == lane&31
+        const float* ea = e + (int64_t)code_row * d + 4 * half;
+        f32x16 acc = {0};
+#pragma unroll 4
+        for (int m = 0; m < d; m += 8) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ea + m);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(zb + m);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (code < k) {
+                const float ab2 = 2.0f * acc[r];
+                float dist;
+                if (ASSOC == 0) dist = __fsub_rn(__fadd_rn(zz, e2[code]), ab2);
+                else            dist = __fadd_rn(__fsub_rn(zz, ab2), e2[code]);
+                if (dist < best) { best = dist; best_i = code; }
+            }
+        }
+    }
+    // the two half-waves hold disjoint code subsets of the same z row
+    {
+        const float od = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(best_i, 32, 64);
+        if (od < best || (od == best && oi < best_i)) { best = od; best_i = oi; }
+    }
+    if (half == 0) { red_d[wave * 32 + j] = best; red_i[wave * 32 + j] = best_i; }
+    __syncthreads();
+    if (tid < 32 && n0 + tid < n) {
+        float bd = red_d[tid]; int bi = red_i[tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float od = red_d[w * 32 + tid]; const int oi = red_i[w * 32 + tid];
+            if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+        }
+        idx[n0 + tid] = (bi == 0x7fffffff) ? 0 : (int64_t)bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// q = e[idx]; sum (q-z)^2; histogram.  One wavefront per row, float4 per lane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ z, const float* __restrict__ e,
+                                                        const int64_t* __restrict__ idx, int64_t n, int d,
+                                                        float* __restrict__ q, bf16_raw* __restrict__ q_lo,
+                                                        float* __restrict__ sse, int32_t* __restrict__ hist) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float local = 0.0f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n; row += (int64_t)gridDim.x * 4) {
+        const int64_t code = idx[row];
+        const float* er = e + code * d;
+        const float* zr = z + row * d;
+        for (int c = lane * 4; c < d; c += 256) {
+            const f32x4 ev = *reinterpret_cast<const f32x4*>(er + c);
+            const f32x4 zv = *reinterpret_cast<const f32x4*>(zr + c);
+            if (q) *reinterpret_cast<f32x4*>(q + row * d + c) = ev;
+            if (q_lo) {
+                u16x4 o = {f32_to_bf16(ev[0]), f32_to_bf16(ev[1]), f32_to_bf16(ev[2]), f32_to_bf16(ev[3])};
+                *reinterpret_cast<u16x4*>(q_lo + row * d + c) = o;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float t = ev[i] - zv[i]; local = __fmaf_rn(t, t, local); }
+        }
+        if (hist && lane == 0) atomicAdd(hist + code, 1);
+    }
+    local = wave_sum(local);
+    if (lane == 0) part[wave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0 && sse) atomicAdd(sse, part[0] + part[1] + part[2] + part[3]);
+}
+
+// dz = dq + cz (z - q);  de[idx] += ce (q - z)
+template <typename TDQ>
+__global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restrict__ z, const float* __restrict__ e,
+                                                          const int64_t* __restrict__ idx, const TDQ* __restrict__ dq,
+                                                          int64_t n, int d, float cz, float ce,
+                                                          const float* __restrict__ gs,
+                                                          float* __restrict__ dz, float* __restrict__ de) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (gs) { const float s = *gs; cz *= s; ce *= s; }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n; row += (int64_t)gridDim.x * 4) {
+        const int64_t code = idx[row];
+        for (int c = lane; c < d; c += 64) {
+            const float zv = z[row * d + c], qv = e[code * d + c];
+            const float g = dq ? Elem<TDQ>::ld(dq + row * d + c) : 0.0f;
+            dz[row * d + c] = __fmaf_rn(cz, zv - qv, g);
+            if (de) atomicAdd(de + code * d + c, ce * (qv - zv));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ema_stats_kernel(const float* __restrict__ z, const int64_t* __restrict__ idx,
+                                                        int64_t n, int d, float* __restrict__ counts,
+                                                        float* __restrict__ dw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n; row += (int64_t)gridDim.x * 4) {
+        const int64_t code = idx[row];
+        if (lane == 0) atomicAdd(counts + code, 1.0f);
+        for (int c = lane; c < d; c += 64) atomicAdd(dw + code * d + c, z[row * d + c]);
+    }
+}
+
+// vector_quantizers.py:161,164
+__global__ void ema_count_kernel(float* __restrict__ ema_count, const float* __restrict__ counts, int k, float decay,
+                                 float eps, float batch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const float c = __fadd_rn(__fmul_rn(ema_count[i], decay), __fmul_rn(1.0f - decay, counts[i]));
+    ema_count[i] = __fmul_rn(__fdiv_rn(__fadd_rn(c, eps), __fadd_rn(batch, __fmul_rn((float)k, eps))), batch);
+}
+
+// vector_quantizers.py:167,169 (ema_count already updated)
+__global__ void ema_weight_kernel(const float* __restrict__ ema_count, float* __restrict__ ema_weight,
+                                  float* __restrict__ codebook, const float* __restrict__ dw, int64_t total, int d,
+                                  float decay) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float w = __fadd_rn(__fmul_rn(ema_weight[i], decay), __fmul_rn(1.0f - decay, dw[i]));
+        ema_weight[i] = w;
+        codebook[i] = __fdiv_rn(w, ema_count[i / d]);
+    }
+}
+
+extern "C" {
+
+int vqk_row_sqnorm_f32(const float* x, int64_t rows, int d, float* out, void* stream) {
+    VQK_REQUIRE(x && out, VQK_ERR_ARG);
+    VQK_REQUIRE(rows >= 0 && d > 0, VQK_ERR_SHAPE);
+    if (rows == 0) return VQK_OK;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, vqk_stream(stream), x, rows, d, out);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_vq_assign_f32(const float* z, const float* e, const float* z2, const float* e2, int64_t n, int k, int d,
+                      int assoc, int64_t* idx, void* stream) {
+    VQK_REQUIRE(z && e && z2 && e2 && idx, VQK_ERR_ARG);
+    VQK_REQUIRE(n >= 0 && k > 0 && d > 0 && (d % 8) == 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(assoc == 0 || assoc == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(z) && vqk_aligned16(e), VQK_ERR_ALIGN);
+    if (n == 0) return VQK_OK;
+    const size_t lds = (size_t)32 * (d + 4) * 4 + 128 * 4 + 128 * 4;
+    VQK_REQUIRE(lds <= 160 * 1024, VQK_ERR_SHAPE);
+    const dim3 grid((unsigned)((n + 31) / 32));
+    if (assoc == 0) {
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)vq_assign_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(vq_assign_kernel<0>, grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx);
+    } else {
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)vq_assign_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(vq_assign_kernel<1>, grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx);
+    }
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_vq_gather_f32(const float* z, const float* e, const int64_t* idx, int64_t n, int k, int d, float* q, void* q_lo,
+                      float* sse, int32_t* hist, void* stream) {
+    VQK_REQUIRE(z && e && idx, VQK_ERR_ARG);
+    VQK_REQUIRE(n >= 0 && k > 0 && d > 0 && (d % 4) == 0, VQK_ERR_SHAPE);
+    if (n == 0) return VQK_OK;
+    hipLaunchKernelGGL(vq_gather_kernel, dim3(vqk_grid_1d(n, 4)), dim3(256), 0, vqk_stream(stream), z, e, idx, n, d, q,
+                       reinterpret_cast<bf16_raw*>(q_lo), sse, hist);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_vq_backward_f32(const float* z, const float* e, const int64_t* idx, const void* dq, int dq_dtype, int64_t n,
+                        int k, int d, float cz, float ce, const float* gscale_dev, float* dz, float* de, void* stream) {
+    VQK_REQUIRE(z && e && idx && dz, VQK_ERR_ARG);
+    VQK_REQUIRE(n >= 0 && k > 0 && d > 0, VQK_ERR_SHAPE);
+    if (n == 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(n, 4));
+    if (dq_dtype == VQK_F32)
+        hipLaunchKernelGGL(vq_backward_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), z, e, idx, (const float*)dq, n, d, cz, ce, gscale_dev, dz, de);
+    else if (dq_dtype == VQK_BF16)
+        hipLaunchKernelGGL(vq_backward_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), z, e, idx, (const bf16_raw*)dq, n, d, cz, ce, gscale_dev, dz, de);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_ema_stats_f32(const float* z, const int64_t* idx, int64_t n, int k, int d, float* counts, float* dw, void* stream) {
+    VQK_REQUIRE(z && idx && counts && dw, VQK_ERR_ARG);
+    VQK_REQUIRE(n >= 0 && k > 0 && d > 0, VQK_ERR_SHAPE);
+    if (n == 0) return VQK_OK;
+    hipLaunchKernelGGL(ema_stats_kernel, dim3(vqk_grid_1d(n, 4)), dim3(256), 0, vqk_stream(stream), z, idx, n, d, counts, dw);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_ema_update_f32(float* ema_count, float* ema_weight, float* codebook, const float* counts, const float* dw, int k,
+                       int d, float decay, float eps, float batch, void* stream) {
+    VQK_REQUIRE(ema_count && ema_weight && codebook && counts && dw, VQK_ERR_ARG);
+    VQK_REQUIRE(k > 0 && d > 0, VQK_ERR_SHAPE);
+    hipLaunchKernelGGL(ema_count_kernel, dim3((k + 255) / 256), dim3(256), 0, vqk_stream(stream), ema_count, counts, k, decay, eps, batch);
+    const int64_t total = (int64_t)k * d;
+    hipLaunchKernelGGL(ema_weight_kernel, dim3(vqk_grid_1d(total, 256)), dim3(256), 0, vqk_stream(stream), ema_count,
+                       ema_weight, codebook, dw, total, d, decay);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+"""``VQVAE``: the reference's LightningModule surface (vqvae/model.py:23-562) over the vqk kernels.
+
+Kept verbatim from the reference: constructor signature and config dictionaries (:25-77), attribute
+names (``encoder``, ``decoder``, ``quantizer``, ``criterion``), ``forward`` return convention (:151-161),
+hook names (:163, :202, :232, :297, :305, :372) and the inference API (:458-489), so the class can be
+handed to a Lightning ``Trainer`` when ``pytorch_lightning`` is installed, or to the bundled
+:class:`~.trainer.MiniTrainer` when it is not.
+
+Deliberate departures (reference defects):
+  * ``training_step`` returns the auto-encoder loss (the reference returns an unbound local on the MSE path);
+  * the epoch usage count is accumulated (the reference overwrites it with a unary plus);
+  * ``configure_optimizers`` by default optimises all 144 tensors; ``optimizer_param_set='reference'``
+    reproduces the reference's name-collision (encoder tensors shadowed by same-named decoder tensors);
+  * ``on_train_end`` tolerates a missing scheduler;
+  * no host synchronisation inside the step: scalars stay on the device.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+from torch import nn
+
+from . import ops
+from .modules.abstract_modules.base_autoencoder import BaseVQVAE
+from .modules.autoencoder import Decoder, Encoder, GroupNorm, Conv2d, set_compute_dtype
+from .modules.vector_quantizers import EMAVectorQuantizer, VectorQuantizer
+from .optim import FlatAdamW
+from .schedulers import CosineScheduler, LinearCosineScheduler, LinearScheduler
+
+try:                                                    # optional: real Lightning when present
+    import pytorch_lightning as pl
+    _LightningBase = pl.LightningModule
+except Exception:                                       # pragma: no cover - not installed in this image
+    class _LightningBase(nn.Module):
+        """duck-typed stand-in for ``pl.LightningModule``: the attributes the hooks touch"""
+
+        def __init__(self):
+            super().__init__()
+            self.trainer = None
+            self.current_epoch = 0
+            self.automatic_optimization = True
+            self.logged = {}
+
+        def log(self, name, value, **_):
+            self.logged[name] = value
+
+        def optimizers(self):
+            return self.trainer.optimizers if len(self.trainer.optimizers) > 1 else self.trainer.optimizers[0]
+
+        def manual_backward(self, loss):
+            loss.backward()
+
+
+class VQVAE(BaseVQVAE, _LightningBase):
+
+    def __init__(self, image_size: int, ae_conf: dict, q_conf: dict, l_conf: dict | None, t_conf: dict | None,
+                 init_cb: bool = True, load_loss: bool = True, compute_dtype: torch.dtype = torch.float32,
+                 optimizer_param_set: str = 'all'):
+        super().__init__(image_size=image_size)
+        self.t_conf = t_conf
+        self.cb_size = q_conf['num_embeddings']
+        self.latent_dim = q_conf['embedding_dim']
+        self.reinit_every_n_epochs = q_conf['reinit_every_n_epochs']
+        self.optimizer_param_set = optimizer_param_set
+        self.kl_warmup_epochs = self.temp_decay_epochs = self.temp_final = None
+
+        qt, qp = q_conf['type'], q_conf['params']
+        if qt == 'standard':
+            self.quantizer = VectorQuantizer(self.cb_size, self.latent_dim, float(qp['commitment_cost']))
+        elif qt == 'ema':
+            self.quantizer = EMAVectorQuantizer(self.cb_size, self.latent_dim, float(qp['commitment_cost']),
+                                                float(qp['decay']), float(qp['epsilon']))
+        elif qt in ('gumbel', 'entropy'):
+            raise NotImplementedError(f'quantizer type {qt!r}: SURVEY 8 row A10/A11, not built yet (see DESIGN.md)')
+        else:
+            raise ValueError(f'unrecognized quantizer: {qt}')
+
+        ch, nrb, mult = ae_conf['channels'], ae_conf['num_res_blocks'], tuple(ae_conf['channel_multipliers'])
+        self.encoder = Encoder(ch, nrb, mult, self.latent_dim)
+        self.decoder = Decoder(ch, nrb, mult, self.latent_dim)
+
+        if load_loss:
+            if l_conf is None:
+                self.criterion = MSELoss()
+            else:
+                raise NotImplementedError('LPIPS / adversarial criterion: SURVEY 8 rows A16-A21, not built yet')
+        else:
+            self.criterion = None
+
+        if init_cb:
+            self.quantizer.init_codebook()
+        self.compute_dtype = compute_dtype
+        set_compute_dtype(self, compute_dtype)
+
+    # ------------------------------------------------------------------ forward (model.py:151-161)
+    def forward(self, x: torch.Tensor):
+        z = self.encoder(x)
+        quantized, used_indices, e_loss = self.quantizer(z)
+        x_recon = self.decoder(quantized)
+        return x_recon, e_loss, used_indices
+
+    # ------------------------------------------------------------------ schedules (model.py:163-230)
+    def on_train_start(self):
+        lr = float(self.t_conf['lr'])
+        nb = self.trainer.num_training_batches
+        wu, de = self.t_conf.get('warmup_epochs'), self.t_conf.get('decay_epochs')
+        if wu is not None and de is not None:
+            self.scheduler = LinearCosineScheduler(0, de * nb, lr, lr / 2., wu * nb)
+        elif wu is not None:
+            self.scheduler = LinearScheduler(0, wu * nb, 1e-20, lr)
+        elif de is not None:
+            self.scheduler = CosineScheduler(0, de * nb, lr, lr / 2.)
+
+    def on_train_batch_start(self, _: Any, batch_index: int):
+        step = self.current_epoch * self.trainer.num_training_batches + batch_index
+        step_lr = self.scheduler.step(step) if self.scheduler is not None else self.t_conf['lr']
+        for optimizer in self.trainer.optimizers:
+            for g in optimizer.param_groups:
+                g['lr'] = step_lr
+        self.log('gumbel_quantizer/temperature', 0.0, sync_dist=True)
+        self.log('gumbel_quantizer/kl_constant', 0.0, sync_dist=True)
+
+    # ------------------------------------------------------------------ the step (model.py:232-295)
+    def _step_losses(self, batch, training: bool):
+        images = batch[0] if isinstance(batch, (tuple, list)) else batch
+        x_pad, target = ops.raw_preprocess(images, self.compute_dtype, want_target=True)   # clamp, normalise, NHWC
+        z = self.encoder(x_pad)
+        quantized, used_indices, q_loss = self.quantizer(z)
+        recon_pad = self.decoder.forward_padded(quantized)
+        l2_loss = ops.mse_loss(recon_pad, target, true_channels=3)
+        return recon_pad, used_indices, q_loss, l2_loss
+
+    def training_step(self, batch: Any, batch_index: int):
+        _, used_indices, q_loss, l2_loss = self._step_losses(batch, training=True)
+        ae_loss = q_loss + l2_loss
+        for name, value in (('train/loss', ae_loss), ('train/l2_loss', l2_loss), ('train/quant_loss', q_loss)):
+            self.log(name, value.detach(), sync_dist=True, on_step=False, on_epoch=True)      # device scalars: no sync
+        hist = self.quantizer.last_hist
+        self.train_epoch_usage_count = hist.clone() if self.train_epoch_usage_count is None \
+            else self.train_epoch_usage_count + hist
+        return ae_loss
+
+    def on_train_epoch_end(self):
+        if (self.reinit_every_n_epochs is not None and self.current_epoch % self.reinit_every_n_epochs == 0
+                and self.current_epoch > 0 and self.train_epoch_usage_count is not None):
+            usage = self.quantizer.get_codebook_usage(self.train_epoch_usage_count.float())[0]
+            self.quantizer.reinit_unused_codes(usage)
+        self.train_epoch_usage_count = None
+
+    def on_train_end(self):
+        if self.scheduler is not None:
+            self.scheduler.destroy()
+
+    @torch.no_grad()
+    def validation_step(self, batch: Any, batch_index: int):
+        _, _, q_loss, l2_loss = self._step_losses(batch, training=False)
+        loss = q_loss + l2_loss
+        self.log('validation/loss', loss, sync_dist=True, on_step=False, on_epoch=True)
+        hist = self.quantizer.last_hist
+        self.val_epoch_usage_count = hist.clone() if self.val_epoch_usage_count is None \
+            else self.val_epoch_usage_count + hist
+        return loss
+
+    def on_validation_epoch_end(self):
+        if self.val_epoch_usage_count is not None:
+            _, perplexity, cb_usage = self.quantizer.get_codebook_usage(self.val_epoch_usage_count.float())
+            self.log('val_metrics/used_codebook', cb_usage, sync_dist=True)
+            self.log('val_metrics/perplexity', perplexity, sync_dist=True)
+        self.val_epoch_usage_count = None
+
+    # ------------------------------------------------------------------ optimizer (model.py:372-440)
+    def optimizer_groups(self):
+        """(decay, no_decay) lists of (full name, parameter).  decay = conv weights; no decay = biases,
+        GroupNorm affine, codebook (model.py:388-396, :424-425)."""
+        decay, no_decay = [], []
+        seen = {}
+        for prefix, sub in (('encoder', self.encoder), ('decoder', self.decoder), ('quantizer', self.quantizer)):
+            for mn, m in sub.named_modules():
+                for pn, p in m.named_parameters(recurse=False):
+                    if not p.requires_grad:
+                        continue
+                    rel = f'{mn}.{pn}' if mn else pn
+                    is_decay = pn.endswith('weight') and isinstance(m, Conv2d)
+                    key = rel if self.optimizer_param_set == 'reference' else f'{prefix}.{rel}'
+                    seen[key] = (f'{prefix}.{rel}', p, is_decay)      # 'reference': later sub-modules shadow earlier ones
+        for full, p, is_decay in seen.values():
+            (decay if is_decay else no_decay).append((full, p))
+        return decay, no_decay
+
+    def configure_optimizers(self):
+        lr = float(self.t_conf['lr'])
+        betas = [float(b) for b in self.t_conf['betas']]
+        eps, wd = float(self.t_conf['eps']), float(self.t_conf['weight_decay'])
+        decay, no_decay = self.optimizer_groups()
+        groups = [{'params': [p for _, p in sorted(decay, key=lambda t: t[0])], 'weight_decay': wd},
+                  {'params': [p for _, p in sorted(no_decay, key=lambda t: t[0])], 'weight_decay': 0.0}]
+        return FlatAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+
+    # ------------------------------------------------------------------ inference API (model.py:458-489)
+    @torch.no_grad()
+    def get_tokens(self, images: torch.Tensor) -> torch.Tensor:
+        return self.quantizer.vec_to_codes(self.encoder(self.preprocess_batch(images)))
+
+    @torch.no_grad()
+    def quantize(self, images: torch.Tensor) -> torch.Tensor:
+        return self.quantizer.codes_to_vec(self.get_tokens(images))
+
+    @torch.no_grad()
+    def reconstruct(self, images: torch.Tensor) -> torch.Tensor:
+        return self.preprocess_visualization(self(self.preprocess_batch(images))[0].float())
+
+    @torch.no_grad()
+    def reconstruct_from_tokens(self, tokens: torch.Tensor) -> torch.Tensor:
+        b, s = tokens.shape
+        side = int(round(s ** 0.5))
+        q = self.quantizer.codes_to_vec(tokens).view(b, side, side, self.latent_dim).permute(0, 3, 1, 2)
+        return self.preprocess_visualization(self.decoder(q).float())
+
+
+class MSELoss(nn.Module):
+    """``torch.nn.MSELoss`` stand-in on the HIP reduction kernel (vqvae/model.py:137)."""
+
+    def forward(self, recon, target):
+        return ops.mse_loss(recon.contiguous(memory_format=torch.channels_last), target)

@@ -1,0 +1,171 @@
+"""Encoder / decoder of the VQ-VAE on the vqk HIP kernels.
+
+Same classes, constructor signatures, attribute names and ``state_dict`` keys as the reference's
+``vqvae/modules/autoencoder.py`` (GroupNorm :7-39, ResBlock :42-77, Downsample :80-91, Upsample :94-106,
+Encoder :109-143, Decoder :146-180); the arithmetic is the NHWC kernel set behind ``libvqk.so``:
+GroupNorm+SiLU is one fused op, the residual add rides in the conv epilogue, the nearest x2 upsample is
+folded into the conv's input addressing, tanh into the last conv's epilogue.
+
+``compute_dtype`` (module attribute, set with :func:`set_compute_dtype`) selects the exact-fp32 MFMA path
+(parity mode, default) or bf16 storage / bf16 MFMA with fp32 accumulation (throughput mode).
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError('compute dtype must be torch.float32 or torch.bfloat16')
+    for m in module.modules():
+        if hasattr(m, 'compute_dtype'):
+            m.compute_dtype = dtype
+    return module
+
+
+class Conv2d(nn.Module):
+    """stride-1 'same' conv (k in {1,3}); weight is logical [O,I,k,k] stored channels_last, i.e. the
+    kernels' [O][kh][kw][I] layout.  Initialised exactly like ``torch.nn.Conv2d``."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, bias: bool = True):
+        super().__init__()
+        if kernel_size not in (1, 3):
+            raise ValueError('only 1x1 and 3x3 convolutions are on the path')
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        w = torch.empty(out_channels, in_channels, kernel_size, kernel_size)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+        if bias:
+            bound = 1 / math.sqrt(in_channels * kernel_size * kernel_size)
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter('bias', None)
+
+    def forward(self, x, residual=None, ups: bool = False, act: int = 0, out_dtype=None):
+        return ops.conv2d(x, self.weight, self.bias, residual, ups, act, out_dtype)
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, num_groups: int, num_channels: int, eps: float = 1e-6):
+        super().__init__()
+        if num_channels % num_groups != 0:
+            raise ValueError('num_channels must be divisible by num_groups')
+        self.num_groups, self.eps = num_groups, eps
+        self.weight = nn.Parameter(torch.ones(1, num_channels, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(1, num_channels, 1, 1))
+
+    def forward(self, x: torch.Tensor, silu: bool = False) -> torch.Tensor:
+        return ops.group_norm_silu(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int = None):
+        super().__init__()
+        if out_channels is None or out_channels == in_channels:
+            out_channels = in_channels
+            self.conv_shortcut = None
+        else:
+            self.conv_shortcut = Conv2d(in_channels, out_channels, 1, bias=False)
+        self.norm1 = GroupNorm(32, in_channels, eps=1e-6)
+        self.conv1 = Conv2d(in_channels, out_channels, 3, bias=False)
+        self.norm2 = GroupNorm(32, out_channels, eps=1e-6)
+        self.conv2 = Conv2d(out_channels, out_channels, 3, bias=False)
+
+    def forward(self, x):
+        r = self.conv1(self.norm1(x, silu=True))
+        r = self.norm2(r, silu=True)
+        skip = x if self.conv_shortcut is None else self.conv_shortcut(x)
+        return self.conv2(r, residual=skip)                   # x + residual, added in the epilogue
+
+
+class Downsample(nn.Module):
+    def __init__(self, kernel_size: int = 2, stride: int = 2, padding: int = 0):
+        super().__init__()
+        if (kernel_size, stride, padding) != (2, 2, 0):
+            raise ValueError('only the 2x2 / stride 2 average pool of the reference is implemented')
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+
+    def forward(self, x):
+        return ops.avg_pool2x2(x)
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels: int, scale_factor: float = 2.0, mode: str = 'nearest-exact'):
+        super().__init__()
+        if scale_factor != 2.0 or mode != 'nearest-exact':
+            raise ValueError('only the nearest-exact x2 upsample of the reference is implemented')
+        self.scale_factor, self.mode = scale_factor, mode
+        self.conv = Conv2d(channels, channels, 3, bias=True)
+
+    def forward(self, x):
+        return self.conv(x, ups=True)
+
+
+def _to_internal(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """layout/dtype plumbing at the module edge: NHWC storage, compute dtype, channels padded with
+    zeros to a whole 16-byte chunk (only the 3-channel image needs it)."""
+    e = ops.epc(dtype)
+    c = x.shape[1]
+    if c % e:
+        x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, e - c % e))
+    return x.to(dtype=dtype, memory_format=torch.channels_last)
+
+
+class Encoder(nn.Module):
+    def __init__(self, channels: int, num_res_blocks: int, channel_multipliers: tuple, embedding_dim: int):
+        super().__init__()
+        self.compute_dtype = torch.float32
+        self.conv_in = Conv2d(3, channels, 3, bias=False)
+        blocks, ch_in = [], channels
+        for mult in channel_multipliers:
+            ch_out = channels * mult
+            for _ in range(num_res_blocks):
+                blocks.append(ResBlock(ch_in, ch_out))
+                ch_in = ch_out
+            blocks.append(Downsample())
+        self.blocks = nn.Sequential(*blocks)
+        self.final_residual = nn.Sequential(*[ResBlock(ch_in) for _ in range(num_res_blocks)])
+        self.norm = GroupNorm(32, ch_in, eps=1e-6)
+        self.conv_out = Conv2d(ch_in, embedding_dim, 1, bias=True)
+
+    def forward(self, x):
+        x = _to_internal(x, self.compute_dtype)
+        x = self.conv_in(x)
+        x = self.blocks(x)
+        x = self.final_residual(x)
+        x = self.norm(x, silu=True)
+        return self.conv_out(x, out_dtype=torch.float32)      # the quantizer always sees fp32 latents
+
+
+class Decoder(nn.Module):
+    def __init__(self, channels: int, num_res_blocks: int, channel_multipliers: tuple, embedding_dim: int):
+        super().__init__()
+        self.compute_dtype = torch.float32
+        ch_in = channels * channel_multipliers[-1]
+        self.conv_in = Conv2d(embedding_dim, ch_in, 3, bias=True)
+        self.initial_residual = nn.Sequential(*[ResBlock(ch_in) for _ in range(num_res_blocks)])
+        blocks = []
+        for i in reversed(range(len(channel_multipliers))):
+            ch_out = channels * channel_multipliers[i - 1] if i > 0 else channels
+            for _ in range(num_res_blocks):
+                blocks.append(ResBlock(ch_in, ch_out))
+                ch_in = ch_out
+            blocks.append(Upsample(ch_out))
+        self.blocks = nn.Sequential(*blocks)
+        self.norm = GroupNorm(32, channels, eps=1e-6)
+        self.conv_out = Conv2d(channels, 3, 3, bias=True)
+
+    def forward_padded(self, x):
+        """reconstruction with its zero pad channels ([N, 4 or 8, H, W], NHWC) -- what the fused loss reads"""
+        x = _to_internal(x, self.compute_dtype)
+        x = self.conv_in(x)
+        x = self.initial_residual(x)
+        x = self.blocks(x)
+        x = self.norm(x, silu=True)
+        return self.conv_out(x, act=1)                        # tanh in the epilogue
+
+    def forward(self, x):
+        return self.forward_padded(x)[:, :3]

@@ -1,0 +1,65 @@
+"""Quantizers on the vqk kernels; same classes / ctor signatures / return conventions as the reference's
+``vqvae/modules/vector_quantizers.py`` (VectorQuantizer :8-84, EMAVectorQuantizer :87-203).
+
+The nearest-codeword search is one exact-fp32 MFMA kernel that never materialises the [N,K] distance
+matrix or a one-hot; the reference's association order of the three distance terms is kept so that the
+indices are bit-exact.  The EMA statistics are all-reduced over the data-parallel
+ranks (a capability the reference lacks -- its ranks silently diverge)."""
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from .abstract_modules.base_quantizer import BaseVectorQuantizer
+
+
+def _flat_view(z: torch.Tensor):
+    b, d, h, w = z.shape
+    return z.permute(0, 2, 3, 1).reshape(b * h * w, d)
+
+
+class VectorQuantizer(BaseVectorQuantizer):
+    def __init__(self, num_embeddings: int, embedding_dim: int, commitment_cost: float = 0.25):
+        super().__init__(num_embeddings, embedding_dim)
+        self.commitment_cost = commitment_cost
+
+    def forward(self, x: torch.Tensor):
+        q, idx, loss, hist = ops.VQLookupFn.apply(x, self.codebook.weight, self.commitment_cost, True, 0,
+                                                  self.compute_dtype)
+        self.last_hist = hist
+        return q, idx, loss
+
+    @torch.no_grad()
+    def vec_to_codes(self, x: torch.Tensor) -> torch.Tensor:
+        z = ops.nhwc(x.to(torch.float32))
+        return ops.vq_assign(_flat_view(z), self.codebook.weight.detach().contiguous(), 0).view(x.shape[0], -1)
+
+
+class EMAVectorQuantizer(BaseVectorQuantizer):
+    def __init__(self, num_embeddings: int, embedding_dim: int, commitment_cost: float = 0.25, decay: float = 0.95,
+                 epsilon: float = 1e-5):
+        super().__init__(num_embeddings, embedding_dim)
+        self.commitment_cost = commitment_cost
+        self.codebook.requires_grad_(False)
+        self.register_buffer('ema_count', torch.zeros(num_embeddings))
+        self.register_buffer('ema_weight', torch.empty(num_embeddings, embedding_dim).uniform_(-1 / num_embeddings,
+                                                                                                1 / num_embeddings))
+        self.decay = decay
+        self.epsilon = epsilon
+
+    def forward(self, x: torch.Tensor):
+        q, idx, loss, hist = ops.VQLookupFn.apply(x, self.codebook.weight, self.commitment_cost, False, 0,
+                                                  self.compute_dtype)
+        self.last_hist = hist
+        if self.training:
+            with torch.no_grad():
+                world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+                reduce_fn = (lambda buf: dist.all_reduce(buf, op=dist.ReduceOp.SUM)) if world > 1 else None
+                z = ops.nhwc(x.detach().to(torch.float32))
+                ops.ema_update(_flat_view(z), idx.reshape(-1), self.ema_count, self.ema_weight, self.codebook.weight.data,
+                               self.decay, self.epsilon, float(x.shape[0] * world), reduce_fn)
+        return q, idx, loss
+
+    @torch.no_grad()
+    def vec_to_codes(self, x: torch.Tensor) -> torch.Tensor:
+        z = ops.nhwc(x.to(torch.float32))
+        return ops.vq_assign(_flat_view(z), self.codebook.weight.detach().contiguous(), 0).view(x.shape[0], -1)

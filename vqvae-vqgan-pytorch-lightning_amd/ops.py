@@ -1,0 +1,533 @@
+"""Host-side operators over the vqk C-ABI: thin launchers (``raw_*``) and the ``torch.autograd.Function``s
+built from them.  PyTorch is used for device memory, streams and the autograd *graph*; every
+arithmetic kernel on the path is a hand-written gfx950 kernel reached through ``libvqk.so``.
+
+Tensor convention: activations keep the reference's logical NCHW shape but are physically NHWC
+(``torch.channels_last``), conv weights keep logical OIHW and are physically [O][kh][kw][I].
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native
+
+F32, BF16 = 0, 1
+_CL = torch.channels_last
+
+
+def dcode(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f'vqk: unsupported dtype {dtype}')
+
+
+def epc(dtype: torch.dtype) -> int:
+    """elements per 16-byte chunk: channel counts handed to the conv kernels are multiples of this"""
+    return 4 if dtype == torch.float32 else 8
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError('vqk: operators run on the GPU only (HIP kernels, no CPU fallback); got a CPU tensor')
+
+
+_zero_pages = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    key = (device.type, device.index)
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(1024, dtype=torch.uint8, device=device)
+    return _zero_pages[key]
+
+
+def nhwc(x: torch.Tensor) -> torch.Tensor:
+    return x.contiguous(memory_format=_CL)
+
+
+def empty_nhwc(n, c, h, w, dtype, device) -> torch.Tensor:
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=_CL)
+
+
+# ------------------------------------------------------------------------------------------------------
+# raw launchers
+# ------------------------------------------------------------------------------------------------------
+def raw_conv_fprop(x, w_krsc, bias, residual, ksize: int, ups: bool, act: int, out_dtype) -> torch.Tensor:
+    """x [N,Cin,H,W] nhwc; w_krsc: tensor whose memory is [Cout][k][k][Cin] in x.dtype."""
+    _require_gpu(x)
+    n, cin, h, w = x.shape
+    cout = w_krsc.shape[0]
+    s = 2 if ups else 1
+    y = empty_nhwc(n, cout, h * s, w * s, out_dtype, x.device)
+    st = _native.lib().vqk_conv2d_fprop(dcode(x.dtype), x.data_ptr(), w_krsc.data_ptr(), _p(bias), _p(residual),
+                                        y.data_ptr(), dcode(out_dtype), n, h, w, cin, cout, ksize, int(ups), act,
+                                        zero_page(x.device).data_ptr(), _stream())
+    _native.check(st, 'conv2d_fprop')
+    return y
+
+
+def raw_pack_dgrad(w_krsc_f32, dtype, cout, cin, ksize) -> torch.Tensor:
+    wt = torch.empty(cin * ksize * ksize * cout, dtype=dtype, device=w_krsc_f32.device)
+    st = _native.lib().vqk_conv_pack_dgrad(w_krsc_f32.data_ptr(), wt.data_ptr(), dcode(dtype), cout, cin, ksize, _stream())
+    _native.check(st, 'conv_pack_dgrad')
+    return wt.view(cin, ksize, ksize, cout)
+
+
+def raw_conv_wgrad(x, dy, ksize: int, ups: bool) -> torch.Tensor:
+    """returns dw as an fp32 tensor with memory [Cout][k][k][Cin] (logical [Cout,Cin,k,k] channels_last)."""
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    dw = torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    st = _native.lib().vqk_conv2d_wgrad(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, cin, cout,
+                                        ksize, int(ups), zero_page(x.device).data_ptr(), _stream())
+    _native.check(st, 'conv2d_wgrad')
+    return dw
+
+
+def raw_colsum(x2d_rows: int, c: int, x) -> torch.Tensor:
+    out = torch.zeros(c, dtype=torch.float32, device=x.device)
+    _native.check(_native.lib().vqk_colsum(dcode(x.dtype), x.data_ptr(), x2d_rows, c, out.data_ptr(), _stream()), 'colsum')
+    return out
+
+
+def raw_cast(src_f32, dtype) -> torch.Tensor:
+    if dtype == torch.float32:
+        return src_f32
+    dst = torch.empty(src_f32.numel(), dtype=dtype, device=src_f32.device)
+    _native.check(_native.lib().vqk_cast(src_f32.data_ptr(), dst.data_ptr(), dcode(dtype), src_f32.numel(), _stream()), 'cast')
+    return dst
+
+
+def raw_gn_stats(x, groups: int, eps: float) -> torch.Tensor:
+    n, c, h, w = x.shape
+    acc = torch.zeros(n * groups * 2, dtype=torch.float64, device=x.device)
+    stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
+    st = _native.lib().vqk_gn_stats(dcode(x.dtype), x.data_ptr(), n, h * w, c, groups, eps, acc.data_ptr(),
+                                    stats.data_ptr(), _stream())
+    _native.check(st, 'gn_stats')
+    return stats
+
+
+def raw_gn_apply(x, stats, w, b, groups: int, silu: bool) -> torch.Tensor:
+    n, c, h, wd = x.shape
+    y = torch.empty_like(x, memory_format=_CL)
+    st = _native.lib().vqk_gn_apply(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                    y.data_ptr(), n, h * wd, c, groups, int(silu), _stream())
+    _native.check(st, 'gn_apply')
+    return y
+
+
+def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool):
+    n, c, h, wd = x.shape
+    dx = torch.empty_like(x, memory_format=_CL)
+    dw = torch.zeros(c, dtype=torch.float32, device=x.device)
+    db = torch.zeros(c, dtype=torch.float32, device=x.device)
+    red = torch.zeros(n * groups * 2, dtype=torch.float64, device=x.device)
+    st = _native.lib().vqk_gn_backward(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                       dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), red.data_ptr(), n,
+                                       h * wd, c, groups, int(silu), 0, _stream())
+    _native.check(st, 'gn_backward')
+    return dx, dw, db
+
+
+def raw_pool(x, scale: float) -> torch.Tensor:
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
+    _native.check(_native.lib().vqk_pool2x2(dcode(x.dtype), x.data_ptr(), y.data_ptr(), n, h, w, c, scale, _stream()), 'pool2x2')
+    return y
+
+
+def raw_unpool(x, scale: float) -> torch.Tensor:
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, h * 2, w * 2, x.dtype, x.device)
+    _native.check(_native.lib().vqk_unpool2x2(dcode(x.dtype), x.data_ptr(), y.data_ptr(), n, h, w, c, scale, _stream()), 'unpool2x2')
+    return y
+
+
+def raw_preprocess(images, dtype, want_target: bool):
+    """images [N,3,H,W] fp32 contiguous NCHW in [0,1] -> (x_pad [N,cpad,H,W] nhwc dtype, target fp32 or None)"""
+    _require_gpu(images)
+    n, c, h, w = images.shape
+    if c != 3 or images.dtype != torch.float32:
+        raise RuntimeError('vqk: preprocess expects fp32 images of shape [N,3,H,W]')
+    images = images.contiguous()
+    cp = epc(dtype)
+    xp = empty_nhwc(n, cp, h, w, dtype, images.device)
+    tgt = empty_nhwc(n, cp, h, w, torch.float32, images.device) if (want_target and dtype != torch.float32) else None
+    st = _native.lib().vqk_preprocess(images.data_ptr(), xp.data_ptr(), dcode(dtype), _p(tgt), n, h, w, cp, _stream())
+    _native.check(st, 'preprocess')
+    return xp, (xp if (want_target and tgt is None) else tgt)
+
+
+# ------------------------------------------------------------------------------------------------------
+# autograd functions
+# ------------------------------------------------------------------------------------------------------
+def _weight_mem(weight, cin_pad: int, cout_pad: int) -> torch.Tensor:
+    """1-D fp32 view/copy of a logical [O,I,k,k] weight in [O][k][k][I] memory order, zero-padded to
+    (cout_pad, cin_pad).  For a channels_last parameter with matching sizes this is a view."""
+    o, i, k, _ = weight.shape
+    w = weight.detach()
+    if cin_pad == i and cout_pad == o:
+        return w.permute(0, 2, 3, 1).reshape(-1)          # view for channels_last storage, copy otherwise
+    wp = torch.zeros((cout_pad, k, k, cin_pad), dtype=torch.float32, device=w.device)
+    wp[:o, :, :, :i] = w.permute(0, 2, 3, 1)
+    return wp.reshape(-1)
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = act(conv(x (nearest-upsampled x2 if ups), W) + bias + residual).
+
+    vqvae/modules/autoencoder.py:57-60,102-105,114,132,153,170.  Channel counts that are not a multiple
+    of the 16-byte chunk (the 3-channel image / reconstruction) are zero-padded: x may carry more
+    (zero) channels than the weight's I, and the output gets ``cout_pad`` channels, the extra ones
+    identically zero."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, ups: bool, act: int, out_dtype):
+        _require_gpu(x)
+        x = nhwc(x)
+        dt = x.dtype
+        out_dtype = out_dtype or dt
+        o, i, k, _ = weight.shape
+        cin = x.shape[1]
+        e = max(epc(dt), epc(out_dtype))
+        cout_pad = -(-o // e) * e
+        if cin < i or cin % epc(dt):
+            raise RuntimeError(f'vqk: conv input has {cin} channels, weight expects {i}')
+        wq = raw_cast(_weight_mem(weight, cin, cout_pad), dt)
+        b32 = None
+        if bias is not None:
+            b32 = bias.detach()
+            if cout_pad != o:
+                b32 = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
+                b32[:o] = bias.detach()
+        res = nhwc(residual) if residual is not None else None
+        y = raw_conv_fprop(x, wq.view(cout_pad, -1), b32, res, k, ups, act, out_dtype)
+        ctx.save_for_backward(x, weight, y if act == 1 else None)
+        ctx.cfg = (k, ups, act, o, i, cin, cout_pad, bias is not None, residual is not None, dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        k, ups, act, o, i, cin, cout_pad, has_bias, has_res, dt = ctx.cfg
+        dy = nhwc(dy)
+        if act == 1:
+            d2 = torch.empty_like(dy, memory_format=_CL)
+            _native.check(_native.lib().vqk_tanh_backward(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), d2.data_ptr(),
+                                                          dy.numel(), _stream()), 'tanh_backward')
+            dy = d2
+        dres = dy if has_res else None
+        dyc = dy if dy.dtype == dt else nhwc(dy.to(dt))      # fp32 head output in bf16 mode: dtype cast only
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = raw_pack_dgrad(_weight_mem(weight, cin, cout_pad), dt, cout_pad, cin, k)
+            dx = raw_conv_fprop(dyc, wt.view(cin, -1), None, None, k, False, 0, dt)
+            if ups:
+                dx = raw_pool(dx, 1.0)
+        if ctx.needs_input_grad[1]:
+            dw = raw_conv_wgrad(x, dyc, k, ups)
+            if cin != i or cout_pad != o:
+                dw = dw[:o, :i]
+        if has_bias and ctx.needs_input_grad[2]:
+            n, c, h, w = dyc.shape
+            db = raw_colsum(n * h * w, c, dyc)[:o]
+        return dx, dw, db, dres, None, None, None
+
+
+def conv2d(x, weight, bias=None, residual=None, ups: bool = False, act: int = 0, out_dtype=None):
+    return Conv2dFn.apply(x, weight, bias, residual, ups, act, out_dtype)
+
+
+class GroupNormSiLUFn(torch.autograd.Function):
+    """y = [silu](GroupNorm(x)) with the reference's unbiased variance (autoencoder.py:25-39)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups: int, eps: float, silu: bool):
+        _require_gpu(x)
+        x = nhwc(x)
+        w = weight.detach().reshape(-1).contiguous()
+        b = bias.detach().reshape(-1).contiguous()
+        stats = raw_gn_stats(x, groups, eps)
+        y = raw_gn_apply(x, stats, w, b, groups, silu)
+        ctx.save_for_backward(x, stats, w, b)
+        ctx.cfg = (groups, silu, weight.shape, bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, w, b = ctx.saved_tensors
+        groups, silu, wshape, bshape = ctx.cfg
+        dx, dw, db = raw_gn_backward(x, stats, w, b, nhwc(dy), groups, silu)
+        return dx, dw.view(wshape), db.view(bshape), None, None, None
+
+
+def group_norm_silu(x, weight, bias, groups: int = 32, eps: float = 1e-6, silu: bool = True):
+    return GroupNormSiLUFn.apply(x, weight, bias, groups, eps, silu)
+
+
+class AvgPool2x2Fn(torch.autograd.Function):
+    """autoencoder.py:89-91"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        return raw_pool(nhwc(x), 0.25)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return raw_unpool(nhwc(dy), 0.25)
+
+
+def avg_pool2x2(x):
+    return AvgPool2x2Fn.apply(x)
+
+
+def mse_loss(recon, target, true_channels: int | None = None):
+    """mean((recon - target)^2)  (vqvae/model.py:137,272); target carries no gradient.
+    ``true_channels``: logical channel count when both tensors carry zero-padded channels (the mean is
+    taken over the un-padded element count)."""
+    n, c, h, w = recon.shape
+    return _MSE.apply(recon, target, float(n * (true_channels or c) * h * w))
+
+
+class _MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, recon, target, denom: float):
+        _require_gpu(recon)
+        recon = nhwc(recon)
+        target = nhwc(target.to(torch.float32))
+        if recon.shape != target.shape:
+            raise RuntimeError(f'vqk: mse shapes differ {tuple(recon.shape)} vs {tuple(target.shape)}')
+        sse = torch.zeros((), dtype=torch.float32, device=recon.device)
+        _native.check(_native.lib().vqk_sse(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(), recon.numel(),
+                                            sse.data_ptr(), _stream()), 'sse')
+        ctx.save_for_backward(recon, target)
+        ctx.denom = denom
+        return sse / denom
+
+    @staticmethod
+    def backward(ctx, dloss):
+        recon, target = ctx.saved_tensors
+        d = torch.empty_like(recon, memory_format=_CL)
+        gs = dloss.to(torch.float32).contiguous()
+        _native.check(_native.lib().vqk_mse_tanh_backward(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(),
+                                                          recon.numel(), 1.0 / ctx.denom, gs.data_ptr(), 0,
+                                                          d.data_ptr(), _stream()), 'mse_backward')
+        return d, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# vector quantizer
+# ------------------------------------------------------------------------------------------------------
+def vq_assign(flat_z: torch.Tensor, codebook: torch.Tensor, assoc: int) -> torch.Tensor:
+    """flat_z [N,D] fp32, codebook [K,D] fp32 -> idx [N] int64 (bit-exact vs oracle/vq_oracle.c)."""
+    _require_gpu(flat_z)
+    n, d = flat_z.shape
+    k = codebook.shape[0]
+    lib = _native.lib()
+    z2 = torch.empty(n, dtype=torch.float32, device=flat_z.device)
+    e2 = torch.empty(k, dtype=torch.float32, device=flat_z.device)
+    idx = torch.empty(n, dtype=torch.int64, device=flat_z.device)
+    s = _stream()
+    _native.check(lib.vqk_row_sqnorm_f32(flat_z.data_ptr(), n, d, z2.data_ptr(), s), 'row_sqnorm(z)')
+    _native.check(lib.vqk_row_sqnorm_f32(codebook.data_ptr(), k, d, e2.data_ptr(), s), 'row_sqnorm(e)')
+    _native.check(lib.vqk_vq_assign_f32(flat_z.data_ptr(), codebook.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d,
+                                        assoc, idx.data_ptr(), s), 'vq_assign')
+    return idx
+
+
+class VQLookupFn(torch.autograd.Function):
+    """Nearest-codeword lookup with straight-through gradient and the (q-z)^2 losses.
+
+    Standard (vector_quantizers.py:23-61): loss = mse(q, z.detach()) + beta * mse(q.detach(), z), grads to z and E.
+    EMA      (vector_quantizers.py:128-180): loss = beta * mse(q.detach(), z), codebook has no grad.
+    Returns (q [B,D,H,W] in out_dtype, idx [B, H*W] int64, loss 0-dim fp32, hist int32 [K])."""
+
+    @staticmethod
+    def forward(ctx, z, codebook, beta: float, codebook_loss: bool, assoc: int, out_dtype):
+        _require_gpu(z)
+        z = nhwc(z.to(torch.float32))
+        b, d, h, w = z.shape
+        n = b * h * w
+        # EMA rewrites the codebook in place right after the lookup: backward must see the pre-update rows
+        cb = codebook.detach().contiguous() if codebook_loss else codebook.detach().clone()
+        k = cb.shape[0]
+        flat = z.permute(0, 2, 3, 1).reshape(n, d)           # a view: NHWC memory is already [N][D]
+        idx = vq_assign(flat, cb, assoc)
+        q32 = empty_nhwc(b, d, h, w, torch.float32, z.device)
+        qlo = empty_nhwc(b, d, h, w, torch.bfloat16, z.device) if out_dtype == torch.bfloat16 else None
+        sse = torch.zeros((), dtype=torch.float32, device=z.device)
+        hist = torch.zeros(k, dtype=torch.int32, device=z.device)
+        _native.check(_native.lib().vqk_vq_gather_f32(flat.data_ptr(), cb.data_ptr(), idx.data_ptr(), n, k, d,
+                                                      q32.data_ptr(), _p(qlo), sse.data_ptr(), hist.data_ptr(),
+                                                      _stream()), 'vq_gather')
+        mse = sse / float(n * d)
+        loss = (mse + beta * mse) if codebook_loss else beta * mse
+        ctx.save_for_backward(z, cb, idx)
+        ctx.cfg = (beta, codebook_loss, n, k, d)
+        ctx.mark_non_differentiable(idx, hist)
+        q = qlo if qlo is not None else q32
+        return q, idx.view(b, h * w), loss, hist
+
+    @staticmethod
+    def backward(ctx, dq, _didx, dloss, _dhist):
+        z, cb, idx = ctx.saved_tensors
+        beta, codebook_loss, n, k, d = ctx.cfg
+        dz = torch.empty_like(z, memory_format=_CL)
+        de = torch.zeros_like(cb) if (codebook_loss and ctx.needs_input_grad[1]) else None
+        gs = dloss.to(torch.float32).contiguous() if dloss is not None else None
+        dqc = nhwc(dq) if dq is not None else None
+        scale = 2.0 / float(n * d)
+        _native.check(_native.lib().vqk_vq_backward_f32(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), _p(dqc),
+                                                        dcode(dqc.dtype) if dqc is not None else F32, n, k, d,
+                                                        beta * scale if gs is not None else 0.0,
+                                                        scale if gs is not None else 0.0, _p(gs), dz.data_ptr(),
+                                                        _p(de), _stream()), 'vq_backward')
+        return dz, de, None, None, None, None
+
+
+def ema_update(flat_z, idx, ema_count, ema_weight, codebook, decay: float, eps: float, batch: float, reduce_fn=None):
+    """EMA statistics + update in place (vector_quantizers.py:159-169).  ``reduce_fn(buf)`` sums the
+    packed [counts | dw] buffer over ranks (one small all-reduce)."""
+    n, d = flat_z.shape
+    k = codebook.shape[0]
+    buf = torch.zeros(k + k * d, dtype=torch.float32, device=flat_z.device)
+    counts, dw = buf[:k], buf[k:]
+    lib = _native.lib()
+    _native.check(lib.vqk_ema_stats_f32(flat_z.data_ptr(), idx.data_ptr(), n, k, d, counts.data_ptr(), dw.data_ptr(),
+                                        _stream()), 'ema_stats')
+    if reduce_fn is not None:
+        reduce_fn(buf)
+    _native.check(lib.vqk_ema_update_f32(ema_count.data_ptr(), ema_weight.data_ptr(), codebook.data_ptr(),
+                                         counts.data_ptr(), dw.data_ptr(), k, d, decay, eps, batch, _stream()), 'ema_update')
+
+
+# ------------------------------------------------------------------------------------------------------
+# StyleGAN2 plugin ops (same call surface as the reference's python wrappers)
+# ------------------------------------------------------------------------------------------------------
+_ACT_IDX = {'linear': 1, 'lrelu': 3}
+
+
+def _bias_act_raw(x, b, yref, dy, grad, dim, act, alpha, gain, clamp):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    inner = 1
+    for s in x.shape[dim + 1:]:
+        inner *= s
+    st = _native.lib().vqk_bias_act(x.data_ptr(), _p(b), 0, _p(yref), _p(dy), y.data_ptr(), x.numel(), inner,
+                                    x.shape[dim] if b is not None else 1, grad, _ACT_IDX[act], alpha, gain, clamp,
+                                    _stream())
+    _native.check(st, 'bias_act')
+    return y
+
+
+class BiasActFn(torch.autograd.Function):
+    """bias_act.py:129-210 (lrelu / linear, first-order; second order re-applies the same mask)."""
+
+    @staticmethod
+    def forward(ctx, x, b, dim, act, alpha, gain, clamp):
+        _require_gpu(x)
+        y = _bias_act_raw(x, b, None, None, 0, dim, act, alpha, gain, clamp)
+        ctx.save_for_backward(y)
+        ctx.cfg = (dim, act, alpha, gain, clamp, b is not None, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dim, act, alpha, gain, clamp, has_b, shape = ctx.cfg
+        dx = BiasActGradFn.apply(dy.contiguous(), y, dim, act, alpha, gain, clamp)
+        db = None
+        if has_b:
+            db = dx.sum([i for i in range(dx.ndim) if i != dim])
+        return dx, db, None, None, None, None, None
+
+
+class BiasActGradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, y, dim, act, alpha, gain, clamp):
+        dx = _bias_act_raw(dy, None, y, None, 1, dim, act, alpha, gain, clamp) if act != 'linear' or gain != 1 or clamp >= 0 \
+            else dy
+        ctx.save_for_backward(y)
+        ctx.cfg = (dim, act, alpha, gain, clamp)
+        return dx
+
+    @staticmethod
+    def backward(ctx, d_dx):
+        (y,) = ctx.saved_tensors
+        dim, act, alpha, gain, clamp = ctx.cfg
+        return BiasActGradFn.apply(d_dx.contiguous(), y, dim, act, alpha, gain, clamp), None, None, None, None, None, None
+
+
+def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None):
+    """Same signature and defaults as the reference's ``bias_act`` (bias_act.py:55-89)."""
+    defaults = {'linear': (0.0, 1.0), 'lrelu': (0.2, 2.0 ** 0.5)}
+    if act not in defaults:
+        raise RuntimeError(f'vqk: bias_act activation {act!r} is not on the discriminator path')
+    alpha = float(defaults[act][0] if alpha is None else alpha)
+    gain = float(defaults[act][1] if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    return BiasActFn.apply(x, b, dim, act, alpha, gain, clamp)
+
+
+def _upfirdn2d_raw(x, f, up, down, pad, flip, gain):
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    fh, fw = f.shape
+    upx, upy = up
+    downx, downy = down
+    px0, px1, py0, py1 = pad
+    ow = (w * upx + px0 + px1 - fw + downx) // downx
+    oh = (h * upy + py0 + py1 - fh + downy) // downy
+    y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
+    st = _native.lib().vqk_upfirdn2d(x.data_ptr(), f.contiguous().data_ptr(), y.data_ptr(), n, c, h, w, fh, fw, upx, upy,
+                                     downx, downy, px0, px1, py0, py1, int(flip), gain, oh, ow, _stream())
+    _native.check(st, 'upfirdn2d')
+    return y
+
+
+class Upfirdn2dFn(torch.autograd.Function):
+    """upfirdn2d.py:214-268: linear op, backward = the same op with up<->down, flipped filter."""
+
+    @staticmethod
+    def forward(ctx, x, f, up, down, pad, flip, gain):
+        _require_gpu(x)
+        ctx.save_for_backward(f)
+        ctx.cfg = (up, down, pad, flip, gain, x.shape)
+        return _upfirdn2d_raw(x, f, up, down, pad, flip, gain)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (f,) = ctx.saved_tensors
+        up, down, pad, flip, gain, xs = ctx.cfg
+        fh, fw = f.shape
+        _, _, ih, iw = xs
+        _, _, oh, ow = dy.shape
+        p = (fw - pad[0] - 1, iw * up[0] - ow * down[0] + pad[0] - up[0] + 1,
+             fh - pad[2] - 1, ih * up[1] - oh * down[1] + pad[2] - up[1] + 1)
+        return Upfirdn2dFn.apply(dy, f, down, up, p, not flip, gain), None, None, None, None, None, None
+
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
+    """Same signature as the reference's ``upfirdn2d`` (upfirdn2d.py:120-164); 2-D filters only."""
+    up = (up, up) if isinstance(up, int) else tuple(up)
+    down = (down, down) if isinstance(down, int) else tuple(down)
+    if isinstance(padding, int):
+        padding = (padding,) * 4
+    padding = tuple(padding)
+    if len(padding) == 2:
+        padding = (padding[0], padding[0], padding[1], padding[1])
+    if f.ndim != 2:
+        raise RuntimeError('vqk: upfirdn2d expects a 2-D FIR filter')
+    return Upfirdn2dFn.apply(x, f.to(torch.float32), up, down, padding, bool(flip_filter), float(gain))

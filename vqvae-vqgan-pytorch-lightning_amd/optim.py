@@ -1,0 +1,108 @@
+"""Flat-arena AdamW: every trainable tensor is a view into ONE fp32 parameter buffer, ONE gradient buffer
+and ONE second-moment buffer, updated by a single HIP launch (``vqk_adamw``) and all-reduced with a single
+collective.  Semantics = ``torch.optim.AdamW`` as the reference configures it (vqvae/model.py:419-428:
+two groups, weight decay only on conv weights; betas (0, 0.99) => the first moment is the gradient itself
+and is not stored)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _native
+
+_ALIGN = 64   # elements; keeps every tensor (fp32 and its bf16 shadow) 16-byte aligned inside the arena
+
+
+def _is_channels_last_param(p: torch.Tensor) -> bool:
+    return p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        plist = [(p, g['weight_decay']) for g in self.param_groups for p in g['params']]
+        if not plist:
+            raise ValueError('FlatAdamW got no parameters')
+        dev = plist[0][0].device
+        offs, total = [], 0
+        for p, _ in plist:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError('FlatAdamW needs fp32 parameters on one device')
+            offs.append(total)
+            total += -(-p.numel() // _ALIGN) * _ALIGN
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        b1 = self.defaults['betas'][0]
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev) if b1 != 0.0 else None
+        seg_end, seg_wd = [], []
+        with torch.no_grad():
+            for (p, wd), off in zip(plist, offs):
+                n = p.numel()
+                for buf, is_grad in ((self.flat_p, False), (self.flat_g, True)):
+                    seg = buf[off:off + n]
+                    if _is_channels_last_param(p):
+                        o, i, kh, kw = p.shape
+                        view = seg.view(o, kh, kw, i).permute(0, 3, 1, 2)
+                    else:
+                        view = seg.view(p.shape)
+                    if is_grad:
+                        p.grad = view
+                    else:
+                        view.copy_(p.data)
+                        p.data = view
+                seg_end.append(off + n)
+                seg_wd.append(float(wd))
+                pad_end = off + -(-n // _ALIGN) * _ALIGN
+                if pad_end != off + n:
+                    seg_end.append(pad_end)
+                    seg_wd.append(0.0)
+        self.seg_end = torch.tensor(seg_end, dtype=torch.int64, device=dev)
+        self.seg_wd = torch.tensor(seg_wd, dtype=torch.float32, device=dev)
+        self.offsets = {id(p): off for (p, _), off in zip(plist, offs)}
+        self.step_count = 0
+        self.grad_scale = 1.0
+        self.shadow = None                    # optional bf16 copy of flat_p refreshed by step()
+        self.generation = 0                   # bumped by every step(): cache key for packed weights
+
+    def enable_bf16_shadow(self):
+        if self.shadow is None:
+            self.shadow = self.flat_p.to(torch.bfloat16)
+        return self.shadow
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_g.zero_()
+
+    def all_reduce_grads(self, world_size: int | None = None):
+        """ONE collective per optimizer step (replaces DDP's bucketed reducer, vqvae/train.py:128)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+            self.grad_scale = 1.0 / dist.get_world_size()
+        else:
+            self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lrs = {g['lr'] for g in self.param_groups}
+        if len(lrs) != 1:
+            raise RuntimeError('FlatAdamW: all param groups must share one learning rate (as the reference sets them)')
+        g0 = self.param_groups[0]
+        b1, b2 = g0['betas']
+        self.step_count += 1
+        if not self.flat_p.is_cuda:
+            raise RuntimeError('vqk: FlatAdamW.step runs on the GPU only (HIP kernel, no CPU fallback)')
+        st = _native.lib().vqk_adamw(self.flat_p.data_ptr(), self.flat_g.data_ptr(),
+                                     0 if self.flat_m is None else self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                     self.flat_p.numel(), self.seg_end.data_ptr(), self.seg_wd.data_ptr(),
+                                     self.seg_end.numel(), float(g0['lr']), float(b1), float(b2), float(g0['eps']),
+                                     self.step_count, float(self.grad_scale),
+                                     0 if self.shadow is None else self.shadow.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+        _native.check(st, 'adamw')
+        self.generation += 1
+        return loss

@@ -1,0 +1,72 @@
+"""``MiniTrainer``: the slice of ``pytorch_lightning.Trainer`` the reference's train loop relies on
+(vqvae/train.py:128-142 + the hook order of SURVEY 3.2), one process per GPU, data parallel by batch.
+
+Where Lightning wraps the model in DDP (bucketed NCCL all-reduce during backward + a buffer broadcast),
+this trainer issues ONE RCCL all-reduce of the flat gradient arena per optimizer step
+(:meth:`FlatAdamW.all_reduce_grads`); the EMA quantizer all-reduces its own statistics."""
+from __future__ import annotations
+
+import os
+from typing import Iterable
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
+    """(rank, local_rank, world) from the torchrun environment; no-op for a single process."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class MiniTrainer:
+    def __init__(self, max_epochs: int = 1, num_training_batches: int | None = None):
+        self.max_epochs = max_epochs
+        self.num_training_batches = num_training_batches
+        self.optimizers = []
+        self.global_step = 0
+
+    def attach(self, model):
+        model.trainer = self
+        opt = model.configure_optimizers()
+        self.optimizers = list(opt[0]) if isinstance(opt, tuple) else [opt]
+        return self.optimizers
+
+    def train_batch(self, model, batch, batch_index: int):
+        """hook order of one Lightning iteration with automatic optimisation"""
+        opt = self.optimizers[0]
+        model.on_train_batch_start(batch, batch_index)
+        opt.zero_grad()
+        loss = model.training_step(batch, batch_index)
+        loss.backward()
+        opt.all_reduce_grads()
+        opt.step()
+        self.global_step += 1
+        return loss
+
+    def fit(self, model, batches: Iterable):
+        batches = list(batches)
+        if self.num_training_batches is None:
+            self.num_training_batches = len(batches)
+        if not self.optimizers:
+            self.attach(model)
+        model.train()
+        model.on_train_start()
+        loss = None
+        for epoch in range(self.max_epochs):
+            model.current_epoch = epoch
+            for i, batch in enumerate(batches):
+                loss = self.train_batch(model, batch, i)
+            model.on_train_epoch_end()
+        model.on_train_end()
+        return loss
