@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Headline benchmark: VQ-VAE train step (BASELINE.json configs[1]: standard K=1024, 256x256, bs=32/GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = preprocess -> encoder -> quantizer -> decoder -> MSE -> backward -> one flat-gradient all-reduce
+-> AdamW, on a synthetic U(0,1) batch that is resident in HBM before the timed region.  Rank 0 prints ONE
+JSON line.  `roofline` is for the dominant kernel (the implicit-GEMM conv): algorithmic FLOPs of its launches
+(2*M*Cout*Cin*k*k each) over their HIP-event durations, recorded on the launch stream inside the timed region.
+`cpu_baseline` times the CPU oracle (oracle/vqvae_oracle.py, a PyTorch-CPU restatement: kind "port") on a
+bounded sample of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+AE_CONF = dict(channels=128, num_res_blocks=2, channel_multipliers=(1, 2, 2, 4))
+T_CONF = dict(lr=1e-4, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
+
+
+def q_conf(qtype: str, k: int):
+    params = {'standard': dict(commitment_cost=0.25),
+              'ema': dict(commitment_cost=0.25, decay=0.95, epsilon=1e-5)}[qtype]
+    return dict(num_embeddings=k, embedding_dim=256, reinit_every_n_epochs=None, type=qtype, params=params)
+
+
+def cpu_baseline(image_size: int, batch: int, steps: int):
+    """CPU oracle train step (fwd + bwd + AdamW), fp32, all host cores."""
+    from oracle import vqvae_oracle as O
+    model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
+    torch.manual_seed(1234)
+    m = model_mod.VQVAE(image_size, AE_CONF, q_conf('standard', 1024), None, T_CONF)     # CPU tensors: init only
+    params = {k: v.detach().clone().contiguous() for k, v in m.state_dict().items()}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:                                       # honour a cgroup CPU quota (containers often expose every host CPU)
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cores = min(cores, 64)                     # torch-CPU conv stops scaling (and starts thrashing) well before that
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1234)
+    images = torch.rand(batch, 3, image_size, image_size, generator=g)
+    decay, _ = O.decay_split(list(params))
+    v = {k: torch.zeros_like(p) for k, p in params.items()}
+    times = []
+    budget_t0 = time.perf_counter()
+    for s in range(steps + 1):
+        if s >= 2 and time.perf_counter() - budget_t0 > 40.0:      # keep the default run within minutes
+            steps = s - 1
+            break
+        t0 = time.perf_counter()
+        r = O.train_step_mse(images, params, 2, 4, 'standard', dict(commitment_cost=0.25))
+        for k_, gr in r['grads'].items():
+            params[k_], _, v[k_] = O.adamw_step(params[k_], gr, v[k_], s + 1, 1e-4, 0.0, 0.99, 1e-8,
+                                                1e-4 if k_ in decay else 0.0)
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / steps
+    return dict(value=round(batch / t, 4), unit='images/sec', cores=cores, kind='port',
+                sample=f'{steps} timed steps (+1 warm-up) of the same train step at batch {batch}, fp32, '
+                       f'torch-CPU oracle on {cores} threads; {t:.2f} s/step')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--image-size', type=int, default=256)
+    ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
+    ap.add_argument('--quantizer', choices=['standard', 'ema'], default='standard')
+    ap.add_argument('--codebook', type=int, default=1024)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--no-kernel-events', action='store_true')
+    args = ap.parse_args()
+
+    trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
+    model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
+    ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+    rank, local, world = trainer_mod.init_distributed('nccl')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the train step is HIP kernels only (no CPU fallback)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+
+    torch.manual_seed(1234)                                   # identical replicas on every rank
+    model = model_mod.VQVAE(args.image_size, AE_CONF, q_conf(args.quantizer, args.codebook), None, T_CONF,
+                            compute_dtype=dtype).to(device)
+    model.train()
+    trainer = trainer_mod.MiniTrainer(num_training_batches=args.steps + args.warmup)
+    trainer.attach(model)
+    model.on_train_start()
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = torch.rand(args.batch, 3, args.image_size, args.image_size, generator=g).to(device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.train_batch(model, images, i)
+    barrier()
+    if not args.no_kernel_events:
+        ops.KERNEL_EVENTS = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.train_batch(model, images, args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    roofline = None
+    if events:
+        by_kernel = {}
+        for name, flops, e0, e1 in events:
+            rec = by_kernel.setdefault(name, [0, 0.0, 0.0])
+            rec[0] += 1
+            rec[1] += flops
+            rec[2] += e0.elapsed_time(e1) * 1e-3
+        name, (count, flops, secs) = max(by_kernel.items(), key=lambda kv: kv[1][2])
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        achieved = flops / secs / 1e12
+        roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
+                        frac=round(achieved / peak, 4), traffic=None, kernel=name,
+                        launches_per_step=count // args.steps, avg_launch_us=round(secs / count * 1e6, 2),
+                        avg_gflop_per_launch=round(flops / count / 1e9, 3),
+                        kernel_time_frac_of_step=round(secs / elapsed, 3),
+                        all_kernels={k: dict(launches=v[0] // args.steps, ms_per_step=round(v[2] / args.steps * 1e3, 3),
+                                             tflops=round(v[1] / v[2] / 1e12, 1)) for k, v in by_kernel.items()})
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.image_size, args.cpu_batch, args.cpu_steps)
+        value = world * args.batch * args.steps / elapsed
+        out = dict(metric='images/sec/node (256x256 bs=32/GPU) VQ-VAE train step', value=round(value, 2),
+                   unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
+                   vs_baseline=None, dtype=args.dtype, data='synthetic',
+                   config=dict(workload=f'{args.quantizer}_vqvae cb={args.codebook}, {args.image_size}x'
+                                        f'{args.image_size} bs={args.batch}/GPU (encoder+VQ+decoder fwd/bwd + AdamW)',
+                               global_batch=world * args.batch, parallelism=f'dp{world}',
+                               final_loss=round(float(loss.item()), 6)),
+                   roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -62,6 +62,20 @@ def empty_nhwc(n, c, h, w, dtype, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------------
 # raw launchers
 # ------------------------------------------------------------------------------------------------------
+KERNEL_EVENTS = None      # bench.py sets this to a list: (kernel name, algorithmic FLOPs, start event, stop event)
+
+
+def _timed(name: str, flops: float, launch):
+    if KERNEL_EVENTS is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    st = launch()
+    e1.record()
+    KERNEL_EVENTS.append((name, flops, e0, e1))
+    return st
+
+
 def raw_conv_fprop(x, w_krsc, bias, residual, ksize: int, ups: bool, act: int, out_dtype) -> torch.Tensor:
     """x [N,Cin,H,W] nhwc; w_krsc: tensor whose memory is [Cout][k][k][Cin] in x.dtype."""
     _require_gpu(x)
@@ -69,9 +83,12 @@ def raw_conv_fprop(x, w_krsc, bias, residual, ksize: int, ups: bool, act: int, o
     cout = w_krsc.shape[0]
     s = 2 if ups else 1
     y = empty_nhwc(n, cout, h * s, w * s, out_dtype, x.device)
-    st = _native.lib().vqk_conv2d_fprop(dcode(x.dtype), x.data_ptr(), w_krsc.data_ptr(), _p(bias), _p(residual),
-                                        y.data_ptr(), dcode(out_dtype), n, h, w, cin, cout, ksize, int(ups), act,
-                                        zero_page(x.device).data_ptr(), _stream())
+    flops = 2.0 * n * h * s * w * s * cout * cin * ksize * ksize
+    st = _timed(f'conv_fprop_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
+                lambda: _native.lib().vqk_conv2d_fprop(dcode(x.dtype), x.data_ptr(), w_krsc.data_ptr(), _p(bias),
+                                                       _p(residual), y.data_ptr(), dcode(out_dtype), n, h, w, cin,
+                                                       cout, ksize, int(ups), act, zero_page(x.device).data_ptr(),
+                                                       _stream()))
     _native.check(st, 'conv2d_fprop')
     return y
 
@@ -88,8 +105,11 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool) -> torch.Tensor:
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     dw = torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
-    st = _native.lib().vqk_conv2d_wgrad(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, cin, cout,
-                                        ksize, int(ups), zero_page(x.device).data_ptr(), _stream())
+    flops = 2.0 * n * dy.shape[2] * dy.shape[3] * cout * cin * ksize * ksize
+    st = _timed(f'conv_wgrad_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
+                lambda: _native.lib().vqk_conv2d_wgrad(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h,
+                                                       w, cin, cout, ksize, int(ups),
+                                                       zero_page(x.device).data_ptr(), _stream()))
     _native.check(st, 'conv2d_wgrad')
     return dw
 

@@ -38,6 +38,8 @@ class MiniTrainer:
 
     def attach(self, model):
         model.trainer = self
+        if self.num_training_batches is None:
+            self.num_training_batches = 1
         opt = model.configure_optimizers()
         self.optimizers = list(opt[0]) if isinstance(opt, tuple) else [opt]
         return self.optimizers
