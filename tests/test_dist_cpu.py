@@ -1,0 +1,94 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel logic: the flat-gradient all-reduce equals the big-batch
+gradient, and the EMA statistics all-reduce is the single-process EMA on the concatenated batch."""
+import importlib
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import vqvae_oracle as O
+
+PKG = 'vqvae-vqgan-pytorch-lightning_amd'
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+
+def _flat_allreduce_worker(rank, world, port, out):
+    _init(rank, world, port)
+    optim = importlib.import_module(PKG + '.optim')
+    torch.manual_seed(0)
+    conv = torch.nn.Parameter(torch.randn(8, 4, 3, 3).contiguous(memory_format=torch.channels_last))
+    bias = torch.nn.Parameter(torch.randn(8))
+    opt = optim.FlatAdamW([{'params': [conv], 'weight_decay': 1e-4}, {'params': [bias], 'weight_decay': 0.0}],
+                          lr=1e-3, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4)
+    assert conv.data_ptr() == opt.flat_p.data_ptr() and conv.grad.data_ptr() == opt.flat_g.data_ptr()
+    assert conv.is_contiguous(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(100)
+    x_all = torch.randn(4, 4, 6, 6, generator=g)
+    x = x_all[rank * 2:(rank + 1) * 2]
+    opt.zero_grad()
+    loss = (torch.nn.functional.conv2d(x, conv, bias, padding=1) ** 2).mean()      # per-rank mean over its half
+    loss.backward()
+    opt.all_reduce_grads()
+    mean_grad = opt.flat_g * opt.grad_scale
+    if rank == 0:
+        c2, b2 = conv.detach().clone().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+        ref = (torch.nn.functional.conv2d(x_all, c2, b2, padding=1) ** 2).mean()
+        gc, gb = torch.autograd.grad(ref, [c2, b2])
+        off_b = opt.offsets[id(bias)]
+        torch.testing.assert_close(mean_grad[:conv.numel()].view(8, 3, 3, 4).permute(0, 3, 1, 2), gc, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(mean_grad[off_b:off_b + 8], gb, rtol=1e-5, atol=1e-6)
+        out.put('ok')
+    dist.destroy_process_group()
+
+
+def _ema_worker(rank, world, port, out):
+    _init(rank, world, port)
+    g = torch.Generator().manual_seed(7)
+    k, d, b = 16, 8, 4
+    z_all = torch.randn(world * b, d, 4, 4, generator=g)
+    cb = torch.randn(k, d, generator=g) * 0.5
+    cnt, w = torch.zeros(k), torch.randn(k, d, generator=g) * 0.1
+    z = z_all[rank * b:(rank + 1) * b]
+    fz = O._flat(z)
+    idx = torch.argmin(O.distances_std(fz, cb), dim=1)
+    # what every rank contributes: packed [counts | dw], summed by ONE all-reduce (ops.ema_update's reduce_fn)
+    buf = torch.zeros(k + k * d)
+    buf[:k] = torch.bincount(idx, minlength=k).float()
+    buf[k:] = torch.zeros(k, d).index_add_(0, idx, fz).reshape(-1)
+    dist.all_reduce(buf)
+    n_k, dw = buf[:k], buf[k:].view(k, d)
+    c = cnt * 0.95 + 0.05 * n_k
+    new_cnt = (c + 1e-5) / (world * b + k * 1e-5) * (world * b)       # smoothing constant = GLOBAL batch
+    new_w = w * 0.95 + 0.05 * dw
+    if rank == 0:
+        _, _, _, rc, rw, rcb = O.vq_ema(z_all, cb, cnt, w, 0.25, 0.95, 1e-5)   # single process, concatenated batch
+        torch.testing.assert_close(new_cnt, rc, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(new_w, rw, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(new_w / new_cnt[:, None], rcb, rtol=1e-5, atol=1e-6)
+        out.put('ok')
+    dist.destroy_process_group()
+
+
+def _run(worker, port):
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get() == 'ok'
+
+
+def test_flat_gradient_allreduce_equals_big_batch():
+    _run(_flat_allreduce_worker, 29611)
+
+
+def test_ema_statistics_allreduce_equals_single_process():
+    _run(_ema_worker, 29612)

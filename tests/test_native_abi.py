@@ -1,0 +1,55 @@
+"""CPU-side checks of the native boundary: the C-ABI library loads and exports every symbol include/vqk.h
+declares (no compute calls without a GPU), and the product package never imports the oracle."""
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = 'vqvae-vqgan-pytorch-lightning_amd'
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'vqk.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(vqk_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    native = importlib.import_module(PKG + '._native')
+    native.build()
+    lib = native.lib()
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(native.EXPORTS) == syms                  # ctypes prototypes cover the whole header
+    assert lib.vqk_arch() == b'gfx950'
+    assert lib.vqk_status_str(0) == b'ok' and lib.vqk_status_str(-1) != b'ok'
+
+
+def test_argument_validation_without_gpu():
+    """shape / pointer validation happens before any launch, so it is testable on the CPU box"""
+    lib = importlib.import_module(PKG + '._native').lib()
+    assert lib.vqk_vq_assign_f32(0, 0, 0, 0, 16, 8, 16, 0, 0, 0) == -5           # NULL pointers
+    assert lib.vqk_conv2d_fprop(0, 16, 16, 0, 0, 16, 0, 1, 4, 4, 3, 8, 3, 0, 0, 16, 0) == -1   # Cin % 4
+    assert lib.vqk_conv2d_fprop(7, 16, 16, 0, 0, 16, 0, 1, 4, 4, 4, 8, 3, 0, 0, 16, 0) == -2   # dtype
+    assert lib.vqk_gn_stats(0, 16, 1, 16, 30, 32, 1e-6, 16, 16, 0) == -1                          # C % groups
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    ops = importlib.import_module(PKG + '.ops')
+    with pytest.raises(RuntimeError, match='GPU only'):
+        ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 3, 3))
+    with pytest.raises(RuntimeError, match='GPU only'):
+        ops.vq_assign(torch.zeros(8, 8), torch.zeros(4, 8), 0)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, PKG)):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
