@@ -86,6 +86,8 @@ int vqk_ema_update_f32(float* ema_count, float* ema_weight, float* codebook, con
 int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                      int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int act,
                      const void* zeros, void* stream);
+/* test / tuning hook for the fprop kernel choice: -1 automatic, 0 im2col kernel only, 1 prefer the halo kernel */
+int vqk_conv_set_variant(int variant);
 /* w [Cout][ks][ks][Cin] -> wt [Cin][ks][ks][Cout] with both taps flipped; src fp32, dst `dtype`. */
 int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, int ksize, void* stream);
 /* dw[Cout][ks][ks][Cin] (fp32) += sum_pix dy[pix][co] * x[pix (+) tap][ci].  dw must be pre-zeroed

@@ -123,6 +123,12 @@ CONV_CASES = [
     (2, 16, 32, 4, 4, 3, False, True, False),
     (1, 256, 512, 8, 8, 3, False, False, False),
     (2, 8, 32, 12, 12, 3, False, False, False),
+    # halo-kernel eligible (W % 32 == 0, H % 8 == 0 or 16x16 patches; Cin a whole 128-byte chunk)
+    (2, 64, 128, 8, 32, 3, False, True, True),
+    (1, 128, 160, 16, 64, 3, False, False, False),
+    (3, 64, 64, 16, 16, 3, False, False, True),
+    (1, 128, 256, 32, 16, 3, False, True, False),
+    (2, 64, 64, 8, 16, 3, True, True, False),
 ]
 
 
@@ -165,6 +171,22 @@ def test_conv_fwd_bwd(case, dtype):
     for a, r in zip(gd, gr):
         assert a.shape == r.shape
         assert rel_err(a, r) < (tol if dtype == torch.float32 else 1e-2)
+
+
+def test_conv_halo_and_im2col_kernels_agree():
+    """the two fprop kernels are interchangeable: same shape through both"""
+    native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
+    g = torch.Generator().manual_seed(11)
+    x = dev(torch.randn(2, 128, 16, 32, generator=g), torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = dev(torch.randn(128, 3, 3, 128, generator=g) * 0.03, torch.bfloat16)
+    try:
+        native.lib().vqk_conv_set_variant(0)
+        y0 = ops.raw_conv_fprop(x, w.view(128, -1), None, None, 3, False, 0, torch.bfloat16)
+        native.lib().vqk_conv_set_variant(1)
+        y1 = ops.raw_conv_fprop(x, w.view(128, -1), None, None, 3, False, 0, torch.bfloat16)
+    finally:
+        native.lib().vqk_conv_set_variant(-1)
+    assert rel_err(y1, y0) < 1e-3
 
 
 def test_conv_padded_edges_fp32():

@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
 
 SHAPES = [  # cin, cout, hw_out, k, ups, count(enc+dec fwd)
     (128, 128, 256, 3, 0, 4), (128, 128, 256, 3, 1, 1), (128, 256, 128, 3, 0, 1), (256, 256, 128, 3, 0, 3),
@@ -38,6 +39,11 @@ def main():
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     n = 32
     tot_f = tot_w = 0.0
+    variant = int(os.environ.get('VQK_VARIANT', '-1'))
+    native.lib().vqk_conv_set_variant(variant)
+    skip_w = os.environ.get('VQK_NO_WGRAD') == '1'
+    skip_f = os.environ.get('VQK_NO_FPROP') == '1'
+    print(f'variant {variant}')
     print(f'{"shape":38s} {"GFLOP":>8s} {"fprop us":>9s} {"TF":>7s} {"wgrad us":>9s} {"TF":>7s}')
     for cin, cout, hw, k, ups, cnt in SHAPES:
         hin = hw >> ups
@@ -45,8 +51,8 @@ def main():
         w = (torch.randn(cout, k, k, cin, device='cuda') * 0.05).to(dt)
         dy = torch.randn(n, cout, hw, hw, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
         fl = 2.0 * n * hw * hw * cin * cout * k * k
-        tf = timeit(lambda: ops.raw_conv_fprop(x, w.view(cout, -1), None, None, k, bool(ups), 0, dt), iters)
-        tw = timeit(lambda: ops.raw_conv_wgrad(x, dy, k, bool(ups)), iters)
+        tf = 1.0 if skip_f else timeit(lambda: ops.raw_conv_fprop(x, w.view(cout, -1), None, None, k, bool(ups), 0, dt), iters)
+        tw = 1.0 if skip_w else timeit(lambda: ops.raw_conv_wgrad(x, dy, k, bool(ups)), iters)
         tot_f += tf * cnt
         tot_w += tw * cnt
         print(f'{cin:4d}->{cout:4d} @{hw:3d}^2 k{k} ups{ups} x{cnt:<2d}          {fl / 1e9:8.1f} {tf * 1e6:9.1f} {fl / tf / 1e12:7.1f} '

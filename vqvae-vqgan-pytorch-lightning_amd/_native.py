@@ -32,6 +32,7 @@ _PROTOS = {
     'vqk_ema_stats_f32': [P, P, L, I, I, P, P, P],
     'vqk_ema_update_f32': [P, P, P, P, P, I, I, F, F, F, P],
     'vqk_conv2d_fprop': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, P],
+    'vqk_conv_set_variant': [I],
     'vqk_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
     'vqk_colsum': [I, P, L, I, P, P],

@@ -15,6 +15,7 @@
 //   (hardware transpose read); fp32 fragments are plain ds_read_b32.  Split-K over pixel ranges,
 //   partials combined with fp32 atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -52,6 +53,15 @@ template <> struct Mma<float> {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
     }
 };
+
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+    f32x4 o = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = o;
+}
+__device__ __forceinline__ void store4(bf16_raw* p, const float (&v)[4]) {
+    u16x4 o = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+    *reinterpret_cast<u16x4*>(p) = o;
+}
 
 __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const VQK_GLB void*)src, (VQK_LDS void*)lds_wave_base, 16, 0, 0);
@@ -193,6 +203,165 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                     if (act == 1) v = tanhf(v);
                     Elem<TO>::st(y + o, v);
                 }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fprop / dgrad, 3x3, "halo" variant: the block owns a TH x TW spatial patch (256 output pixels) x 128
+// couts.  For every 128-byte channel chunk the (TH+2) x (TW+2) input halo is staged ONCE and all nine
+// taps read it at shifted row offsets, so activation traffic into LDS drops 9x against the im2col
+// variant; only the 16 KB weight tile per tap is streamed (double-buffered, prefetched one tap ahead).
+// 4 waves as 2(M) x 2(N), wave tile 128 pixels x 64 couts = 4x2 MFMA 32x32 tiles (128 accumulators).
+// LDS: halo 44 KB + 2 x 16 KB weights = 76 KB -> two blocks per CU.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TO, int TWLOG>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restrict__ x, const T* __restrict__ wgt,
+                                                              const float* __restrict__ bias,
+                                                              const TO* __restrict__ res, TO* __restrict__ y,
+                                                              const char* __restrict__ zeros, ConvGeom g, int act) {
+    constexpr int EPC = Mma<T>::EPC;
+    constexpr int TW = 1 << TWLOG, TH = 256 / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr int HALO_INSTR = (HROWS + 7) / 8;                 // wave instructions (8 rows each)
+    constexpr int HALO_BYTES = ((HALO_INSTR + 3) / 4) * 4 * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_h = smem;
+    char* lds_b = smem + HALO_BYTES;                             // 2 x [128][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = g.w >> TWLOG, tiles_y = g.h / TH;
+    const int total = g.n * tiles_y * tiles_x * g.tiles_n;
+    int tile = xcd_remap(blockIdx.x, total);
+    const int nt = tile % g.tiles_n; tile /= g.tiles_n;
+    const int txi = tile % tiles_x; tile /= tiles_x;
+    const int tyi = tile % tiles_y;
+    const int img = tile / tiles_y;
+    const int py0 = tyi * TH, px0 = txi * TW, n0 = nt * 128;
+    const T* ximg = x + (int64_t)img * g.h_in * g.w_in * g.cin;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int p = lane & 31, kg = lane >> 5;
+    // halo row of this lane's pixel for MFMA row tile i (tap (0,0)); patch pixel (ty, tx)
+    int hbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ty, tx;
+        if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
+        else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+        hbase[i] = ty * HW2 + tx;
+    }
+    int fb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = (wn * 64 + j * 32 + p) * 128;
+    const int bswz = (p >> 1) & 7;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // B-tile load slots: row = 8*(4*wave+t) + lane/8, logical chunk as in the im2col kernel
+    const char* b_row[4];
+    bool b_ok[4];
+    int lchunk[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int co = n0 + 8 * (4 * wave + t) + (lane >> 3);
+        b_ok[t] = co < g.cout;
+        b_row[t] = reinterpret_cast<const char*>(wgt) + (int64_t)(b_ok[t] ? co : 0) * g.kchunks * 16;
+    }
+    lchunk[0] = (lane & 7) ^ ((lane >> 4) & 7);
+    lchunk[1] = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
+
+    const int nchunks = g.cpt >> 3;                              // 128-byte channel chunks
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();                                         // previous chunk fully consumed
+        // ---- halo: HALO_INSTR wave instructions, round-robin over the 4 waves
+        for (int q = wave; q < HALO_INSTR; q += 4) {
+            const int hr = q * 8 + (lane >> 3);
+            const int lc = (lane & 7) ^ ((hr >> 1) & 7);
+            const int hy = hr / HW2, hx = hr - hy * HW2;
+            const int iy = py0 + hy - 1, ix = px0 + hx - 1;
+            const bool ok = hr < HROWS && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+            const T* src = ximg + ((int64_t)(iy >> g.ups) * g.w_in + (ix >> g.ups)) * g.cin + (cc * 8 + lc) * EPC;
+            glds16(ok ? (const void*)src : (const void*)zeros, lds_h + q * 1024);
+        }
+        // ---- weights of tap 0
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int gch = cc * 8 + lchunk[t & 1];
+            glds16(b_ok[t] ? (const void*)(b_row[t] + (int64_t)gch * 16) : (const void*)zeros,
+                   lds_b + (4 * wave + t) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const char* bcur = lds_b + (tap & 1) * 16384;
+            if (tap < 8) {                                       // prefetch the next tap's weights
+                char* bnext = lds_b + ((tap + 1) & 1) * 16384;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int gch = (tap + 1) * g.cpt + cc * 8 + lchunk[t & 1];
+                    glds16(b_ok[t] ? (const void*)(b_row[t] + (int64_t)gch * 16) : (const void*)zeros,
+                           bnext + (4 * wave + t) * 1024);
+                }
+            }
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int toff = kh * HW2 + kw;
+            int ha[4], hs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hr = hbase[i] + toff;
+                ha[i] = hr * 128;
+                hs[i] = (hr >> 1) & 7;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int lc = 2 * ks + kg;
+                const int boff = (lc ^ bswz) * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const char* pa = lds_h + ha[i] + ((lc ^ hs[i]) << 4);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Mma<T>::run(bcur + fb[j] + boff, pa, acc[i][j]);   // D[co][pixel]
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue: lane = one pixel (p) x 4 consecutive couts per register quad
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ty, tx;
+        if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
+        else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+        const int64_t pix = ((int64_t)img * g.h + py0 + ty) * g.w + px0 + tx;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int co = n0 + wn * 64 + j * 32 + 8 * rq + 4 * kg;
+                if (co >= g.cout) continue;
+                const int64_t o = pix * g.cout + co;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rq + e] + (bias ? bias[co + e] : 0.0f);
+                if (res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += Elem<TO>::ld(res + o + e);
+                }
+                if (act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                }
+                store4(y + o, v);
             }
     }
 }
@@ -435,9 +604,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
         atomicAdd(out + col, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+static int g_force_variant = -1;   // test hook: -1 auto, 0 im2col kernel only, 1 halo kernel when eligible
+
 template <typename T, typename TO>
 int launch_fprop(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                  const ConvGeom& g, int act, hipStream_t st) {
+    const bool halo_ok = g.ks == 3 && (g.cpt % 8) == 0 && g_force_variant != 0;
+    if (halo_ok && (g.w % 32) == 0 && (g.h % 8) == 0) {
+        constexpr int lds = 11 * 4096 + 32768;
+        const dim3 grid((unsigned)(g.n * (g.h / 8) * (g.w / 32) * g.tiles_n));
+        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<T, TO, 5>), grid, dim3(256), lds, st, (const T*)x, (const T*)w, bias,
+                           (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+        if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+        return VQK_OK;
+    }
+    if (halo_ok && (g.w % 16) == 0 && (g.h % 16) == 0) {
+        constexpr int lds = 11 * 4096 + 32768;
+        const dim3 grid((unsigned)(g.n * (g.h / 16) * (g.w / 16) * g.tiles_n));
+        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<T, TO, 4>), grid, dim3(256), lds, st, (const T*)x, (const T*)w, bias,
+                           (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+        if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+        return VQK_OK;
+    }
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
     const bool fastk = (g.cpt % 8) == 0;
     if (fastk)
@@ -472,6 +662,9 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
 }  // namespace
 
 extern "C" {
+
+/* test / tuning hook: -1 automatic choice, 0 force the im2col kernel, 1 prefer the halo kernel */
+int vqk_conv_set_variant(int v) { g_force_variant = v; return VQK_OK; }
 
 int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                      int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int act,
@@ -513,7 +706,8 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
     const int kp = dtype == VQK_F32 ? 32 : 64;
     const int tiles = ((cout + 127) / 128) * ((cin + 127) / 128) * ksize * ksize;
     // split the pixel range so that ~2048 blocks are in flight, each with >= 4 K-steps
-    int splits = (2048 + tiles - 1) / tiles;
+    static const int target_blocks = getenv("VQK_WGRAD_BLOCKS") ? atoi(getenv("VQK_WGRAD_BLOCKS")) : 2048;
+    int splits = (target_blocks + tiles - 1) / tiles;
     const int max_splits = (g.m + 4 * kp - 1) / (4 * kp);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
