@@ -173,20 +173,24 @@ def test_conv_fwd_bwd(case, dtype):
         assert rel_err(a, r) < (tol if dtype == torch.float32 else 1e-2)
 
 
-def test_conv_halo_and_im2col_kernels_agree():
-    """the two fprop kernels are interchangeable: same shape through both"""
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_kernel_variants_agree(dtype):
+    """im2col kernel, halo kernel with LDS-staged weights, halo kernel with register weights: same answer"""
     native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
     g = torch.Generator().manual_seed(11)
-    x = dev(torch.randn(2, 128, 16, 32, generator=g), torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = dev(torch.randn(128, 3, 3, 128, generator=g) * 0.03, torch.bfloat16)
+    x = dev(torch.randn(2, 128, 16, 32, generator=g), dtype).contiguous(memory_format=torch.channels_last)
+    w = dev(torch.randn(160, 3, 3, 128, generator=g) * 0.03).reshape(-1)
+    outs = []
     try:
-        native.lib().vqk_conv_set_variant(0)
-        y0 = ops.raw_conv_fprop(x, w.view(128, -1), None, None, 3, False, 0, torch.bfloat16)
-        native.lib().vqk_conv_set_variant(1)
-        y1 = ops.raw_conv_fprop(x, w.view(128, -1), None, None, 3, False, 0, torch.bfloat16)
+        for variant in (0, 2, 1):
+            native.lib().vqk_conv_set_variant(variant)
+            layout = ops.weight_layout(dtype, 2, 16, 32, 128, 160, 3, False)
+            assert layout == (1 if variant == 1 else 0)
+            wq = ops.pack_weights(w, dtype, 160, 128, 3, False, layout)
+            outs.append(ops.raw_conv_fprop(x, wq, None, None, 3, False, 0, dtype, 160, layout))
     finally:
         native.lib().vqk_conv_set_variant(-1)
-    assert rel_err(y1, y0) < 1e-3
+    assert rel_err(outs[1], outs[0]) < 1e-3 and rel_err(outs[2], outs[0]) < 1e-3
 
 
 def test_conv_padded_edges_fp32():

@@ -51,7 +51,9 @@ def main():
         w = (torch.randn(cout, k, k, cin, device='cuda') * 0.05).to(dt)
         dy = torch.randn(n, cout, hw, hw, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
         fl = 2.0 * n * hw * hw * cin * cout * k * k
-        tf = 1.0 if skip_f else timeit(lambda: ops.raw_conv_fprop(x, w.view(cout, -1), None, None, k, bool(ups), 0, dt), iters)
+        layout = ops.weight_layout(dt, n, hin, hin, cin, cout, k, bool(ups))
+        wq = ops.pack_weights(w.float().reshape(-1), dt, cout, cin, k, False, layout)
+        tf = 1.0 if skip_f else timeit(lambda: ops.raw_conv_fprop(x, wq, None, None, k, bool(ups), 0, dt, cout, layout), iters)
         tw = 1.0 if skip_w else timeit(lambda: ops.raw_conv_wgrad(x, dy, k, bool(ups)), iters)
         tot_f += tf * cnt
         tot_w += tw * cnt

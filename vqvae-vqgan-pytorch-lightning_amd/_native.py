@@ -31,7 +31,9 @@ _PROTOS = {
     'vqk_vq_backward_f32': [P, P, P, P, I, L, I, I, F, F, P, P, P, P],
     'vqk_ema_stats_f32': [P, P, L, I, I, P, P, P],
     'vqk_ema_update_f32': [P, P, P, P, P, I, I, F, F, F, P],
-    'vqk_conv2d_fprop': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, P],
+    'vqk_conv2d_fprop': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
+    'vqk_conv_weight_layout': [I, I, I, I, I, I, I, I],
+    'vqk_conv_pack_weights': [P, P, I, I, I, I, I, I, P],
     'vqk_conv_set_variant': [I],
     'vqk_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
@@ -51,7 +53,7 @@ _PROTOS = {
     'vqk_bias_act': [P, P, P, P, P, P, L, L, I, I, I, F, F, F, P],
     'vqk_upfirdn2d': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, I, P],
 }
-_SPECIAL = {'vqk_status_str': (c_char_p, [I]), 'vqk_version': (I, []), 'vqk_arch': (c_char_p, [])}
+_SPECIAL = {'vqk_conv_packed_elems': (c_int64, [I, I, I, I]), 'vqk_status_str': (c_char_p, [I]), 'vqk_version': (I, []), 'vqk_arch': (c_char_p, [])}
 EXPORTS = sorted(list(_PROTOS) + list(_SPECIAL))
 
 

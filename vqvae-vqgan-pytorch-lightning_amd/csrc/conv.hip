@@ -54,6 +54,23 @@ template <> struct Mma<float> {
     }
 };
 
+template <typename T> struct Frag;
+template <> struct Frag<bf16_raw> {
+    typedef bf16x8_t type;
+    __device__ static __forceinline__ void mma(const type& a, const type& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+};
+template <> struct Frag<float> {
+    typedef f32x4 type;
+    __device__ static __forceinline__ void mma(const type& a, const type& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+    }
+};
+
 __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
     f32x4 o = {v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p) = o;
@@ -367,6 +384,180 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Halo variant with the weights in REGISTERS.  Weights are pre-packed "fragment-major"
+// (vqk_conv_pack_weights, layout 1): for (cout tile of 32, tap, channel chunk, k-substep) the 64 lanes'
+// 16-byte MFMA operands are 1 KiB contiguous, so one coalesced global_load_dwordx4 per fragment, prefetched
+// one tap ahead.  LDS holds only the input halo => no barrier inside the nine taps; the block
+// synchronises once per 128-byte channel chunk.  4 waves as 2(M) x 2(N), wave tile 128 pixels x 64 couts.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TO, int TWLOG>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_breg_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+                                                                   const float* __restrict__ bias,
+                                                                   const TO* __restrict__ res, TO* __restrict__ y,
+                                                                   const char* __restrict__ zeros, ConvGeom g, int act) {
+    constexpr int EPC = Mma<T>::EPC;
+    constexpr int TW = 1 << TWLOG, TH = 256 / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr int HALO_INSTR = (HROWS + 7) / 8;
+    typedef typename Frag<T>::type frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_h = smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = g.w >> TWLOG, tiles_y = g.h / TH;
+    const int total = g.n * tiles_y * tiles_x * g.tiles_n;
+    int tile = xcd_remap(blockIdx.x, total);
+    const int nt = tile % g.tiles_n; tile /= g.tiles_n;
+    const int txi = tile % tiles_x; tile /= tiles_x;
+    const int tyi = tile % tiles_y;
+    const int img = tile / tiles_y;
+    const int py0 = tyi * TH, px0 = txi * TW, n0 = nt * 128;
+    const T* ximg = x + (int64_t)img * g.h_in * g.w_in * g.cin;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int p = lane & 31, kg = lane >> 5;
+    int hbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ty, tx;
+        if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
+        else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+        hbase[i] = ty * HW2 + tx;
+    }
+    const int nchunks = g.cpt >> 3;
+    // fragment (j, tap, cc, ks) of this wave: wbase + ((((cot0 + j)*9 + tap)*nchunks + cc)*4 + ks) * 1 KiB + lane*16
+    const char* wbase = reinterpret_cast<const char*>(wp) + (int64_t)lane * 16;
+    const int cot0 = (n0 + wn * 64) >> 5;
+    auto wfrag = [&](int j, int tap, int cc, int ks) -> frag_t {
+        const int64_t f = (((int64_t)(cot0 + j) * 9 + tap) * nchunks + cc) * 4 + ks;
+        return *reinterpret_cast<const frag_t*>(wbase + f * 1024);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    frag_t bw[2][4];                                             // this tap's weight fragments
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bw[j][ks] = wfrag(j, 0, 0, ks);
+
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();                                         // previous chunk's halo fully consumed
+        for (int q = wave; q < HALO_INSTR; q += 4) {
+            const int hr = q * 8 + (lane >> 3);
+            const int lc = (lane & 7) ^ ((hr >> 1) & 7);
+            const int hy = hr / HW2, hx = hr - hy * HW2;
+            const int iy = py0 + hy - 1, ix = px0 + hx - 1;
+            const bool ok = hr < HROWS && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+            const T* src = ximg + ((int64_t)(iy >> g.ups) * g.w_in + (ix >> g.ups)) * g.cin + (cc * 8 + lc) * EPC;
+            glds16(ok ? (const void*)src : (const void*)zeros, lds_h + q * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            // next (tap, chunk) whose weights get prefetched; past the end the loads are redundant but stay
+            // UNCONDITIONAL so that the compiler's vmcnt bookkeeping stays exact (a branch around them makes it
+            // wait for the youngest load at the top of every tap).
+            int ntap = tap + 1, ncc = cc;
+            if (ntap == 9) { ntap = 0; ncc = (cc + 1 < nchunks) ? cc + 1 : 0; }
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int toff = kh * HW2 + kw;
+            const char* prow[4];
+            int hs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hr = hbase[i] + toff;
+                prow[i] = lds_h + hr * 128;
+                hs[i] = (hr >> 1) & 7;
+            }
+            frag_t a[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(prow[i] + ((kg ^ hs[i]) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {                                    // next k-substep's pixel fragments
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        a[(ks + 1) & 1][i] = *reinterpret_cast<const frag_t*>(prow[i] + (((2 * ks + 2 + kg) ^ hs[i]) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Frag<T>::mma(bw[j][ks], a[ks & 1][i], acc[i][j]);       // D[co][pixel]
+                // rolling prefetch: these registers are dead until the next tap's k-substep ks
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bw[j][ks] = wfrag(j, ntap, ncc, ks);
+                __builtin_amdgcn_sched_barrier(0);               // keep the prefetch here (hipcc sinks it to the loop end)
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ty, tx;
+        if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
+        else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+        const int64_t pix = ((int64_t)img * g.h + py0 + ty) * g.w + px0 + tx;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int co = n0 + wn * 64 + j * 32 + 8 * rq + 4 * kg;
+                if (co >= g.cout) continue;
+                const int64_t o = pix * g.cout + co;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rq + e] + (bias ? bias[co + e] : 0.0f);
+                if (res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += Elem<TO>::ld(res + o + e);
+                }
+                if (act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                }
+                store4(y + o, v);
+            }
+    }
+}
+
+// fragment-major weight pack (layout 1).  src w: fp32 [Cout][taps][Cin]; transpose: produce the dgrad operand
+// (roles of Cout/Cin swapped, taps flipped).  dst element order: [cot][tap][cc][ks][kg][co32][EPC].
+template <typename TD>
+__global__ void pack_frag_kernel(const float* __restrict__ w, TD* __restrict__ out, int cout, int cin, int taps,
+                                 int transpose, int cot_tiles) {
+    constexpr int E = Elem<TD>::kPer16B;
+    const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
+    const int ncc = dcin / (8 * E);
+    const int64_t total = (int64_t)cot_tiles * taps * ncc * 4 * 64 * E;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = o;
+        const int e = (int)(r % E); r /= E;
+        const int co32 = (int)(r % 32); r /= 32;
+        const int kg = (int)(r % 2); r /= 2;
+        const int ks = (int)(r % 4); r /= 4;
+        const int cc = (int)(r % ncc); r /= ncc;
+        const int tap = (int)(r % taps);
+        const int cot = (int)(r / taps);
+        const int co = cot * 32 + co32;
+        const int ci = ((cc * 4 + ks) * 2 + kg) * E + e;
+        float v = 0.0f;
+        if (co < dcout) {
+            v = transpose ? w[((int64_t)ci * taps + (taps - 1 - tap)) * cin + co]
+                          : w[((int64_t)co * taps + tap) * cin + ci];
+        }
+        Elem<TD>::st(out + o, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad.  grid = (co tiles * ci tiles, taps, splits).  Tile 128 co x 128 ci, K-step KP pixels.
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct WgradFrag;
@@ -604,27 +795,47 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
         atomicAdd(out + col, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-static int g_force_variant = -1;   // test hook: -1 auto, 0 im2col kernel only, 1 halo kernel when eligible
+static int g_force_variant = -1;   // test hook: -1 auto, 0 im2col kernel only, 1 halo kernels when eligible
+
+// 0: not eligible for the halo kernels; 5 / 4: patch width log2 (8x32 / 16x16 pixel patches)
+inline int halo_twlog(const ConvGeom& g) {
+    if (g.ks != 3 || (g.cpt % 8) != 0 || g_force_variant == 0) return 0;
+    if ((g.w % 32) == 0 && (g.h % 8) == 0) return 5;
+    if ((g.w % 16) == 0 && (g.h % 16) == 0) return 4;
+    return 0;
+}
 
 template <typename T, typename TO>
 int launch_fprop(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
-                 const ConvGeom& g, int act, hipStream_t st) {
-    const bool halo_ok = g.ks == 3 && (g.cpt % 8) == 0 && g_force_variant != 0;
-    if (halo_ok && (g.w % 32) == 0 && (g.h % 8) == 0) {
-        constexpr int lds = 11 * 4096 + 32768;
-        const dim3 grid((unsigned)(g.n * (g.h / 8) * (g.w / 32) * g.tiles_n));
-        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((conv3x3_halo_kernel<T, TO, 5>), grid, dim3(256), lds, st, (const T*)x, (const T*)w, bias,
-                           (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+                 const ConvGeom& g, int act, int wlayout, hipStream_t st) {
+    const int tw = halo_twlog(g);
+    if (wlayout == 1) {
+        if (!tw) return VQK_ERR_SHAPE;                       // fragment-major weights need a halo-eligible shape
+        constexpr int lds = 11 * 4096;
+        const int th = 256 >> tw;
+        const dim3 grid((unsigned)(g.n * (g.h / th) * (g.w >> tw) * g.tiles_n));
+        if (tw == 5)
+            hipLaunchKernelGGL((conv3x3_halo_breg_kernel<T, TO, 5>), grid, dim3(256), lds, st, (const T*)x, (const T*)w,
+                               bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+        else
+            hipLaunchKernelGGL((conv3x3_halo_breg_kernel<T, TO, 4>), grid, dim3(256), lds, st, (const T*)x, (const T*)w,
+                               bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
         if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
         return VQK_OK;
     }
-    if (halo_ok && (g.w % 16) == 0 && (g.h % 16) == 0) {
+    if (tw) {
         constexpr int lds = 11 * 4096 + 32768;
-        const dim3 grid((unsigned)(g.n * (g.h / 16) * (g.w / 16) * g.tiles_n));
-        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((conv3x3_halo_kernel<T, TO, 4>), grid, dim3(256), lds, st, (const T*)x, (const T*)w, bias,
-                           (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+        const int th = 256 >> tw;
+        const dim3 grid((unsigned)(g.n * (g.h / th) * (g.w >> tw) * g.tiles_n));
+        if (tw == 5) {
+            hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((conv3x3_halo_kernel<T, TO, 5>), grid, dim3(256), lds, st, (const T*)x, (const T*)w, bias,
+                               (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+        } else {
+            hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((conv3x3_halo_kernel<T, TO, 4>), grid, dim3(256), lds, st, (const T*)x, (const T*)w, bias,
+                               (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+        }
         if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
         return VQK_OK;
     }
@@ -668,18 +879,62 @@ int vqk_conv_set_variant(int v) { g_force_variant = v; return VQK_OK; }
 
 int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                      int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int act,
-                     const void* zeros, void* stream) {
+                     int wlayout, const void* zeros, void* stream) {
     VQK_REQUIRE(x && w && y && zeros, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
     VQK_REQUIRE(act == 0 || act == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(wlayout == 0 || wlayout == 1, VQK_ERR_ARG);
     ConvGeom g;
     const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
     if (rc) return rc;
     hipStream_t st = vqk_stream(stream);
-    if (dtype == VQK_F32 && out_dtype == VQK_F32) return launch_fprop<float, float>(x, w, bias, residual, y, zeros, g, act, st);
-    if (dtype == VQK_BF16 && out_dtype == VQK_BF16) return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, act, st);
-    if (dtype == VQK_BF16 && out_dtype == VQK_F32) return launch_fprop<bf16_raw, float>(x, w, bias, residual, y, zeros, g, act, st);
+    if (dtype == VQK_F32 && out_dtype == VQK_F32) return launch_fprop<float, float>(x, w, bias, residual, y, zeros, g, act, wlayout, st);
+    if (dtype == VQK_BF16 && out_dtype == VQK_BF16) return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, act, wlayout, st);
+    if (dtype == VQK_BF16 && out_dtype == VQK_F32) return launch_fprop<bf16_raw, float>(x, w, bias, residual, y, zeros, g, act, wlayout, st);
     return VQK_ERR_DTYPE;
+}
+
+int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups) {
+    ConvGeom g;
+    const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
+    if (rc) return rc;
+    return (halo_twlog(g) && g_force_variant != 2) ? 1 : 0;
+}
+
+int64_t vqk_conv_packed_elems(int cout, int cin, int ksize, int layout) {
+    if (layout == 0) return (int64_t)cout * cin * ksize * ksize;
+    return (int64_t)((cout + 127) / 128) * 128 * cin * ksize * ksize;
+}
+
+int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int cin, int ksize, int transpose, int layout,
+                          void* stream) {
+    VQK_REQUIRE(w && out, VQK_ERR_ARG);
+    VQK_REQUIRE(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), VQK_ERR_SHAPE);
+    VQK_REQUIRE(dtype == VQK_F32 || dtype == VQK_BF16, VQK_ERR_DTYPE);
+    const int taps = ksize * ksize;
+    hipStream_t st = vqk_stream(stream);
+    if (layout == 0) {
+        const int64_t total = (int64_t)cout * cin * taps;
+        const dim3 grid(vqk_grid_1d(total, 256));
+        if (transpose) {
+            if (dtype == VQK_F32) hipLaunchKernelGGL(pack_dgrad_kernel<float>, grid, dim3(256), 0, st, w, (float*)out, cout, cin, taps);
+            else hipLaunchKernelGGL(pack_dgrad_kernel<bf16_raw>, grid, dim3(256), 0, st, w, (bf16_raw*)out, cout, cin, taps);
+        } else {
+            if (dtype == VQK_F32) hipLaunchKernelGGL(cast_kernel<float>, grid, dim3(256), 0, st, w, (float*)out, total);
+            else hipLaunchKernelGGL(cast_kernel<bf16_raw>, grid, dim3(256), 0, st, w, (bf16_raw*)out, total);
+        }
+    } else if (layout == 1) {
+        const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
+        const int e = dtype == VQK_F32 ? 4 : 8;
+        VQK_REQUIRE(ksize == 3 && dcin % (8 * e) == 0, VQK_ERR_SHAPE);
+        const int cot_tiles = ((dcout + 127) / 128) * 4;
+        const int64_t total = (int64_t)cot_tiles * 32 * taps * dcin;
+        const dim3 grid(vqk_grid_1d(total, 256));
+        if (dtype == VQK_F32) hipLaunchKernelGGL(pack_frag_kernel<float>, grid, dim3(256), 0, st, w, (float*)out, cout, cin, taps, transpose, cot_tiles);
+        else hipLaunchKernelGGL(pack_frag_kernel<bf16_raw>, grid, dim3(256), 0, st, w, (bf16_raw*)out, cout, cin, taps, transpose, cot_tiles);
+    } else return VQK_ERR_ARG;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
 }
 
 int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, int ksize, void* stream) {

@@ -76,28 +76,41 @@ def _timed(name: str, flops: float, launch):
     return st
 
 
-def raw_conv_fprop(x, w_krsc, bias, residual, ksize: int, ups: bool, act: int, out_dtype) -> torch.Tensor:
-    """x [N,Cin,H,W] nhwc; w_krsc: tensor whose memory is [Cout][k][k][Cin] in x.dtype."""
+def weight_layout(dtype, n, h_in, w_in, cin, cout, ksize, ups) -> int:
+    """operand layout the fprop launcher wants for this problem (include/vqk.h: 0 = [O][kh][kw][I], 1 = fragment-major)"""
+    r = _native.lib().vqk_conv_weight_layout(dcode(dtype), n, h_in, w_in, cin, cout, ksize, int(ups))
+    if r < 0:
+        _native.check(r, 'conv_weight_layout')
+    return r
+
+
+def pack_weights(w_mem_f32, dtype, cout, cin, ksize, transpose: bool, layout: int) -> torch.Tensor:
+    """fp32 [Cout][k][k][Cin] master memory -> conv operand (cast / transpose+flip for dgrad / fragment-major)"""
+    if layout == 0 and not transpose and dtype == torch.float32:
+        return w_mem_f32
+    dc, di = (cin, cout) if transpose else (cout, cin)
+    n = _native.lib().vqk_conv_packed_elems(dc, di, ksize, layout)
+    out = torch.empty(n, dtype=dtype, device=w_mem_f32.device)
+    st = _native.lib().vqk_conv_pack_weights(w_mem_f32.data_ptr(), out.data_ptr(), dcode(dtype), cout, cin, ksize,
+                                             int(transpose), layout, _stream())
+    _native.check(st, 'conv_pack_weights')
+    return out
+
+
+def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_dtype, cout: int, wlayout: int = 0):
+    """x [N,Cin,H,W] nhwc; wq: packed weights (pack_weights) in x.dtype with layout ``wlayout``."""
     _require_gpu(x)
     n, cin, h, w = x.shape
-    cout = w_krsc.shape[0]
     s = 2 if ups else 1
     y = empty_nhwc(n, cout, h * s, w * s, out_dtype, x.device)
     flops = 2.0 * n * h * s * w * s * cout * cin * ksize * ksize
-    st = _timed(f'conv_fprop_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
-                lambda: _native.lib().vqk_conv2d_fprop(dcode(x.dtype), x.data_ptr(), w_krsc.data_ptr(), _p(bias),
+    st = _timed(f'conv_fprop<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
+                lambda: _native.lib().vqk_conv2d_fprop(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias),
                                                        _p(residual), y.data_ptr(), dcode(out_dtype), n, h, w, cin,
-                                                       cout, ksize, int(ups), act, zero_page(x.device).data_ptr(),
-                                                       _stream()))
+                                                       cout, ksize, int(ups), act, wlayout,
+                                                       zero_page(x.device).data_ptr(), _stream()))
     _native.check(st, 'conv2d_fprop')
     return y
-
-
-def raw_pack_dgrad(w_krsc_f32, dtype, cout, cin, ksize) -> torch.Tensor:
-    wt = torch.empty(cin * ksize * ksize * cout, dtype=dtype, device=w_krsc_f32.device)
-    st = _native.lib().vqk_conv_pack_dgrad(w_krsc_f32.data_ptr(), wt.data_ptr(), dcode(dtype), cout, cin, ksize, _stream())
-    _native.check(st, 'conv_pack_dgrad')
-    return wt.view(cin, ksize, ksize, cout)
 
 
 def raw_conv_wgrad(x, dy, ksize: int, ups: bool) -> torch.Tensor:
@@ -224,7 +237,9 @@ class Conv2dFn(torch.autograd.Function):
         cout_pad = -(-o // e) * e
         if cin < i or cin % epc(dt):
             raise RuntimeError(f'vqk: conv input has {cin} channels, weight expects {i}')
-        wq = raw_cast(_weight_mem(weight, cin, cout_pad), dt)
+        n_img, _, h_in, w_in = x.shape
+        layout = weight_layout(dt, n_img, h_in, w_in, cin, cout_pad, k, ups)
+        wq = pack_weights(_weight_mem(weight, cin, cout_pad), dt, cout_pad, cin, k, False, layout)
         b32 = None
         if bias is not None:
             b32 = bias.detach()
@@ -232,7 +247,7 @@ class Conv2dFn(torch.autograd.Function):
                 b32 = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
                 b32[:o] = bias.detach()
         res = nhwc(residual) if residual is not None else None
-        y = raw_conv_fprop(x, wq.view(cout_pad, -1), b32, res, k, ups, act, out_dtype)
+        y = raw_conv_fprop(x, wq, b32, res, k, ups, act, out_dtype, cout_pad, layout)
         ctx.save_for_backward(x, weight, y if act == 1 else None)
         ctx.cfg = (k, ups, act, o, i, cin, cout_pad, bias is not None, residual is not None, dt)
         return y
@@ -251,8 +266,10 @@ class Conv2dFn(torch.autograd.Function):
         dyc = dy if dy.dtype == dt else nhwc(dy.to(dt))      # fp32 head output in bf16 mode: dtype cast only
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = raw_pack_dgrad(_weight_mem(weight, cin, cout_pad), dt, cout_pad, cin, k)
-            dx = raw_conv_fprop(dyc, wt.view(cin, -1), None, None, k, False, 0, dt)
+            n_img, _, h_out, w_out = dyc.shape
+            layout = weight_layout(dt, n_img, h_out, w_out, cout_pad, cin, k, False)
+            wt = pack_weights(_weight_mem(weight, cin, cout_pad), dt, cout_pad, cin, k, True, layout)
+            dx = raw_conv_fprop(dyc, wt, None, None, k, False, 0, dt, cin, layout)
             if ups:
                 dx = raw_pool(dx, 1.0)
         if ctx.needs_input_grad[1]:
