@@ -129,6 +129,8 @@ CONV_CASES = [
     (3, 64, 64, 16, 16, 3, False, False, True),
     (1, 128, 256, 32, 16, 3, False, True, False),
     (2, 64, 64, 8, 16, 3, True, True, False),
+    (2, 16, 24, 8, 8, 3, False, True, False),           # partial co / ci tiles in the all-taps wgrad kernel
+    (1, 72, 40, 16, 8, 3, False, False, False),
 ]
 
 
