@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='issue every kernel eagerly instead of replaying a hipGraph')
     args = ap.parse_args()
 
     trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
@@ -117,14 +118,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = not args.no_graph
+    if use_graph:
+        trainer.capture(model, images, warmup=max(1, min(3, args.warmup)))
+        step_fn = trainer.train_batch_graphed
+    else:
+        step_fn = trainer.train_batch
     for i in range(args.warmup):
-        trainer.train_batch(model, images, i)
+        step_fn(model, images, i)
     barrier()
-    if not args.no_kernel_events:
+    if not use_graph and not args.no_kernel_events:
         ops.KERNEL_EVENTS = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = trainer.train_batch(model, images, args.warmup + i)
+        loss = step_fn(model, images, args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
@@ -132,6 +139,16 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    event_steps = args.steps
+    if use_graph and not args.no_kernel_events:
+        # per-kernel HIP-event timing cannot be recorded inside a replayed graph: time the SAME kernels (same
+        # shapes, same stream) in eager steps right after the timed region
+        event_steps = 3
+        ops.KERNEL_EVENTS = []
+        for i in range(event_steps):
+            trainer.train_batch(model, images, args.warmup + args.steps + i)
+        barrier()
+        events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
 
     roofline = None
     if events:
@@ -146,10 +163,11 @@ def main():
         achieved = flops / secs / 1e12
         roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
                         frac=round(achieved / peak, 4), traffic=None, kernel=name,
-                        launches_per_step=count // args.steps, avg_launch_us=round(secs / count * 1e6, 2),
+                        launches_per_step=count // event_steps, avg_launch_us=round(secs / count * 1e6, 2),
                         avg_gflop_per_launch=round(flops / count / 1e9, 3),
-                        kernel_time_frac_of_step=round(secs / elapsed, 3),
-                        all_kernels={k: dict(launches=v[0] // args.steps, ms_per_step=round(v[2] / args.steps * 1e3, 3),
+                        kernel_time_frac_of_step=round((secs / event_steps) / (elapsed / args.steps), 3),
+                        event_pass=('eager steps after the timed region' if use_graph else 'timed region'),
+                        all_kernels={k: dict(launches=v[0] // event_steps, ms_per_step=round(v[2] / event_steps * 1e3, 3),
                                              tflops=round(v[1] / v[2] / 1e12, 1)) for k, v in by_kernel.items()})
 
     if rank == 0:
@@ -164,6 +182,7 @@ def main():
                    config=dict(workload=f'{args.quantizer}_vqvae cb={args.codebook}, {args.image_size}x'
                                         f'{args.image_size} bs={args.batch}/GPU (encoder+VQ+decoder fwd/bwd + AdamW)',
                                global_batch=world * args.batch, parallelism=f'dp{world}',
+                               launch=('hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
                                final_loss=round(float(loss.item()), 6)),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)

@@ -143,3 +143,28 @@ def test_multi_step_loss_decreases():
         loss = tr.train_batch(m, images, i)
         first = first if first is not None else loss.item()
     assert loss.item() < first
+
+
+def test_graph_replay_matches_eager():
+    """hipGraph replay of fwd+bwd (MiniTrainer.capture) walks the same trajectory as eager launches"""
+    qc = dict(num_embeddings=64, embedding_dim=16, reinit_every_n_epochs=None, type='standard', params=QP['standard'])
+    tc = dict(TC, lr=1e-3)
+    images = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(DEV)
+    losses = {}
+    for mode in ('eager', 'graph'):
+        torch.manual_seed(0)
+        m = model_mod.VQVAE(32, AE, qc, None, tc).to(DEV).train()
+        tr = trainer_mod.MiniTrainer(num_training_batches=100)
+        tr.attach(m)
+        m.on_train_start()
+        out = []
+        if mode == 'graph':
+            tr.capture(m, images, warmup=2)
+            for i in range(4):
+                out.append(tr.train_batch_graphed(m, images, 2 + i).item())
+        else:
+            for i in range(6):
+                out.append(tr.train_batch(m, images, i).item())
+            out = out[2:]
+        losses[mode] = out
+    np.testing.assert_allclose(losses['graph'], losses['eager'], rtol=2e-3)

@@ -33,8 +33,8 @@ def test_argument_validation_without_gpu():
     """shape / pointer validation happens before any launch, so it is testable on the CPU box"""
     lib = importlib.import_module(PKG + '._native').lib()
     assert lib.vqk_vq_assign_f32(0, 0, 0, 0, 16, 8, 16, 0, 0, 0) == -5           # NULL pointers
-    assert lib.vqk_conv2d_fprop(0, 16, 16, 0, 0, 16, 0, 1, 4, 4, 3, 8, 3, 0, 0, 16, 0) == -1   # Cin % 4
-    assert lib.vqk_conv2d_fprop(7, 16, 16, 0, 0, 16, 0, 1, 4, 4, 4, 8, 3, 0, 0, 16, 0) == -2   # dtype
+    assert lib.vqk_conv2d_fprop(0, 16, 16, 0, 0, 16, 0, 1, 4, 4, 3, 8, 3, 0, 0, 0, 16, 0) == -1   # Cin % 4
+    assert lib.vqk_conv2d_fprop(7, 16, 16, 0, 0, 16, 0, 1, 4, 4, 4, 8, 3, 0, 0, 0, 16, 0) == -2   # dtype
     assert lib.vqk_gn_stats(0, 16, 1, 16, 30, 32, 1e-6, 16, 16, 0) == -1                          # C % groups
 
 

@@ -932,11 +932,13 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         const int th = 256 >> tw;
         const dim3 grid((unsigned)(g.n * (g.h / th) * (g.w >> tw) * g.tiles_n));
         if (tw == 5) {
-            hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            static const hipError_t attr5 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)attr5;
             hipLaunchKernelGGL((conv3x3_halo_kernel<T, TO, 5>), grid, dim3(256), lds, st, (const T*)x, (const T*)w, bias,
                                (const TO*)res, (TO*)y, (const char*)zeros, g, act);
         } else {
-            hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            static const hipError_t attr4 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)attr4;
             hipLaunchKernelGGL((conv3x3_halo_kernel<T, TO, 4>), grid, dim3(256), lds, st, (const T*)x, (const T*)w, bias,
                                (const TO*)res, (TO*)y, (const char*)zeros, g, act);
         }

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < V; ++i) { s[i] = 0.f; ss[i] = 0.f; }
     const T* base = x + (int64_t)n * hw * c + slot * V;
+#pragma unroll 4
     for (int64_t p = p0 + prow; p < p1; p += pstep) {
         float v[V];
         Vec16<T>::load(base + p * c, v);
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     const int64_t off = (int64_t)n * hw * c + slot * V;
+#pragma unroll 4
     for (int64_t p = p0 + prow; p < p1; p += pstep) {
         float v[V];
         Vec16<T>::load(x + off + p * c, v);
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     const int64_t off = (int64_t)n * hw * c + slot * V;
+#pragma unroll 4
     for (int64_t p = p0 + prow; p < p1; p += pstep) {
         float xv[V], gv[V];
         Vec16<T>::load(x + off + p * c, xv);
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     const int64_t off = (int64_t)n * hw * c + slot * V;
+#pragma unroll 4
     for (int64_t p = p0 + prow; p < p1; p += pstep) {
         float xv[V], gv[V], ov[V];
         Vec16<T>::load(x + off + p * c, xv);

@@ -113,11 +113,21 @@ def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_d
     return y
 
 
-def raw_conv_wgrad(x, dy, ksize: int, ups: bool) -> torch.Tensor:
-    """returns dw as an fp32 tensor with memory [Cout][k][k][Cin] (logical [Cout,Cin,k,k] channels_last)."""
+def direct_grad(param):
+    """The flat-arena gradient view of ``param`` when the HIP kernels may accumulate straight into it
+    (FlatAdamW marks its parameters; the arena is zeroed once per step by ``zero_grad``), else None."""
+    if getattr(param, '_vqk_direct_grad', False) and param.grad is not None:
+        return param.grad
+    return None
+
+
+def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None) -> torch.Tensor:
+    """dw as fp32 with memory [Cout][k][k][Cin] (logical [Cout,Cin,k,k] channels_last); ``out``: accumulate
+    into this (pre-existing) buffer instead of a fresh zeroed one."""
     n, cin, h, w = x.shape
     cout = dy.shape[1]
-    dw = torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    dw = out if out is not None else \
+        torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
     flops = 2.0 * n * dy.shape[2] * dy.shape[3] * cout * cin * ksize * ksize
     st = _timed(f'conv_wgrad_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
                 lambda: _native.lib().vqk_conv2d_wgrad(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h,
@@ -127,8 +137,8 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool) -> torch.Tensor:
     return dw
 
 
-def raw_colsum(x2d_rows: int, c: int, x) -> torch.Tensor:
-    out = torch.zeros(c, dtype=torch.float32, device=x.device)
+def raw_colsum(x2d_rows: int, c: int, x, out=None) -> torch.Tensor:
+    out = out if out is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     _native.check(_native.lib().vqk_colsum(dcode(x.dtype), x.data_ptr(), x2d_rows, c, out.data_ptr(), _stream()), 'colsum')
     return out
 
@@ -160,11 +170,11 @@ def raw_gn_apply(x, stats, w, b, groups: int, silu: bool) -> torch.Tensor:
     return y
 
 
-def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool):
+def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None):
     n, c, h, wd = x.shape
     dx = torch.empty_like(x, memory_format=_CL)
-    dw = torch.zeros(c, dtype=torch.float32, device=x.device)
-    db = torch.zeros(c, dtype=torch.float32, device=x.device)
+    dw = dw if dw is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
+    db = db if db is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     red = torch.zeros(n * groups * 2, dtype=torch.float64, device=x.device)
     st = _native.lib().vqk_gn_backward(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(), b.data_ptr(),
                                        dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), red.data_ptr(), n,
@@ -249,6 +259,7 @@ class Conv2dFn(torch.autograd.Function):
         res = nhwc(residual) if residual is not None else None
         y = raw_conv_fprop(x, wq, b32, res, k, ups, act, out_dtype, cout_pad, layout)
         ctx.save_for_backward(x, weight, y if act == 1 else None)
+        ctx.bias_ref, ctx.weight_ref = bias, weight
         ctx.cfg = (k, ups, act, o, i, cin, cout_pad, bias is not None, residual is not None, dt)
         return y
 
@@ -272,13 +283,19 @@ class Conv2dFn(torch.autograd.Function):
             dx = raw_conv_fprop(dyc, wt, None, None, k, False, 0, dt, cin, layout)
             if ups:
                 dx = raw_pool(dx, 1.0)
+        padded = cin != i or cout_pad != o
         if ctx.needs_input_grad[1]:
-            dw = raw_conv_wgrad(x, dyc, k, ups)
-            if cin != i or cout_pad != o:
+            tgt = None if padded else direct_grad(ctx.weight_ref)
+            dw = raw_conv_wgrad(x, dyc, k, ups, out=tgt)
+            if tgt is not None:
+                dw = None                                        # already accumulated in the flat arena
+            elif padded:
                 dw = dw[:o, :i]
         if has_bias and ctx.needs_input_grad[2]:
             n, c, h, w = dyc.shape
-            db = raw_colsum(n * h * w, c, dyc)[:o]
+            tgt = None if padded else direct_grad(ctx.bias_ref)
+            db = raw_colsum(n * h * w, c, dyc, out=tgt)
+            db = None if tgt is not None else db[:o]
         return dx, dw, db, dres, None, None, None
 
 
@@ -298,6 +315,7 @@ class GroupNormSiLUFn(torch.autograd.Function):
         stats = raw_gn_stats(x, groups, eps)
         y = raw_gn_apply(x, stats, w, b, groups, silu)
         ctx.save_for_backward(x, stats, w, b)
+        ctx.params = (weight, bias)
         ctx.cfg = (groups, silu, weight.shape, bias.shape)
         return y
 
@@ -305,7 +323,12 @@ class GroupNormSiLUFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, stats, w, b = ctx.saved_tensors
         groups, silu, wshape, bshape = ctx.cfg
-        dx, dw, db = raw_gn_backward(x, stats, w, b, nhwc(dy), groups, silu)
+        tw, tb = direct_grad(ctx.params[0]), direct_grad(ctx.params[1])
+        direct = tw is not None and tb is not None
+        dx, dw, db = raw_gn_backward(x, stats, w, b, nhwc(dy), groups, silu, tw if direct else None,
+                                     tb if direct else None)
+        if direct:
+            return dx, None, None, None, None, None
         return dx, dw.view(wshape), db.view(bshape), None, None, None
 
 

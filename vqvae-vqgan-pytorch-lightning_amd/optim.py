@@ -49,6 +49,7 @@ class FlatAdamW(torch.optim.Optimizer):
                         view = seg.view(p.shape)
                     if is_grad:
                         p.grad = view
+                        p._vqk_direct_grad = True     # ops.* may accumulate into the arena and skip AccumulateGrad
                     else:
                         view.copy_(p.data)
                         p.data = view

@@ -56,6 +56,50 @@ class MiniTrainer:
         self.global_step += 1
         return loss
 
+    # ------------------------------------------------------------------ hipGraph replay of forward + backward
+    def capture(self, model, example_batch, warmup: int = 3):
+        """Capture zero_grad + training_step + backward of ONE step into a hipGraph (shapes are static in
+        training) and replay it afterwards: the step is ~600 short kernel launches, which is host-bound when
+        issued one by one.  The gradient all-reduce and the AdamW launch stay outside the graph (one call
+        each), so schedules (lr) remain ordinary host scalars.  ``warmup`` eager steps run first (they DO
+        update the model) so that every lazy allocation / kernel attribute is settled before capture."""
+        opt = self.optimizers[0]
+        self._static_in = example_batch.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warmup):
+                self._eager_step(model, self._static_in, i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            opt.zero_grad()
+            self._static_loss = model.training_step(self._static_in, 0)
+            self._static_loss.backward()
+        self._static_hist = model.quantizer.last_hist
+        return self._graph
+
+    def _eager_step(self, model, batch, batch_index):
+        opt = self.optimizers[0]
+        opt.zero_grad()
+        loss = model.training_step(batch, batch_index)
+        loss.backward()
+        opt.all_reduce_grads()
+        opt.step()
+        return loss
+
+    def train_batch_graphed(self, model, batch, batch_index: int):
+        opt = self.optimizers[0]
+        model.on_train_batch_start(batch, batch_index)
+        if batch is not self._static_in:
+            self._static_in.copy_(batch, non_blocking=True)
+        self._graph.replay()
+        opt.all_reduce_grads()
+        opt.step()
+        self.global_step += 1
+        return self._static_loss
+
     def fit(self, model, batches: Iterable):
         batches = list(batches)
         if self.num_training_batches is None:
