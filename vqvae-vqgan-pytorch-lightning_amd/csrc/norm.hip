@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < V; ++i) { s[i] = 0.f; ss[i] = 0.f; }
     const T* base = x + (int64_t)n * hw * c + slot * V;
-#pragma unroll 4
+#pragma unroll 2
     for (int64_t p = p0 + prow; p < p1; p += pstep) {
         float v[V];
         Vec16<T>::load(base + p * c, v);
@@ -58,7 +58,9 @@ __global__ void gn_finalize_kernel(const double* __restrict__ acc, float* __rest
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+// sigmoid via v_exp_f32 + v_rcp_f32 (1 ulp): an IEEE division costs ~10 VALU ops and made these passes VALU-bound
+__device__ __forceinline__ float sigmoid_f(float y) { return __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
+__device__ __forceinline__ float silu_f(float y) { return y * sigmoid_f(y); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     const int64_t off = (int64_t)n * hw * c + slot * V;
-#pragma unroll 4
+#pragma unroll 2
     for (int64_t p = p0 + prow; p < p1; p += pstep) {
         float v[V];
         Vec16<T>::load(x + off + p * c, v);
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     const int64_t off = (int64_t)n * hw * c + slot * V;
-#pragma unroll 4
+#pragma unroll 2
     for (int64_t p = p0 + prow; p < p1; p += pstep) {
         float xv[V], gv[V];
         Vec16<T>::load(x + off + p * c, xv);
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
             float g = gv[i];
             if (silu) {
                 const float yv = __fmaf_rn(xh, wv[i], bv[i]);
-                const float sg = 1.0f / (1.0f + __expf(-yv));
+                const float sg = sigmoid_f(yv);
                 g *= sg * (1.0f + yv * (1.0f - sg));
             }
             a[i] += g;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     const int64_t off = (int64_t)n * hw * c + slot * V;
-#pragma unroll 4
+#pragma unroll 2
     for (int64_t p = p0 + prow; p < p1; p += pstep) {
         float xv[V], gv[V], ov[V];
         Vec16<T>::load(x + off + p * c, xv);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
             float g = gv[i];
             if (silu) {
                 const float yv = __fmaf_rn(xh, wv[i], bv[i]);
-                const float sg = 1.0f / (1.0f + __expf(-yv));
+                const float sg = sigmoid_f(yv);
                 g *= sg * (1.0f + yv * (1.0f - sg));
             }
             const float r = (g * wv[i] - k1[i] - xh * k2[i]) * rstd[i];
