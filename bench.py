@@ -32,7 +32,8 @@ MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, den
 
 def q_conf(qtype: str, k: int):
     params = {'standard': dict(commitment_cost=0.25),
-              'ema': dict(commitment_cost=0.25, decay=0.95, epsilon=1e-5)}[qtype]
+              'ema': dict(commitment_cost=0.25, decay=0.95, epsilon=1e-5),
+              'entropy': dict(commitment_cost=0.25, ent_loss_ratio=0.1, ent_temperature=0.01, ent_loss_type='softmax')}[qtype]
     return dict(num_embeddings=k, embedding_dim=256, reinit_every_n_epochs=None, type=qtype, params=params)
 
 
@@ -82,7 +83,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--image-size', type=int, default=256)
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
-    ap.add_argument('--quantizer', choices=['standard', 'ema'], default='standard')
+    ap.add_argument('--quantizer', choices=['standard', 'ema', 'entropy'], default='standard')
     ap.add_argument('--codebook', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)

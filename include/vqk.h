@@ -57,6 +57,19 @@ const char* vqk_arch(void);
 int vqk_row_sqnorm_f32(const float* x, int64_t rows, int d, float* out, void* stream);
 int vqk_vq_assign_f32(const float* z, const float* e, const float* z2, const float* e2,
                       int64_t n, int k, int d, int assoc, int64_t* idx, void* stream);
+/* Same search, additionally writing the full fp32 distance matrix dmat[N][K] (Entropy quantizer). */
+int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const float* e2,
+                         int64_t n, int k, int d, int assoc, int64_t* idx, float* dmat, void* stream);
+/* Entropy loss on dmat (vector_quantizers.py:296-328, 'softmax' type): per row lse[N], hrow[N] (sample entropies),
+ * hsum[0] += sum_i h_i, psum[K] += sum_i p_ik, u[K] = log(pbar+1e-5) + pbar/(pbar+1e-5), avg_term[0] += sum_k pbar
+ * log(pbar+1e-5) (pbar = psum/N).  hsum, psum, avg_term pre-zeroed.  loss_ent = ratio * (hsum/N + avg_term). */
+int vqk_entropy_forward_f32(const float* dmat, int64_t n, int k, float temperature, float* lse, float* hrow,
+                            float* hsum, float* psum, float* u, float* avg_term, void* stream);
+/* In place dmat <- dL_ent/dd (scaled by *gscale_dev): the cotangent that the two GEMMs turn into dz and dE. */
+int vqk_entropy_backward_f32(float* dmat, const float* lse, const float* hrow, const float* u, int64_t n, int k,
+                             float temperature, float ratio, const float* gscale_dev, void* stream);
+/* out[r][c] += a * scale[r] * m[r][c] */
+int vqk_row_scale_add_f32(float* out, const float* m, const float* scale, int64_t rows, int c, float a, void* stream);
 /* q = e[idx] (written as fp32 and, if q_lo != NULL, also as bf16), sse[0] += sum (q - z)^2,
  * hist[idx] += 1 (int32, optional).  sse must be zeroed by the caller. */
 int vqk_vq_gather_f32(const float* z, const float* e, const int64_t* idx, int64_t n, int k, int d,

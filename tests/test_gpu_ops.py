@@ -112,6 +112,42 @@ def test_vq_ema_module_trajectory(golden):
         close(dz, g[f'ema.dz{s}'], rtol=1e-5, atol=1e-7)
 
 
+def test_vq_entropy_module_golden(golden):
+    g = golden('vq')
+    q = vqm.EntropyVectorQuantizer(64, 16, 0.1, 0.01, 'softmax', 0.25).to(DEV)
+    with torch.no_grad():
+        q.codebook.weight.copy_(dev(g['ent.e']))
+    z = dev(g['ent.z']).requires_grad_(True)
+    qz, idx, loss = q(z)
+    assert np.array_equal(idx.cpu().numpy(), g['ent.idx'])
+    assert np.array_equal(q.vec_to_codes(z.detach()).cpu().numpy(), g['ent.idx'])
+    close(qz, g['ent.q'], rtol=1e-5, atol=1e-6)
+    close(loss, g['ent.loss'], rtol=2e-5, atol=1e-7)
+    dz, de = torch.autograd.grad([qz, loss], [z, q.codebook.weight], [dev(g['ent.dq']), torch.ones((), device=DEV)])
+    assert rel_err(dz, T(g['ent.dz'])) < 2e-4
+    assert rel_err(de, T(g['ent.de'])) < 2e-4
+
+
+def test_vq_entropy_large_vs_oracle():
+    """K = 1024, N = 2048, D = 256 (config-5-like aspect, bounded for the CPU oracle): loss and both gradients"""
+    g = torch.Generator().manual_seed(77)
+    z = (torch.randn(8, 256, 16, 16, generator=g) * 0.05)
+    e = (torch.randn(1024, 256, generator=g) * 0.05)
+    zr, er = z.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    qr, idxr, lossr = O.vq_entropy(zr, er, 0.25, 0.1, 0.01)
+    dq = torch.randn(qr.shape, generator=g) * 1e-3
+    gz, ge = torch.autograd.grad([qr, lossr], [zr, er], [dq, torch.tensor(1.0)])
+    q = vqm.EntropyVectorQuantizer(1024, 256, 0.1, 0.01, 'softmax', 0.25).to(DEV)
+    with torch.no_grad():
+        q.codebook.weight.copy_(dev(e))
+    zd = dev(z).requires_grad_(True)
+    qz, idx, loss = q(zd)
+    assert (idx.cpu() != idxr).float().mean() < 2e-3
+    close(loss, lossr, rtol=1e-4, atol=1e-6)
+    dz, de = torch.autograd.grad([qz, loss], [zd, q.codebook.weight], [dev(dq), torch.ones((), device=DEV)])
+    assert rel_err(dz, gz) < 1e-3 and rel_err(de, ge) < 1e-3
+
+
 # ------------------------------------------------------------------------------------------ conv
 CONV_CASES = [
     # n, cin, cout, h, w, k, ups, bias, residual

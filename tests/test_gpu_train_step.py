@@ -17,7 +17,8 @@ T = torch.from_numpy
 
 AE = dict(channels=32, num_res_blocks=1, channel_multipliers=(1, 2))
 TC = dict(lr=1e-4, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
-QP = {'standard': dict(commitment_cost=0.25), 'ema': dict(commitment_cost=0.25, decay=0.95, epsilon=1e-5)}
+QP = {'standard': dict(commitment_cost=0.25), 'ema': dict(commitment_cost=0.25, decay=0.95, epsilon=1e-5),
+      'entropy': dict(commitment_cost=0.25, ent_loss_ratio=0.1, ent_temperature=0.01, ent_loss_type='softmax')}
 
 
 def rel(a, b, floor=1e-7):
@@ -45,7 +46,7 @@ def build(golden, qtype, dtype=torch.float32):
     return base, g, m.to(DEV).train()
 
 
-@pytest.mark.parametrize('qtype', ['standard', 'ema'])
+@pytest.mark.parametrize('qtype', ['standard', 'ema', 'entropy'])
 def test_train_step_fp32_golden(golden, qtype):
     base, g, m = build(golden, qtype)
     tr = trainer_mod.MiniTrainer(num_training_batches=1)

@@ -27,6 +27,10 @@ I, L, F = c_int, c_int64, c_float
 _PROTOS = {
     'vqk_row_sqnorm_f32': [P, L, I, P, P],
     'vqk_vq_assign_f32': [P, P, P, P, L, I, I, I, P, P],
+    'vqk_vq_distances_f32': [P, P, P, P, L, I, I, I, P, P, P],
+    'vqk_entropy_forward_f32': [P, L, I, F, P, P, P, P, P, P, P],
+    'vqk_entropy_backward_f32': [P, P, P, P, L, I, F, F, P, P],
+    'vqk_row_scale_add_f32': [P, P, P, L, I, F, P],
     'vqk_vq_gather_f32': [P, P, P, L, I, I, P, P, P, P, P],
     'vqk_vq_backward_f32': [P, P, P, P, I, L, I, I, F, F, P, P, P, P],
     'vqk_ema_stats_f32': [P, P, L, I, I, P, P, P],

@@ -1,0 +1,147 @@
+// Entropy (MaskGIT-style) quantizer loss, vqvae/modules/vector_quantizers.py:296-356 of the reference, on the
+// materialised fp32 distance matrix d[N][K] (vqk_vq_distances_f32):
+//   a = -d/T, p = softmax_k(a), h_i = -sum_k p log p, pbar_k = mean_i p_ik,
+//   L_ent = ratio * (mean_i h_i + sum_k pbar_k log(pbar_k + 1e-5))
+// and its backward:  u_k = log(pbar_k+1e-5) + pbar_k/(pbar_k+1e-5), ubar_i = sum_k p_ik u_k,
+//   dL/dd_ik = -(1/T) * ratio/N * p_ik * ( -(log p_ik + h_i) + (u_k - ubar_i) )
+// dz / dE then follow from two fp32 GEMMs that reuse the 1x1 conv kernels (ops.py).
+// One wavefront per row for the row passes (K up to tens of thousands), fp32 throughout.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// lse_i = logsumexp_k(a_ik), h_i = lse_i - sum_k p_ik a_ik ; hsum += sum_i h_i
+__global__ __launch_bounds__(256) void entropy_rows_kernel(const float* __restrict__ dmat, int64_t n, int k, float inv_t,
+                                                           float* __restrict__ lse, float* __restrict__ hrow,
+                                                           float* __restrict__ hsum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* dr = dmat + row * k;
+    float m = -INFINITY;
+    for (int c = lane; c < k; c += 64) m = fmaxf(m, -dr[c] * inv_t);
+    m = wave_max(m);
+    float s = 0.f, sa = 0.f;
+    for (int c = lane; c < k; c += 64) {
+        const float a = -dr[c] * inv_t;
+        const float ex = __expf(a - m);
+        s += ex;
+        sa = __fmaf_rn(ex, a, sa);
+    }
+    s = wave_sum(s);
+    sa = wave_sum(sa);
+    if (lane == 0) {
+        const float l = m + __logf(s);
+        const float h = l - sa / s;
+        lse[row] = l;
+        hrow[row] = h;
+        atomicAdd(hsum, h);
+    }
+}
+
+// psum[k] += sum over a slab of rows of p_ik  (thread = column, loop over the slab's rows)
+__global__ __launch_bounds__(256) void entropy_colsum_kernel(const float* __restrict__ dmat, const float* __restrict__ lse,
+                                                             int64_t n, int k, float inv_t, int rows_per_block,
+                                                             float* __restrict__ psum) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= k) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(n, r0 + rows_per_block);
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc += __expf(-dmat[r * k + col] * inv_t - lse[r]);
+    atomicAdd(psum + col, acc);
+}
+
+// pbar = psum/N ; u_k ; loss_terms[0] = sum_k pbar log(pbar + eps)
+__global__ __launch_bounds__(256) void entropy_finalize_kernel(const float* __restrict__ psum, int k, float inv_n,
+                                                               float* __restrict__ u, float* __restrict__ avg_term) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < k; c += gridDim.x * 256) {
+        const float pb = psum[c] * inv_n;
+        const float lg = __logf(pb + 1e-5f);
+        acc = __fmaf_rn(pb, lg, acc);
+        u[c] = lg + pb / (pb + 1e-5f);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(avg_term, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// in place: d_ik <- dd_ik = coef * p_ik * ( -(log p_ik + h_i) + (u_k - ubar_i) ),  coef = -gs*ratio/(N*T)
+__global__ __launch_bounds__(256) void entropy_dd_kernel(float* __restrict__ dmat, const float* __restrict__ lse,
+                                                         const float* __restrict__ hrow, const float* __restrict__ u,
+                                                         int64_t n, int k, float inv_t, float coef,
+                                                         const float* __restrict__ gs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    if (gs) coef *= *gs;
+    float* dr = dmat + row * k;
+    const float l = lse[row], h = hrow[row];
+    float ub = 0.f;
+    for (int c = lane; c < k; c += 64) ub = __fmaf_rn(__expf(-dr[c] * inv_t - l), u[c], ub);
+    ub = wave_sum(ub);
+    for (int c = lane; c < k; c += 64) {
+        const float lp = -dr[c] * inv_t - l;
+        const float p = __expf(lp);
+        dr[c] = coef * p * (-(lp + h) + (u[c] - ub));
+    }
+}
+
+// out[r][c] += a * scale[r] * m[r][c]
+__global__ __launch_bounds__(256) void row_scale_add_kernel(float* __restrict__ out, const float* __restrict__ m,
+                                                            const float* __restrict__ scale, int64_t rows, int c,
+                                                            float a) {
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        out[i] = __fmaf_rn(a * scale[i / c], m[i], out[i]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqk_entropy_forward_f32(const float* dmat, int64_t n, int k, float temperature, float* lse, float* hrow, float* hsum,
+                            float* psum, float* u, float* avg_term, void* stream) {
+    VQK_REQUIRE(dmat && lse && hrow && hsum && psum && u && avg_term, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && k > 0 && temperature > 0.f, VQK_ERR_SHAPE);
+    hipStream_t st = vqk_stream(stream);
+    const float inv_t = 1.0f / temperature;
+    hipLaunchKernelGGL(entropy_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, dmat, n, k, inv_t, lse, hrow, hsum);
+    int rpb = (int)((n + 255) / 256); if (rpb < 16) rpb = 16;
+    const dim3 grid((unsigned)((k + 255) / 256), (unsigned)((n + rpb - 1) / rpb));
+    hipLaunchKernelGGL(entropy_colsum_kernel, grid, dim3(256), 0, st, dmat, lse, n, k, inv_t, rpb, psum);
+    hipLaunchKernelGGL(entropy_finalize_kernel, dim3(vqk_grid_1d(k, 256, 64)), dim3(256), 0, st, psum, k, 1.0f / (float)n, u, avg_term);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_entropy_backward_f32(float* dmat, const float* lse, const float* hrow, const float* u, int64_t n, int k,
+                             float temperature, float ratio, const float* gscale_dev, void* stream) {
+    VQK_REQUIRE(dmat && lse && hrow && u, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && k > 0 && temperature > 0.f, VQK_ERR_SHAPE);
+    const float coef = -ratio / ((float)n * temperature);
+    hipLaunchKernelGGL(entropy_dd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, vqk_stream(stream), dmat, lse, hrow, u,
+                       n, k, 1.0f / temperature, coef, gscale_dev);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_row_scale_add_f32(float* out, const float* m, const float* scale, int64_t rows, int c, float a, void* stream) {
+    VQK_REQUIRE(out && m && scale, VQK_ERR_ARG);
+    VQK_REQUIRE(rows >= 0 && c > 0, VQK_ERR_SHAPE);
+    if (rows == 0) return VQK_OK;
+    hipLaunchKernelGGL(row_scale_add_kernel, dim3(vqk_grid_1d(rows * c, 256)), dim3(256), 0, vqk_stream(stream), out, m, scale, rows, c, a);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+}  // extern "C"

@@ -27,10 +27,11 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
 // and 16 codes of the tile, so the running (min, argmin) is lane-local; k is consumed in the order
 // 8m+{0,4,1,5,2,6,3,7} because lane (., half) holds the float4 at k = 8m + 4*half.
 // ------------------------------------------------------------------------------------------------
-template <int ASSOC>
+template <int ASSOC, bool WRITE_D>
 __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict__ z, const float* __restrict__ e,
                                                         const float* __restrict__ z2, const float* __restrict__ e2,
-                                                        int64_t n, int k, int d, int64_t* __restrict__ idx) {
+                                                        int64_t n, int k, int d, int64_t* __restrict__ idx,
+                                                        float* __restrict__ dmat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* zt = reinterpret_cast<float*>(smem);                 // [32][d + 4]
     const int ld = d + 4;
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
                 if (ASSOC == 0) dist = __fsub_rn(__fadd_rn(zz, e2[code]), ab2);
                 else            dist = __fadd_rn(__fsub_rn(zz, ab2), e2[code]);
                 if (dist < best) { best = dist; best_i = code; }
+                if (WRITE_D && n0 + j < n) dmat[(n0 + j) * (int64_t)k + code] = dist;
             }
         }
     }
@@ -211,12 +213,28 @@ int vqk_vq_assign_f32(const float* z, const float* e, const float* z2, const flo
     VQK_REQUIRE(lds <= 160 * 1024, VQK_ERR_SHAPE);
     const dim3 grid((unsigned)((n + 31) / 32));
     if (assoc == 0) {
-        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)vq_assign_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(vq_assign_kernel<0>, grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx);
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)vq_assign_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((vq_assign_kernel<0, false>), grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx, (float*)nullptr);
     } else {
-        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)vq_assign_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(vq_assign_kernel<1>, grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx);
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)vq_assign_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((vq_assign_kernel<1, false>), grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx, (float*)nullptr);
     }
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const float* e2, int64_t n, int k, int d,
+                         int assoc, int64_t* idx, float* dmat, void* stream) {
+    VQK_REQUIRE(z && e && z2 && e2 && idx && dmat, VQK_ERR_ARG);
+    VQK_REQUIRE(n >= 0 && k > 0 && d > 0 && (d % 8) == 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(assoc == 0 || assoc == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(z) && vqk_aligned16(e), VQK_ERR_ALIGN);
+    if (n == 0) return VQK_OK;
+    const size_t lds = (size_t)32 * (d + 4) * 4 + 128 * 4 + 128 * 4;
+    VQK_REQUIRE(lds <= 64 * 1024, VQK_ERR_SHAPE);
+    const dim3 grid((unsigned)((n + 31) / 32));
+    if (assoc == 0) hipLaunchKernelGGL((vq_assign_kernel<0, true>), grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx, dmat);
+    else hipLaunchKernelGGL((vq_assign_kernel<1, true>), grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx, dmat);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

@@ -24,7 +24,7 @@ from torch import nn
 from . import ops
 from .modules.abstract_modules.base_autoencoder import BaseVQVAE
 from .modules.autoencoder import Decoder, Encoder, GroupNorm, Conv2d, set_compute_dtype
-from .modules.vector_quantizers import EMAVectorQuantizer, VectorQuantizer
+from .modules.vector_quantizers import EMAVectorQuantizer, EntropyVectorQuantizer, VectorQuantizer
 from .optim import FlatAdamW
 from .schedulers import CosineScheduler, LinearCosineScheduler, LinearScheduler
 
@@ -71,8 +71,12 @@ class VQVAE(BaseVQVAE, _LightningBase):
         elif qt == 'ema':
             self.quantizer = EMAVectorQuantizer(self.cb_size, self.latent_dim, float(qp['commitment_cost']),
                                                 float(qp['decay']), float(qp['epsilon']))
-        elif qt in ('gumbel', 'entropy'):
-            raise NotImplementedError(f'quantizer type {qt!r}: SURVEY 8 row A10/A11, not built yet (see DESIGN.md)')
+        elif qt == 'entropy':
+            self.quantizer = EntropyVectorQuantizer(self.cb_size, self.latent_dim, float(qp['ent_loss_ratio']),
+                                                    float(qp['ent_temperature']), str(qp['ent_loss_type']),
+                                                    float(qp['commitment_cost']))
+        elif qt == 'gumbel':
+            raise NotImplementedError("quantizer type 'gumbel': SURVEY 8 row A10, not built yet (see DESIGN.md)")
         else:
             raise ValueError(f'unrecognized quantizer: {qt}')
 

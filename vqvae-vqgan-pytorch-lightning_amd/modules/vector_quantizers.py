@@ -1,5 +1,6 @@
 """Quantizers on the vqk kernels; same classes / ctor signatures / return conventions as the reference's
-``vqvae/modules/vector_quantizers.py`` (VectorQuantizer :8-84, EMAVectorQuantizer :87-203).
+``vqvae/modules/vector_quantizers.py`` (VectorQuantizer :8-84, EMAVectorQuantizer :87-203,
+EntropyVectorQuantizer :277-381).
 
 The nearest-codeword search is one exact-fp32 MFMA kernel that never materialises the [N,K] distance
 matrix or a one-hot; the reference's association order of the three distance terms is kept so that the
@@ -63,3 +64,27 @@ class EMAVectorQuantizer(BaseVectorQuantizer):
     def vec_to_codes(self, x: torch.Tensor) -> torch.Tensor:
         z = ops.nhwc(x.to(torch.float32))
         return ops.vq_assign(_flat_view(z), self.codebook.weight.detach().contiguous(), 0).view(x.shape[0], -1)
+
+
+class EntropyVectorQuantizer(BaseVectorQuantizer):
+    def __init__(self, num_embeddings: int, embedding_dim: int, ent_loss_ratio: float = 0.1,
+                 ent_temperature: float = 0.01, ent_loss_type: str = 'softmax', commitment_cost: float = 0.25):
+        super().__init__(num_embeddings, embedding_dim)
+        if ent_loss_type != 'softmax':
+            raise NotImplementedError("ent_loss_type 'argmax' (straight-through one-hot targets) is not built; the "
+                                      "reference configs use 'softmax' (example_confs/entropy_vqvae.yaml)")
+        self.ent_loss_ratio = ent_loss_ratio
+        self.ent_temperature = ent_temperature
+        self.ent_loss_type = ent_loss_type
+        self.commitment_cost = commitment_cost
+
+    def forward(self, x: torch.Tensor):
+        q, idx, loss, hist = ops.EntropyVQFn.apply(x, self.codebook.weight, self.commitment_cost, self.ent_loss_ratio,
+                                                   self.ent_temperature, self.compute_dtype)
+        self.last_hist = hist
+        return q, idx, loss
+
+    @torch.no_grad()
+    def vec_to_codes(self, x: torch.Tensor) -> torch.Tensor:
+        z = ops.nhwc(x.to(torch.float32))
+        return ops.vq_assign(_flat_view(z), self.codebook.weight.detach().contiguous(), 1).view(x.shape[0], -1)

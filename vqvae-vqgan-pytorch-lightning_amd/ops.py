@@ -457,6 +457,85 @@ class VQLookupFn(torch.autograd.Function):
         return dz, de, None, None, None, None
 
 
+class EntropyVQFn(torch.autograd.Function):
+    """Entropy-regularised lookup (vector_quantizers.py:290-356, ent_loss_type='softmax'):
+    loss = beta*mse(q.detach(), z) + mse(q, z.detach()) + ratio*(mean_i H(p_i) - H(mean_i p_i)),  p = softmax(-d/T).
+    The fp32 distance matrix is materialised once (N*K*4 bytes: 0.5 GB at N=16384, K=8192, against 288 GB of
+    HBM) and overwritten in place by its cotangent in backward; dz / dE come from two fp32-MFMA GEMMs that
+    reuse the 1x1 conv kernels.  Returns (q, idx [B,HW], loss, hist)."""
+
+    @staticmethod
+    def forward(ctx, z, codebook, beta: float, ratio: float, temperature: float, out_dtype):
+        _require_gpu(z)
+        z = nhwc(z.to(torch.float32))
+        b, d, h, w = z.shape
+        n = b * h * w
+        cb = codebook.detach().contiguous()
+        k = cb.shape[0]
+        if k % 4:
+            raise RuntimeError('vqk: entropy quantizer needs num_embeddings % 4 == 0')
+        flat = z.permute(0, 2, 3, 1).reshape(n, d)
+        lib, st, dev = _native.lib(), _stream(), z.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        z2, e2 = torch.empty(n, **f32), torch.empty(k, **f32)
+        idx = torch.empty(n, dtype=torch.int64, device=dev)
+        dmat = torch.empty((n, k), **f32)
+        _native.check(lib.vqk_row_sqnorm_f32(flat.data_ptr(), n, d, z2.data_ptr(), st), 'row_sqnorm(z)')
+        _native.check(lib.vqk_row_sqnorm_f32(cb.data_ptr(), k, d, e2.data_ptr(), st), 'row_sqnorm(e)')
+        _native.check(lib.vqk_vq_distances_f32(flat.data_ptr(), cb.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d, 1,
+                                               idx.data_ptr(), dmat.data_ptr(), st), 'vq_distances')
+        q32 = empty_nhwc(b, d, h, w, torch.float32, dev)
+        qlo = empty_nhwc(b, d, h, w, torch.bfloat16, dev) if out_dtype == torch.bfloat16 else None
+        scal = torch.zeros(3, **f32)                           # sse, hsum, avg_term
+        hist = torch.zeros(k, dtype=torch.int32, device=dev)
+        _native.check(lib.vqk_vq_gather_f32(flat.data_ptr(), cb.data_ptr(), idx.data_ptr(), n, k, d, q32.data_ptr(),
+                                            _p(qlo), scal[0:1].data_ptr(), hist.data_ptr(), st), 'vq_gather')
+        lse, hrow = torch.empty(n, **f32), torch.empty(n, **f32)
+        psum, u = torch.zeros(k, **f32), torch.empty(k, **f32)
+        _native.check(lib.vqk_entropy_forward_f32(dmat.data_ptr(), n, k, temperature, lse.data_ptr(), hrow.data_ptr(),
+                                                  scal[1:2].data_ptr(), psum.data_ptr(), u.data_ptr(),
+                                                  scal[2:3].data_ptr(), st), 'entropy_forward')
+        mse = scal[0] / float(n * d)
+        loss = beta * mse + mse + (scal[1] / float(n) + scal[2]) * ratio
+        ctx.save_for_backward(z, cb, idx, dmat, lse, hrow, u)
+        ctx.cfg = (beta, ratio, temperature, n, k, d)
+        ctx.mark_non_differentiable(idx, hist)
+        return (qlo if qlo is not None else q32), idx.view(b, h * w), loss, hist
+
+    @staticmethod
+    def backward(ctx, dq, _didx, dloss, _dhist):
+        z, cb, idx, dmat, lse, hrow, u = ctx.saved_tensors
+        beta, ratio, temperature, n, k, d = ctx.cfg
+        lib, st = _native.lib(), _stream()
+        flat = z.permute(0, 2, 3, 1).reshape(n, d)
+        gs = dloss.to(torch.float32).contiguous() if dloss is not None else None
+        dqc = nhwc(dq) if dq is not None else None
+        scale = 2.0 / float(n * d) if gs is not None else 0.0
+        dz = torch.empty_like(z, memory_format=_CL)
+        de = torch.zeros_like(cb)
+        _native.check(lib.vqk_vq_backward_f32(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), _p(dqc),
+                                              dcode(dqc.dtype) if dqc is not None else F32, n, k, d, beta * scale, scale,
+                                              _p(gs), dz.data_ptr(), de.data_ptr(), st), 'vq_backward')
+        if gs is None:
+            return dz, de, None, None, None, None
+        # dmat <- dL_ent/dd  (rows sum to zero)
+        _native.check(lib.vqk_entropy_backward_f32(dmat.data_ptr(), lse.data_ptr(), hrow.data_ptr(), u.data_ptr(), n, k,
+                                                   temperature, ratio, gs.data_ptr(), st), 'entropy_backward')
+        dd = dmat.view(1, n, 1, k).permute(0, 3, 1, 2)            # [1, K, N, 1] logical, [N][K] memory (NHWC)
+        # dz += -2 dd @ E      (1x1 conv: pixels = rows of dd, Cin = K, Cout = D, weight [D][K] = E^T)
+        et = cb.t().contiguous()
+        g1 = raw_conv_fprop(dd, et, None, None, 1, False, 0, torch.float32, d, 0)        # [1, D, N, 1] -> memory [N][D]
+        _native.check(lib.vqk_axpby(F32, g1.data_ptr(), dz.data_ptr(), dz.data_ptr(), -2.0, 1.0, n * d, st), 'axpby')
+        # dE += -2 dd^T @ Z + 2 E * colsum(dd)   (1x1 wgrad: contraction over the N rows)
+        zimg = flat.view(1, n, 1, d).permute(0, 3, 1, 2)
+        g2 = raw_conv_wgrad(zimg, dd, 1, False)                                           # memory [K][D]
+        g2 = g2.permute(0, 2, 3, 1).reshape(k, d)
+        _native.check(lib.vqk_axpby(F32, g2.data_ptr(), de.data_ptr(), de.data_ptr(), -2.0, 1.0, k * d, st), 'axpby')
+        cs = raw_colsum(n, k, dmat)
+        _native.check(lib.vqk_row_scale_add_f32(de.data_ptr(), cb.data_ptr(), cs.data_ptr(), k, d, 2.0, st), 'row_scale_add')
+        return dz, de, None, None, None, None
+
+
 def ema_update(flat_z, idx, ema_count, ema_weight, codebook, decay: float, eps: float, batch: float, reduce_fn=None):
     """EMA statistics + update in place (vector_quantizers.py:159-169).  ``reduce_fn(buf)`` sums the
     packed [counts | dw] buffer over ranks (one small all-reduce)."""
