@@ -70,6 +70,14 @@ int vqk_entropy_backward_f32(float* dmat, const float* lse, const float* hrow, c
                              float temperature, float ratio, const float* gscale_dev, void* stream);
 /* out[r][c] += a * scale[r] * m[r][c] */
 int vqk_row_scale_add_f32(float* out, const float* m, const float* scale, int64_t rows, int c, float a, void* stream);
+/* Gumbel-softmax rows (vector_quantizers.py:232-243): y = softmax((logits - log(noise))/tau) [hard: one-hot of its
+ * argmax] written as `dtype`, idx = argmax y, klsum[0] += sum_i sum_n qy log(qy*K + 1e-10), qy = softmax(logits).
+ * noise ~ Exp(1) is drawn by the caller (the reference's F.gumbel_softmax draws the same tensor first). */
+int vqk_gumbel_forward(int dtype, const float* logits, const float* noise, int64_t n, int k, float tau, int hard,
+                       void* y, int64_t* idx, float* klsum, int32_t* hist /* optional */, void* stream);
+/* dlogits = y (dy - <y,dy>)/tau + s*(kl_cost/n) qy (r - <qy,r>), s = *gscale_dev (soft sample path). */
+int vqk_gumbel_backward(int dtype, const float* logits, const float* noise, const void* dy, int64_t n, int k,
+                        float tau, float kl_cost, const float* gscale_dev, float* dlogits, void* stream);
 /* q = e[idx] (written as fp32 and, if q_lo != NULL, also as bf16), sse[0] += sum (q - z)^2,
  * hist[idx] += 1 (int32, optional).  sse must be zeroed by the caller. */
 int vqk_vq_gather_f32(const float* z, const float* e, const int64_t* idx, int64_t n, int k, int d,

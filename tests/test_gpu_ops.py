@@ -128,6 +128,29 @@ def test_vq_entropy_module_golden(golden):
     assert rel_err(de, T(g['ent.de'])) < 2e-4
 
 
+def test_vq_gumbel_module_golden(golden):
+    g = golden('vq')
+    q = vqm.GumbelVectorQuantizer(32, 8, False, 0.7, 5e-4).to(DEV)
+    with torch.no_grad():
+        q.codebook.weight.copy_(dev(g['gum.e']))
+        q.x_to_logits.weight.copy_(dev(g['gum.w']))
+        q.x_to_logits.bias.copy_(dev(g['gum.b']))
+    q.train()
+    x = dev(g['gum.x']).requires_grad_(True)
+    qz, idx, loss = q(x, exp_noise=dev(g['gum.noise']))
+    assert np.array_equal(idx.cpu().numpy(), g['gum.idx'])
+    close(qz, g['gum.q'], rtol=1e-4, atol=1e-6)
+    close(loss, g['gum.loss'], rtol=1e-4, atol=1e-9)
+    gr = torch.autograd.grad([qz, loss], [x, q.codebook.weight, q.x_to_logits.weight, q.x_to_logits.bias],
+                             [dev(g['gum.dq']), torch.ones((), device=DEV)])
+    for a, key in zip(gr, ('gum.dx', 'gum.de', 'gum.dw', 'gum.db')):
+        assert rel_err(a, T(g[key])) < 2e-4, key
+    # hard (straight-through) forward picks exactly one code per position
+    q.eval()
+    qh, idxh, _ = q(x.detach(), exp_noise=dev(g['gum.noise']))
+    close(qh, q.codebook.weight.detach()[idxh].permute(0, 3, 1, 2), rtol=1e-6, atol=1e-7)
+
+
 def test_vq_entropy_large_vs_oracle():
     """K = 1024, N = 2048, D = 256 (config-5-like aspect, bounded for the CPU oracle): loss and both gradients"""
     g = torch.Generator().manual_seed(77)

@@ -145,3 +145,130 @@ int vqk_row_scale_add_f32(float* out, const float* m, const float* scale, int64_
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Gumbel-softmax quantizer rows, vqvae/modules/vector_quantizers.py:223-245 of the reference:
+//   y = softmax((logits + g)/tau), g = -log(noise), noise ~ Exp(1) (drawn by the caller);
+//   qy = softmax(logits); kl_i = sum_n qy log(qy*K + 1e-10); idx = argmax y (first maximum).
+// backward: dlogits = y (dy - sum y dy)/tau + (klc/M) qy (r - sum qy r),
+//   r = log(qy K + 1e-10) + qy K / (qy K + 1e-10).
+// One wavefront per row; logits fp32; y / dy in the GEMM dtype T.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void gumbel_rows_fwd_kernel(const float* __restrict__ logits,
+                                                              const float* __restrict__ noise, int64_t n, int k,
+                                                              float inv_tau, int hard, T* __restrict__ y,
+                                                              int64_t* __restrict__ idx, float* __restrict__ klsum,
+                                                              int32_t* __restrict__ hist) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* lr = logits + row * k;
+    const float* nr = noise + row * k;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int am = 0x7fffffff;
+    for (int c = lane; c < k; c += 64) {
+        const float t = (lr[c] - __logf(nr[c])) * inv_tau;
+        if (t > m1) { m1 = t; am = c; }
+        m2 = fmaxf(m2, lr[c]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float o = __shfl_xor(m1, off, 64);
+        const int oi = __shfl_xor(am, off, 64);
+        if (o > m1 || (o == m1 && oi < am)) { m1 = o; am = oi; }
+    }
+    m2 = wave_max(m2);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < k; c += 64) {
+        s1 += __expf((lr[c] - __logf(nr[c])) * inv_tau - m1);
+        s2 += __expf(lr[c] - m2);
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const float r1 = 1.0f / s1, r2 = 1.0f / s2;
+    float kl = 0.f;
+    for (int c = lane; c < k; c += 64) {
+        const float yv = __expf((lr[c] - __logf(nr[c])) * inv_tau - m1) * r1;
+        const float qy = __expf(lr[c] - m2) * r2;
+        kl = __fmaf_rn(qy, __logf(qy * (float)k + 1e-10f), kl);
+        Elem<T>::st(y + row * k + c, hard ? (c == am ? 1.0f : 0.0f) : yv);
+    }
+    kl = wave_sum(kl);
+    if (lane == 0) { idx[row] = am; atomicAdd(klsum, kl); if (hist) atomicAdd(hist + am, 1); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gumbel_rows_bwd_kernel(const float* __restrict__ logits,
+                                                              const float* __restrict__ noise, const T* __restrict__ dy,
+                                                              int64_t n, int k, float inv_tau, float klc_over_m,
+                                                              const float* __restrict__ gs, float* __restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    if (gs) klc_over_m *= *gs;
+    const float* lr = logits + row * k;
+    const float* nr = noise + row * k;
+    const T* dr = dy + row * k;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (int c = lane; c < k; c += 64) {
+        m1 = fmaxf(m1, (lr[c] - __logf(nr[c])) * inv_tau);
+        m2 = fmaxf(m2, lr[c]);
+    }
+    m1 = wave_max(m1); m2 = wave_max(m2);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < k; c += 64) {
+        s1 += __expf((lr[c] - __logf(nr[c])) * inv_tau - m1);
+        s2 += __expf(lr[c] - m2);
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const float r1 = 1.0f / s1, r2 = 1.0f / s2;
+    float ydy = 0.f, qr = 0.f;
+    for (int c = lane; c < k; c += 64) {
+        const float yv = __expf((lr[c] - __logf(nr[c])) * inv_tau - m1) * r1;
+        const float qy = __expf(lr[c] - m2) * r2;
+        const float qk = qy * (float)k;
+        ydy = __fmaf_rn(yv, Elem<T>::ld(dr + c), ydy);
+        qr = __fmaf_rn(qy, __logf(qk + 1e-10f) + qk / (qk + 1e-10f), qr);
+    }
+    ydy = wave_sum(ydy); qr = wave_sum(qr);
+    for (int c = lane; c < k; c += 64) {
+        const float yv = __expf((lr[c] - __logf(nr[c])) * inv_tau - m1) * r1;
+        const float qy = __expf(lr[c] - m2) * r2;
+        const float qk = qy * (float)k;
+        const float r = __logf(qk + 1e-10f) + qk / (qk + 1e-10f);
+        dlogits[row * k + c] = yv * (Elem<T>::ld(dr + c) - ydy) * inv_tau + klc_over_m * qy * (r - qr);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqk_gumbel_forward(int dtype, const float* logits, const float* noise, int64_t n, int k, float tau, int hard, void* y,
+                       int64_t* idx, float* klsum, int32_t* hist, void* stream) {
+    VQK_REQUIRE(logits && noise && y && idx && klsum, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && k > 0 && tau > 0.f, VQK_ERR_SHAPE);
+    const dim3 grid((unsigned)((n + 3) / 4));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(gumbel_rows_fwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, n, k, 1.0f / tau, hard, (float*)y, idx, klsum, hist);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(gumbel_rows_fwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, n, k, 1.0f / tau, hard, (bf16_raw*)y, idx, klsum, hist);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_gumbel_backward(int dtype, const float* logits, const float* noise, const void* dy, int64_t n, int k, float tau,
+                        float kl_cost, const float* gscale_dev, float* dlogits, void* stream) {
+    VQK_REQUIRE(logits && noise && dy && dlogits, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && k > 0 && tau > 0.f, VQK_ERR_SHAPE);
+    const dim3 grid((unsigned)((n + 3) / 4));
+    const float c = kl_cost / (float)n;
+    if (dtype == VQK_F32) hipLaunchKernelGGL(gumbel_rows_bwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, (const float*)dy, n, k, 1.0f / tau, c, gscale_dev, dlogits);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(gumbel_rows_bwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, (const bf16_raw*)dy, n, k, 1.0f / tau, c, gscale_dev, dlogits);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+}  // extern "C"

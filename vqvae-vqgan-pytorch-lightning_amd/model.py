@@ -24,7 +24,8 @@ from torch import nn
 from . import ops
 from .modules.abstract_modules.base_autoencoder import BaseVQVAE
 from .modules.autoencoder import Decoder, Encoder, GroupNorm, Conv2d, set_compute_dtype
-from .modules.vector_quantizers import EMAVectorQuantizer, EntropyVectorQuantizer, VectorQuantizer
+from .modules.vector_quantizers import (EMAVectorQuantizer, EntropyVectorQuantizer, GumbelVectorQuantizer,
+                                        VectorQuantizer)
 from .optim import FlatAdamW
 from .schedulers import CosineScheduler, LinearCosineScheduler, LinearScheduler
 
@@ -76,12 +77,16 @@ class VQVAE(BaseVQVAE, _LightningBase):
                                                     float(qp['ent_temperature']), str(qp['ent_loss_type']),
                                                     float(qp['commitment_cost']))
         elif qt == 'gumbel':
-            raise NotImplementedError("quantizer type 'gumbel': SURVEY 8 row A10, not built yet (see DESIGN.md)")
+            self.quantizer = GumbelVectorQuantizer(self.cb_size, self.latent_dim, bool(qp['straight_through']),
+                                                   float(qp['temp']), float(qp['kl_cost']))
+            self.kl_warmup_epochs = qp.get('kl_warmup_epochs')
+            self.temp_decay_epochs = qp.get('temp_decay_epochs')
+            self.temp_final = qp.get('temp_final')
         else:
             raise ValueError(f'unrecognized quantizer: {qt}')
 
         ch, nrb, mult = ae_conf['channels'], ae_conf['num_res_blocks'], tuple(ae_conf['channel_multipliers'])
-        self.encoder = Encoder(ch, nrb, mult, self.latent_dim)
+        self.encoder = Encoder(ch, nrb, mult, self.cb_size if qt == 'gumbel' else self.latent_dim)   # model.py:130
         self.decoder = Decoder(ch, nrb, mult, self.latent_dim)
 
         if load_loss:
@@ -115,6 +120,12 @@ class VQVAE(BaseVQVAE, _LightningBase):
             self.scheduler = LinearScheduler(0, wu * nb, 1e-20, lr)
         elif de is not None:
             self.scheduler = CosineScheduler(0, de * nb, lr, lr / 2.)
+        if isinstance(self.quantizer, GumbelVectorQuantizer):                  # model.py:189-200
+            temp, kl = self.quantizer.get_consts()
+            if self.kl_warmup_epochs is not None:
+                self.quantizer.kl_warmup = CosineScheduler(0, int(self.kl_warmup_epochs * nb), 0.0, kl)
+            if self.temp_decay_epochs is not None and self.temp_final is not None:
+                self.quantizer.temp_decay = CosineScheduler(0, int(self.temp_decay_epochs * nb), temp, self.temp_final)
 
     def on_train_batch_start(self, _: Any, batch_index: int):
         step = self.current_epoch * self.trainer.num_training_batches + batch_index
@@ -122,8 +133,16 @@ class VQVAE(BaseVQVAE, _LightningBase):
         for optimizer in self.trainer.optimizers:
             for g in optimizer.param_groups:
                 g['lr'] = step_lr
-        self.log('gumbel_quantizer/temperature', 0.0, sync_dist=True)
-        self.log('gumbel_quantizer/kl_constant', 0.0, sync_dist=True)
+        this_temp, this_kl = 0.0, 0.0
+        if isinstance(self.quantizer, GumbelVectorQuantizer):                  # model.py:218-225
+            this_temp, this_kl = self.quantizer.get_consts()
+            if self.quantizer.kl_warmup is not None:
+                this_kl = self.quantizer.kl_warmup.step(step)
+            if self.quantizer.temp_decay is not None:
+                this_temp = self.quantizer.temp_decay.step(step)
+            self.quantizer.set_consts(this_temp, this_kl)
+        self.log('gumbel_quantizer/temperature', this_temp, sync_dist=True)
+        self.log('gumbel_quantizer/kl_constant', this_kl, sync_dist=True)
 
     # ------------------------------------------------------------------ the step (model.py:232-295)
     def _step_losses(self, batch, training: bool):

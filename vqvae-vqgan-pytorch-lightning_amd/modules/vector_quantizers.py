@@ -1,6 +1,6 @@
 """Quantizers on the vqk kernels; same classes / ctor signatures / return conventions as the reference's
 ``vqvae/modules/vector_quantizers.py`` (VectorQuantizer :8-84, EMAVectorQuantizer :87-203,
-EntropyVectorQuantizer :277-381).
+EntropyVectorQuantizer :277-381, GumbelVectorQuantizer :206-274).
 
 The nearest-codeword search is one exact-fp32 MFMA kernel that never materialises the [N,K] distance
 matrix or a one-hot; the reference's association order of the three distance terms is kept so that the
@@ -11,6 +11,7 @@ import torch.distributed as dist
 
 from .. import ops
 from .abstract_modules.base_quantizer import BaseVectorQuantizer
+from .autoencoder import Conv2d
 
 
 def _flat_view(z: torch.Tensor):
@@ -88,3 +89,44 @@ class EntropyVectorQuantizer(BaseVectorQuantizer):
     def vec_to_codes(self, x: torch.Tensor) -> torch.Tensor:
         z = ops.nhwc(x.to(torch.float32))
         return ops.vq_assign(_flat_view(z), self.codebook.weight.detach().contiguous(), 1).view(x.shape[0], -1)
+
+
+class GumbelVectorQuantizer(BaseVectorQuantizer):
+    """Input is the encoder's K-channel logit map (B,K,H,W).  Unlike the other quantizers the indices come back
+    shaped (B,H,W) -- the reference's own quirk (vector_quantizers.py:243), kept."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, straight_through: bool = False, temp: float = 1.0,
+                 kl_cost: float = 5e-4):
+        super().__init__(num_embeddings, embedding_dim)
+        self.x_to_logits = Conv2d(num_embeddings, num_embeddings, 1, bias=True)
+        self.straight_through = straight_through
+        self.temp = temp
+        self.kl_cost = kl_cost
+
+    def forward(self, x: torch.Tensor, exp_noise: torch.Tensor = None):
+        """``exp_noise`` ~ Exp(1) with the shape of x: injected for parity tests; drawn with torch's RNG otherwise."""
+        hard = self.straight_through if self.training else True
+        logits = self.x_to_logits(ops.nhwc(x.to(self.compute_dtype)), out_dtype=torch.float32)
+        if exp_noise is None:
+            exp_noise = torch.empty_like(logits).exponential_()
+        q, idx, kl, hist = ops.GumbelVQFn.apply(logits, self.codebook.weight, exp_noise, float(self.temp),
+                                                float(self.kl_cost), bool(hard), self.compute_dtype)
+        self.last_hist = hist
+        return q, idx, kl
+
+    def get_consts(self):
+        return self.temp, self.kl_cost
+
+    def set_consts(self, temp: float = None, kl_cost: float = None) -> None:
+        if temp is not None:
+            self.temp = temp
+        if kl_cost is not None:
+            self.kl_cost = kl_cost
+
+    @torch.no_grad()
+    def vec_to_codes(self, x: torch.Tensor) -> torch.Tensor:
+        """hard Gumbel sample of x itself at tau = 1 (the reference skips x_to_logits here, :272-273)"""
+        lg = ops.nhwc(x.to(torch.float32))
+        noise = torch.empty_like(lg).exponential_()
+        _, idx, _, _ = ops.GumbelVQFn.apply(lg, self.codebook.weight, noise, 1.0, 0.0, True, self.compute_dtype)
+        return idx

@@ -536,6 +536,58 @@ class EntropyVQFn(torch.autograd.Function):
         return dz, de, None, None, None, None
 
 
+class GumbelVQFn(torch.autograd.Function):
+    """Gumbel-softmax quantization of logits [B,K,H,W] (vector_quantizers.py:233-243): y = softmax((logits+g)/tau),
+    q = y @ E, kl = kl_cost * mean_i sum_n qy log(qy K + 1e-10).  The Exp(1) noise is an INPUT (drawn with torch's
+    RNG by the module, or injected for parity).  Both GEMMs (y@E, dq@E^T) and dE = y^T@dq run on the 1x1 conv
+    kernels.  Returns (q [B,D,H,W], idx [B,H,W], kl, hist)."""
+
+    @staticmethod
+    def forward(ctx, logits, codebook, noise, tau: float, kl_cost: float, hard: bool, out_dtype):
+        _require_gpu(logits)
+        logits = nhwc(logits.to(torch.float32))
+        noise = nhwc(noise.to(torch.float32))
+        b, k, h, w = logits.shape
+        n = b * h * w
+        cb = codebook.detach().contiguous()
+        d = cb.shape[1]
+        dt = out_dtype
+        lib, st, dev = _native.lib(), _stream(), logits.device
+        y = torch.empty(n * k, dtype=dt, device=dev).view(1, n, 1, k).permute(0, 3, 1, 2)
+        idx = torch.empty(n, dtype=torch.int64, device=dev)
+        klsum = torch.zeros((), dtype=torch.float32, device=dev)
+        hist = torch.zeros(k, dtype=torch.int32, device=dev)
+        _native.check(lib.vqk_gumbel_forward(dcode(dt), logits.data_ptr(), noise.data_ptr(), n, k, tau, int(hard),
+                                             y.data_ptr(), idx.data_ptr(), klsum.data_ptr(), hist.data_ptr(), st),
+                      'gumbel_forward')
+        et = pack_weights(cb.t().contiguous().reshape(-1), dt, d, k, 1, False, 0)                # [D][K]
+        q = raw_conv_fprop(y, et, None, None, 1, False, 0, dt, d, 0)                              # [1,D,N,1] == [N][D]
+        q = q.permute(0, 2, 3, 1).reshape(b, h, w, d).permute(0, 3, 1, 2)                         # [B,D,H,W] nhwc view
+        ctx.save_for_backward(logits, noise, cb, y)
+        ctx.cfg = (tau, kl_cost, n, k, d, dt, (b, h, w))
+        ctx.mark_non_differentiable(idx, hist)
+        return q, idx.view(b, h, w), klsum * (kl_cost / float(n)), hist
+
+    @staticmethod
+    def backward(ctx, dq, _didx, dkl, _dhist):
+        logits, noise, cb, y = ctx.saved_tensors
+        tau, kl_cost, n, k, d, dt, (b, h, w) = ctx.cfg
+        lib, st = _native.lib(), _stream()
+        dqc = nhwc(dq.to(dt)) if dq is not None else torch.zeros((b, d, h, w), dtype=dt, device=logits.device).contiguous(memory_format=_CL)
+        dq_img = dqc.permute(0, 2, 3, 1).reshape(1, n, 1, d).permute(0, 3, 1, 2)                  # [1,D,N,1], memory [N][D]
+        e_w = pack_weights(cb.reshape(-1), dt, k, d, 1, False, 0)                                 # [K][D]
+        dyv = raw_conv_fprop(dq_img, e_w, None, None, 1, False, 0, dt, k, 0)                      # [N][K]
+        gs = dkl.to(torch.float32).contiguous() if dkl is not None else None
+        dlogits = torch.empty_like(logits, memory_format=_CL)
+        _native.check(lib.vqk_gumbel_backward(dcode(dt), logits.data_ptr(), noise.data_ptr(), dyv.data_ptr(), n, k, tau,
+                                              kl_cost if gs is not None else 0.0, _p(gs), dlogits.data_ptr(), st),
+                      'gumbel_backward')
+        de = None
+        if ctx.needs_input_grad[1]:
+            de = raw_conv_wgrad(dq_img, y, 1, False).permute(0, 2, 3, 1).reshape(k, d)            # y^T @ dq
+        return dlogits, de, None, None, None, None, None
+
+
 def ema_update(flat_z, idx, ema_count, ema_weight, codebook, decay: float, eps: float, batch: float, reduce_fn=None):
     """EMA statistics + update in place (vector_quantizers.py:159-169).  ``reduce_fn(buf)`` sums the
     packed [counts | dw] buffer over ranks (one small all-reduce)."""
