@@ -109,8 +109,8 @@ int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias,
                      int wlayout, const void* zeros, void* stream);
 /* Weight operand layouts.  0: [Cout][ks][ks][Cin] (any shape).  1: "fragment-major" for the register-weight halo
  * kernel (3x3, Cin a whole 128-byte chunk, W%32==0 && H%8==0 or W%16==0 && H%16==0): Cout padded to a multiple of
- * 128, element order [Cout/32][tap][Cin chunk][k-substep][lane 0..63][16 bytes] so that every MFMA operand
- * fragment is one coalesced 1 KiB load.  vqk_conv_weight_layout() returns the layout the fprop launcher wants for
+ * 128, element order [Cout/32][64-byte Cin chunk][tap][k-substep 0..1][lane 0..63][16 bytes]: every MFMA operand
+ * fragment is one coalesced 1 KiB load and the 18 fragments of a (cout tile, chunk) are contiguous.  vqk_conv_weight_layout() returns the layout the fprop launcher wants for
  * a problem (>= 0) or a negative status; vqk_conv_packed_elems() the element count of the packed buffer;
  * vqk_conv_pack_weights() builds it from the fp32 [Cout][ks][ks][Cin] master (transpose = 1: the dgrad operand,
  * i.e. Cin/Cout swapped and both taps flipped). */
@@ -119,7 +119,8 @@ int64_t vqk_conv_packed_elems(int cout, int cin, int ksize, int layout);
 int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int cin, int ksize, int transpose,
                           int layout, void* stream);
 /* test / tuning hook for the fprop kernel choice: -1 automatic, 0 im2col kernel only, 1 halo kernels when
- * eligible, 2 halo kernel with LDS-staged weights (layout 0) instead of register weights */
+ * eligible, 2 halo kernel with LDS-staged weights (layout 0) instead of register weights, 3 one-tile-per-block
+ * register-weight halo kernel instead of the persistent stream kernel (bf16) */
 int vqk_conv_set_variant(int variant);
 /* w [Cout][ks][ks][Cin] -> wt [Cin][ks][ks][Cout] with both taps flipped; src fp32, dst `dtype`. */
 int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, int ksize, void* stream);

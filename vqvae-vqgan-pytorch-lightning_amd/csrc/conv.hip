@@ -425,11 +425,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_breg_kernel(const T* __re
         hbase[i] = ty * HW2 + tx;
     }
     const int nchunks = g.cpt >> 3;
-    // fragment (j, tap, cc, ks) of this wave: wbase + ((((cot0 + j)*9 + tap)*nchunks + cc)*4 + ks) * 1 KiB + lane*16
+    // fragment (j, tap, cc, ks) of this wave in the [cot][cc32][tap][ks2] layout: cc32 = 2*cc + ks/2, ks2 = ks & 1
     const char* wbase = reinterpret_cast<const char*>(wp) + (int64_t)lane * 16;
     const int cot0 = (n0 + wn * 64) >> 5;
     auto wfrag = [&](int j, int tap, int cc, int ks) -> frag_t {
-        const int64_t f = (((int64_t)(cot0 + j) * 9 + tap) * nchunks + cc) * 4 + ks;
+        const int64_t f = (((int64_t)(cot0 + j) * (2 * nchunks) + 2 * cc + (ks >> 1)) * 9 + tap) * 2 + (ks & 1);
         return *reinterpret_cast<const frag_t*>(wbase + f * 1024);
     };
 
@@ -528,26 +528,221 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_breg_kernel(const T* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent "stream" variant of the register-weight halo kernel (bf16).  Each block walks a strided list of
+// (patch, cout-tile) tiles; inside a tile it walks 64-byte (32-channel) chunks.  The (tile, chunk) units form
+// one continuous software pipeline: while unit u is computed out of LDS buffer u&1, the halo of unit u+1 is in
+// flight from HBM into REGISTERS (ordinary loads, so hipcc's counted vmcnt keeps the rolling weight prefetch
+// un-drained) and is written to buffer (u+1)&1 after the compute; one barrier per unit.
+//
+// The inner loop is address-arithmetic free: LDS rows are padded to 80 B (16 consecutive rows -> 16 distinct
+// 16-byte bank slots, no XOR swizzle), so a pixel fragment is `lane base + compile-time immediate` for every
+// (tap, k-substep); the nine taps are fully unrolled; the weights of one unit are 18 contiguous 1 KiB fragments
+// read as `uniform base + lane*16`.  (PMC on the previous version: 4.4 VALU + 4.3 SALU per MFMA, issue-bound.)
+// ------------------------------------------------------------------------------------------------
+template <typename TO, int TWLOG>
+__global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* __restrict__ x,
+                                                                const bf16_raw* __restrict__ wp,
+                                                                const float* __restrict__ bias,
+                                                                const TO* __restrict__ res, TO* __restrict__ y,
+                                                                const char* __restrict__ zeros, ConvGeom g, int act) {
+    constexpr int TW = 1 << TWLOG, TH = 256 / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr int RS = 80;                                       // padded LDS row stride (64 B payload)
+    constexpr int HALO_INSTR = (HROWS + 15) / 16;                // register pieces: 16 rows x 64 B per wave load
+    constexpr int BUF = 28 * 1024;
+    constexpr int NSLOT = (HALO_INSTR + 3) / 4;
+    typedef bf16x8_t frag_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = g.w >> TWLOG, tiles_y = g.h / TH;
+    const int total_tiles = g.n * tiles_y * tiles_x * g.tiles_n;
+    const int nch = g.cpt >> 2;                                  // 32-channel chunks
+    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int units = my_tiles * nch;
+    if (units <= 0) return;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int p = lane & 31, kg = lane >> 5;
+    unsigned abase[4];                                           // LDS byte offset of tile i's pixel, tap (0,0), ks 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ty, tx;
+        if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
+        else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+        abase[i] = (unsigned)((ty * HW2 + tx) * RS + kg * 16);
+    }
+    int slot_hy[NSLOT], slot_hx[NSLOT];
+    unsigned slot_dst[NSLOT];
+    bool slot_ok[NSLOT];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+        const int q = wave + 4 * sl;
+        const int hr = q * 16 + (lane >> 2);
+        slot_ok[sl] = q < HALO_INSTR && hr < HROWS;
+        slot_hy[sl] = hr / HW2;
+        slot_hx[sl] = hr - slot_hy[sl] * HW2;
+        slot_dst[sl] = (unsigned)(hr * RS + (lane & 3) * 16);
+    }
+    const int lchan = (lane & 3) * 8;
+
+    struct TilePos { int img, py0, px0, nt; };
+    auto tile_pos = [&](int j) -> TilePos {
+        int t = (int)blockIdx.x + j * (int)gridDim.x;
+        TilePos tp;
+        tp.nt = t % g.tiles_n; t /= g.tiles_n;
+        const int txi = t % tiles_x; t /= tiles_x;
+        const int tyi = t % tiles_y;
+        tp.img = t / tiles_y; tp.py0 = tyi * TH; tp.px0 = txi * TW;
+        return tp;
+    };
+    u32x4 hreg[NSLOT];
+    auto load_halo = [&](const TilePos& tp, int c) {
+        const bf16_raw* ximg = x + (int64_t)tp.img * g.h_in * g.w_in * g.cin + c * 32 + lchan;
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int iy = tp.py0 + slot_hy[sl] - 1, ix = tp.px0 + slot_hx[sl] - 1;
+            const bool ok = slot_ok[sl] && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+            const bf16_raw* src = ximg + ((int64_t)(iy >> g.ups) * g.w_in + (ix >> g.ups)) * g.cin;
+            const void* sp = ok ? (const void*)src : (const void*)zeros;      // select, not branch
+            hreg[sl] = *reinterpret_cast<const u32x4*>(sp);
+        }
+    };
+    auto store_halo = [&](char* buf) {
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl)
+            if (wave + 4 * sl < HALO_INSTR) *reinterpret_cast<u32x4*>(buf + slot_dst[sl]) = hreg[sl];
+    };
+    // weights of unit (cout tile pair of this wave, chunk c): 2 x 18 contiguous 1 KiB fragments
+    const unsigned lane16 = (unsigned)lane * 16;
+    const char* wroot = reinterpret_cast<const char*>(wp);
+    auto unit_w = [&](int nt, int c, int j) -> const char* {
+        const int cot = ((nt * 128 + wn * 64) >> 5) + j;
+        return wroot + ((int64_t)cot * nch + c) * (18 * 1024);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    TilePos cur = tile_pos(0);
+    load_halo(cur, 0);
+    frag_t bw[2][2];
+    const char* wcur[2] = {unit_w(cur.nt, 0, 0), unit_w(cur.nt, 0, 1)};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bw[j][ks] = *reinterpret_cast<const frag_t*>(wcur[j] + ks * 1024 + lane16);
+    store_halo(smem);
+    __syncthreads();
+
+    int tj = 0, c = 0;
+    for (int u = 0; u < units; ++u) {
+        const unsigned boff = (unsigned)((u & 1) * BUF);
+        int ntj = tj, nc = c + 1;
+        if (nc == nch) { nc = 0; ntj = tj + 1; }
+        const bool has_next = u + 1 < units;
+        if (!has_next) { ntj = tj; nc = c; }                     // clamp: loads stay unconditional
+        const TilePos nxt = (ntj == tj) ? cur : tile_pos(ntj);
+        load_halo(nxt, nc);                                      // in flight during this unit's MFMAs
+        const char* wnxt[2] = {unit_w(nxt.nt, nc, 0), unit_w(nxt.nt, nc, 1)};
+        const char* lbase[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lbase[i] = smem + boff + abase[i];
+
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            constexpr int dummy = 0; (void)dummy;
+            const int toff = ((tap / 3) * HW2 + (tap % 3)) * RS;        // compile-time after unrolling
+            frag_t a[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks], a[ks][i], acc[i][j], 0, 0, 0);
+                // rolling prefetch of the same slot for the next tap (next unit after tap 8)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const char* src = (tap == 8) ? wnxt[j] + ks * 1024 : wcur[j] + ((tap + 1) * 2 + ks) * 1024;
+                    bw[j][ks] = *reinterpret_cast<const frag_t*>(src + lane16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (c == nch - 1) {                                        // tile finished: epilogue, accumulators reset
+            const int n0 = cur.nt * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int ty, tx;
+                if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
+                else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+                const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int co = n0 + wn * 64 + j * 32 + 8 * rq + 4 * kg;
+                        if (co < g.cout) {
+                            const int64_t o = pix * g.cout + co;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rq + e] + (bias ? bias[co + e] : 0.0f);
+                            if (res) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += Elem<TO>::ld(res + o + e);
+                            }
+                            if (act == 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                            }
+                            store4(y + o, v);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * rq + e] = 0.0f;
+                    }
+            }
+        }
+        if (has_next) store_halo(smem + ((u + 1) & 1) * BUF);
+        __syncthreads();
+        cur = nxt; tj = ntj; c = nc;
+        wcur[0] = wnxt[0]; wcur[1] = wnxt[1];
+    }
+}
+
 // fragment-major weight pack (layout 1).  src w: fp32 [Cout][taps][Cin]; transpose: produce the dgrad operand
-// (roles of Cout/Cin swapped, taps flipped).  dst element order: [cot][tap][cc][ks][kg][co32][EPC].
+// (roles of Cout/Cin swapped, taps flipped).  dst element order: [cot][cc][tap][ks][kg][co32][EPC] with
+// cc = 64-byte channel chunk (4 x 16 B), ks in {0,1}: channel = ((cc*2 + ks)*2 + kg)*EPC + e.  All 18
+// (tap, ks) fragments of one (cout tile, chunk) are contiguous (18 KiB), which is what one pipeline unit reads.
 template <typename TD>
 __global__ void pack_frag_kernel(const float* __restrict__ w, TD* __restrict__ out, int cout, int cin, int taps,
                                  int transpose, int cot_tiles) {
     constexpr int E = Elem<TD>::kPer16B;
     const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
-    const int ncc = dcin / (8 * E);
-    const int64_t total = (int64_t)cot_tiles * taps * ncc * 4 * 64 * E;
+    const int ncc = dcin / (4 * E);
+    const int64_t total = (int64_t)cot_tiles * ncc * taps * 2 * 64 * E;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = o;
         const int e = (int)(r % E); r /= E;
         const int co32 = (int)(r % 32); r /= 32;
         const int kg = (int)(r % 2); r /= 2;
-        const int ks = (int)(r % 4); r /= 4;
-        const int cc = (int)(r % ncc); r /= ncc;
-        const int tap = (int)(r % taps);
-        const int cot = (int)(r / taps);
+        const int ks = (int)(r % 2); r /= 2;
+        const int tap = (int)(r % taps); r /= taps;
+        const int cc = (int)(r % ncc);
+        const int cot = (int)(r / ncc);
         const int co = cot * 32 + co32;
-        const int ci = ((cc * 4 + ks) * 2 + kg) * E + e;
+        const int ci = ((cc * 2 + ks) * 2 + kg) * E + e;
         float v = 0.0f;
         if (co < dcout) {
             v = transpose ? w[((int64_t)ci * taps + (taps - 1 - tap)) * cin + co]
@@ -913,6 +1108,22 @@ template <typename T, typename TO>
 int launch_fprop(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                  const ConvGeom& g, int act, int wlayout, hipStream_t st) {
     const int tw = halo_twlog(g);
+    if (wlayout == 1 && sizeof(T) == 2 && g_force_variant != 3) {
+        if (!tw) return VQK_ERR_SHAPE;
+        const int th = 256 >> tw;
+        const int total = g.n * (g.h / th) * (g.w >> tw) * g.tiles_n;
+        static const int persist = getenv("VQK_STREAM_BLOCKS") ? atoi(getenv("VQK_STREAM_BLOCKS")) : 512;
+        const dim3 grid((unsigned)(total < persist ? total : persist));
+        constexpr int lds = 2 * 28 * 1024;
+        if (tw == 5)
+            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 5>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+                               bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+        else
+            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 4>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+                               bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+        if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+        return VQK_OK;
+    }
     if (wlayout == 1) {
         if (!tw) return VQK_ERR_SHAPE;                       // fragment-major weights need a halo-eligible shape
         constexpr int lds = 11 * 4096;
