@@ -960,19 +960,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<float>(const float* 
 // range of 8x8 pixel patches.  Per patch it stages dy [64 px][64 co] and the x HALO [10x10 px][64 ci] once;
 // the nine taps read the halo at shifted rows (ds_read_b64_tr_b16 fragments), so each input byte enters LDS
 // once instead of nine times.  Wave (i, j) owns the 32 co x 32 ci tile of all 9 taps (144 accumulators).
-// LDS rows are 128 B; the 64-byte half of a row is XORed with bit 1 of the row index, which makes the four
-// consecutive rows of a transpose read land in four different bank quadrants.  Stages are double-buffered.
+//
+// LDS layout: every tile is split into two 32-channel HALF tiles of [rows][64 B].  One global_load_lds piece
+// (1 KiB) is 16 rows of one half tile, and one transpose read of a wave (4 rows x 64 B per 32 lanes) is 256
+// contiguous bytes => conflict-free with no swizzle, and every fragment address is `lane base + immediate`
+// once the (pixel group, tap) loops are unrolled (the XOR-swizzled version spent ~5 VALU per MFMA on addresses).
+// Stages are double-buffered (2 x 22 KiB).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int row0, int cbase, int lane) {
-    // 8 k-rows (row0 .. row0+7) x 32 columns starting at cbase  ->  MFMA 32x32x16 operand of this lane's k-group
-    const int i = lane & 15, grp = (lane >> 4) & 1;
-    const int col = cbase + 16 * grp + 4 * (i & 3);
-    const int r0 = row0 + (i >> 2), r1 = r0 + 4;
-    const int c0 = ((col >> 3) ^ (((r0 >> 1) & 1) << 2)), c1 = ((col >> 3) ^ (((r1 >> 1) & 1) << 2));
-    const char* p0 = tile + r0 * 128 + (c0 << 4) + ((col & 7) << 1);
-    const char* p1 = tile + r1 * 128 + (c1 << 4) + ((col & 7) << 1);
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VQK_LDS s16x4*)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VQK_LDS s16x4*)p1);
+__device__ __forceinline__ bf16x8_t tr_frag2(const char* p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VQK_LDS s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VQK_LDS s16x4*)(p + 256));      // rows +4
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
@@ -983,17 +980,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
                                                                     float* __restrict__ dw,
                                                                     const char* __restrict__ zeros, ConvGeom g,
                                                                     int patches_per_split) {
-    constexpr int DY_BYTES = 8192, X_INSTR = 13, STAGE = DY_BYTES + X_INSTR * 1024;   // 21 KB per stage
+    constexpr int DY_HALF = 64 * 64, X_ROWS = 112, X_HALF = X_ROWS * 64;       // bytes per half tile
+    constexpr int STAGE = 2 * DY_HALF + 2 * X_HALF;                           // 22528
+    constexpr int PIECES = 8 + 14, NSLOT = (PIECES + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_ci = (g.cin + 63) >> 6;
     const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
     const int co0 = tco * 64, ci0 = tci * 64;
-    const int pw = g.w >> 3, ph = g.h >> 3;                    // patches per row / column
+    const int pw = g.w >> 3, ph = g.h >> 3;
     const int total_patches = g.n * ph * pw;
     const int p_begin = blockIdx.y * patches_per_split;
     const int p_end = min(total_patches, p_begin + patches_per_split);
+    if (p_begin >= p_end) return;
 
     const int wi = wave >> 1, wj = wave & 1;
     f32x16 acc[9];
@@ -1002,47 +1002,68 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    // one stage = 8 dy instructions (8 rows x 8 chunks each) + 13 halo instructions; 21 instructions over 4 waves
+    // ---- per-lane load slots (fixed over the patch loop): piece q = wave + 4*s
+    //   q <  8 : dy, half = q >> 2, rows 16*(q&3) .. +15 ; q >= 8 : x halo, half = (q-8)/7, rows 16*((q-8)%7) ..
+    int s_dy[NSLOT], s_dx[NSLOT], s_choff[NSLOT];
+    unsigned s_dst[NSLOT];
+    bool s_isdy[NSLOT], s_ok[NSLOT];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+        const int q = wave + 4 * sl;
+        const bool isdy = q < 8;
+        const int half = isdy ? (q >> 2) : (q - 8) / 7;
+        const int row = (isdy ? (q & 3) : (q - 8) % 7) * 16 + (lane >> 2);
+        s_isdy[sl] = isdy;
+        s_choff[sl] = half * 32 + (lane & 3) * 8;
+        if (isdy) {
+            s_dy[sl] = row >> 3; s_dx[sl] = row & 7;
+            s_ok[sl] = (co0 + s_choff[sl]) < g.cout;
+            s_dst[sl] = (unsigned)(half * DY_HALF + (q & 3) * 1024);
+        } else {
+            const int hy = row / 10, hx = row - hy * 10;
+            s_dy[sl] = hy - 1; s_dx[sl] = hx - 1;
+            s_ok[sl] = q < PIECES && row < 100 && (ci0 + s_choff[sl]) < g.cin;
+            s_dst[sl] = (unsigned)(2 * DY_HALF + half * X_HALF + ((q - 8) % 7) * 1024);
+        }
+    }
     auto issue = [&](int patch, char* st) {
         const int img = patch / (ph * pw), rem = patch - img * (ph * pw);
         const int pyi = rem / pw, pxi = rem - pyi * pw;
         const int py0 = pyi * 8, px0 = pxi * 8;
-        for (int q = wave; q < 8 + X_INSTR; q += 4) {
-            const int row = (q < 8 ? q : q - 8) * 8 + (lane >> 3);
-            const int lc = (lane & 7) ^ (((row >> 1) & 1) << 2);
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            if (wave + 4 * sl >= PIECES) continue;
+            const int iy = py0 + s_dy[sl], ix = px0 + s_dx[sl];
             const void* src = zeros;
-            if (q < 8) {                                       // dy: row = pixel k of the patch
-                const int iy = py0 + (row >> 3), ix = px0 + (row & 7);
-                if (co0 + lc * 8 < g.cout)
-                    src = dy + (((int64_t)img * g.h + iy) * g.w + ix) * g.cout + co0 + lc * 8;
-                glds16(src, st + q * 1024);
-            } else {                                           // x halo: row = hy*10 + hx
-                const int hy = row / 10, hx = row - hy * 10;
-                const int iy = py0 + hy - 1, ix = px0 + hx - 1;
-                if (row < 100 && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w && ci0 + lc * 8 < g.cin)
-                    src = x + (((int64_t)img * g.h_in + (iy >> g.ups)) * g.w_in + (ix >> g.ups)) * g.cin + ci0 + lc * 8;
-                glds16(src, st + DY_BYTES + (q - 8) * 1024);
+            if (s_isdy[sl]) {
+                if (s_ok[sl]) src = dy + (((int64_t)img * g.h + iy) * g.w + ix) * g.cout + co0 + s_choff[sl];
+            } else if (s_ok[sl] && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w) {
+                src = x + (((int64_t)img * g.h_in + (iy >> g.ups)) * g.w_in + (ix >> g.ups)) * g.cin + ci0 + s_choff[sl];
             }
+            glds16(src, st + s_dst[sl]);
         }
     };
 
-    if (p_begin < p_end) issue(p_begin, smem);
-    const int kgrp = lane >> 5;
+    // ---- fragment lane bases: half tile of this wave + (i>>2)*64 + 32*grp + 8*(i&3) + k-group rows
+    const int li = lane & 15, grp = (lane >> 4) & 1, kgrp = lane >> 5;
+    const unsigned frag_lane = (unsigned)((li >> 2) * 64 + 32 * grp + 8 * (li & 3));
+    const unsigned a_lane = (unsigned)(wi * DY_HALF) + frag_lane + (unsigned)(kgrp * 8 * 64);
+    const unsigned b_lane = (unsigned)(2 * DY_HALF + wj * X_HALF) + frag_lane + (unsigned)(kgrp * 10 * 64);
+
+    issue(p_begin, smem);
     for (int pch = p_begin; pch < p_end; ++pch) {
-        char* cur = smem + ((pch - p_begin) & 1) * STAGE;
-        char* nxt = smem + ((pch - p_begin + 1) & 1) * STAGE;
+        const unsigned cur = (unsigned)(((pch - p_begin) & 1) * STAGE);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                       // stage `cur` landed; everyone left stage `nxt`
-        if (pch + 1 < p_end) issue(pch + 1, nxt);
-        const char* tdy = cur;
-        const char* tx = cur + DY_BYTES;
+        __syncthreads();                                       // stage `cur` landed; everyone left the other stage
+        if (pch + 1 < p_end) issue(pch + 1, smem + (STAGE - cur));
+        const char* pa = smem + cur + a_lane;
+        const char* pb = smem + cur + b_lane;
 #pragma unroll
         for (int gk = 0; gk < 4; ++gk) {                       // 16 pixels = patch rows 2gk, 2gk+1
-            const bf16x8_t a = tr_frag(tdy, 16 * gk + 8 * kgrp, wi * 32, lane);
+            const bf16x8_t a = tr_frag2(pa + gk * 16 * 64);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int kh = t / 3, kw = t - kh * 3;
-                const bf16x8_t b = tr_frag(tx, (2 * gk + kgrp + kh) * 10 + kw, wj * 32, lane);
+                const bf16x8_t b = tr_frag2(pb + ((2 * gk + t / 3) * 10 + (t % 3)) * 64);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
             }
         }
@@ -1285,7 +1306,7 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
         const int pps = (total_patches + splits - 1) / splits;
         splits = (total_patches + pps - 1) / pps;
         const dim3 grid((unsigned)tiles, (unsigned)splits);
-        hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, grid, dim3(256), 2 * (8192 + 13 * 1024), vqk_stream(stream),
+        hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, grid, dim3(256), 2 * 22528, vqk_stream(stream),
                            (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
         VQK_CHECK_LAUNCH();
         return VQK_OK;
