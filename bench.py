@@ -120,6 +120,8 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = not args.no_graph
+    if world > 1 and args.quantizer == 'ema':
+        use_graph = False      # the EMA statistics all-reduce sits inside forward: keep collectives out of graph capture
     if use_graph:
         trainer.capture(model, images, warmup=max(1, min(3, args.warmup)))
         step_fn = trainer.train_batch_graphed
