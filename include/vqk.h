@@ -101,12 +101,24 @@ int vqk_ema_update_f32(float* ema_count, float* ema_weight, float* codebook, con
  *   x [N][Hin][Win][Cin], w [Cout][ks][ks][Cin], y [N][H][W][Cout]; (H,W) = (Hin,Win) << ups.
  *   ups = 1 fuses a nearest x2 upsample of x into the input addressing (autoencoder.py:104-106).
  *   bias (fp32, optional), residual (same dtype/shape as y, optional) are fused into the epilogue;
- *   act: 0 none, 1 tanh.  in/w dtype = `dtype`; y/residual dtype = out_dtype.
+ *   act: 0 none, 1 tanh, 2 relu, 3 leaky-relu(0.2).  in/w dtype = `dtype`; y/residual dtype = out_dtype.
  *   Cin must be a multiple of 16 bytes worth of elements (4 fp32 / 8 bf16).
  * dgrad is the same entry point with weights repacked by vqk_conv_pack_dgrad. */
 int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                      int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int act,
                      int wlayout, const void* zeros, void* stream);
+/* General form (im2col kernel when not plain): stride in {1,2}, explicit zero padding `pad`, explicit output size;
+ * mode 0: x as is, 1: nearest x2 upsample of x, 2: x zero-stuffed x2 (the dgrad of a stride-2 conv, with flipped /
+ * transposed weights and pad = ks-1-pad_fwd).  Epilogue: y = out_gain * act(acc * acc_scale + bias) + residual, act 0
+ * none, 1 tanh, 2 relu, 3 leaky-relu(0.2) -- acc_scale is the StyleGAN2 runtime weight gain (discriminator.py:165),
+ * out_gain the bias_act gain (bias_act.py:55).  Strided/padded problems need weight layout 0. */
+int vqk_conv2d_general(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                       int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int stride, int pad,
+                       int mode, int h_out, int w_out, int act, float acc_scale, float out_gain, int wlayout,
+                       const void* zeros, void* stream);
+int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
+                             int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out,
+                             const void* zeros, void* stream);
 /* Weight operand layouts.  0: [Cout][ks][ks][Cin] (any shape).  1: "fragment-major" for the register-weight halo
  * kernel (3x3, Cin a whole 128-byte chunk, W%32==0 && H%8==0 or W%16==0 && H%16==0): Cout padded to a multiple of
  * 128, element order [Cout/32][64-byte Cin chunk][tap][k-substep 0..1][lane 0..63][16 bytes]: every MFMA operand
@@ -188,6 +200,39 @@ int vqk_bias_act(const float* x, const float* b, const float* xref, const float*
 int vqk_upfirdn2d(const float* x, const float* f, float* y, int n, int c, int in_h, int in_w, int fh, int fw,
                   int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip,
                   float gain, int out_h, int out_w, void* stream);
+
+/* ---------------------------------------------------------------- VQ-GAN loss path (NHWC) ---
+ * dx = dy * scale * act'(y), act' recovered from the saved OUTPUT y (bias_act.cu grad=1 semantics): 1 tanh, 2 relu,
+ * 3 leaky-relu(0.2), 0 plain scaling.  `scale` carries the activation gain and the runtime weight gain. */
+int vqk_act_backward(int dtype, const void* dy, const void* y, void* dx, int64_t n, int act, float scale, void* stream);
+/* upfirdn2d (upfirdn2d.cpp:16 argument meaning) on NHWC tensors of `dtype`, C a whole 16-byte chunk. */
+int vqk_upfirdn2d_nhwc(int dtype, const void* x, const float* f, void* y, int n, int h, int w, int c, int fh, int fw,
+                       int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip,
+                       float gain, int out_h, int out_w, void* stream);
+/* 2x2/stride-2 max pool: backward = 0: out[N][H/2][W/2][C] = max ; backward = 1: out[N][H][W][C] = dy routed to the
+ * first maximum of each window (x is the forward input). */
+int vqk_maxpool2x2(int dtype, const void* x, const void* dy, void* out, int n, int h, int w, int c, int backward,
+                   void* stream);
+/* y[pix][c] = x[pix][c] * scale[c] + shift[c]   (LPIPS z-score, networks.py:51-52; shift may be NULL) */
+int vqk_channel_affine(int dtype, const void* x, const float* scale, const float* shift, void* y, int64_t npix, int c,
+                       void* stream);
+/* LPIPS tap (lpips.py:31-38, utils.py:6-8): dfy == NULL: out[n] += (1/hw) sum_pix sum_c lin[c] (fx/(|fx|+1e-10) -
+ * fy/(|fy|+1e-10))^2 (out pre-zeroed);  dfy != NULL: gradient w.r.t. fy for upstream gscale * gout[0] / n-independent
+ * (the batch mean is folded into gscale by the caller). */
+int vqk_lpips_tap(int dtype, const void* fx, const void* fy, const float* lin, int n, int64_t hw, int c, float* out,
+                  const float* gout, float gscale, void* dfy, void* stream);
+/* minibatch-stddev layer (discriminator.py:271-293), F = 1 feature: forward writes out[N][hw][cpad] = [x | stat | 0..]
+ * and stat[N/group]; backward writes dx[N][hw][c] from dy[N][hw][cpad]. */
+int vqk_mbstd(int dtype, const void* x, const void* dy, void* out, float* stat, int n, int64_t hw, int c, int cpad,
+              int group, int backward, void* stream);
+/* out[0] += sum |target - recon| ;  d (+)= s * (a1 sign(recon-target) + a2 * 2 (recon-target)), s = *gscale_dev */
+int vqk_l1_sum(int dtype, const void* recon, const float* target, int64_t n, float* out, void* stream);
+int vqk_l1l2_backward(int dtype, const void* recon, const float* target, int64_t n, float a1, float a2,
+                      const float* gscale_dev, void* d, int accumulate, void* stream);
+/* loss.py:11-51 on [n] logits.  mode 0 hinge / 1 non-saturating; which 0 generator_loss(fake) / 1
+ * discriminator_loss(real, fake).  loss[0] = value; dreal/dfake (optional) = gradients times *gscale_dev. */
+int vqk_gan_loss(const float* logits_real, const float* logits_fake, int n, int mode, int which, float* loss,
+                 float* dreal, float* dfake, const float* gscale_dev, void* stream);
 
 #ifdef __cplusplus
 }

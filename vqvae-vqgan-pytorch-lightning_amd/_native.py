@@ -38,6 +38,8 @@ _PROTOS = {
     'vqk_ema_stats_f32': [P, P, L, I, I, P, P, P],
     'vqk_ema_update_f32': [P, P, P, P, P, I, I, F, F, F, P],
     'vqk_conv2d_fprop': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
+    'vqk_conv2d_general': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, I, P, P],
+    'vqk_conv2d_wgrad_general': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P],
     'vqk_conv_weight_layout': [I, I, I, I, I, I, I, I],
     'vqk_conv_pack_weights': [P, P, I, I, I, I, I, I, P],
     'vqk_conv_set_variant': [I],
@@ -56,6 +58,15 @@ _PROTOS = {
     'vqk_tanh_backward': [I, P, P, P, L, P],
     'vqk_axpby': [I, P, P, P, F, F, L, P],
     'vqk_adamw': [P, P, P, P, L, P, P, I, F, F, F, F, I, F, P, P],
+    'vqk_act_backward': [I, P, P, P, L, I, F, P],
+    'vqk_upfirdn2d_nhwc': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, I, P],
+    'vqk_maxpool2x2': [I, P, P, P, I, I, I, I, I, P],
+    'vqk_channel_affine': [I, P, P, P, P, L, I, P],
+    'vqk_lpips_tap': [I, P, P, P, I, L, I, P, P, F, P, P],
+    'vqk_mbstd': [I, P, P, P, P, I, L, I, I, I, I, P],
+    'vqk_l1_sum': [I, P, P, L, P, P],
+    'vqk_l1l2_backward': [I, P, P, L, F, F, P, P, I, P],
+    'vqk_gan_loss': [P, P, I, I, I, P, P, P, P, P],
     'vqk_bias_act': [P, P, P, P, P, P, L, L, I, I, I, F, F, F, P],
     'vqk_upfirdn2d': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, I, P],
 }

@@ -21,11 +21,24 @@ namespace {
 
 struct ConvGeom {
     int n, h_in, w_in, h, w, cin, cout, ks, ups;
+    // general (im2col kernels only): output pixel (oh, ow) reads virtual-input pixel (oh*stride + kh - pad, ...);
+    // the virtual input is x itself (ups = 0), its nearest x2 upsample (ups = 1) or x zero-stuffed x2 (ups = 1,
+    // zs = 1: only even coordinates carry data -- the dgrad of a stride-2 conv); vh/vw = its extent.
+    int stride, pad, zs, vh, vw;
+    float acc_scale, out_gain;      // epilogue: y = out_gain * act(acc * acc_scale + bias) + residual
     int m;          // n*h*w output pixels
     int cpt;        // 16-byte chunks per tap  (cin / elems-per-16B)
     int kchunks;    // ks*ks*cpt
     int tiles_m, tiles_n;
 };
+
+// epilogue activations: 0 none, 1 tanh, 2 relu, 3 leaky relu (slope 0.2)
+__device__ __forceinline__ float epi_act(float v, int act) {
+    if (act == 1) return tanhf(v);
+    if (act == 2) return fmaxf(v, 0.0f);
+    if (act == 3) return v > 0.0f ? v : 0.2f * v;
+    return v;
+}
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
     // contiguous chunk of tiles per XCD (block b runs on XCD b % 8); bijective for any total
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             a_ow[t] = rem - a_oh[t] * g.w;
             a_img[t] = x + (int64_t)img * g.h_in * g.w_in * g.cin;
         } else {
-            a_oh[t] = -100000; a_ow[t] = 0; a_img[t] = x;
+            a_oh[t] = -1000000; a_ow[t] = 0; a_img[t] = x;
         }
         const int co = n0 + r;
         b_ok[t] = co < g.cout;
@@ -176,8 +189,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                 coff = gch - tap * g.cpt;
                 kh = tap / g.ks; kw = tap - kh * g.ks;
             }
-            const int ih = a_oh[t] + kh - pad, iw = a_ow[t] + kw - pad;
-            ok = ok && ih >= 0 && ih < g.h && iw >= 0 && iw < g.w;
+            const int ih = a_oh[t] * g.stride + kh - g.pad, iw = a_ow[t] * g.stride + kw - g.pad;
+            ok = ok && ih >= 0 && ih < g.vh && iw >= 0 && iw < g.vw && !(g.zs && ((ih | iw) & 1));
             const T* src = a_img[t] + ((int64_t)(ih >> g.ups) * g.w_in + (iw >> g.ups)) * g.cin + coff * EPC;
             const void* sa = ok ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(zeros);
             glds16(sa, lds_a + (4 * wave + t) * 1024);
@@ -215,9 +228,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + orow;
                 if (m < g.m) {
                     const int64_t o = (int64_t)m * g.cout + co;
-                    float v = acc[i][j][r] + bv;
+                    float v = epi_act(acc[i][j][r] * g.acc_scale + bv, act) * g.out_gain;
                     if (res) v += Elem<TO>::ld(res + o);
-                    if (act == 1) v = tanhf(v);
                     Elem<TO>::st(y + o, v);
                 }
             }
@@ -369,14 +381,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const T* __restric
                 const int64_t o = pix * g.cout + co;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rq + e] + (bias ? bias[co + e] : 0.0f);
+                for (int e = 0; e < 4; ++e)
+                    v[e] = epi_act(acc[i][j][4 * rq + e] * g.acc_scale + (bias ? bias[co + e] : 0.0f), act) * g.out_gain;
                 if (res) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += Elem<TO>::ld(res + o + e);
-                }
-                if (act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
                 }
                 store4(y + o, v);
             }
@@ -514,14 +523,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_breg_kernel(const T* __re
                 const int64_t o = pix * g.cout + co;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rq + e] + (bias ? bias[co + e] : 0.0f);
+                for (int e = 0; e < 4; ++e)
+                    v[e] = epi_act(acc[i][j][4 * rq + e] * g.acc_scale + (bias ? bias[co + e] : 0.0f), act) * g.out_gain;
                 if (res) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += Elem<TO>::ld(res + o + e);
-                }
-                if (act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
                 }
                 store4(y + o, v);
             }
@@ -698,14 +704,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
                             const int64_t o = pix * g.cout + co;
                             float v[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rq + e] + (bias ? bias[co + e] : 0.0f);
+                            for (int e = 0; e < 4; ++e)
+                                v[e] = epi_act(acc[i][j][4 * rq + e] * g.acc_scale + (bias ? bias[co + e] : 0.0f), act) * g.out_gain;
                             if (res) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] += Elem<TO>::ld(res + o + e);
-                            }
-                            if (act == 1) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
                             }
                             store4(y + o, v);
                         }
@@ -831,8 +834,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
             if (okb) {
                 const int img = p / hw, rem = p - img * hw;
                 const int oh = rem / g.w, ow = rem - oh * g.w;
-                const int ih = oh + kh - pad, iw = ow + kw - pad;
-                if (ih >= 0 && ih < g.h && iw >= 0 && iw < g.w)
+                const int ih = oh * g.stride + kh - g.pad, iw = ow * g.stride + kw - g.pad;
+                if (ih >= 0 && ih < g.vh && iw >= 0 && iw < g.vw && !(g.zs && ((ih | iw) & 1)))
                     sb = x + (((int64_t)img * g.h_in + (ih >> g.ups)) * g.w_in + (iw >> g.ups)) * g.cin + ci0 + lc * 8;
             }
             glds16(sb, lds_b + (4 * wave + t) * 1024);
@@ -915,8 +918,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<float>(const float* 
             if (okb) {
                 const int img = p / hw, rem = p - img * hw;
                 const int oh = rem / g.w, ow = rem - oh * g.w;
-                const int ih = oh + kh - pad, iw = ow + kw - pad;
-                if (ih >= 0 && ih < g.h && iw >= 0 && iw < g.w)
+                const int ih = oh * g.stride + kh - g.pad, iw = ow * g.stride + kw - g.pad;
+                if (ih >= 0 && ih < g.vh && iw >= 0 && iw < g.vw && !(g.zs && ((ih | iw) & 1)))
                     sb = x + (((int64_t)img * g.h_in + (ih >> g.ups)) * g.w_in + (iw >> g.ups)) * g.cin + ci0 + pc * 4;
             }
             glds16(sb, lds_b + (4 * wave + t) * 1024);
@@ -1198,6 +1201,8 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     if (cin % epc) return VQK_ERR_SHAPE;
     g.n = n; g.h_in = h_in; g.w_in = w_in; g.h = h_in << ups; g.w = w_in << ups;
     g.cin = cin; g.cout = cout; g.ks = ksize; g.ups = ups;
+    g.stride = 1; g.pad = ksize >> 1; g.zs = 0; g.vh = g.h; g.vw = g.w;
+    g.acc_scale = 1.0f; g.out_gain = 1.0f;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
     g.m = (int)m;
@@ -1215,21 +1220,61 @@ extern "C" {
 /* test / tuning hook: -1 automatic choice, 0 force the im2col kernel, 1 prefer the halo kernel */
 int vqk_conv_set_variant(int v) { g_force_variant = v; return VQK_OK; }
 
+static int conv_general(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                        int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int stride, int pad,
+                        int mode, int h_out, int w_out, int act, float acc_scale, float out_gain, int wlayout,
+                        const void* zeros, void* stream) {
+    VQK_REQUIRE(x && w && y && zeros, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
+    VQK_REQUIRE(act >= 0 && act <= 3, VQK_ERR_ARG);
+    VQK_REQUIRE(wlayout == 0 || wlayout == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(mode >= 0 && mode <= 2 && (stride == 1 || stride == 2) && pad >= 0, VQK_ERR_ARG);
+    ConvGeom g;
+    const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, mode ? 1 : 0);
+    if (rc) return rc;
+    const bool plain = stride == 1 && pad == (ksize >> 1) && mode != 2 && h_out == g.h && w_out == g.w;
+    if (!plain) {
+        VQK_REQUIRE(wlayout == 0, VQK_ERR_ARG);             // strided / explicitly padded convs run on the im2col kernel
+        g.zs = mode == 2;
+        g.vh = mode == 2 ? 2 * h_in - 1 : g.h;
+        g.vw = mode == 2 ? 2 * w_in - 1 : g.w;
+        g.stride = stride; g.pad = pad;
+        VQK_REQUIRE(h_out > 0 && w_out > 0, VQK_ERR_SHAPE);
+        VQK_REQUIRE((h_out - 1) * stride + ksize - pad <= g.vh + pad + stride, VQK_ERR_SHAPE);
+        g.h = h_out; g.w = w_out;
+        const int64_t m = (int64_t)n * h_out * w_out;
+        VQK_REQUIRE(m < 0x7fffff00, VQK_ERR_SHAPE);
+        g.m = (int)m;
+        g.tiles_m = (g.m + 127) / 128;
+    }
+    g.acc_scale = acc_scale; g.out_gain = out_gain;
+    hipStream_t st = vqk_stream(stream);
+    const int fv = plain ? -1 : 0;
+    const int saved = g_force_variant;
+    if (!plain) g_force_variant = 0;                        // force the general im2col kernel
+    int r = VQK_ERR_DTYPE;
+    if (dtype == VQK_F32 && out_dtype == VQK_F32) r = launch_fprop<float, float>(x, w, bias, residual, y, zeros, g, act, wlayout, st);
+    else if (dtype == VQK_BF16 && out_dtype == VQK_BF16) r = launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, act, wlayout, st);
+    else if (dtype == VQK_BF16 && out_dtype == VQK_F32) r = launch_fprop<bf16_raw, float>(x, w, bias, residual, y, zeros, g, act, wlayout, st);
+    (void)fv;
+    g_force_variant = saved;
+    return r;
+}
+
 int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                      int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int act,
                      int wlayout, const void* zeros, void* stream) {
-    VQK_REQUIRE(x && w && y && zeros, VQK_ERR_ARG);
-    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
-    VQK_REQUIRE(act == 0 || act == 1, VQK_ERR_ARG);
-    VQK_REQUIRE(wlayout == 0 || wlayout == 1, VQK_ERR_ARG);
-    ConvGeom g;
-    const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
-    if (rc) return rc;
-    hipStream_t st = vqk_stream(stream);
-    if (dtype == VQK_F32 && out_dtype == VQK_F32) return launch_fprop<float, float>(x, w, bias, residual, y, zeros, g, act, wlayout, st);
-    if (dtype == VQK_BF16 && out_dtype == VQK_BF16) return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, act, wlayout, st);
-    if (dtype == VQK_BF16 && out_dtype == VQK_F32) return launch_fprop<bf16_raw, float>(x, w, bias, residual, y, zeros, g, act, wlayout, st);
-    return VQK_ERR_DTYPE;
+    VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
+    return conv_general(dtype, x, w, bias, residual, y, out_dtype, n, h_in, w_in, cin, cout, ksize, 1, ksize >> 1, ups,
+                        h_in << ups, w_in << ups, act, 1.0f, 1.0f, wlayout, zeros, stream);
+}
+
+int vqk_conv2d_general(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                       int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int stride, int pad,
+                       int mode, int h_out, int w_out, int act, float acc_scale, float out_gain, int wlayout,
+                       const void* zeros, void* stream) {
+    return conv_general(dtype, x, w, bias, residual, y, out_dtype, n, h_in, w_in, cin, cout, ksize, stride, pad, mode,
+                        h_out, w_out, act, acc_scale, out_gain, wlayout, zeros, stream);
 }
 
 int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups) {
@@ -1287,16 +1332,26 @@ int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, 
     return VQK_OK;
 }
 
-int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin, int cout,
-                     int ksize, int ups, const void* zeros, void* stream) {
+static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin, int cout,
+                         int ksize, int stride, int pad, int mode, int h_out, int w_out, const void* zeros, void* stream) {
     VQK_REQUIRE(x && dy && dw && zeros, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
+    VQK_REQUIRE(mode >= 0 && mode <= 1 && (stride == 1 || stride == 2) && pad >= 0, VQK_ERR_ARG);
     ConvGeom g;
-    const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
+    const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, mode);
     if (rc) return rc;
     const int epc = dtype == VQK_F32 ? 4 : 8;
     VQK_REQUIRE(cout % epc == 0, VQK_ERR_SHAPE);
-    if (dtype == VQK_BF16 && ksize == 3 && (g.h % 8) == 0 && (g.w % 8) == 0 && g_force_variant != 0) {
+    const bool plain = stride == 1 && pad == (ksize >> 1) && h_out == g.h && w_out == g.w;
+    if (!plain) {
+        g.stride = stride; g.pad = pad;
+        VQK_REQUIRE(h_out > 0 && w_out > 0, VQK_ERR_SHAPE);
+        g.h = h_out; g.w = w_out;
+        const int64_t m = (int64_t)n * h_out * w_out;
+        VQK_REQUIRE(m < 0x7fffff00, VQK_ERR_SHAPE);
+        g.m = (int)m;
+    }
+    if (plain && dtype == VQK_BF16 && ksize == 3 && (g.h % 8) == 0 && (g.w % 8) == 0 && g_force_variant != 0) {
         const int tiles = ((cout + 63) / 64) * ((cin + 63) / 64);
         const int total_patches = g.n * (g.h / 8) * (g.w / 8);
         static const int target = getenv("VQK_WGRAD_BLOCKS") ? atoi(getenv("VQK_WGRAD_BLOCKS")) : 512;
@@ -1314,8 +1369,7 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
     const int kp = dtype == VQK_F32 ? 32 : 64;
     const int tiles = ((cout + 127) / 128) * ((cin + 127) / 128) * ksize * ksize;
     // split the pixel range so that ~2048 blocks are in flight, each with >= 4 K-steps
-    static const int target_blocks = getenv("VQK_WGRAD_BLOCKS") ? atoi(getenv("VQK_WGRAD_BLOCKS")) : 2048;
-    int splits = (target_blocks + tiles - 1) / tiles;
+    int splits = (2048 + tiles - 1) / tiles;
     const int max_splits = (g.m + 4 * kp - 1) / (4 * kp);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1329,6 +1383,19 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
         hipLaunchKernelGGL(conv_wgrad_kernel<bf16_raw>, grid, dim3(256), 32768, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
+}
+
+int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin, int cout,
+                     int ksize, int ups, const void* zeros, void* stream) {
+    VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
+    return wgrad_general(dtype, x, dy, dw, n, h_in, w_in, cin, cout, ksize, 1, ksize >> 1, ups, h_in << ups, w_in << ups,
+                         zeros, stream);
+}
+
+int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
+                             int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out, const void* zeros,
+                             void* stream) {
+    return wgrad_general(dtype, x, dy, dw, n, h_in, w_in, cin, cout, ksize, stride, pad, mode, h_out, w_out, zeros, stream);
 }
 
 int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream) {

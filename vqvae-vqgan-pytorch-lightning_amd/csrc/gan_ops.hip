@@ -1,0 +1,456 @@
+// Small kernels of the VQ-GAN losses (LPIPS / StyleGAN2 discriminator path), NHWC:
+//   activation backward (bias_act grad=1 semantics for relu / lrelu, bias_act.cu:60-75 of the reference)
+//   upfirdn2d in NHWC (upfirdn2d.cu:29-92 semantics: zero-stuff, pad, FIR, decimate)
+//   max-pool 2x2 fwd/bwd (torchvision vgg16.features pools), per-channel affine (LPIPS z-score, networks.py:51-52)
+//   LPIPS tap: unit-normalise over channels, squared difference, 1x1 "lin", spatial mean (lpips.py:31-38, utils.py:6-8)
+//   minibatch-stddev layer fwd/bwd (discriminator.py:271-293), L1 loss, GAN losses (loss.py:11-51)
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                      int64_t n, int act, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float yv = Elem<T>::ld(y + i);
+        float g = Elem<T>::ld(dy + i) * scale;
+        if (act == 1) g *= 1.0f - yv * yv;
+        else if (act == 2) g = yv > 0.0f ? g : 0.0f;
+        else if (act == 3) g = yv > 0.0f ? g : 0.2f * g;
+        Elem<T>::st(dx + i, g);
+    }
+}
+
+// y[n,oy,ox,:] = gain * sum_{fy,fx} F[fy][fx] * U[oy*down + fy - pad0][...]; U = zero-stuffed x
+template <typename T>
+__global__ __launch_bounds__(256) void upfirdn_nhwc_kernel(const T* __restrict__ x, const float* __restrict__ f,
+                                                           T* __restrict__ y, int n, int h, int w, int c, int fh, int fw,
+                                                           int upx, int upy, int downx, int downy, int px0, int py0,
+                                                           int flip, float gain, int oh, int ow) {
+    constexpr int V = Vec16<T>::N;
+    const int vpp = c / V;
+    const int64_t total = (int64_t)n * oh * ow * vpp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpp);
+        int64_t p = i / vpp;
+        const int ox = (int)(p % ow); p /= ow;
+        const int oy = (int)(p % oh);
+        const int img = (int)(p / oh);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.0f;
+        for (int ky = 0; ky < fh; ++ky) {
+            const int uy = oy * downy + ky - py0;
+            if (uy < 0 || uy % upy) continue;
+            const int iy = uy / upy;
+            if (iy >= h) continue;
+            for (int kx = 0; kx < fw; ++kx) {
+                const int ux = ox * downx + kx - px0;
+                if (ux < 0 || ux % upx) continue;
+                const int ix = ux / upx;
+                if (ix >= w) continue;
+                const float fv = flip ? f[ky * fw + kx] : f[(fh - 1 - ky) * fw + (fw - 1 - kx)];
+                float xv[V];
+                Vec16<T>::load(x + (((int64_t)img * h + iy) * w + ix) * c + v * V, xv);
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc[k] = __fmaf_rn(xv[k], fv, acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] *= gain;
+        Vec16<T>::store(y + i * V, acc);
+    }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out,
+                                                      int n, int h, int w, int c) {
+    constexpr int V = Vec16<T>::N;
+    const int oh = h >> 1, ow = w >> 1, vpp = c / V;
+    const int64_t total = (int64_t)n * oh * ow * vpp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpp);
+        int64_t p = i / vpp;
+        const int ox = (int)(p % ow); p /= ow;
+        const int oy = (int)(p % oh);
+        const int img = (int)(p / oh);
+        const int64_t base = (((int64_t)img * h + 2 * oy) * w + 2 * ox) * c + v * V;
+        float a[4][V];
+        Vec16<T>::load(x + base, a[0]); Vec16<T>::load(x + base + c, a[1]);
+        Vec16<T>::load(x + base + (int64_t)w * c, a[2]); Vec16<T>::load(x + base + (int64_t)w * c + c, a[3]);
+        if (!BWD) {
+            float o[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = fmaxf(fmaxf(a[0][k], a[1][k]), fmaxf(a[2][k], a[3][k]));
+            Vec16<T>::store(out + i * V, o);
+        } else {
+            float g[V], o[4][V];
+            Vec16<T>::load(dy + i * V, g);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                int arg = 0; float m = a[0][k];                 // first maximum in window scan order wins
+#pragma unroll
+                for (int q = 1; q < 4; ++q) if (a[q][k] > m) { m = a[q][k]; arg = q; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q][k] = q == arg ? g[k] : 0.0f;
+            }
+            Vec16<T>::store(out + base, o[0]); Vec16<T>::store(out + base + c, o[1]);
+            Vec16<T>::store(out + base + (int64_t)w * c, o[2]); Vec16<T>::store(out + base + (int64_t)w * c + c, o[3]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, T* __restrict__ y,
+                                                             int64_t npix, int c) {
+    const int64_t total = npix * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        Elem<T>::st(y + i, __fmaf_rn(Elem<T>::ld(x + i), scale[ch], shift ? shift[ch] : 0.0f));
+    }
+}
+
+// one wavefront per pixel.  out[img] += (1/hw) sum_c w_c (fx_c/(|fx|+eps) - fy_c/(|fy|+eps))^2
+template <typename T>
+__global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const T* __restrict__ fx, const T* __restrict__ fy,
+                                                            const float* __restrict__ lin, int64_t npix, int64_t hw, int c,
+                                                            float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (int64_t)gridDim.x * 4) {
+        const T* px = fx + pix * c;
+        const T* py = fy + pix * c;
+        float sx = 0.f, sy = 0.f;
+        for (int k = lane; k < c; k += 64) {
+            const float a = Elem<T>::ld(px + k), b = Elem<T>::ld(py + k);
+            sx = __fmaf_rn(a, a, sx); sy = __fmaf_rn(b, b, sy);
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy);
+        const float rx = 1.0f / (sqrtf(sx) + 1e-10f), ry = 1.0f / (sqrtf(sy) + 1e-10f);
+        float acc = 0.f;
+        for (int k = lane; k < c; k += 64) {
+            const float d = Elem<T>::ld(px + k) * rx - Elem<T>::ld(py + k) * ry;
+            acc = __fmaf_rn(lin[k] * d, d, acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) atomicAdd(out + pix / hw, acc / (float)hw);
+    }
+}
+
+// d fy:  t_c = -2 g w_c d_c / hw ;  dfy_k = t_k/(ny+eps) - fy_k <t, fy> / (ny (ny+eps)^2)
+template <typename T>
+__global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const T* __restrict__ fx, const T* __restrict__ fy,
+                                                            const float* __restrict__ lin, const float* __restrict__ gout,
+                                                            float gscale, int64_t npix, int64_t hw, int c,
+                                                            T* __restrict__ dfy) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (int64_t)gridDim.x * 4) {
+        const T* px = fx + pix * c;
+        const T* py = fy + pix * c;
+        const float g = gscale * (gout ? gout[0] : 1.0f) / (float)hw;
+        float sx = 0.f, sy = 0.f;
+        for (int k = lane; k < c; k += 64) {
+            const float a = Elem<T>::ld(px + k), b = Elem<T>::ld(py + k);
+            sx = __fmaf_rn(a, a, sx); sy = __fmaf_rn(b, b, sy);
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy);
+        const float nx = sqrtf(sx), ny = sqrtf(sy);
+        const float rx = 1.0f / (nx + 1e-10f), ry = 1.0f / (ny + 1e-10f);
+        float tdot = 0.f;
+        for (int k = lane; k < c; k += 64) {
+            const float b = Elem<T>::ld(py + k);
+            const float d = Elem<T>::ld(px + k) * rx - b * ry;
+            tdot = __fmaf_rn(-2.0f * g * lin[k] * d, b, tdot);
+        }
+        tdot = wave_sum(tdot);
+        const float corr = ny > 0.f ? tdot * ry * ry / ny : 0.0f;
+        for (int k = lane; k < c; k += 64) {
+            const float b = Elem<T>::ld(py + k);
+            const float d = Elem<T>::ld(px + k) * rx - b * ry;
+            Elem<T>::st(dfy + pix * c + k, -2.0f * g * lin[k] * d * ry - b * corr);
+        }
+    }
+}
+
+// minibatch-stddev: sample b = g*(n/G) + m.  stat[m] = mean_{c,h,w} sqrt(var_g + 1e-8).  one block per m.
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_stat_kernel(const T* __restrict__ x, int n, int64_t chw, int gsz,
+                                                         float* __restrict__ stat) {
+    __shared__ float part[4];
+    const int m = blockIdx.x, cols = n / gsz;
+    float acc = 0.f;
+    for (int64_t e = threadIdx.x; e < chw; e += 256) {
+        float mean = 0.f, v[8];
+        for (int g = 0; g < gsz; ++g) { v[g] = Elem<T>::ld(x + ((int64_t)(g * cols + m)) * chw + e); mean += v[g]; }
+        mean /= (float)gsz;
+        float var = 0.f;
+        for (int g = 0; g < gsz; ++g) var += (v[g] - mean) * (v[g] - mean);
+        acc += sqrtf(var / (float)gsz + 1e-8f);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) stat[m] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)chw;
+}
+
+// y[b][pix][0..c) = x ; y[b][pix][c] = stat[b % cols] ; y[b][pix][c+1..cp) = 0
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_concat_kernel(const T* __restrict__ x, const float* __restrict__ stat,
+                                                           T* __restrict__ y, int n, int64_t hw, int c, int cp, int cols) {
+    const int64_t total = (int64_t)n * hw * cp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % cp);
+        const int64_t pix = i / cp;
+        const int b = (int)(pix / hw);
+        float v = 0.f;
+        if (ch < c) v = Elem<T>::ld(x + pix * c + ch);
+        else if (ch == c) v = stat[b % cols];
+        Elem<T>::st(y + i, v);
+    }
+}
+
+// dx[b][e] = dy[b][e (channels < c)] + dstat[m] * (x - mean_g) / (G * chw * std_e),  dstat[m] = sum dy[.., channel c]
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                        int n, int64_t hw, int c, int cp, int gsz) {
+    __shared__ float part[4];
+    __shared__ float dstat;
+    const int m = blockIdx.x, cols = n / gsz;
+    const int64_t chw = hw * c;
+    float acc = 0.f;
+    for (int64_t q = threadIdx.x; q < (int64_t)gsz * hw; q += 256) {
+        const int g = (int)(q / hw);
+        const int64_t pix = (int64_t)(g * cols + m) * hw + (q - g * hw);
+        acc += Elem<T>::ld(dy + pix * cp + c);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dstat = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+    const float ds = dstat / ((float)gsz * (float)chw);
+    for (int64_t e = threadIdx.x; e < chw; e += 256) {
+        const int64_t pixe = e / c; const int ch = (int)(e - pixe * c);
+        float mean = 0.f, v[8];
+        for (int g = 0; g < gsz; ++g) { v[g] = Elem<T>::ld(x + ((int64_t)(g * cols + m)) * chw + e); mean += v[g]; }
+        mean /= (float)gsz;
+        float var = 0.f;
+        for (int g = 0; g < gsz; ++g) var += (v[g] - mean) * (v[g] - mean);
+        const float sd = sqrtf(var / (float)gsz + 1e-8f);
+        for (int g = 0; g < gsz; ++g) {
+            const int64_t b = (int64_t)(g * cols + m);
+            const float up = Elem<T>::ld(dy + (b * hw + pixe) * cp + ch);
+            Elem<T>::st(dx + b * chw + e, up + ds * (v[g] - mean) / sd);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l1_sum_kernel(const T* __restrict__ r, const float* __restrict__ t, int64_t n,
+                                                     float* __restrict__ out) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        acc += fabsf(t[i] - Elem<T>::ld(r + i));
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// d = s * (a1 * sign(r - t) + a2 * 2 (r - t))      (L1 + L2 reconstruction terms, loss.py:118-121)
+template <typename T>
+__global__ __launch_bounds__(256) void l1l2_bwd_kernel(const T* __restrict__ r, const float* __restrict__ t, int64_t n,
+                                                       float a1, float a2, const float* __restrict__ gs,
+                                                       T* __restrict__ d, int accumulate) {
+    const float s = gs ? *gs : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float df = Elem<T>::ld(r + i) - t[i];
+        float g = s * (a1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) + a2 * 2.0f * df);
+        if (accumulate) g += Elem<T>::ld(d + i);
+        Elem<T>::st(d + i, g);
+    }
+}
+
+__device__ __forceinline__ float softplus_f(float v) { return fmaxf(v, 0.f) + log1pf(__expf(-fabsf(v))); }
+
+// loss.py:11-51.  mode 0 hinge, 1 non-saturating.  which 0: generator(fake) ; 1: discriminator(real, fake)
+__global__ void gan_loss_kernel(const float* __restrict__ real, const float* __restrict__ fake, int n, int mode, int which,
+                                float* __restrict__ loss, float* __restrict__ dreal, float* __restrict__ dfake,
+                                const float* __restrict__ gs) {
+    __shared__ float part[4];
+    const float s = (gs ? *gs : 1.0f) / (float)n;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float f = fake[i];
+        if (which == 0) {
+            if (mode == 0) { acc += -f; if (dfake) dfake[i] = -s; }
+            else { acc += softplus_f(-f); if (dfake) dfake[i] = -s / (1.0f + __expf(f)); }
+        } else {
+            const float r = real[i];
+            if (mode == 0) {
+                acc += fmaxf(1.0f - r, 0.f) + fmaxf(1.0f + f, 0.f);
+                if (dreal) dreal[i] = (1.0f - r > 0.f) ? -s : 0.f;
+                if (dfake) dfake[i] = (1.0f + f > 0.f) ? s : 0.f;
+            } else {
+                acc += softplus_f(-r) + softplus_f(f);
+                if (dreal) dreal[i] = -s / (1.0f + __expf(r));
+                if (dfake) dfake[i] = s / (1.0f + __expf(-f));
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) loss[0] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
+}
+
+}  // namespace
+
+#define LAUNCH_T(dtype, K, grid, st, ...)                                                                    \
+    do {                                                                                                     \
+        if ((dtype) == VQK_F32) hipLaunchKernelGGL((K<float>), grid, dim3(256), 0, st, __VA_ARGS__);         \
+        else if ((dtype) == VQK_BF16) hipLaunchKernelGGL((K<bf16_raw>), grid, dim3(256), 0, st, __VA_ARGS__); \
+        else return VQK_ERR_DTYPE;                                                                           \
+    } while (0)
+
+extern "C" {
+
+int vqk_act_backward(int dtype, const void* dy, const void* y, void* dx, int64_t n, int act, float scale, void* stream) {
+    VQK_REQUIRE(dy && y && dx, VQK_ERR_ARG);
+    VQK_REQUIRE(act >= 0 && act <= 3, VQK_ERR_ARG);
+    if (n <= 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(n, 256 * 4));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)dy, (const float*)y, (float*)dx, n, act, scale);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)dy, (const bf16_raw*)y, (bf16_raw*)dx, n, act, scale);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_upfirdn2d_nhwc(int dtype, const void* x, const float* f, void* y, int n, int h, int w, int c, int fh, int fw, int upx,
+                       int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                       int out_h, int out_w, void* stream) {
+    VQK_REQUIRE(x && f && y, VQK_ERR_ARG);
+    const int v = dtype == VQK_F32 ? 4 : 8;
+    VQK_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % v == 0 && fh >= 1 && fw >= 1, VQK_ERR_SHAPE);
+    VQK_REQUIRE(upx >= 1 && upy >= 1 && downx >= 1 && downy >= 1, VQK_ERR_ARG);
+    VQK_REQUIRE(out_w == (w * upx + padx0 + padx1 - fw + downx) / downx, VQK_ERR_SHAPE);
+    VQK_REQUIRE(out_h == (h * upy + pady0 + pady1 - fh + downy) / downy, VQK_ERR_SHAPE);
+    VQK_REQUIRE(out_w >= 1 && out_h >= 1, VQK_ERR_SHAPE);
+    const int64_t total = (int64_t)n * out_h * out_w * (c / v);
+    const dim3 grid(vqk_grid_1d(total, 256, 256 * 16));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(upfirdn_nhwc_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, f, (float*)y, n, h, w, c, fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain, out_h, out_w);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(upfirdn_nhwc_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)x, f, (bf16_raw*)y, n, h, w, c, fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain, out_h, out_w);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_maxpool2x2(int dtype, const void* x, const void* dy, void* out, int n, int h, int w, int c, int backward, void* stream) {
+    VQK_REQUIRE(x && out && (!backward || dy), VQK_ERR_ARG);
+    const int v = dtype == VQK_F32 ? 4 : 8;
+    VQK_REQUIRE(n > 0 && h > 0 && w > 0 && !(h & 1) && !(w & 1) && c > 0 && c % v == 0, VQK_ERR_SHAPE);
+    const int64_t total = (int64_t)n * (h / 2) * (w / 2) * (c / v);
+    const dim3 grid(vqk_grid_1d(total, 256, 256 * 16));
+    hipStream_t st = vqk_stream(stream);
+    if (dtype == VQK_F32) {
+        if (backward) hipLaunchKernelGGL((maxpool_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)out, n, h, w, c);
+        else hipLaunchKernelGGL((maxpool_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)out, n, h, w, c);
+    } else if (dtype == VQK_BF16) {
+        if (backward) hipLaunchKernelGGL((maxpool_kernel<bf16_raw, true>), grid, dim3(256), 0, st, (const bf16_raw*)x, (const bf16_raw*)dy, (bf16_raw*)out, n, h, w, c);
+        else hipLaunchKernelGGL((maxpool_kernel<bf16_raw, false>), grid, dim3(256), 0, st, (const bf16_raw*)x, (const bf16_raw*)dy, (bf16_raw*)out, n, h, w, c);
+    } else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_channel_affine(int dtype, const void* x, const float* scale, const float* shift, void* y, int64_t npix, int c, void* stream) {
+    VQK_REQUIRE(x && scale && y, VQK_ERR_ARG);
+    VQK_REQUIRE(npix >= 0 && c > 0, VQK_ERR_SHAPE);
+    if (npix == 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(npix * c, 256 * 4));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(channel_affine_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, scale, shift, (float*)y, npix, c);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(channel_affine_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)x, scale, shift, (bf16_raw*)y, npix, c);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_lpips_tap(int dtype, const void* fx, const void* fy, const float* lin, int n, int64_t hw, int c, float* out,
+                  const float* gout, float gscale, void* dfy, void* stream) {
+    VQK_REQUIRE(fx && fy && lin && (out || dfy), VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0 && c > 0, VQK_ERR_SHAPE);
+    const int64_t npix = (int64_t)n * hw;
+    const dim3 grid(vqk_grid_1d(npix, 4));
+    hipStream_t st = vqk_stream(stream);
+    if (dfy) {
+        if (dtype == VQK_F32) hipLaunchKernelGGL(lpips_tap_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)fx, (const float*)fy, lin, gout, gscale, npix, hw, c, (float*)dfy);
+        else if (dtype == VQK_BF16) hipLaunchKernelGGL(lpips_tap_bwd_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)fx, (const bf16_raw*)fy, lin, gout, gscale, npix, hw, c, (bf16_raw*)dfy);
+        else return VQK_ERR_DTYPE;
+    } else {
+        if (dtype == VQK_F32) hipLaunchKernelGGL(lpips_tap_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)fx, (const float*)fy, lin, npix, hw, c, out);
+        else if (dtype == VQK_BF16) hipLaunchKernelGGL(lpips_tap_fwd_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)fx, (const bf16_raw*)fy, lin, npix, hw, c, out);
+        else return VQK_ERR_DTYPE;
+    }
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_mbstd(int dtype, const void* x, const void* dy, void* out, float* stat, int n, int64_t hw, int c, int cpad, int group,
+              int backward, void* stream) {
+    VQK_REQUIRE(x && out && (backward ? dy != nullptr : stat != nullptr), VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0 && c > 0 && cpad > c && group >= 1 && group <= 8 && n % group == 0, VQK_ERR_SHAPE);
+    const int cols = n / group;
+    hipStream_t st = vqk_stream(stream);
+    if (!backward) {
+        if (dtype == VQK_F32) {
+            hipLaunchKernelGGL(mbstd_stat_kernel<float>, dim3(cols), dim3(256), 0, st, (const float*)x, n, hw * c, group, stat);
+            hipLaunchKernelGGL(mbstd_concat_kernel<float>, dim3(vqk_grid_1d((int64_t)n * hw * cpad, 256)), dim3(256), 0, st, (const float*)x, stat, (float*)out, n, hw, c, cpad, cols);
+        } else if (dtype == VQK_BF16) {
+            hipLaunchKernelGGL(mbstd_stat_kernel<bf16_raw>, dim3(cols), dim3(256), 0, st, (const bf16_raw*)x, n, hw * c, group, stat);
+            hipLaunchKernelGGL(mbstd_concat_kernel<bf16_raw>, dim3(vqk_grid_1d((int64_t)n * hw * cpad, 256)), dim3(256), 0, st, (const bf16_raw*)x, stat, (bf16_raw*)out, n, hw, c, cpad, cols);
+        } else return VQK_ERR_DTYPE;
+    } else {
+        if (dtype == VQK_F32) hipLaunchKernelGGL(mbstd_bwd_kernel<float>, dim3(cols), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)out, n, hw, c, cpad, group);
+        else if (dtype == VQK_BF16) hipLaunchKernelGGL(mbstd_bwd_kernel<bf16_raw>, dim3(cols), dim3(256), 0, st, (const bf16_raw*)x, (const bf16_raw*)dy, (bf16_raw*)out, n, hw, c, cpad, group);
+        else return VQK_ERR_DTYPE;
+    }
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_l1_sum(int dtype, const void* recon, const float* target, int64_t n, float* out, void* stream) {
+    VQK_REQUIRE(recon && target && out, VQK_ERR_ARG);
+    if (n <= 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(n, 256 * 8));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(l1_sum_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)recon, target, n, out);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(l1_sum_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)recon, target, n, out);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_l1l2_backward(int dtype, const void* recon, const float* target, int64_t n, float a1, float a2, const float* gscale_dev,
+                      void* d, int accumulate, void* stream) {
+    VQK_REQUIRE(recon && target && d, VQK_ERR_ARG);
+    if (n <= 0) return VQK_OK;
+    const dim3 grid(vqk_grid_1d(n, 256 * 4));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(l1l2_bwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)recon, target, n, a1, a2, gscale_dev, (float*)d, accumulate);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(l1l2_bwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)recon, target, n, a1, a2, gscale_dev, (bf16_raw*)d, accumulate);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_gan_loss(const float* logits_real, const float* logits_fake, int n, int mode, int which, float* loss, float* dreal,
+                 float* dfake, const float* gscale_dev, void* stream) {
+    VQK_REQUIRE(logits_fake && (which == 0 || logits_real), VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && (mode == 0 || mode == 1) && (which == 0 || which == 1), VQK_ERR_ARG);
+    hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(256), 0, vqk_stream(stream), logits_real, logits_fake, n, mode, which, loss,
+                       dreal, dfake, gscale_dev);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+}  // extern "C"
