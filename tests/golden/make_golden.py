@@ -282,9 +282,92 @@ def gen_stylegan_ops():
     save('stylegan_ops', **out)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'gan' not in sys.argv[1:]:
     gen_ops()
     gen_vq()
     gen_vq_large()
     gen_train_step()
     gen_stylegan_ops()
+
+
+# ---------------------------------------------------------------- VQ-GAN loss path
+def _stub_torchvision():
+    """torchvision is not installed: provide just enough for `vqvae.modules.loss` to import.  vgg16().features is
+    a hand-assembled cfg-"D" Sequential with PyTorch-default (seeded) weights -- pretrained values stay unpinned."""
+    import types
+    tv = types.ModuleType('torchvision')
+    models = types.ModuleType('torchvision.models')
+
+    def vgg16(weights=None):
+        cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+        layers, cin = [], 3
+        for v in cfg:
+            if v == 'M':
+                layers.append(torch.nn.MaxPool2d(2, 2))
+            else:
+                layers += [torch.nn.Conv2d(cin, v, 3, padding=1), torch.nn.ReLU(inplace=True)]
+                cin = v
+        m = types.SimpleNamespace()
+        m.features = torch.nn.Sequential(*layers)
+        return m
+    models.vgg16 = vgg16
+    models.VGG16_Weights = types.SimpleNamespace(DEFAULT=None)
+    tv.models = models
+    sys.modules['torchvision'] = tv
+    sys.modules['torchvision.models'] = models
+
+
+def gen_gan():
+    _stub_torchvision()
+    from vqvae.modules.loss.stylegan2_discriminator.discriminator import Discriminator
+    from vqvae.modules.loss import loss as ref_loss
+    from vqvae.modules.loss.lpips_pytorch.modules import lpips as ref_lpips
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    # discriminator: 32x32, 289k parameters
+    torch.manual_seed(5)
+    d = Discriminator(32, channel_base=1024, channel_max=64)
+    with torch.no_grad():
+        for n_, p in d.named_parameters():
+            if n_.endswith('bias'):
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+    x = (torch.randn(4, 3, 32, 32, generator=g) * 0.5).requires_grad_(True)
+    logits = d(x)
+    r = torch.randn(4, 1, generator=g)
+    named = list(d.named_parameters())
+    grads = torch.autograd.grad((logits * r).sum(), [x] + [p for _, p in named])
+    out.update({'d.' + k: npy(v) for k, v in d.state_dict().items()})
+    out.update({'d_in.x': npy(x), 'd_in.r': npy(r), 'd_out.logits': npy(logits), 'd_out.dx': npy(grads[0])})
+    out.update({'d_grad.' + n_: npy(gr) for (n_, _), gr in zip(named, grads[1:])})
+    # GAN losses
+    lr_, lf_ = torch.randn(8, 1, generator=g) * 2, torch.randn(8, 1, generator=g) * 2
+    for lt in ('hinge', 'non-saturating'):
+        a, b = lr_.clone().requires_grad_(True), lf_.clone().requires_grad_(True)
+        gl = ref_loss.generator_loss(b, lt)
+        out[f'gan.{lt}.g'] = npy(gl)
+        out[f'gan.{lt}.g_dfake'] = npy(torch.autograd.grad(gl, b)[0])
+        dl = ref_loss.discriminator_loss(a, b, lt)
+        da, db = torch.autograd.grad(dl, [a, b])
+        out.update({f'gan.{lt}.d': npy(dl), f'gan.{lt}.d_dreal': npy(da), f'gan.{lt}.d_dfake': npy(db)})
+    out.update({'gan.real': npy(lr_), 'gan.fake': npy(lf_)})
+    # LPIPS (random, seeded backbone + random lin layers; weights are regenerated from the seed by the test)
+    torch.manual_seed(77)
+    lin_w = {f'{i}.1.weight': torch.rand(1, c, 1, 1, generator=g) for i, c in enumerate([64, 128, 256, 512, 512])}
+    ref_lpips.get_state_dict = lambda *a, **k: lin_w
+    lp = ref_lpips.LPIPS('vgg')
+    imgs = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    rec = (imgs + 0.3 * torch.randn(2, 3, 32, 32, generator=g)).clamp(-1, 1).requires_grad_(True)
+    val = lp(imgs, rec)
+    out.update({'lpips.images': npy(imgs), 'lpips.recon': npy(rec), 'lpips.value': npy(val),
+                'lpips.drecon': npy(torch.autograd.grad(val, rec)[0])})
+    out.update({f'lpips.lin{i}': npy(v).reshape(-1) for i, v in enumerate(lin_w.values())})
+    # recon loss terms
+    l1 = (imgs - rec).abs().mean()
+    l2 = (imgs - rec).pow(2).mean()
+    gl1, = torch.autograd.grad(0.8 * l1 + 0.2 * l2, rec)
+    out.update({'recon.l1': npy(l1), 'recon.l2': npy(l2), 'recon.d': npy(gl1)})
+    save('gan', **out)
+
+
+if __name__ == '__main__' and 'gan' in sys.argv[1:]:
+    gen_gan()

@@ -1,0 +1,124 @@
+"""GPU parity of the VQ-GAN loss path (StyleGAN2 discriminator, LPIPS/VGG16, GAN + reconstruction losses) against
+vectors captured from the reference (tests/golden/gan.npz)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+disc = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.loss.discriminator')
+lpips_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.loss.lpips')
+loss_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.loss.loss')
+DEV = 'cuda:0'
+T = torch.from_numpy
+
+
+def rel(a, b, floor=1e-8):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + floor * b.numel() ** 0.5)).item()
+
+
+def test_discriminator_golden(golden):
+    g = golden('gan')
+    d = disc.Discriminator(32, channel_base=1024, channel_max=64)
+    sd = {k[2:]: T(v) for k, v in g.items() if k.startswith('d.')}
+    res = d.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    d = d.to(DEV)
+    x = T(g['d_in.x']).to(DEV).requires_grad_(True)
+    logits = d(x)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g['d_out.logits'], rtol=2e-4, atol=2e-5)
+    named = list(d.named_parameters())
+    grads = torch.autograd.grad((logits * T(g['d_in.r']).to(DEV)).sum(), [x] + [p for _, p in named])
+    assert rel(grads[0], T(g['d_out.dx'])) < 1e-3
+    for (n, _), gr in zip(named, grads[1:]):
+        assert rel(gr, T(g['d_grad.' + n])) < 1e-3, n
+
+
+def test_discriminator_bf16_tracks_fp32(golden):
+    g = golden('gan')
+    outs = []
+    for dt in (torch.float32, torch.bfloat16):
+        d = disc.Discriminator(32, channel_base=1024, channel_max=64)
+        d.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith('d.')})
+        d.compute_dtype = dt
+        outs.append(d.to(DEV)(T(g['d_in.x']).to(DEV)).detach())
+    assert rel(outs[1], outs[0]) < 5e-2
+
+
+@pytest.mark.parametrize('lt', ['hinge', 'non-saturating'])
+def test_gan_losses_golden(golden, lt):
+    g = golden('gan')
+    a = T(g['gan.real']).to(DEV).requires_grad_(True)
+    b = T(g['gan.fake']).to(DEV).requires_grad_(True)
+    gl = loss_mod.generator_loss(b, lt)
+    np.testing.assert_allclose(gl.item(), g[f'gan.{lt}.g'], rtol=1e-5)
+    np.testing.assert_allclose(torch.autograd.grad(gl, b)[0].cpu().numpy(), g[f'gan.{lt}.g_dfake'], rtol=1e-5, atol=1e-7)
+    dl = loss_mod.discriminator_loss(a, b, lt)
+    np.testing.assert_allclose(dl.item(), g[f'gan.{lt}.d'], rtol=1e-5)
+    da, db = torch.autograd.grad(dl, [a, b])
+    np.testing.assert_allclose(da.cpu().numpy(), g[f'gan.{lt}.d_dreal'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(db.cpu().numpy(), g[f'gan.{lt}.d_dfake'], rtol=1e-5, atol=1e-7)
+
+
+def _seeded_vgg_features():
+    """the same hand-assembled cfg-D backbone (PyTorch default init under seed 77) the fixture was made with"""
+    torch.manual_seed(77)
+    cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+    layers, cin = [], 3
+    for v in cfg:
+        if v == 'M':
+            layers.append(torch.nn.MaxPool2d(2, 2))
+        else:
+            layers += [torch.nn.Conv2d(cin, v, 3, padding=1), torch.nn.ReLU(inplace=True)]
+            cin = v
+    return torch.nn.Sequential(*layers)
+
+
+def test_lpips_golden(golden):
+    g = golden('gan')
+    feats = _seeded_vgg_features()
+    lp = lpips_mod.LPIPS('vgg')
+    sd = {}
+    for i, m in enumerate(feats):
+        if isinstance(m, torch.nn.Conv2d):
+            sd[f'net.layers.{i}.weight'] = m.weight.detach()
+            sd[f'net.layers.{i}.bias'] = m.bias.detach()
+    for i in range(5):
+        sd[f'lin.{i}.1.weight'] = T(g[f'lpips.lin{i}']).reshape(1, -1, 1, 1)
+    res = lp.load_state_dict(sd, strict=False)
+    assert set(res.missing_keys) <= {'net.mean', 'net.std'} and not res.unexpected_keys
+    lp = lp.to(DEV)
+    rec = T(g['lpips.recon']).to(DEV).requires_grad_(True)
+    val = lp(T(g['lpips.images']).to(DEV), rec)
+    np.testing.assert_allclose(val.item(), g['lpips.value'], rtol=5e-4)
+    dr, = torch.autograd.grad(val, rec)
+    assert rel(dr, T(g['lpips.drecon'])) < 2e-3
+
+
+def test_recon_losses_golden(golden):
+    g = golden('gan')
+    imgs = T(g['lpips.images']).to(DEV)
+    rec = T(g['lpips.recon']).to(DEV).requires_grad_(True)
+    l1, l2 = ops.ReconLossFn.apply(rec, imgs, float(rec.numel()))
+    np.testing.assert_allclose(l1.item(), g['recon.l1'], rtol=1e-5)
+    np.testing.assert_allclose(l2.item(), g['recon.l2'], rtol=1e-5)
+    d, = torch.autograd.grad(0.8 * l1 + 0.2 * l2, rec)
+    np.testing.assert_allclose(d.cpu().numpy(), g['recon.d'], rtol=1e-4, atol=1e-8)
+
+
+def test_upfirdn_nhwc_matches_nchw_plugin(golden):
+    g = golden('stylegan_ops')
+    f = T(g['uf.f']).to(DEV)
+    for tag, kw in {'down2_pad1': dict(up=1, down=2, padding=(1, 1, 1, 1), flip_filter=False),
+                    'filt_pad2': dict(up=1, down=1, padding=(2, 2, 2, 2), flip_filter=False)}.items():
+        x = torch.nn.functional.pad(T(g[f'uf.{tag}.x']), (0, 0, 0, 0, 0, 3)).to(DEV)       # 5 -> 8 channels
+        x = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = ops.upfirdn2d_nhwc(x, f, **kw)
+        np.testing.assert_allclose(y[:, :5].detach().cpu().numpy(), g[f'uf.{tag}.y'], rtol=1e-5, atol=1e-6)
+        dy = torch.nn.functional.pad(T(g[f'uf.{tag}.dy']), (0, 0, 0, 0, 0, 3)).to(DEV)
+        dx, = torch.autograd.grad(y, x, dy)
+        np.testing.assert_allclose(dx[:, :5].cpu().numpy(), g[f'uf.{tag}.dx'], rtol=1e-5, atol=1e-6)

@@ -722,3 +722,322 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
     if f.ndim != 2:
         raise RuntimeError('vqk: upfirdn2d expects a 2-D FIR filter')
     return Upfirdn2dFn.apply(x, f.to(torch.float32), up, down, padding, bool(flip_filter), float(gain))
+
+
+# ------------------------------------------------------------------------------------------------------
+# VQ-GAN loss path: general conv + activation, NHWC resampling, pooling, LPIPS tap, minibatch-stddev, losses
+# ------------------------------------------------------------------------------------------------------
+ACT_CODE = {'linear': 0, 'tanh': 1, 'relu': 2, 'lrelu': 3}
+
+
+def _conv_general_raw(x, wq, bias, residual, cout, k, stride, pad, mode, h_out, w_out, act, acc_scale, out_gain, out_dtype,
+                      wlayout=0):
+    n, cin, h, w = x.shape
+    y = empty_nhwc(n, cout, h_out, w_out, out_dtype, x.device)
+    flops = 2.0 * n * h_out * w_out * cout * cin * k * k
+    st = _timed(f'conv_fprop<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
+                lambda: _native.lib().vqk_conv2d_general(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias), _p(residual),
+                                                         y.data_ptr(), dcode(out_dtype), n, h, w, cin, cout, k, stride, pad,
+                                                         mode, h_out, w_out, act, float(acc_scale), float(out_gain), wlayout,
+                                                         zero_page(x.device).data_ptr(), _stream()))
+    _native.check(st, 'conv2d_general')
+    return y
+
+
+class ConvActFn(torch.autograd.Function):
+    """y = out_gain * act(conv(x, W) * wgain + bias), stride in {1,2}, explicit zero padding.
+
+    The StyleGAN2 ``Conv2dLayer`` / ``FullyConnectedLayer`` arithmetic (discriminator.py:104-120, :164-173: runtime
+    weight gain 1/sqrt(fan_in), fused bias + activation + gain = the reference's ``bias_act`` plugin) and the VGG16
+    conv+bias+ReLU of LPIPS, all in the conv kernel's epilogue.  Backward: t = out_gain * act'(y) * dy (``bias_act``
+    grad=1), db = colsum(t), dx = wgain * dgrad(t) (zero-stuffed gather for stride 2), dW = wgain * wgrad(x, t)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k: int, stride: int, pad: int, act: int, wgain: float, out_gain: float, out_dtype):
+        _require_gpu(x)
+        x = nhwc(x)
+        dt = x.dtype
+        out_dtype = out_dtype or dt
+        o, i = weight.shape[0], weight.shape[1]
+        cin = x.shape[1]
+        e = max(epc(dt), epc(out_dtype))
+        cout_pad = -(-o // e) * e
+        if cin < i or cin % epc(dt):
+            raise RuntimeError(f'vqk: conv input has {cin} channels, weight expects {i}')
+        n, _, h, w = x.shape
+        h_out = (h + 2 * pad - k) // stride + 1
+        w_out = (w + 2 * pad - k) // stride + 1
+        plain = stride == 1 and pad == k // 2
+        layout = weight_layout(dt, n, h, w, cin, cout_pad, k, False) if plain else 0
+        w4 = weight.reshape(o, i, k, k)
+        wq = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, False, layout)
+        b32 = None
+        if bias is not None:
+            b32 = bias.detach().to(torch.float32)
+            if cout_pad != o:
+                b32 = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
+                b32[:o] = bias.detach()
+        y = _conv_general_raw(x, wq, b32, None, cout_pad, k, stride, pad, 0, h_out, w_out, act, wgain, out_gain, out_dtype,
+                              layout)
+        ctx.save_for_backward(x, y)
+        ctx.refs = (weight, bias)
+        ctx.cfg = (k, stride, pad, act, wgain, out_gain, o, i, cin, cout_pad, dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, bias = ctx.refs
+        k, stride, pad, act, wgain, out_gain, o, i, cin, cout_pad, dt = ctx.cfg
+        dy = nhwc(dy)
+        lib, st = _native.lib(), _stream()
+        t = torch.empty_like(dy, memory_format=_CL)
+        _native.check(lib.vqk_act_backward(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(), dy.numel(), act,
+                                           float(out_gain), st), 'act_backward')
+        tc = t if t.dtype == dt else nhwc(t.to(dt))
+        n, _, h, w = x.shape
+        _, _, h_out, w_out = tc.shape
+        w4 = weight.reshape(o, i, k, k)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1 and pad == k // 2:
+                layout = weight_layout(dt, n, h_out, w_out, cout_pad, cin, k, False)
+                wt = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, True, layout)
+                dx = _conv_general_raw(tc, wt, None, None, cin, k, 1, k // 2, 0, h, w, 0, wgain, 1.0, dt, layout)
+            else:
+                wt = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, True, 0)
+                mode = 2 if stride == 2 else 0
+                dx = _conv_general_raw(tc, wt, None, None, cin, k, 1, k - 1 - pad, mode, h, w, 0, wgain, 1.0, dt, 0)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=x.device)
+            _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tc.data_ptr(), dwp.data_ptr(), n, h, w, cin,
+                                                       cout_pad, k, stride, pad, 0, h_out, w_out,
+                                                       zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
+            if wgain != 1.0:
+                _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain), 0.0, dwp.numel(), st), 'axpby')
+            dw = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
+        if bias is not None and ctx.needs_input_grad[2]:
+            db = raw_colsum(n * h_out * w_out, cout_pad, tc)[:o]
+        return dx, dw, db, None, None, None, None, None, None, None
+
+
+def conv_act(x, weight, bias=None, k=3, stride=1, pad=None, act='linear', wgain=1.0, out_gain=1.0, out_dtype=None):
+    return ConvActFn.apply(x, weight, bias, k, stride, k // 2 if pad is None else pad, ACT_CODE[act], float(wgain),
+                           float(out_gain), out_dtype)
+
+
+class UpfirdnNhwcFn(torch.autograd.Function):
+    """upfirdn2d on NHWC activations (same op, same padding algebra, same backward rule as upfirdn2d.py:214-268)."""
+
+    @staticmethod
+    def forward(ctx, x, f, up, down, pad, flip, gain):
+        _require_gpu(x)
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        fh, fw = f.shape
+        ow = (w * up + pad[0] + pad[1] - fw + down) // down
+        oh = (h * up + pad[2] + pad[3] - fh + down) // down
+        y = empty_nhwc(n, c, oh, ow, x.dtype, x.device)
+        st = _native.lib().vqk_upfirdn2d_nhwc(dcode(x.dtype), x.data_ptr(), f.data_ptr(), y.data_ptr(), n, h, w, c, fh, fw,
+                                              up, up, down, down, pad[0], pad[1], pad[2], pad[3], int(flip), float(gain),
+                                              oh, ow, _stream())
+        _native.check(st, 'upfirdn2d_nhwc')
+        ctx.save_for_backward(f)
+        ctx.cfg = (up, down, pad, flip, gain, (h, w))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (f,) = ctx.saved_tensors
+        up, down, pad, flip, gain, (ih, iw) = ctx.cfg
+        fh, fw = f.shape
+        _, _, oh, ow = dy.shape
+        p = (fw - pad[0] - 1, iw * up - ow * down + pad[0] - up + 1, fh - pad[2] - 1, ih * up - oh * down + pad[2] - up + 1)
+        return UpfirdnNhwcFn.apply(dy, f, down, up, p, not flip, gain), None, None, None, None, None, None
+
+
+def upfirdn2d_nhwc(x, f, up=1, down=1, padding=(0, 0, 0, 0), flip_filter=False, gain=1.0):
+    return UpfirdnNhwcFn.apply(x, f.to(torch.float32).contiguous(), int(up), int(down), tuple(padding), bool(flip_filter),
+                               float(gain))
+
+
+class MaxPool2x2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
+        _native.check(_native.lib().vqk_maxpool2x2(dcode(x.dtype), x.data_ptr(), 0, y.data_ptr(), n, h, w, c, 0, _stream()), 'maxpool')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x, memory_format=_CL)
+        _native.check(_native.lib().vqk_maxpool2x2(dcode(x.dtype), x.data_ptr(), nhwc(dy).data_ptr(), dx.data_ptr(), n, h, w, c,
+                                                   1, _stream()), 'maxpool_backward')
+        return dx
+
+
+class ChannelAffineFn(torch.autograd.Function):
+    """y = x * scale[c] + shift[c] (constants)"""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        _require_gpu(x)
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = torch.empty_like(x, memory_format=_CL)
+        _native.check(_native.lib().vqk_channel_affine(dcode(x.dtype), x.data_ptr(), scale.data_ptr(), _p(shift), y.data_ptr(),
+                                                       n * h * w, c, _stream()), 'channel_affine')
+        ctx.save_for_backward(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        dy = nhwc(dy)
+        n, c, h, w = dy.shape
+        dx = torch.empty_like(dy, memory_format=_CL)
+        _native.check(_native.lib().vqk_channel_affine(dcode(dy.dtype), dy.data_ptr(), scale.data_ptr(), 0, dx.data_ptr(),
+                                                       n * h * w, c, _stream()), 'channel_affine')
+        return dx, None, None
+
+
+class LpipsTapFn(torch.autograd.Function):
+    """per-image LPIPS contribution of one feature tap; gradient flows to ``fy`` (the reconstruction branch) only"""
+
+    @staticmethod
+    def forward(ctx, fx, fy, lin):
+        _require_gpu(fx)
+        fx, fy = nhwc(fx), nhwc(fy)
+        n, c, h, w = fx.shape
+        out = torch.zeros(n, dtype=torch.float32, device=fx.device)
+        _native.check(_native.lib().vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
+                                                  out.data_ptr(), 0, 1.0, 0, _stream()), 'lpips_tap')
+        ctx.save_for_backward(fx, fy, lin)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        fx, fy, lin = ctx.saved_tensors
+        n, c, h, w = fx.shape
+        # dout is [n]; the reference reduces with a batch mean, so every entry is the same scalar: use per-image scale
+        dfy = torch.empty_like(fy, memory_format=_CL)
+        if bool((dout != dout[0]).any()):                      # general upstream: one launch per image
+            for b in range(n):
+                _native.check(_native.lib().vqk_lpips_tap(dcode(fx.dtype), fx[b:b + 1].data_ptr(), fy[b:b + 1].data_ptr(),
+                                                          lin.data_ptr(), 1, h * w, c, 0, dout[b:b + 1].contiguous().data_ptr(),
+                                                          1.0, dfy[b:b + 1].data_ptr(), _stream()), 'lpips_tap_backward')
+        else:
+            _native.check(_native.lib().vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
+                                                      0, dout[0:1].contiguous().data_ptr(), 1.0, dfy.data_ptr(), _stream()),
+                          'lpips_tap_backward')
+        return None, dfy, None
+
+
+class MbstdFn(torch.autograd.Function):
+    """minibatch-stddev feature appended as one extra channel (discriminator.py:277-293); output channels are
+    padded with zeros to a whole 16-byte chunk"""
+
+    @staticmethod
+    def forward(ctx, x, group: int):
+        _require_gpu(x)
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        g = min(group, n)
+        cp = -(-(c + 1) // epc(x.dtype)) * epc(x.dtype)
+        y = empty_nhwc(n, cp, h, w, x.dtype, x.device)
+        stat = torch.empty(n // g, dtype=torch.float32, device=x.device)
+        _native.check(_native.lib().vqk_mbstd(dcode(x.dtype), x.data_ptr(), 0, y.data_ptr(), stat.data_ptr(), n, h * w, c, cp, g,
+                                              0, _stream()), 'mbstd')
+        ctx.save_for_backward(x)
+        ctx.cfg = (g, cp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        g, cp = ctx.cfg
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x, memory_format=_CL)
+        _native.check(_native.lib().vqk_mbstd(dcode(x.dtype), x.data_ptr(), nhwc(dy).data_ptr(), dx.data_ptr(), 0, n, h * w, c, cp,
+                                              g, 1, _stream()), 'mbstd_backward')
+        return dx, None
+
+
+class AddFn(torch.autograd.Function):
+    """a + b on the HIP axpby kernel (the resnet skip add of the discriminator, discriminator.py:259)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = nhwc(a), nhwc(b)
+        y = torch.empty_like(a, memory_format=_CL)
+        _native.check(_native.lib().vqk_axpby(dcode(a.dtype), a.data_ptr(), b.data_ptr(), y.data_ptr(), 1.0, 1.0, a.numel(),
+                                              _stream()), 'axpby')
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class ReconLossFn(torch.autograd.Function):
+    """(l1, l2) = (mean |t - r|, mean (t - r)^2) over the un-padded element count (loss.py:58-63,118-119)"""
+
+    @staticmethod
+    def forward(ctx, recon, target, denom: float):
+        _require_gpu(recon)
+        recon = nhwc(recon)
+        target = nhwc(target.to(torch.float32))
+        sums = torch.zeros(2, dtype=torch.float32, device=recon.device)
+        lib, st = _native.lib(), _stream()
+        _native.check(lib.vqk_l1_sum(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(), recon.numel(), sums[0:1].data_ptr(), st), 'l1')
+        _native.check(lib.vqk_sse(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(), recon.numel(), sums[1:2].data_ptr(), st), 'sse')
+        ctx.save_for_backward(recon, target)
+        ctx.denom = denom
+        return sums[0] / denom, sums[1] / denom
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        recon, target = ctx.saved_tensors
+        d = torch.empty_like(recon, memory_format=_CL)
+        lib, st = _native.lib(), _stream()
+        one = torch.ones((), dtype=torch.float32, device=recon.device)
+        g1 = (d1 if d1 is not None else one * 0).to(torch.float32).contiguous()
+        g2 = (d2 if d2 is not None else one * 0).to(torch.float32).contiguous()
+        _native.check(lib.vqk_l1l2_backward(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(), recon.numel(),
+                                            1.0 / ctx.denom, 0.0, g1.data_ptr(), d.data_ptr(), 0, st), 'l1_backward')
+        _native.check(lib.vqk_l1l2_backward(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(), recon.numel(),
+                                            0.0, 1.0 / ctx.denom, g2.data_ptr(), d.data_ptr(), 1, st), 'l2_backward')
+        return d, None, None
+
+
+class GanLossFn(torch.autograd.Function):
+    """generator_loss / discriminator_loss of loss.py:11-51 on [B,1] logits"""
+
+    @staticmethod
+    def forward(ctx, logits_real, logits_fake, mode: int, which: int):
+        lf = logits_fake.to(torch.float32).contiguous()
+        lr = logits_real.to(torch.float32).contiguous() if logits_real is not None else None
+        _require_gpu(lf)
+        loss = torch.zeros((), dtype=torch.float32, device=lf.device)
+        _native.check(_native.lib().vqk_gan_loss(_p(lr), lf.data_ptr(), lf.numel(), mode, which, loss.data_ptr(), 0, 0, 0,
+                                                 _stream()), 'gan_loss')
+        ctx.save_for_backward(lr, lf)
+        ctx.cfg = (mode, which, logits_fake.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lr, lf = ctx.saved_tensors
+        mode, which, shape = ctx.cfg
+        dfake = torch.empty_like(lf)
+        dreal = torch.empty_like(lr) if lr is not None else None
+        gs = dloss.to(torch.float32).contiguous()
+        _native.check(_native.lib().vqk_gan_loss(_p(lr), lf.data_ptr(), lf.numel(), mode, which, 0, _p(dreal), dfake.data_ptr(),
+                                                 gs.data_ptr(), _stream()), 'gan_loss_backward')
+        return (dreal.view(shape) if dreal is not None else None), dfake.view(shape), None, None
