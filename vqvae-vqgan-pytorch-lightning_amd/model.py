@@ -26,6 +26,7 @@ from .modules.abstract_modules.base_autoencoder import BaseVQVAE
 from .modules.autoencoder import Decoder, Encoder, GroupNorm, Conv2d, set_compute_dtype
 from .modules.vector_quantizers import (EMAVectorQuantizer, EntropyVectorQuantizer, GumbelVectorQuantizer,
                                         VectorQuantizer)
+from .modules.loss.loss import VQLPIPSWithDiscriminator
 from .optim import FlatAdamW
 from .schedulers import CosineScheduler, LinearCosineScheduler, LinearScheduler
 
@@ -92,8 +93,11 @@ class VQVAE(BaseVQVAE, _LightningBase):
         if load_loss:
             if l_conf is None:
                 self.criterion = MSELoss()
+            elif l_conf['adversarial_params'] is None:
+                raise NotImplementedError('VQLPIPS (AlexNet ablation, loss.py:167-199) is out of scope (SURVEY 2 row 7)')
             else:
-                raise NotImplementedError('LPIPS / adversarial criterion: SURVEY 8 rows A16-A21, not built yet')
+                self.criterion = VQLPIPSWithDiscriminator(image_size, l_conf['l1_weight'], l_conf['l2_weight'],
+                                                          l_conf['perc_weight'], l_conf['adversarial_params'])
         else:
             self.criterion = None
 
@@ -154,7 +158,40 @@ class VQVAE(BaseVQVAE, _LightningBase):
         l2_loss = ops.mse_loss(recon_pad, target, true_channels=3)
         return recon_pad, used_indices, q_loss, l2_loss
 
+    def _gan_training_step(self, batch: Any, batch_index: int):
+        """manual optimisation, model.py:244-264: AE step (nll + g_weight * g_loss + q_loss), then discriminator step"""
+        images = batch[0] if isinstance(batch, (tuple, list)) else batch
+        x_pad, target = ops.raw_preprocess(images, self.compute_dtype, want_target=True)
+        z = self.encoder(x_pad)
+        quantized, _, q_loss = self.quantizer(z)
+        recon_pad = self.decoder.forward_padded(quantized)
+        ae_opt, disc_opt = self.optimizers()
+        ae_opt.zero_grad()
+        res = self.criterion.forward_autoencoder(q_loss, target, recon_pad, self.current_epoch,
+                                                 last_layer=self.decoder.conv_out.weight)
+        ae_loss, l1_loss, l2_loss, p_loss, g_loss, g_weight = res
+        self.manual_backward(ae_loss)
+        ae_opt.all_reduce_grads()
+        ae_opt.step()
+        step = self.current_epoch * self.trainer.num_training_batches + batch_index
+        loss, d_loss, r1_penalty = self.criterion.forward_discriminator(target, recon_pad, self.current_epoch, step)
+        if loss is not None:
+            disc_opt.zero_grad()
+            self.manual_backward(loss)
+            disc_opt.all_reduce_grads()
+            disc_opt.step()
+        for name, value in (('train/loss', ae_loss), ('train/l1_loss', l1_loss), ('train/l2_loss', l2_loss),
+                            ('train/quant_loss', q_loss), ('train/perc_loss', p_loss), ('train/gen_loss', g_loss),
+                            ('train/disc_loss', d_loss)):
+            self.log(name, value.detach(), sync_dist=True, on_step=False, on_epoch=True)
+        hist = self.quantizer.last_hist
+        self.train_epoch_usage_count = hist.clone() if self.train_epoch_usage_count is None \
+            else self.train_epoch_usage_count + hist
+        return ae_loss
+
     def training_step(self, batch: Any, batch_index: int):
+        if isinstance(self.criterion, VQLPIPSWithDiscriminator):
+            return self._gan_training_step(batch, batch_index)
         _, used_indices, q_loss, l2_loss = self._step_losses(batch, training=True)
         ae_loss = q_loss + l2_loss
         for name, value in (('train/loss', ae_loss), ('train/l2_loss', l2_loss), ('train/quant_loss', q_loss)):
@@ -218,7 +255,13 @@ class VQVAE(BaseVQVAE, _LightningBase):
         decay, no_decay = self.optimizer_groups()
         groups = [{'params': [p for _, p in sorted(decay, key=lambda t: t[0])], 'weight_decay': wd},
                   {'params': [p for _, p in sorted(no_decay, key=lambda t: t[0])], 'weight_decay': 0.0}]
-        return FlatAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+        ae_optimizer = FlatAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+        if isinstance(self.criterion, VQLPIPSWithDiscriminator):                      # model.py:431-438
+            disc_optimizer = FlatAdamW(list(self.criterion.discriminator.parameters()), lr=lr, betas=betas, eps=eps,
+                                       weight_decay=wd)
+            self.automatic_optimization = False
+            return [ae_optimizer, disc_optimizer], []
+        return ae_optimizer
 
     # ------------------------------------------------------------------ inference API (model.py:458-489)
     @torch.no_grad()

@@ -48,6 +48,10 @@ class MiniTrainer:
         """hook order of one Lightning iteration with automatic optimisation"""
         opt = self.optimizers[0]
         model.on_train_batch_start(batch, batch_index)
+        if not getattr(model, 'automatic_optimization', True):       # VQ-GAN: the module steps both optimizers itself
+            loss = model.training_step(batch, batch_index)
+            self.global_step += 1
+            return loss
         opt.zero_grad()
         loss = model.training_step(batch, batch_index)
         loss.backward()
