@@ -33,7 +33,9 @@ MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, den
 def q_conf(qtype: str, k: int):
     params = {'standard': dict(commitment_cost=0.25),
               'ema': dict(commitment_cost=0.25, decay=0.95, epsilon=1e-5),
-              'entropy': dict(commitment_cost=0.25, ent_loss_ratio=0.1, ent_temperature=0.01, ent_loss_type='softmax')}[qtype]
+              'entropy': dict(commitment_cost=0.25, ent_loss_ratio=0.1, ent_temperature=0.01, ent_loss_type='softmax'),
+              'gumbel': dict(straight_through=False, temp=1.0, kl_cost=0.00859375, kl_warmup_epochs=None,
+                             temp_decay_epochs=None, temp_final=None)}[qtype]
     return dict(num_embeddings=k, embedding_dim=256, reinit_every_n_epochs=None, type=qtype, params=params)
 
 
@@ -83,7 +85,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--image-size', type=int, default=256)
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
-    ap.add_argument('--quantizer', choices=['standard', 'ema', 'entropy'], default='standard')
+    ap.add_argument('--quantizer', choices=['standard', 'ema', 'entropy', 'gumbel'], default='standard')
+    ap.add_argument('--gan', action='store_true', help='VQ-GAN criterion (LPIPS + StyleGAN2 discriminator, hinge, no R1)')
     ap.add_argument('--codebook', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
@@ -105,8 +108,16 @@ def main():
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
 
     torch.manual_seed(1234)                                   # identical replicas on every rank
-    model = model_mod.VQVAE(args.image_size, AE_CONF, q_conf(args.quantizer, args.codebook), None, T_CONF,
+    l_conf = None
+    if args.gan:
+        l_conf = dict(l1_weight=0.8, l2_weight=0.2, perc_weight=1.0,
+                      adversarial_params=dict(start_epoch=0, loss_type='non-saturating', g_weight=0.1, use_adaptive=False,
+                                              r1_reg_weight=None, r1_reg_every=16))
+    model = model_mod.VQVAE(args.image_size, AE_CONF, q_conf(args.quantizer, args.codebook), l_conf, T_CONF,
                             compute_dtype=dtype).to(device)
+    if args.gan:
+        model.criterion.discriminator.compute_dtype = dtype
+        model.criterion.perceptual_loss.net.compute_dtype = dtype
     model.train()
     trainer = trainer_mod.MiniTrainer(num_training_batches=args.steps + args.warmup)
     trainer.attach(model)
@@ -120,7 +131,7 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = not args.no_graph
-    if world > 1 and args.quantizer == 'ema':
+    if args.gan or (world > 1 and args.quantizer == 'ema'):
         use_graph = False      # the EMA statistics all-reduce sits inside forward: keep collectives out of graph capture
     if use_graph:
         trainer.capture(model, images, warmup=max(1, min(3, args.warmup)))
@@ -156,16 +167,25 @@ def main():
     roofline = None
     if events:
         by_kernel = {}
-        for name, flops, e0, e1 in events:
-            rec = by_kernel.setdefault(name, [0, 0.0, 0.0])
+        for name, flops, nbytes, e0, e1 in events:
+            rec = by_kernel.setdefault(name, [0, 0.0, 0.0, 0.0])
             rec[0] += 1
             rec[1] += flops
             rec[2] += e0.elapsed_time(e1) * 1e-3
-        name, (count, flops, secs) = max(by_kernel.items(), key=lambda kv: kv[1][2])
+            rec[3] += nbytes
+        name, (count, flops, secs, nbytes) = max(by_kernel.items(), key=lambda kv: kv[1][2])
+        traffic = None
+        try:                                   # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'round1_traffic.json')))
+            if tj['kernel'].startswith(name.split('<')[0]):
+                traffic = tj['hbm_bytes_per_launch']
+        except Exception:
+            pass
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = flops / secs / 1e12
         roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                        frac=round(achieved / peak, 4), traffic=None, kernel=name,
+                        frac=round(achieved / peak, 4), traffic=traffic, kernel=name,
+                        algorithmic_bytes_per_launch=int(nbytes / count),
                         launches_per_step=count // event_steps, avg_launch_us=round(secs / count * 1e6, 2),
                         avg_gflop_per_launch=round(flops / count / 1e9, 3),
                         kernel_time_frac_of_step=round((secs / event_steps) / (elapsed / args.steps), 3),
@@ -182,8 +202,9 @@ def main():
                    unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype=args.dtype, data='synthetic',
-                   config=dict(workload=f'{args.quantizer}_vqvae cb={args.codebook}, {args.image_size}x'
-                                        f'{args.image_size} bs={args.batch}/GPU (encoder+VQ+decoder fwd/bwd + AdamW)',
+                   config=dict(workload=f'{args.quantizer}_{"vqgan" if args.gan else "vqvae"} cb={args.codebook}, '
+                                        f'{args.image_size}x{args.image_size} bs={args.batch}/GPU (encoder+VQ+decoder '
+                                        f'{"+LPIPS+discriminator " if args.gan else ""}fwd/bwd + AdamW)',
                                global_batch=world * args.batch, parallelism=f'dp{world}',
                                launch=('hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
                                final_loss=round(float(loss.item()), 6)),

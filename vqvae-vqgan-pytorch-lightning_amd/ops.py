@@ -62,18 +62,26 @@ def empty_nhwc(n, c, h, w, dtype, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------------
 # raw launchers
 # ------------------------------------------------------------------------------------------------------
-KERNEL_EVENTS = None      # bench.py sets this to a list: (kernel name, algorithmic FLOPs, start event, stop event)
+KERNEL_EVENTS = None      # bench.py sets this to a list: (kernel, algorithmic FLOPs, algorithmic bytes, start, stop)
 
 
-def _timed(name: str, flops: float, launch):
+def _timed(name: str, flops: float, launch, nbytes: float = 0.0):
     if KERNEL_EVENTS is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     st = launch()
     e1.record()
-    KERNEL_EVENTS.append((name, flops, e0, e1))
+    KERNEL_EVENTS.append((name, flops, nbytes, e0, e1))
     return st
+
+
+def _fprop_kernel_name(dtype, wlayout: int) -> str:
+    """the kernel symbol the launcher picks (csrc/conv.hip::launch_fprop), for the per-kernel event statistics"""
+    if wlayout == 1:
+        return 'conv3x3_stream_kernel<bf16>' if dtype == torch.bfloat16 else 'conv3x3_halo_breg_kernel<f32>'
+    return f'conv_fprop_kernel<{"f32" if dtype == torch.float32 else "bf16"}>'
+
 
 
 def weight_layout(dtype, n, h_in, w_in, cin, cout, ksize, ups) -> int:
@@ -104,11 +112,13 @@ def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_d
     s = 2 if ups else 1
     y = empty_nhwc(n, cout, h * s, w * s, out_dtype, x.device)
     flops = 2.0 * n * h * s * w * s * cout * cin * ksize * ksize
-    st = _timed(f'conv_fprop<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
+    nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size() * (2 if residual is not None else 1)
+              + cout * cin * ksize * ksize * x.element_size())
+    st = _timed(_fprop_kernel_name(x.dtype, wlayout), flops,
                 lambda: _native.lib().vqk_conv2d_fprop(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias),
                                                        _p(residual), y.data_ptr(), dcode(out_dtype), n, h, w, cin,
                                                        cout, ksize, int(ups), act, wlayout,
-                                                       zero_page(x.device).data_ptr(), _stream()))
+                                                       zero_page(x.device).data_ptr(), _stream()), nbytes)
     _native.check(st, 'conv2d_fprop')
     return y
 
@@ -735,7 +745,7 @@ def _conv_general_raw(x, wq, bias, residual, cout, k, stride, pad, mode, h_out, 
     n, cin, h, w = x.shape
     y = empty_nhwc(n, cout, h_out, w_out, out_dtype, x.device)
     flops = 2.0 * n * h_out * w_out * cout * cin * k * k
-    st = _timed(f'conv_fprop<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
+    st = _timed(_fprop_kernel_name(x.dtype, wlayout), flops,
                 lambda: _native.lib().vqk_conv2d_general(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias), _p(residual),
                                                          y.data_ptr(), dcode(out_dtype), n, h, w, cin, cout, k, stride, pad,
                                                          mode, h_out, w_out, act, float(acc_scale), float(out_gain), wlayout,
