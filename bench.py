@@ -121,23 +121,29 @@ def main():
     model.train()
     trainer = trainer_mod.MiniTrainer(num_training_batches=args.steps + args.warmup)
     trainer.attach(model)
+    if os.environ.get('VQK_FORCE_DIST') == '1':
+        trainer.optimizers[0].force_collective = True
     model.on_train_start()
     g = torch.Generator().manual_seed(1234 + rank)
     images = torch.rand(args.batch, 3, args.image_size, args.image_size, generator=g).to(device)
 
     def barrier():
-        if world > 1:
+        if world > 1 or dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
     use_graph = not args.no_graph
     if args.gan or (world > 1 and args.quantizer == 'ema'):
         use_graph = False      # the EMA statistics all-reduce sits inside forward: keep collectives out of graph capture
+    step_fn = trainer.train_batch
     if use_graph:
-        trainer.capture(model, images, warmup=max(1, min(3, args.warmup)))
-        step_fn = trainer.train_batch_graphed
-    else:
-        step_fn = trainer.train_batch
+        try:
+            trainer.capture(model, images, warmup=max(1, min(3, args.warmup)))
+            step_fn = trainer.train_batch_graphed
+        except Exception as exc:               # never lose the run to a capture problem: fall back to eager launches
+            print(f'[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly', file=sys.stderr)
+            torch.cuda.synchronize()
+            use_graph = False
     for i in range(args.warmup):
         step_fn(model, images, i)
     barrier()

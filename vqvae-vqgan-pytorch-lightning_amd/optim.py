@@ -63,6 +63,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.seg_wd = torch.tensor(seg_wd, dtype=torch.float32, device=dev)
         self.offsets = {id(p): off for (p, _), off in zip(plist, offs)}
         self.step_count = 0
+        self.force_collective = False         # issue the all-reduce even at world size 1 (single-GPU RCCL smoke test)
         self.grad_scale = 1.0
         self.shadow = None                    # optional bf16 copy of flat_p refreshed by step()
         self.generation = 0                   # bumped by every step(): cache key for packed weights
@@ -77,7 +78,7 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def all_reduce_grads(self, world_size: int | None = None):
         """ONE collective per optimizer step (replaces DDP's bucketed reducer, vqvae/train.py:128)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective):
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
             self.grad_scale = 1.0 / dist.get_world_size()
         else:

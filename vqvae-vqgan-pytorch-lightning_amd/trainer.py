@@ -18,7 +18,8 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('VQK_FORCE_DIST') == '1'          # exercise the RCCL path on a single GPU (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -77,7 +78,9 @@ class MiniTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # thread_local: the autograd worker thread and (multi-GPU) the RCCL watchdog thread issue runtime calls
+        # of their own while this thread captures
+        with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
             opt.zero_grad()
             self._static_loss = model.training_step(self._static_in, 0)
             self._static_loss.backward()
