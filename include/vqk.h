@@ -225,6 +225,10 @@ int vqk_lpips_tap(int dtype, const void* fx, const void* fy, const float* lin, i
  * and stat[N/group]; backward writes dx[N][hw][c] from dy[N][hw][cpad]. */
 int vqk_mbstd(int dtype, const void* x, const void* dy, void* out, float* stat, int n, int64_t hw, int c, int cpad,
               int group, int backward, void* stream);
+/* Second-order piece of the layer (R1 differentiates the backward pass): given v = cotangent of the first backward's
+ * dx, writes ddy[N][hw][cpad] (cotangent of dy) and dxx[N][hw][c] (cotangent of x). */
+int vqk_mbstd_double_backward(int dtype, const void* x, const void* dy, const void* v, void* ddy, void* dxx, int n,
+                               int64_t hw, int c, int cpad, int group, void* stream);
 /* out[0] += sum |target - recon| ;  d (+)= s * (a1 sign(recon-target) + a2 * 2 (recon-target)), s = *gscale_dev */
 int vqk_l1_sum(int dtype, const void* recon, const float* target, int64_t n, float* out, void* stream);
 int vqk_l1l2_backward(int dtype, const void* recon, const float* target, int64_t n, float a1, float a2,

@@ -339,6 +339,14 @@ def gen_gan():
     out.update({'d.' + k: npy(v) for k, v in d.state_dict().items()})
     out.update({'d_in.x': npy(x), 'd_in.r': npy(r), 'd_out.logits': npy(logits), 'd_out.dx': npy(grads[0])})
     out.update({'d_grad.' + n_: npy(gr) for (n_, _), gr in zip(named, grads[1:])})
+    # R1 regularisation (loss.py:98-112): second-order through the whole discriminator
+    xr = x.detach().clone().requires_grad_(True)
+    lg = d(xr)
+    gimg, = torch.autograd.grad(lg.sum(), xr, create_graph=True)
+    r1 = 10.0 * gimg.pow(2).view(gimg.shape[0], -1).sum(1).mean()
+    r1_grads = torch.autograd.grad(r1, [p for _, p in named], allow_unused=True)
+    out.update({'r1.value': npy(r1), 'r1.gimg': npy(gimg)})
+    out.update({'r1_grad.' + n_: npy(gr) for (n_, _), gr in zip(named, r1_grads) if gr is not None})
     # GAN losses
     lr_, lf_ = torch.randn(8, 1, generator=g) * 2, torch.randn(8, 1, generator=g) * 2
     for lt in ('hinge', 'non-saturating'):

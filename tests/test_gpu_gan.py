@@ -38,6 +38,25 @@ def test_discriminator_golden(golden):
         assert rel(gr, T(g['d_grad.' + n])) < 1e-3, n
 
 
+def test_r1_regularisation_golden(golden):
+    """second-order path: R1 value, the image gradient it is built from, and d(R1)/d(theta) for every parameter"""
+    g = golden('gan')
+    d = disc.Discriminator(32, channel_base=1024, channel_max=64)
+    d.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith('d.')})
+    d = d.to(DEV)
+    x = T(g['d_in.x']).to(DEV).requires_grad_(True)
+    logits = d(x)
+    gimg, = torch.autograd.grad(logits.sum(), x, create_graph=True)
+    assert rel(gimg, T(g['r1.gimg'])) < 1e-3
+    r1 = 10.0 * ops.SumSqFn.apply(gimg) / gimg.shape[0]
+    np.testing.assert_allclose(r1.item(), g['r1.value'], rtol=2e-3)
+    named = [(n, p) for n, p in d.named_parameters() if 'r1_grad.' + n in g]
+    grads = torch.autograd.grad(r1, [p for _, p in named], allow_unused=True)
+    for (n, _), gr in zip(named, grads):
+        assert gr is not None, n
+        assert rel(gr, T(g['r1_grad.' + n]), floor=1e-9) < 5e-3, n
+
+
 def test_discriminator_bf16_tracks_fp32(golden):
     g = golden('gan')
     outs = []
@@ -135,7 +154,7 @@ def test_vqgan_training_step_runs_and_learns():
                           temp_final=None))
     lc = dict(l1_weight=0.8, l2_weight=0.2, perc_weight=1.0,
               adversarial_params=dict(start_epoch=0, loss_type='hinge', g_weight=0.1, use_adaptive=False,
-                                      r1_reg_weight=None, r1_reg_every=16))
+                                      r1_reg_weight=10.0, r1_reg_every=2))
     tc = dict(lr=1e-3, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
     m = model_mod.VQVAE(32, ae, qc, lc, tc).to(DEV).train()
     tr = trainer_mod.MiniTrainer(num_training_batches=10)

@@ -64,6 +64,7 @@ _PROTOS = {
     'vqk_channel_affine': [I, P, P, P, P, L, I, P],
     'vqk_lpips_tap': [I, P, P, P, I, L, I, P, P, F, P, P],
     'vqk_mbstd': [I, P, P, P, P, I, L, I, I, I, I, P],
+    'vqk_mbstd_double_backward': [I, P, P, P, P, P, I, L, I, I, I, P],
     'vqk_l1_sum': [I, P, P, L, P, P],
     'vqk_l1l2_backward': [I, P, P, L, F, F, P, P, I, P],
     'vqk_gan_loss': [P, P, I, I, I, P, P, P, P, P],

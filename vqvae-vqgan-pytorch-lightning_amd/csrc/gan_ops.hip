@@ -245,6 +245,76 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ x,
     }
 }
 
+// second-order piece of the minibatch-stddev layer (R1 regularisation differentiates the backward pass):
+// first backward   dx_ge = up_ge + c_m r_ge,  r = (x - mean_g)/sd,  c_m = ds_m/(G E),  ds_m = sum of dy's extra channel
+// given v = cotangent of dx:  d(dy)[.., ch<c] = v ;  d(dy)[.., c] = A_m/(G E), A_m = sum_{g,e} v r  (every pixel of the
+// group) ;  d(x)_ge = c_m [ (v_ge - mean_g v)/sd - r_ge (sum_g v r)/(G sd) ].   one block per m.
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_bwd_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            const T* __restrict__ v, T* __restrict__ ddy,
+                                                            T* __restrict__ dxx, int n, int64_t hw, int c, int cp, int gsz) {
+    __shared__ float part[2][4];
+    __shared__ float tot[2];
+    const int m = blockIdx.x, cols = n / gsz;
+    const int64_t chw = hw * c;
+    float ds = 0.f, am = 0.f;
+    for (int64_t q = threadIdx.x; q < (int64_t)gsz * hw; q += 256) {
+        const int g = (int)(q / hw);
+        ds += Elem<T>::ld(dy + ((int64_t)(g * cols + m) * hw + (q - g * hw)) * cp + c);
+    }
+    for (int64_t e = threadIdx.x; e < chw; e += 256) {
+        float mean = 0.f, xv[8], vv[8];
+        for (int g = 0; g < gsz; ++g) {
+            xv[g] = Elem<T>::ld(x + ((int64_t)(g * cols + m)) * chw + e);
+            vv[g] = Elem<T>::ld(v + ((int64_t)(g * cols + m)) * chw + e);
+            mean += xv[g];
+        }
+        mean /= (float)gsz;
+        float var = 0.f;
+        for (int g = 0; g < gsz; ++g) var += (xv[g] - mean) * (xv[g] - mean);
+        const float sd = sqrtf(var / (float)gsz + 1e-8f);
+        for (int g = 0; g < gsz; ++g) am += vv[g] * (xv[g] - mean) / sd;
+    }
+    ds = wave_sum(ds); am = wave_sum(am);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = ds; part[1][threadIdx.x >> 6] = am; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tot[0] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+        tot[1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+    }
+    __syncthreads();
+    const float ge = (float)gsz * (float)chw;
+    const float cm = tot[0] / ge, aext = tot[1] / ge;
+    for (int64_t e = threadIdx.x; e < chw; e += 256) {
+        const int64_t pixe = e / c; const int ch = (int)(e - pixe * c);
+        float mean = 0.f, vmean = 0.f, xv[8], vv[8];
+        for (int g = 0; g < gsz; ++g) {
+            xv[g] = Elem<T>::ld(x + ((int64_t)(g * cols + m)) * chw + e);
+            vv[g] = Elem<T>::ld(v + ((int64_t)(g * cols + m)) * chw + e);
+            mean += xv[g]; vmean += vv[g];
+        }
+        mean /= (float)gsz; vmean /= (float)gsz;
+        float var = 0.f;
+        for (int g = 0; g < gsz; ++g) var += (xv[g] - mean) * (xv[g] - mean);
+        const float sd = sqrtf(var / (float)gsz + 1e-8f);
+        float svr = 0.f;
+        for (int g = 0; g < gsz; ++g) svr += vv[g] * (xv[g] - mean) / sd;
+        for (int g = 0; g < gsz; ++g) {
+            const int64_t b = (int64_t)(g * cols + m);
+            const float r = (xv[g] - mean) / sd;
+            Elem<T>::st(dxx + b * chw + e, cm * ((vv[g] - vmean) / sd - r * svr / ((float)gsz * sd)));
+            Elem<T>::st(ddy + (b * hw + pixe) * cp + ch, vv[g]);
+        }
+    }
+    for (int64_t q = threadIdx.x; q < (int64_t)gsz * hw * (cp - c); q += 256) {
+        const int extra = (int)(q % (cp - c));
+        const int64_t gp = q / (cp - c);
+        const int g = (int)(gp / hw);
+        const int64_t pix = (int64_t)(g * cols + m) * hw + (gp - g * hw);
+        Elem<T>::st(ddy + pix * cp + c + extra, extra == 0 ? aext : 0.0f);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void l1_sum_kernel(const T* __restrict__ r, const float* __restrict__ t, int64_t n,
                                                      float* __restrict__ out) {
@@ -416,6 +486,19 @@ int vqk_mbstd(int dtype, const void* x, const void* dy, void* out, float* stat, 
         else if (dtype == VQK_BF16) hipLaunchKernelGGL(mbstd_bwd_kernel<bf16_raw>, dim3(cols), dim3(256), 0, st, (const bf16_raw*)x, (const bf16_raw*)dy, (bf16_raw*)out, n, hw, c, cpad, group);
         else return VQK_ERR_DTYPE;
     }
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_mbstd_double_backward(int dtype, const void* x, const void* dy, const void* v, void* ddy, void* dxx, int n,
+                               int64_t hw, int c, int cpad, int group, void* stream) {
+    VQK_REQUIRE(x && dy && v && ddy && dxx, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0 && c > 0 && cpad > c && group >= 1 && group <= 8 && n % group == 0, VQK_ERR_SHAPE);
+    const int cols = n / group;
+    hipStream_t st = vqk_stream(stream);
+    if (dtype == VQK_F32) hipLaunchKernelGGL(mbstd_bwd_bwd_kernel<float>, dim3(cols), dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)v, (float*)ddy, (float*)dxx, n, hw, c, cpad, group);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(mbstd_bwd_bwd_kernel<bf16_raw>, dim3(cols), dim3(256), 0, st, (const bf16_raw*)x, (const bf16_raw*)dy, (const bf16_raw*)v, (bf16_raw*)ddy, (bf16_raw*)dxx, n, hw, c, cpad, group);
+    else return VQK_ERR_DTYPE;
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

@@ -1,9 +1,9 @@
 """VQ-GAN criteria on the vqk kernels; same names / signatures / return tuples as the reference's
 ``vqvae/modules/loss/loss.py`` (generator_loss :11-26, discriminator_loss :29-51, VQLPIPSWithDiscriminator :54-164).
 
-Not built yet: R1 regularisation (needs the double backward of the conv / upfirdn / lrelu chain -- SURVEY "hard
-parts"; ``r1_reg_weight`` must be None) and the adaptive generator weight (two extra autograd.grad passes to the last
-decoder layer); ``VQLPIPS`` (AlexNet ablation) is out of scope."""
+R1 regularisation (loss.py:98-112) is built on double-differentiable backward pieces (``ops.ConvDgradFn``,
+``ops.ActBwdFn``, ``ops.MbstdBwdFn``, ``ops.UpfirdnNhwcFn``).  Not built yet: the adaptive generator weight (two extra
+autograd.grad passes to the last decoder layer); ``VQLPIPS`` (AlexNet ablation) is out of scope."""
 import torch
 from torch import nn
 
@@ -40,9 +40,6 @@ class VQLPIPSWithDiscriminator(nn.Module):
         self.r1_regularization_every = adversarial_conf['r1_reg_every']
         if self.use_adaptive_g_weight:
             raise NotImplementedError('adaptive generator weight (loss.py:80-96) is not built yet')
-        if self.r1_regularization_cost is not None:
-            raise NotImplementedError('R1 regularisation (loss.py:98-112) needs double backward: not built yet; '
-                                      'set adversarial_params.r1_reg_weight to null')
 
     def forward_autoencoder(self, quantizer_loss, images, reconstructions, current_epoch: int, last_layer=None):
         n, c, h, w = reconstructions.shape
@@ -60,10 +57,23 @@ class VQLPIPSWithDiscriminator(nn.Module):
             loss = nll_loss + quantizer_loss
         return loss, l1_loss, l2_loss, p_loss, g_loss, g_weight
 
+    def calculate_r1_regularization_term(self, logits_real, images, compute_r1: bool):
+        """w * mean_b sum_chw (d sum(logits_real) / d images)^2, differentiable w.r.t. the discriminator weights.
+        Weight gradients of the inner autograd.grad are simply not requested (the reference wraps it in
+        ``no_weight_gradients``)."""
+        if not compute_r1:
+            return 0.
+        gradients, = torch.autograd.grad(outputs=logits_real.sum(), inputs=images, create_graph=True)
+        return self.r1_regularization_cost * ops.SumSqFn.apply(gradients) / gradients.shape[0]
+
     def forward_discriminator(self, images, reconstructions, current_epoch: int, current_step: int):
         if current_epoch >= self.adversarial_start_epoch:
+            compute_r1 = (self.training and current_step % self.r1_regularization_every == 0
+                          and self.r1_regularization_cost is not None)
+            images = images.detach().requires_grad_(compute_r1)
             logits_real = self.discriminator(images)
             logits_fake = self.discriminator(reconstructions.detach())
             d_loss = discriminator_loss(logits_real, logits_fake, loss_type=self.adversarial_loss_type)
-            return d_loss, d_loss, 0.
+            r1_term = self.calculate_r1_regularization_term(logits_real, images, compute_r1)
+            return d_loss + r1_term, d_loss, r1_term
         return None, torch.zeros((1,), device=images.device), 0.

@@ -799,36 +799,101 @@ class ConvActFn(torch.autograd.Function):
         x, y = ctx.saved_tensors
         weight, bias = ctx.refs
         k, stride, pad, act, wgain, out_gain, o, i, cin, cout_pad, dt = ctx.cfg
-        dy = nhwc(dy)
         lib, st = _native.lib(), _stream()
-        t = torch.empty_like(dy, memory_format=_CL)
-        _native.check(lib.vqk_act_backward(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(), dy.numel(), act,
-                                           float(out_gain), st), 'act_backward')
+        # t and dx are built from differentiable Functions so that R1 (autograd.grad(..., create_graph=True) through
+        # this backward, loss.py:98-112) can differentiate them again; in an ordinary backward they record nothing.
+        t = ActBwdFn.apply(nhwc(dy), y, act, float(out_gain))
         tc = t if t.dtype == dt else nhwc(t.to(dt))
         n, _, h, w = x.shape
         _, _, h_out, w_out = tc.shape
-        w4 = weight.reshape(o, i, k, k)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if stride == 1 and pad == k // 2:
-                layout = weight_layout(dt, n, h_out, w_out, cout_pad, cin, k, False)
-                wt = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, True, layout)
-                dx = _conv_general_raw(tc, wt, None, None, cin, k, 1, k // 2, 0, h, w, 0, wgain, 1.0, dt, layout)
-            else:
-                wt = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, True, 0)
-                mode = 2 if stride == 2 else 0
-                dx = _conv_general_raw(tc, wt, None, None, cin, k, 1, k - 1 - pad, mode, h, w, 0, wgain, 1.0, dt, 0)
+            dx = ConvDgradFn.apply(tc, weight, k, stride, pad, float(wgain), cin, cout_pad, h, w)
         if ctx.needs_input_grad[1]:
+            tcd = tc.detach()
             dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=x.device)
-            _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tc.data_ptr(), dwp.data_ptr(), n, h, w, cin,
+            _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tcd.data_ptr(), dwp.data_ptr(), n, h, w, cin,
                                                        cout_pad, k, stride, pad, 0, h_out, w_out,
                                                        zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
             if wgain != 1.0:
                 _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain), 0.0, dwp.numel(), st), 'axpby')
             dw = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
         if bias is not None and ctx.needs_input_grad[2]:
-            db = raw_colsum(n * h_out * w_out, cout_pad, tc)[:o]
+            db = raw_colsum(n * h_out * w_out, cout_pad, tc.detach())[:o]
         return dx, dw, db, None, None, None, None, None, None, None
+
+
+class ActBwdFn(torch.autograd.Function):
+    """t = scale * act'(y) * dy -- linear in dy for the piecewise-linear / saved-output activations used here, so
+    its own backward is the same op (bias_act.py:197-198: lrelu / relu have no second-order term)"""
+
+    @staticmethod
+    def forward(ctx, dy, y, act: int, scale: float):
+        t = torch.empty_like(dy, memory_format=_CL)
+        _native.check(_native.lib().vqk_act_backward(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(), dy.numel(),
+                                                     act, scale, _stream()), 'act_backward')
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, scale)
+        if act == 1:
+            ctx.set_materialize_grads(False)
+        return t
+
+    @staticmethod
+    def backward(ctx, v):
+        (y,) = ctx.saved_tensors
+        act, scale = ctx.cfg
+        if act == 1:
+            raise NotImplementedError('second-order tanh epilogue is not on any path')
+        return ActBwdFn.apply(nhwc(v), y, act, scale), None, None, None
+
+
+class ConvDgradFn(torch.autograd.Function):
+    """dx = wgain * dgrad(t, W): bilinear in (t, W).  Differentiating it (R1) gives a FORWARD conv of the incoming
+    cotangent and a wgrad with the cotangent in the role of the layer input."""
+
+    @staticmethod
+    def forward(ctx, t, weight, k: int, stride: int, pad: int, wgain: float, cin: int, cout_pad: int, h: int, w: int):
+        dt = t.dtype
+        o, i = weight.shape[0], weight.shape[1]
+        w4 = weight.detach().reshape(o, i, k, k)
+        n, _, h_out, w_out = t.shape
+        if stride == 1 and pad == k // 2:
+            layout = weight_layout(dt, n, h_out, w_out, cout_pad, cin, k, False)
+            wt = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, True, layout)
+            dx = _conv_general_raw(t, wt, None, None, cin, k, 1, k // 2, 0, h, w, 0, wgain, 1.0, dt, layout)
+        else:
+            wt = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, True, 0)
+            dx = _conv_general_raw(t, wt, None, None, cin, k, 1, k - 1 - pad, 2 if stride == 2 else 0, h, w, 0, wgain, 1.0,
+                                   dt, 0)
+        ctx.save_for_backward(t)
+        ctx.refs = (weight,)
+        ctx.cfg = (k, stride, pad, wgain, cin, cout_pad, o, i)
+        return dx
+
+    @staticmethod
+    def backward(ctx, v):
+        (t,) = ctx.saved_tensors
+        (weight,) = ctx.refs
+        k, stride, pad, wgain, cin, cout_pad, o, i = ctx.cfg
+        v = nhwc(v)
+        dt = t.dtype
+        n, _, h, w = v.shape
+        _, _, h_out, w_out = t.shape
+        w4 = weight.detach().reshape(o, i, k, k)
+        lib, st = _native.lib(), _stream()
+        d_t = d_w = None
+        if ctx.needs_input_grad[0]:
+            wq = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, False, 0)
+            d_t = _conv_general_raw(v, wq, None, None, cout_pad, k, stride, pad, 0, h_out, w_out, 0, wgain, 1.0, dt, 0)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=v.device)
+            _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), v.data_ptr(), t.data_ptr(), dwp.data_ptr(), n, h, w, cin,
+                                                       cout_pad, k, stride, pad, 0, h_out, w_out,
+                                                       zero_page(v.device).data_ptr(), st), 'conv2d_wgrad_general')
+            if wgain != 1.0:
+                _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain), 0.0, dwp.numel(), st), 'axpby')
+            d_w = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
+        return d_t, d_w, None, None, None, None, None, None, None, None
 
 
 def conv_act(x, weight, bias=None, k=3, stride=1, pad=None, act='linear', wgain=1.0, out_gain=1.0, out_dtype=None):
@@ -972,11 +1037,35 @@ class MbstdFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         g, cp = ctx.cfg
+        return MbstdBwdFn.apply(x, nhwc(dy), g, cp), None
+
+
+class MbstdBwdFn(torch.autograd.Function):
+    """first backward of the minibatch-stddev layer as a differentiable op (it is non-linear in x, and R1
+    differentiates the backward pass)"""
+
+    @staticmethod
+    def forward(ctx, x, dy, g: int, cp: int):
         n, c, h, w = x.shape
         dx = torch.empty_like(x, memory_format=_CL)
-        _native.check(_native.lib().vqk_mbstd(dcode(x.dtype), x.data_ptr(), nhwc(dy).data_ptr(), dx.data_ptr(), 0, n, h * w, c, cp,
+        _native.check(_native.lib().vqk_mbstd(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, n, h * w, c, cp,
                                               g, 1, _stream()), 'mbstd_backward')
-        return dx, None
+        ctx.save_for_backward(x, dy)
+        ctx.cfg = (g, cp)
+        return dx
+
+    @staticmethod
+    def backward(ctx, v):
+        x, dy = ctx.saved_tensors
+        g, cp = ctx.cfg
+        n, c, h, w = x.shape
+        v = nhwc(v)
+        ddy = torch.empty_like(dy, memory_format=_CL)
+        dxx = torch.empty_like(x, memory_format=_CL)
+        _native.check(_native.lib().vqk_mbstd_double_backward(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), v.data_ptr(),
+                                                              ddy.data_ptr(), dxx.data_ptr(), n, h * w, c, cp, g, _stream()),
+                      'mbstd_double_backward')
+        return dxx, ddy, None, None
 
 
 class AddFn(torch.autograd.Function):
@@ -1051,3 +1140,27 @@ class GanLossFn(torch.autograd.Function):
         _native.check(_native.lib().vqk_gan_loss(_p(lr), lf.data_ptr(), lf.numel(), mode, which, 0, _p(dreal), dfake.data_ptr(),
                                                  gs.data_ptr(), _stream()), 'gan_loss_backward')
         return (dreal.view(shape) if dreal is not None else None), dfake.view(shape), None, None
+
+
+class SumSqFn(torch.autograd.Function):
+    """sum(g^2) over all elements (R1 penalty, loss.py:108); backward 2 g * upstream"""
+
+    @staticmethod
+    def forward(ctx, gimg):
+        gimg = gimg.contiguous()
+        zero = torch.zeros(gimg.numel(), dtype=torch.float32, device=gimg.device)
+        out = torch.zeros((), dtype=torch.float32, device=gimg.device)
+        _native.check(_native.lib().vqk_sse(dcode(gimg.dtype), gimg.data_ptr(), zero.data_ptr(), gimg.numel(), out.data_ptr(),
+                                            _stream()), 'sse')
+        ctx.save_for_backward(gimg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (gimg,) = ctx.saved_tensors
+        zero = torch.zeros(gimg.numel(), dtype=torch.float32, device=gimg.device)
+        d = torch.empty_like(gimg)
+        _native.check(_native.lib().vqk_mse_tanh_backward(dcode(gimg.dtype), gimg.data_ptr(), zero.data_ptr(), gimg.numel(), 1.0,
+                                                          dout.to(torch.float32).contiguous().data_ptr(), 0, d.data_ptr(),
+                                                          _stream()), 'sumsq_backward')
+        return d
