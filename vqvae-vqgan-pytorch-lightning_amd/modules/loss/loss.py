@@ -2,8 +2,7 @@
 ``vqvae/modules/loss/loss.py`` (generator_loss :11-26, discriminator_loss :29-51, VQLPIPSWithDiscriminator :54-164).
 
 R1 regularisation (loss.py:98-112) is built on double-differentiable backward pieces (``ops.ConvDgradFn``,
-``ops.ActBwdFn``, ``ops.MbstdBwdFn``, ``ops.UpfirdnNhwcFn``).  Not built yet: the adaptive generator weight (two extra
-autograd.grad passes to the last decoder layer); ``VQLPIPS`` (AlexNet ablation) is out of scope."""
+``ops.ActBwdFn``, ``ops.MbstdBwdFn``, ``ops.UpfirdnNhwcFn``).  ``VQLPIPS`` (AlexNet ablation) is out of scope."""
 import torch
 from torch import nn
 
@@ -38,8 +37,14 @@ class VQLPIPSWithDiscriminator(nn.Module):
         self.use_adaptive_g_weight = adversarial_conf['use_adaptive']
         self.r1_regularization_cost = adversarial_conf['r1_reg_weight']
         self.r1_regularization_every = adversarial_conf['r1_reg_every']
-        if self.use_adaptive_g_weight:
-            raise NotImplementedError('adaptive generator weight (loss.py:80-96) is not built yet')
+
+    def calculate_adaptive_weight(self, nll_loss, g_loss, last_layer):
+        """lambda = clamp(|d nll / d W_last| / (|d g / d W_last| + 1e-8), 0, 1e4) * g_weight   (loss.py:80-96)"""
+        with ops.no_direct_grad():
+            nll_grads = torch.autograd.grad(nll_loss, last_layer, retain_graph=True)[0].detach()
+            g_grads = torch.autograd.grad(g_loss, last_layer, retain_graph=True)[0].detach()
+        w = torch.norm(nll_grads, p=2) / (torch.norm(g_grads, p=2) + 1e-8)
+        return torch.clamp(w, 0.0, 1e4).detach() * self.generator_weight
 
     def forward_autoencoder(self, quantizer_loss, images, reconstructions, current_epoch: int, last_layer=None):
         n, c, h, w = reconstructions.shape
@@ -49,7 +54,10 @@ class VQLPIPSWithDiscriminator(nn.Module):
         if current_epoch >= self.adversarial_start_epoch:
             logits_fake = self.discriminator(reconstructions)
             g_loss = generator_loss(logits_fake, loss_type=self.adversarial_loss_type)
-            g_weight = self.generator_weight
+            if self.training and self.use_adaptive_g_weight:
+                g_weight = self.calculate_adaptive_weight(p_loss, g_loss, last_layer=last_layer)   # p_loss, as the reference
+            else:
+                g_weight = self.generator_weight
             loss = nll_loss + g_loss * g_weight + quantizer_loss
         else:
             g_loss = torch.zeros_like(nll_loss, requires_grad=False)

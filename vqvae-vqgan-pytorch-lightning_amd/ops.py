@@ -123,10 +123,26 @@ def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_d
     return y
 
 
+_DIRECT_GRAD = True
+
+
+class no_direct_grad:
+    """context: gradients are RETURNED through autograd instead of being accumulated into the flat arena
+    (needed by ``torch.autograd.grad`` calls such as the adaptive generator weight, loss.py:80-96)"""
+
+    def __enter__(self):
+        global _DIRECT_GRAD
+        self._prev, _DIRECT_GRAD = _DIRECT_GRAD, False
+
+    def __exit__(self, *exc):
+        global _DIRECT_GRAD
+        _DIRECT_GRAD = self._prev
+
+
 def direct_grad(param):
     """The flat-arena gradient view of ``param`` when the HIP kernels may accumulate straight into it
     (FlatAdamW marks its parameters; the arena is zeroed once per step by ``zero_grad``), else None."""
-    if getattr(param, '_vqk_direct_grad', False) and param.grad is not None:
+    if _DIRECT_GRAD and getattr(param, '_vqk_direct_grad', False) and param.grad is not None:
         return param.grad
     return None
 
