@@ -154,10 +154,11 @@ int vqk_gn_stats(int dtype, const void* x, int n, int64_t hw, int c, int groups,
 int vqk_gn_apply(int dtype, const void* x, const float* stats, const float* w, const float* b, void* y,
                  int n, int64_t hw, int c, int groups, int silu, void* stream);
 /* backward of y = act(GN(x)): needs x, stats, w, b and dy.  red = N*G*2 doubles scratch, dw/db [C] fp32;
- * all three pre-zeroed.  dx may alias nothing; if accumulate != 0, dx += result. */
+ * all three pre-zeroed.  accumulate != 0: dx += result; add != NULL: dx = result + add (the residual-branch
+ * gradient of a ResBlock, fused instead of a separate add pass). */
 int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
                     void* dx, float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu,
-                    int accumulate, void* stream);
+                    int accumulate, const void* add, void* stream);
 
 /* ---------------------------------------------------------------- pooling / pointwise -------
  * 2x2 stride-2 pooling with a scale: scale = 0.25 is avg_pool2d (autoencoder.py:89-91), scale = 1 is the

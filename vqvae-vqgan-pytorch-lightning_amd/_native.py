@@ -49,7 +49,7 @@ _PROTOS = {
     'vqk_cast': [P, P, I, L, P],
     'vqk_gn_stats': [I, P, I, L, I, I, F, P, P, P],
     'vqk_gn_apply': [I, P, P, P, P, P, I, L, I, I, I, P],
-    'vqk_gn_backward': [I, P, P, P, P, P, P, P, P, P, I, L, I, I, I, I, P],
+    'vqk_gn_backward': [I, P, P, P, P, P, P, P, P, P, I, L, I, I, I, I, P, P],
     'vqk_pool2x2': [I, P, P, I, I, I, I, F, P],
     'vqk_unpool2x2': [I, P, P, I, I, I, I, F, P],
     'vqk_preprocess': [P, P, I, P, I, I, I, I, P],

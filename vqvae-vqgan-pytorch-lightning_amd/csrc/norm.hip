@@ -164,6 +164,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const T* __restrict__ dy, T* __restrict__ dx,
+                                                           const T* __restrict__ add,
                                                            const double* __restrict__ red, int64_t hw, int c,
                                                            int groups, int silu, int accumulate, int pix_per_block) {
     constexpr int V = Vec16<T>::N;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         float xv[V], gv[V], ov[V];
         Vec16<T>::load(x + off + p * c, xv);
         Vec16<T>::load(dy + off + p * c, gv);
-        if (accumulate) Vec16<T>::load(dx + off + p * c, ov);
+        if (accumulate) Vec16<T>::load((add ? add : dx) + off + p * c, ov);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const float xh = (xv[i] - mean[i]) * rstd[i];
@@ -263,7 +264,7 @@ int vqk_gn_apply(int dtype, const void* x, const float* stats, const float* w, c
 
 int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy, void* dx,
                     float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu, int accumulate,
-                    void* stream) {
+                    const void* add, void* stream) {
     VQK_REQUIRE(x && stats && w && b && dy && dx && dw && db && red, VQK_ERR_ARG);
     VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
     const int rc = check_gn(dtype, c, groups);
@@ -275,10 +276,10 @@ int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w
     hipStream_t st = vqk_stream(stream);
     if (dtype == VQK_F32) {
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, ppb);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, red, hw, c, groups, silu, accumulate, ppb);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
     } else {
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_raw>, grid, dim3(256), lds, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, dw, db, red, hw, c, groups, silu, ppb);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, red, hw, c, groups, silu, accumulate, ppb);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
     }
     VQK_CHECK_LAUNCH();
     return VQK_OK;

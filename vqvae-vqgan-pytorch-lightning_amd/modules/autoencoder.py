@@ -75,10 +75,11 @@ class ResBlock(nn.Module):
         self.conv2 = Conv2d(out_channels, out_channels, 3, bias=False)
 
     def forward(self, x):
-        r = self.conv1(self.norm1(x, silu=True))
-        r = self.norm2(r, silu=True)
-        skip = x if self.conv_shortcut is None else self.conv_shortcut(x)
-        return self.conv2(r, residual=skip)                   # x + residual, added in the epilogue
+        # one fused autograd node: residual add in conv2's epilogue, skip-gradient add in norm1's backward sweep
+        return ops.res_block(x, self.norm1.weight, self.norm1.bias, self.conv1.weight, self.norm2.weight,
+                             self.norm2.bias, self.conv2.weight,
+                             None if self.conv_shortcut is None else self.conv_shortcut.weight,
+                             self.norm1.num_groups, self.norm1.eps)
 
 
 class Downsample(nn.Module):

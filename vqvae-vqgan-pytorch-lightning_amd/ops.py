@@ -196,7 +196,7 @@ def raw_gn_apply(x, stats, w, b, groups: int, silu: bool) -> torch.Tensor:
     return y
 
 
-def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None):
+def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None, add=None):
     n, c, h, wd = x.shape
     dx = torch.empty_like(x, memory_format=_CL)
     dw = dw if dw is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
@@ -204,7 +204,7 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
     red = torch.zeros(n * groups * 2, dtype=torch.float64, device=x.device)
     st = _native.lib().vqk_gn_backward(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(), b.data_ptr(),
                                        dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), red.data_ptr(), n,
-                                       h * wd, c, groups, int(silu), 0, _stream())
+                                       h * wd, c, groups, int(silu), 0, _p(add), _stream())
     _native.check(st, 'gn_backward')
     return dx, dw, db
 
@@ -356,6 +356,84 @@ class GroupNormSiLUFn(torch.autograd.Function):
         if direct:
             return dx, None, None, None, None, None
         return dx, dw.view(wshape), db.view(bshape), None, None, None
+
+
+class ResBlockFn(torch.autograd.Function):
+    """One pre-activation residual block (autoencoder.py:63-77) as a single autograd node:
+    GN+SiLU -> 3x3 -> GN+SiLU -> 3x3 (+ skip, optionally through a 1x1), with a hand-scheduled backward whose last
+    GroupNorm-backward pass adds the skip-branch gradient in the same sweep (no separate add kernel, no autograd
+    bookkeeping for eight intermediate nodes)."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups: int, eps: float):
+        _require_gpu(x)
+        x = nhwc(x)
+        dt = x.dtype
+        n, cin, h, w = x.shape
+        cout = c1w.shape[0]
+        if cin % epc(dt) or cout % epc(dt):
+            raise RuntimeError('vqk: ResBlock channels must be whole 16-byte chunks')
+        w1 = n1w.detach().reshape(-1).contiguous(); b1 = n1b.detach().reshape(-1).contiguous()
+        w2 = n2w.detach().reshape(-1).contiguous(); b2 = n2b.detach().reshape(-1).contiguous()
+        st1 = raw_gn_stats(x, groups, eps)
+        a1 = raw_gn_apply(x, st1, w1, b1, groups, True)
+        l1 = weight_layout(dt, n, h, w, cin, cout, 3, False)
+        r1 = raw_conv_fprop(a1, pack_weights(_weight_mem(c1w, cin, cout), dt, cout, cin, 3, False, l1), None, None, 3,
+                            False, 0, dt, cout, l1)
+        st2 = raw_gn_stats(r1, groups, eps)
+        a2 = raw_gn_apply(r1, st2, w2, b2, groups, True)
+        skip = x
+        if scw is not None:
+            skip = raw_conv_fprop(x, pack_weights(_weight_mem(scw, cin, cout), dt, cout, cin, 1, False, 0), None, None, 1,
+                                  False, 0, dt, cout, 0)
+        l2 = weight_layout(dt, n, h, w, cout, cout, 3, False)
+        out = raw_conv_fprop(a2, pack_weights(_weight_mem(c2w, cout, cout), dt, cout, cout, 3, False, l2), None, skip, 3,
+                             False, 0, dt, cout, l2)
+        ctx.save_for_backward(x, st1, a1, r1, st2, a2, w1, b1, w2, b2)
+        ctx.params = (n1w, n1b, c1w, n2w, n2b, c2w, scw)
+        ctx.cfg = (groups, cin, cout)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, st1, a1, r1, st2, a2, w1, b1, w2, b2 = ctx.saved_tensors
+        n1w, n1b, c1w, n2w, n2b, c2w, scw = ctx.params
+        groups, cin, cout = ctx.cfg
+        dt = x.dtype
+        dout = nhwc(dout)
+        n, _, h, w = x.shape
+
+        def conv_bwd(inp, dy, wparam, k, ci, co, need_dx=True):
+            dx = None
+            if need_dx:
+                lay = weight_layout(dt, n, h, w, co, ci, k, False)
+                wt = pack_weights(_weight_mem(wparam, ci, co), dt, co, ci, k, True, lay)
+                dx = raw_conv_fprop(dy, wt, None, None, k, False, 0, dt, ci, lay)
+            tgt = direct_grad(wparam)
+            dw = raw_conv_wgrad(inp, dy, k, False, out=tgt)
+            return dx, (None if tgt is not None else dw)
+
+        def gn_bwd(inp, st, wv, bv, dy, wparam, bparam, add=None):
+            tw, tb = direct_grad(wparam), direct_grad(bparam)
+            direct = tw is not None and tb is not None
+            dx, dw, db = raw_gn_backward(inp, st, wv, bv, dy, groups, True, tw if direct else None,
+                                         tb if direct else None, add=add)
+            if direct:
+                return dx, None, None
+            return dx, dw.view(wparam.shape), db.view(bparam.shape)
+
+        d_a2, dw2 = conv_bwd(a2, dout, c2w, 3, cout, cout)
+        d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
+        d_a1, dw1 = conv_bwd(a1, d_r1, c1w, 3, cin, cout)
+        dskip, dwsc = dout, None
+        if scw is not None:
+            dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
+        dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip)
+        return dx, dn1w, dn1b, dw1, dn2w, dn2b, dw2, dwsc, None, None
+
+
+def res_block(x, n1w, n1b, c1w, n2w, n2b, c2w, scw=None, groups: int = 32, eps: float = 1e-6):
+    return ResBlockFn.apply(x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups, eps)
 
 
 def group_norm_silu(x, weight, bias, groups: int = 32, eps: float = 1e-6, silu: bool = True):
