@@ -15,6 +15,7 @@
 //   (hardware transpose read); fp32 fragments are plain ds_read_b32.  Split-K over pixel ranges,
 //   partials combined with fp32 atomics.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -88,9 +89,28 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
     f32x4 o = {v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p) = o;
 }
+// two fp32 -> packed bf16 pair (v_cvt_pk_bf16_f32: hardware round-to-nearest-even)
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ void store4(bf16_raw* p, const float (&v)[4]) {
-    u16x4 o = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
-    *reinterpret_cast<u16x4*>(p) = o;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(p) = o;
+}
+// v[0..3] += four consecutive residual elements (one 8-byte / 16-byte load)
+__device__ __forceinline__ void add4(const bf16_raw* p, float (&v)[4]) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+    v[0] += __uint_as_float(r[0] << 16); v[1] += __uint_as_float(r[0] & 0xffff0000u);
+    v[2] += __uint_as_float(r[1] << 16); v[3] += __uint_as_float(r[1] & 0xffff0000u);
+}
+__device__ __forceinline__ void add4(const float* p, float (&v)[4]) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
 }
 
 __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
@@ -630,12 +650,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
     };
 
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     TilePos cur = tile_pos(0);
     load_halo(cur, 0);
@@ -673,11 +687,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
             for (int i = 0; i < 4; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (tap == 0 && ks == 0 && c == 0) {             // first MFMA of a tile starts from C = 0: no
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll                                                   // accumulator clears in the epilogue
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks], a[ks][i], zero, 0, 0, 0);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks], a[ks][i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks], a[ks][i], acc[i][j], 0, 0, 0);
+                }
                 // rolling prefetch of the same slot for the next tap (next unit after tap 8)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -689,6 +712,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
         }
         if (c == nch - 1) {                                        // tile finished: epilogue, accumulators reset
             const int n0 = cur.nt * 128;
+            // Straight-line fast paths (no activation, unit gains, full cout tile): the epilogue runs on the same
+            // SIMD as the MFMAs, so every branch / select per element is stolen from the matrix pipe.
+            auto epi_plain = [&](auto has_bias, auto has_res) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int ty, tx;
+                    if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
+                    else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+                    const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
+                    const int64_t o0 = pix * g.cout + n0 + wn * 64 + 4 * kg;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int cw = j * 32 + 8 * rq;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rq + e];
+                            if constexpr (decltype(has_bias)::value) add4(bias + n0 + wn * 64 + 4 * kg + cw, v);
+                            if constexpr (decltype(has_res)::value) add4(res + o0 + cw, v);
+                            store4(y + o0 + cw, v);
+                        }
+                }
+            };
+            typedef std::integral_constant<bool, true> yes_t;
+            typedef std::integral_constant<bool, false> no_t;
+            const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
+            if (plain && !bias && !res) epi_plain(no_t{}, no_t{});
+            else if (plain && !bias) epi_plain(no_t{}, yes_t{});
+            else if (plain && !res) epi_plain(yes_t{}, no_t{});
+            else if (plain) epi_plain(yes_t{}, yes_t{});
+            else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int ty, tx;
@@ -706,15 +761,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
                                 v[e] = epi_act(acc[i][j][4 * rq + e] * g.acc_scale + (bias ? bias[co + e] : 0.0f), act) * g.out_gain;
-                            if (res) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += Elem<TO>::ld(res + o + e);
-                            }
+                            if (res) add4(res + o, v);
                             store4(y + o, v);
                         }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][j][4 * rq + e] = 0.0f;
                     }
+            }
             }
         }
         if (has_next) store_halo(smem + ((u + 1) & 1) * BUF);
