@@ -130,6 +130,11 @@ int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int co
 int64_t vqk_conv_packed_elems(int cout, int cin, int ksize, int layout);
 int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int cin, int ksize, int transpose,
                           int layout, void* stream);
+/* Every conv operand of a model in ONE launch: descs_dev is a device array of ndesc descriptors of eight int64 words
+ * {src, dst, dtype, cout, cin, ksize, transpose, layout}, each with the meaning of the vqk_conv_pack_weights
+ * arguments.  Issued once per optimizer step (after vqk_adamw) instead of one pack launch per conv call; replaces
+ * the per-call weight casts autocast performs in the reference's conv calls (vqvae/modules/autoencoder.py:57-60). */
+int vqk_conv_pack_multi(const int64_t* descs_dev, int ndesc, int blocks_per_desc, void* stream);
 /* test / tuning hook for the fprop kernel choice: -1 automatic, 0 im2col kernel only, 1 halo kernels when
  * eligible, 2 halo kernel with LDS-staged weights (layout 0) instead of register weights, 3 one-tile-per-block
  * register-weight halo kernel instead of the persistent stream kernel (bf16) */
@@ -153,8 +158,14 @@ int vqk_gn_stats(int dtype, const void* x, int n, int64_t hw, int c, int groups,
                  double* acc, float* stats, void* stream);
 int vqk_gn_apply(int dtype, const void* x, const float* stats, const float* w, const float* b, void* y,
                  int n, int64_t hw, int c, int groups, int silu, void* stream);
-/* backward of y = act(GN(x)): needs x, stats, w, b and dy.  red = N*G*2 doubles scratch, dw/db [C] fp32;
- * all three pre-zeroed.  accumulate != 0: dx += result; add != NULL: dx = result + add (the residual-branch
+/* statistics + normalisation (+SiLU) as one call: two launches (sums; finalize folded into the apply pass), stats
+ * are also stored for the backward.  ws = N*G*2 doubles of sums + N 8-byte counter slots (N*G*2+N doubles), ZERO on entry and
+ * left ZERO on exit (the last block of each sample in the apply pass clears that sample's slots), so one persistent workspace per stream serves every call
+ * with no memset in between. */
+int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, void* y, float* stats, double* ws, int n,
+                   int64_t hw, int c, int groups, float eps, int silu, void* stream);
+/* backward of y = act(GN(x)): needs x, stats, w, b and dy.  red = N*G*2+N doubles scratch with the vqk_gn_forward
+ * workspace protocol (zero on entry, zero again on exit); dw/db [C] fp32 pre-zeroed (accumulated into).  accumulate != 0: dx += result; add != NULL: dx = result + add (the residual-branch
  * gradient of a ResBlock, fused instead of a separate add pass). */
 int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
                     void* dx, float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu,

@@ -32,6 +32,7 @@ for c, hw in [(128, 256), (256, 128), (128, 128), (256, 64), (512, 32), (512, 16
     nbytes = x.numel() * 2
     t1 = timeit(lambda: ops.raw_gn_stats(x, 32, 1e-6))
     t2 = timeit(lambda: ops.raw_gn_apply(x, stats, w, b, 32, True))
+    t12 = timeit(lambda: ops.raw_gn_forward(x, w, b, 32, 1e-6, True))
     t3 = timeit(lambda: ops.raw_gn_backward(x, stats, w, b, dy, 32, True))
     print(f'C={c:3d} {hw:3d}^2  stats {t1 * 1e6:7.1f} us {nbytes / t1 / 1e12:5.2f} TB/s | apply {t2 * 1e6:7.1f} us '
-          f'{2 * nbytes / t2 / 1e12:5.2f} TB/s | bwd(2 kernels) {t3 * 1e6:7.1f} us {5 * nbytes / t3 / 1e12:5.2f} TB/s')
+          f'{2 * nbytes / t2 / 1e12:5.2f} TB/s | fwd(2 kernels) {t12 * 1e6:7.1f} us | bwd(2 kernels) {t3 * 1e6:7.1f} us {5 * nbytes / t3 / 1e12:5.2f} TB/s')

@@ -42,6 +42,7 @@ _PROTOS = {
     'vqk_conv2d_wgrad_general': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P],
     'vqk_conv_weight_layout': [I, I, I, I, I, I, I, I],
     'vqk_conv_pack_weights': [P, P, I, I, I, I, I, I, P],
+    'vqk_conv_pack_multi': [P, I, I, P],
     'vqk_conv_set_variant': [I],
     'vqk_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
@@ -49,6 +50,7 @@ _PROTOS = {
     'vqk_cast': [P, P, I, L, P],
     'vqk_gn_stats': [I, P, I, L, I, I, F, P, P, P],
     'vqk_gn_apply': [I, P, P, P, P, P, I, L, I, I, I, P],
+    'vqk_gn_forward': [I, P, P, P, P, P, P, I, L, I, I, F, I, P],
     'vqk_gn_backward': [I, P, P, P, P, P, P, P, P, P, I, L, I, I, I, I, P, P],
     'vqk_pool2x2': [I, P, P, I, I, I, I, F, P],
     'vqk_unpool2x2': [I, P, P, I, I, I, I, F, P],

@@ -1153,6 +1153,71 @@ __global__ void cast_kernel(const float* __restrict__ s, TD* __restrict__ d, int
         Elem<TD>::st(d + i, s[i]);
 }
 
+// One launch for every conv operand of the model: desc d is packed by blocks (blockIdx.y == d).  The descriptor
+// is eight int64 words {src, dst, dtype, cout, cin, ksize, transpose, layout} with the meaning of the arguments of
+// vqk_conv_pack_weights (src: fp32 [Cout][taps][Cin] master memory, typically a view into the AdamW arena).
+template <typename TD>
+__device__ __forceinline__ void pack_any(const float* __restrict__ w, TD* __restrict__ out, int cout, int cin, int taps,
+                                         int transpose, int layout) {
+    constexpr int E = Elem<TD>::kPer16B;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    if (layout == 0) {
+        const int64_t total = (int64_t)cout * taps * cin;
+        if (!transpose) {
+            for (int64_t o = tid; o < total; o += nthr) Elem<TD>::st(out + o, w[o]);
+        } else {
+            for (int64_t o = tid; o < total; o += nthr) {
+                const int co = (int)(o % cout);
+                const int64_t r = o / cout;
+                const int tap = (int)(r % taps), ci = (int)(r / taps);
+                Elem<TD>::st(out + o, w[((int64_t)co * taps + (taps - 1 - tap)) * cin + ci]);
+            }
+        }
+        return;
+    }
+    // fragment-major: one thread builds one 16-byte piece (E consecutive input channels of one output channel)
+    const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
+    const int cot_tiles = ((dcout + 127) / 128) * 4;
+    const int ncc = dcin / (4 * E);
+    const int64_t total = (int64_t)cot_tiles * ncc * taps * 2 * 64;
+    for (int64_t o = tid; o < total; o += nthr) {
+        int64_t r = o;
+        const int co32 = (int)(r & 31); r >>= 5;
+        const int kg = (int)(r & 1); r >>= 1;
+        const int ks = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % taps); r /= taps;
+        const int cc = (int)(r % ncc);
+        const int cot = (int)(r / ncc);
+        const int co = cot * 32 + co32;
+        const int ci = ((cc * 2 + ks) * 2 + kg) * E;
+        float v[E];
+        if (co >= dcout) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = 0.0f;
+        } else if (!transpose) {
+            const float* src = w + ((int64_t)co * taps + tap) * cin + ci;
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
+                v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+            }
+        } else {
+            const float* src = w + ((int64_t)ci * taps + (taps - 1 - tap)) * cin + co;
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = src[(int64_t)e * taps * cin];
+        }
+        Vec16<TD>::store(out + o * E, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restrict__ descs) {
+    const int64_t* d = descs + (int64_t)blockIdx.y * 8;
+    const float* src = reinterpret_cast<const float*>(d[0]);
+    const int dtype = (int)d[2], cout = (int)d[3], cin = (int)d[4], ks = (int)d[5], tr = (int)d[6], lay = (int)d[7];
+    if (dtype == VQK_F32) pack_any<float>(src, reinterpret_cast<float*>(d[1]), cout, cin, ks * ks, tr, lay);
+    else pack_any<bf16_raw>(src, reinterpret_cast<bf16_raw*>(d[1]), cout, cin, ks * ks, tr, lay);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t rows, int c, float* __restrict__ out) {
     // thread owns a column (grid.x covers columns), grid.y strides over rows
@@ -1367,6 +1432,15 @@ int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int ci
         if (dtype == VQK_F32) hipLaunchKernelGGL(pack_frag_kernel<float>, grid, dim3(256), 0, st, w, (float*)out, cout, cin, taps, transpose, cot_tiles);
         else hipLaunchKernelGGL(pack_frag_kernel<bf16_raw>, grid, dim3(256), 0, st, w, (bf16_raw*)out, cout, cin, taps, transpose, cot_tiles);
     } else return VQK_ERR_ARG;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_conv_pack_multi(const int64_t* descs_dev, int ndesc, int blocks_per_desc, void* stream) {
+    VQK_REQUIRE(descs_dev && ndesc >= 0 && blocks_per_desc > 0 && blocks_per_desc <= 4096 && ndesc <= 65535, VQK_ERR_ARG);
+    if (ndesc == 0) return VQK_OK;
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)blocks_per_desc, (unsigned)ndesc), dim3(256), 0, vqk_stream(stream),
+                       descs_dev);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

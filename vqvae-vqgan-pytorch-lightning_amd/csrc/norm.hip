@@ -94,6 +94,72 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// Workspace protocol shared by the forward and backward pairs: ws = N*G*2 doubles of partial sums followed by N
+// block counters (one per sample, each in its own 8-byte slot), all ZERO on entry; the LAST block of a sample to
+// finish the consumer kernel (atomic census at the very end, so nobody waits on it) zeroes that sample's slots again:
+// one persistent workspace serves every GroupNorm call of a stream without a memset launch in between.
+__device__ __forceinline__ void ws_release(double* __restrict__ ws, int n_samples, int groups) {
+    __shared__ unsigned last;
+    unsigned* counter = reinterpret_cast<unsigned*>(ws + (int64_t)n_samples * groups * 2 + blockIdx.y);
+    if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (last) {
+        double* mine = ws + (int64_t)blockIdx.y * groups * 2;
+        for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) mine[i] = 0.0;
+        if (threadIdx.x == 0) *counter = 0u;
+    }
+}
+
+// gn_finalize + gn_apply in one pass: every thread derives (mean, rstd) of its channels' groups from the double
+// sums; the first pixel block of each sample also stores them as fp32 stats for the backward.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_fin_kernel(const T* __restrict__ x, double* __restrict__ ws,
+                                                           float* __restrict__ stats, const float* __restrict__ w,
+                                                           const float* __restrict__ b, T* __restrict__ y, int64_t hw,
+                                                           int c, int groups, int silu, int pix_per_block, float eps) {
+    constexpr int V = Vec16<T>::N;
+    const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
+    const int n = blockIdx.y, cpg = c / groups;
+    const double m = (double)hw * cpg;
+    float scale[V], shift[V];
+    int gprev = -1;
+    float mean_f = 0.f, rstd_f = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = slot * V + i, g = ch / cpg;
+        if (g != gprev) {
+            const double s = ws[((int64_t)n * groups + g) * 2], ss = ws[((int64_t)n * groups + g) * 2 + 1];
+            const double mean = s / m;
+            double var = (ss - s * mean) / (m - 1.0);          // unbiased (torch.var default)
+            if (var < 0.0) var = 0.0;
+            mean_f = (float)mean;
+            rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+            gprev = g;
+            if (blockIdx.x == 0 && prow == 0 && ch == g * cpg) {
+                stats[((int64_t)n * groups + g) * 2] = mean_f;
+                stats[((int64_t)n * groups + g) * 2 + 1] = rstd_f;
+            }
+        }
+        scale[i] = rstd_f * w[ch];
+        shift[i] = __fmaf_rn(-mean_f, scale[i], b[ch]);
+    }
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = min(hw, p0 + pix_per_block);
+    const int64_t off = (int64_t)n * hw * c + slot * V;
+#pragma unroll 2
+    for (int64_t p = p0 + prow; p < p1; p += pstep) {
+        float v[V];
+        Vec16<T>::load(x + off + p * c, v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float t = __fmaf_rn(v[i], scale[i], shift[i]);
+            v[i] = silu ? silu_f(t) : t;
+        }
+        Vec16<T>::store(y + off + p * c, v);
+    }
+    ws_release(ws, gridDim.y, groups);
+}
+
 // pass 1 of the backward: per-channel sums of dy_pre and dy_pre*xhat (-> dw, db) and the per-group
 // sums of dxhat and dxhat*xhat (-> red[n][g][2], double).
 template <typename T>
@@ -165,7 +231,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const T* __restrict__ dy, T* __restrict__ dx,
                                                            const T* __restrict__ add,
-                                                           const double* __restrict__ red, int64_t hw, int c,
+                                                           double* __restrict__ red, int64_t hw, int c,
                                                            int groups, int silu, int accumulate, int pix_per_block) {
     constexpr int V = Vec16<T>::N;
     const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
@@ -203,6 +269,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         }
         Vec16<T>::store(dx + off + p * c, ov);
     }
+    ws_release(red, gridDim.y, groups);
 }
 
 int check_gn(int dtype, int c, int groups) {
@@ -258,6 +325,28 @@ int vqk_gn_apply(int dtype, const void* x, const float* stats, const float* w, c
     hipStream_t st = vqk_stream(stream);
     if (dtype == VQK_F32) hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (float*)y, hw, c, groups, silu, ppb);
     else hipLaunchKernelGGL(gn_apply_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, void* y, float* stats, double* ws, int n,
+                   int64_t hw, int c, int groups, float eps, int silu, void* stream) {
+    VQK_REQUIRE(x && w && b && y && stats && ws, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
+    const int rc = check_gn(dtype, c, groups);
+    if (rc) return rc;
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    const int ppb = pick_ppb(n, hw);
+    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
+    const size_t lds = (size_t)2 * c * sizeof(double);
+    hipStream_t st = vqk_stream(stream);
+    if (dtype == VQK_F32) {
+        hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), lds, st, (const float*)x, hw, c, groups, ppb, ws);
+        hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, grid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, ppb, ws);
+        hipLaunchKernelGGL(gn_apply_fin_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps);
+    }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

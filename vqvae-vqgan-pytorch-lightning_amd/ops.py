@@ -7,6 +7,8 @@ Tensor convention: activations keep the reference's logical NCHW shape but are p
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _native
@@ -105,6 +107,89 @@ def pack_weights(w_mem_f32, dtype, cout, cin, ksize, transpose: bool, layout: in
     return out
 
 
+class _PackEntry:
+    __slots__ = ('wref', 'src', 'dst', 'desc', 'stamp')
+
+
+_PACK_CACHE: dict = {}          # (data_ptr, o, i, k, transpose, layout, dtype) -> _PackEntry
+_PACK_TABLE = None              # (tuple of keys, device int64 [n, 8]) of the last repack launch
+
+
+def _pack_stamp(weight):
+    """(in-place version of the parameter, generation of the FlatAdamW that owns it): changes whenever the master
+    weights change, through torch (``_version``) or through the AdamW kernel (``generation``)."""
+    owner = getattr(weight, '_vqk_owner', None)
+    return (weight._version, owner.generation if owner is not None else -1)
+
+
+def packed_weight(weight, cin_pad: int, cout_pad: int, dtype, ksize: int, transpose: bool, layout: int) -> torch.Tensor:
+    """The conv operand of ``weight`` (logical [O,I,k,k]) in ``dtype`` / ``layout``, from a cache of persistent buffers
+    that is refreshed by ONE multi-tensor launch per optimizer step (:func:`repack_owned`) instead of one pack launch
+    per conv call.  Falls back to a per-call pack for zero-padded or non-channels_last weights."""
+    w = weight.detach()
+    o, i = w.shape[0], w.shape[1]
+    if not (cin_pad == i and cout_pad == o and w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()):
+        return pack_weights(_weight_mem(weight, cin_pad, cout_pad), dtype, cout_pad, cin_pad, ksize, transpose, layout)
+    if layout == 0 and not transpose and dtype == torch.float32:
+        return w.permute(0, 2, 3, 1).reshape(-1)
+    key = (w.data_ptr(), o, i, ksize, bool(transpose), layout, dtype)
+    ent = _PACK_CACHE.get(key)
+    stamp = _pack_stamp(weight)
+    if ent is not None and ent.wref() is not weight:
+        ent = None                                       # the address was recycled by another parameter
+    if ent is not None and ent.stamp == stamp:
+        return ent.dst
+    if ent is None:
+        dc, di = (i, o) if transpose else (o, i)
+        ent = _PackEntry()
+        ent.wref, ent.src = weakref.ref(weight), w.permute(0, 2, 3, 1).reshape(-1)
+        ent.dst = torch.empty(_native.lib().vqk_conv_packed_elems(dc, di, ksize, layout), dtype=dtype, device=w.device)
+        ent.desc = [ent.src.data_ptr(), ent.dst.data_ptr(), dcode(dtype), o, i, ksize, int(transpose), layout]
+        _PACK_CACHE[key] = ent
+    st = _native.lib().vqk_conv_pack_weights(ent.src.data_ptr(), ent.dst.data_ptr(), dcode(dtype), o, i, ksize,
+                                             int(transpose), layout, _stream())
+    _native.check(st, 'conv_pack_weights')
+    ent.stamp = stamp
+    return ent.dst
+
+
+def repack_owned(owner=None) -> int:
+    """Refresh every cached operand whose master weight belongs to ``owner`` (a FlatAdamW; None: every stale entry)
+    with one ``vqk_conv_pack_multi`` launch.  Called by ``FlatAdamW.step`` right after the AdamW kernel."""
+    global _PACK_TABLE
+    keys, dead = [], []
+    for key, ent in _PACK_CACHE.items():
+        weight = ent.wref()
+        if weight is None or weight.data_ptr() != key[0]:
+            dead.append(key)                             # parameter freed or re-pointed (e.g. into a flat arena)
+        elif owner is not None:
+            if getattr(weight, '_vqk_owner', None) is owner:
+                keys.append(key)
+        elif ent.stamp != _pack_stamp(weight):
+            keys.append(key)
+    for key in dead:
+        del _PACK_CACHE[key]
+    if not keys:
+        return 0
+    keys = tuple(keys)
+    if _PACK_TABLE is None or _PACK_TABLE[0] != keys:
+        dev = _PACK_CACHE[keys[0]].dst.device
+        table = torch.tensor([_PACK_CACHE[k].desc for k in keys], dtype=torch.int64).to(dev)
+        _PACK_TABLE = (keys, table)
+    table = _PACK_TABLE[1]
+    _native.check(_native.lib().vqk_conv_pack_multi(table.data_ptr(), len(keys), 32, _stream()), 'conv_pack_multi')
+    for k in keys:
+        ent = _PACK_CACHE[k]
+        ent.stamp = _pack_stamp(ent.wref())
+    return len(keys)
+
+
+def clear_pack_cache():
+    global _PACK_TABLE
+    _PACK_CACHE.clear()
+    _PACK_TABLE = None
+
+
 def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_dtype, cout: int, wlayout: int = 0):
     """x [N,Cin,H,W] nhwc; wq: packed weights (pack_weights) in x.dtype with layout ``wlayout``."""
     _require_gpu(x)
@@ -177,6 +262,20 @@ def raw_cast(src_f32, dtype) -> torch.Tensor:
     return dst
 
 
+_GN_WS: dict = {}
+
+
+def _gn_ws(device, n_doubles: int) -> torch.Tensor:
+    """Persistent fp64 workspace of the GroupNorm kernels for the current stream (include/vqk.h: zero on entry, the
+    consumer kernel leaves it zero again -> no memset launch per call)."""
+    key = (device, _stream())
+    ws = _GN_WS.get(key)
+    if ws is None or ws.numel() < n_doubles:
+        ws = torch.zeros(max(n_doubles, 8192), dtype=torch.float64, device=device)
+        _GN_WS[key] = ws
+    return ws
+
+
 def raw_gn_stats(x, groups: int, eps: float) -> torch.Tensor:
     n, c, h, w = x.shape
     acc = torch.zeros(n * groups * 2, dtype=torch.float64, device=x.device)
@@ -196,12 +295,24 @@ def raw_gn_apply(x, stats, w, b, groups: int, silu: bool) -> torch.Tensor:
     return y
 
 
+def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool):
+    """(y, stats): sums kernel + finalize-and-apply kernel on the persistent workspace"""
+    n, c, h, wd = x.shape
+    y = torch.empty_like(x, memory_format=_CL)
+    stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
+    ws = _gn_ws(x.device, n * groups * 2 + n)
+    st = _native.lib().vqk_gn_forward(dcode(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                      stats.data_ptr(), ws.data_ptr(), n, h * wd, c, groups, eps, int(silu), _stream())
+    _native.check(st, 'gn_forward')
+    return y, stats
+
+
 def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None, add=None):
     n, c, h, wd = x.shape
     dx = torch.empty_like(x, memory_format=_CL)
     dw = dw if dw is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     db = db if db is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
-    red = torch.zeros(n * groups * 2, dtype=torch.float64, device=x.device)
+    red = _gn_ws(x.device, n * groups * 2 + n)
     st = _native.lib().vqk_gn_backward(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(), b.data_ptr(),
                                        dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), red.data_ptr(), n,
                                        h * wd, c, groups, int(silu), 0, _p(add), _stream())
@@ -275,7 +386,7 @@ class Conv2dFn(torch.autograd.Function):
             raise RuntimeError(f'vqk: conv input has {cin} channels, weight expects {i}')
         n_img, _, h_in, w_in = x.shape
         layout = weight_layout(dt, n_img, h_in, w_in, cin, cout_pad, k, ups)
-        wq = pack_weights(_weight_mem(weight, cin, cout_pad), dt, cout_pad, cin, k, False, layout)
+        wq = packed_weight(weight, cin, cout_pad, dt, k, False, layout)
         b32 = None
         if bias is not None:
             b32 = bias.detach()
@@ -305,7 +416,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             n_img, _, h_out, w_out = dyc.shape
             layout = weight_layout(dt, n_img, h_out, w_out, cout_pad, cin, k, False)
-            wt = pack_weights(_weight_mem(weight, cin, cout_pad), dt, cout_pad, cin, k, True, layout)
+            wt = packed_weight(weight, cin, cout_pad, dt, k, True, layout)
             dx = raw_conv_fprop(dyc, wt, None, None, k, False, 0, dt, cin, layout)
             if ups:
                 dx = raw_pool(dx, 1.0)
@@ -338,8 +449,7 @@ class GroupNormSiLUFn(torch.autograd.Function):
         x = nhwc(x)
         w = weight.detach().reshape(-1).contiguous()
         b = bias.detach().reshape(-1).contiguous()
-        stats = raw_gn_stats(x, groups, eps)
-        y = raw_gn_apply(x, stats, w, b, groups, silu)
+        y, stats = raw_gn_forward(x, w, b, groups, eps, silu)
         ctx.save_for_backward(x, stats, w, b)
         ctx.params = (weight, bias)
         ctx.cfg = (groups, silu, weight.shape, bias.shape)
@@ -375,19 +485,17 @@ class ResBlockFn(torch.autograd.Function):
             raise RuntimeError('vqk: ResBlock channels must be whole 16-byte chunks')
         w1 = n1w.detach().reshape(-1).contiguous(); b1 = n1b.detach().reshape(-1).contiguous()
         w2 = n2w.detach().reshape(-1).contiguous(); b2 = n2b.detach().reshape(-1).contiguous()
-        st1 = raw_gn_stats(x, groups, eps)
-        a1 = raw_gn_apply(x, st1, w1, b1, groups, True)
+        a1, st1 = raw_gn_forward(x, w1, b1, groups, eps, True)
         l1 = weight_layout(dt, n, h, w, cin, cout, 3, False)
-        r1 = raw_conv_fprop(a1, pack_weights(_weight_mem(c1w, cin, cout), dt, cout, cin, 3, False, l1), None, None, 3,
+        r1 = raw_conv_fprop(a1, packed_weight(c1w, cin, cout, dt, 3, False, l1), None, None, 3,
                             False, 0, dt, cout, l1)
-        st2 = raw_gn_stats(r1, groups, eps)
-        a2 = raw_gn_apply(r1, st2, w2, b2, groups, True)
+        a2, st2 = raw_gn_forward(r1, w2, b2, groups, eps, True)
         skip = x
         if scw is not None:
-            skip = raw_conv_fprop(x, pack_weights(_weight_mem(scw, cin, cout), dt, cout, cin, 1, False, 0), None, None, 1,
+            skip = raw_conv_fprop(x, packed_weight(scw, cin, cout, dt, 1, False, 0), None, None, 1,
                                   False, 0, dt, cout, 0)
         l2 = weight_layout(dt, n, h, w, cout, cout, 3, False)
-        out = raw_conv_fprop(a2, pack_weights(_weight_mem(c2w, cout, cout), dt, cout, cout, 3, False, l2), None, skip, 3,
+        out = raw_conv_fprop(a2, packed_weight(c2w, cout, cout, dt, 3, False, l2), None, skip, 3,
                              False, 0, dt, cout, l2)
         ctx.save_for_backward(x, st1, a1, r1, st2, a2, w1, b1, w2, b2)
         ctx.params = (n1w, n1b, c1w, n2w, n2b, c2w, scw)
@@ -407,7 +515,7 @@ class ResBlockFn(torch.autograd.Function):
             dx = None
             if need_dx:
                 lay = weight_layout(dt, n, h, w, co, ci, k, False)
-                wt = pack_weights(_weight_mem(wparam, ci, co), dt, co, ci, k, True, lay)
+                wt = packed_weight(wparam, ci, co, dt, k, True, lay)
                 dx = raw_conv_fprop(dy, wt, None, None, k, False, 0, dt, ci, lay)
             tgt = direct_grad(wparam)
             dw = raw_conv_wgrad(inp, dy, k, False, out=tgt)
@@ -848,6 +956,13 @@ def _conv_general_raw(x, wq, bias, residual, cout, k, stride, pad, mode, h_out, 
     return y
 
 
+def _packed_w4(weight, w4, cin, cout_pad, dt, k, transpose, layout):
+    """cached operand for 4-D conv parameters; 2-D (fully connected) weights viewed as 1x1 convs are packed per call"""
+    if weight.dim() == 4:
+        return packed_weight(weight, cin, cout_pad, dt, k, transpose, layout)
+    return pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, transpose, layout)
+
+
 class ConvActFn(torch.autograd.Function):
     """y = out_gain * act(conv(x, W) * wgain + bias), stride in {1,2}, explicit zero padding.
 
@@ -874,7 +989,7 @@ class ConvActFn(torch.autograd.Function):
         plain = stride == 1 and pad == k // 2
         layout = weight_layout(dt, n, h, w, cin, cout_pad, k, False) if plain else 0
         w4 = weight.reshape(o, i, k, k)
-        wq = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, False, layout)
+        wq = _packed_w4(weight, w4, cin, cout_pad, dt, k, False, layout)
         b32 = None
         if bias is not None:
             b32 = bias.detach().to(torch.float32)
@@ -953,10 +1068,10 @@ class ConvDgradFn(torch.autograd.Function):
         n, _, h_out, w_out = t.shape
         if stride == 1 and pad == k // 2:
             layout = weight_layout(dt, n, h_out, w_out, cout_pad, cin, k, False)
-            wt = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, True, layout)
+            wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, layout)
             dx = _conv_general_raw(t, wt, None, None, cin, k, 1, k // 2, 0, h, w, 0, wgain, 1.0, dt, layout)
         else:
-            wt = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, True, 0)
+            wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 0)
             dx = _conv_general_raw(t, wt, None, None, cin, k, 1, k - 1 - pad, 2 if stride == 2 else 0, h, w, 0, wgain, 1.0,
                                    dt, 0)
         ctx.save_for_backward(t)
@@ -977,7 +1092,7 @@ class ConvDgradFn(torch.autograd.Function):
         lib, st = _native.lib(), _stream()
         d_t = d_w = None
         if ctx.needs_input_grad[0]:
-            wq = pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, False, 0)
+            wq = _packed_w4(weight, w4, cin, cout_pad, dt, k, False, 0)
             d_t = _conv_general_raw(v, wq, None, None, cout_pad, k, stride, pad, 0, h_out, w_out, 0, wgain, 1.0, dt, 0)
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=v.device)

@@ -50,6 +50,7 @@ class FlatAdamW(torch.optim.Optimizer):
                     if is_grad:
                         p.grad = view
                         p._vqk_direct_grad = True     # ops.* may accumulate into the arena and skip AccumulateGrad
+                        p._vqk_owner = self           # packed conv operands are refreshed by this optimizer's step()
                     else:
                         view.copy_(p.data)
                         p.data = view
@@ -107,4 +108,6 @@ class FlatAdamW(torch.optim.Optimizer):
                                      torch.cuda.current_stream().cuda_stream)
         _native.check(st, 'adamw')
         self.generation += 1
+        from . import ops
+        ops.repack_owned(self)               # every cached conv operand of these weights, one launch
         return loss

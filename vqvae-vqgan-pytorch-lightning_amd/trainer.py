@@ -12,6 +12,8 @@ from typing import Iterable
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     """(rank, local_rank, world) from the torchrun environment; no-op for a single process."""
@@ -101,6 +103,7 @@ class MiniTrainer:
         model.on_train_batch_start(batch, batch_index)
         if batch is not self._static_in:
             self._static_in.copy_(batch, non_blocking=True)
+        ops.repack_owned(None)               # operands of weights changed outside the optimizer (normally none)
         self._graph.replay()
         opt.all_reduce_grads()
         opt.step()
