@@ -190,6 +190,12 @@ CONV_CASES = [
     (2, 64, 64, 8, 16, 3, True, True, False),
     (2, 16, 24, 8, 8, 3, False, True, False),           # partial co / ci tiles in the all-taps wgrad kernel
     (1, 72, 40, 16, 8, 3, False, False, False),
+    # one-chunk inputs / outputs on W % 32 == 0 maps: the dedicated edge-conv kernels (bf16)
+    (2, 8, 128, 8, 32, 3, False, True, False),
+    (1, 8, 64, 6, 64, 3, False, False, False),
+    (1, 8, 96, 5, 32, 3, False, True, False),
+    (2, 128, 8, 8, 32, 3, False, True, False),
+    (1, 64, 8, 16, 64, 3, False, False, False),
 ]
 
 
@@ -276,6 +282,33 @@ def test_conv_padded_edges_fp32():
     gd = torch.autograd.grad(y, [w1d, w2d, b2d], dyp)
     for a, r in zip(gd, gr):
         assert rel_err(a, r) < 3e-5
+
+
+def test_conv_padded_edges_bf16():
+    """bf16 throughput mode: 3-channel image in (padded to 8), 3-channel reconstruction out (padded to 8) + tanh,
+    on a map wide enough (W % 32 == 0) for the dedicated edge-conv kernels."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 16, 32, generator=g).bfloat16().float()
+    w1 = (torch.randn(128, 3, 3, 3, generator=g) * 0.2).bfloat16().float()
+    w2 = (torch.randn(3, 128, 3, 3, generator=g) * 0.05).bfloat16().float()
+    b2 = torch.randn(3, generator=g) * 0.1
+    leaves = [t.clone().requires_grad_(True) for t in (x, w1, w2, b2)]
+    hr = F.conv2d(leaves[0], leaves[1], None, padding=1)
+    yr = torch.tanh(F.conv2d(hr, leaves[2], leaves[3], padding=1))
+    dy = torch.randn(yr.shape, generator=g).bfloat16().float()
+    gr = torch.autograd.grad(yr, leaves[1:], dy)
+    xd = ae._to_internal(dev(x), torch.bfloat16)
+    w1d, w2d, b2d = (dev(t).requires_grad_(True) for t in (w1, w2, b2))
+    h = ops.conv2d(xd, w1d)
+    assert rel_err(h, hr) < 6e-3
+    y = ops.conv2d(h, w2d, b2d, None, False, 1, None)
+    assert y.shape == (2, 8, 16, 32) and y.dtype == torch.bfloat16
+    assert rel_err(y[:, :3], yr) < 2e-2
+    assert float(y.detach()[:, 3:].abs().max()) == 0.0
+    dyp = F.pad(dev(dy), (0, 0, 0, 0, 0, 5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gd = torch.autograd.grad(y, [w1d, w2d, b2d], dyp)
+    for a, r in zip(gd, gr):
+        assert a.shape == r.shape and rel_err(a, r) < 3e-2
 
 
 # ------------------------------------------------------------------------------------------ GN / pooling

@@ -566,7 +566,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_breg_kernel(const T* __re
 // (tap, k-substep); the nine taps are fully unrolled; the weights of one unit are 18 contiguous 1 KiB fragments
 // read as `uniform base + lane*16`.  (PMC on the previous version: 4.4 VALU + 4.3 SALU per MFMA, issue-bound.)
 // ------------------------------------------------------------------------------------------------
-template <typename TO, int TWLOG>
+// THIN: couts fit ONE 32-wide MFMA tile (the decoder's 3-channel head, autoencoder.py:170): the four waves split the
+// 256 pixels four ways (wave tile 64 pixels x 32 couts) instead of 2 x 2 (128 x 64), cout tiles are 32 wide.
+template <typename TO, int TWLOG, bool THIN>
 __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* __restrict__ x,
                                                                 const bf16_raw* __restrict__ wp,
                                                                 const float* __restrict__ bias,
@@ -577,6 +579,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
     constexpr int HALO_INSTR = (HROWS + 15) / 16;                // register pieces: 16 rows x 64 B per wave load
     constexpr int BUF = 28 * 1024;
     constexpr int NSLOT = (HALO_INSTR + 3) / 4;
+    constexpr int NI = THIN ? 2 : 4, NJ = THIN ? 1 : 2, COT = THIN ? 32 : 128;
     typedef bf16x8_t frag_t;
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -590,14 +593,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
     const int units = my_tiles * nch;
     if (units <= 0) return;
 
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = THIN ? wave : wave >> 1, wn = THIN ? 0 : wave & 1;
     const int p = lane & 31, kg = lane >> 5;
-    unsigned abase[4];                                           // LDS byte offset of tile i's pixel, tap (0,0), ks 0
+    auto pix_of = [&](int i, int& ty, int& tx) {                 // patch pixel of this lane in the wave's MFMA tile i
+        if (TWLOG == 5) { ty = wm * NI + i; tx = p; }
+        else { ty = wm * 2 * NI + 2 * i + (p >> 4); tx = p & 15; }
+    };
+    unsigned abase[NI];                                          // LDS byte offset of tile i's pixel, tap (0,0), ks 0
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         int ty, tx;
-        if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
-        else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+        pix_of(i, ty, tx);
         abase[i] = (unsigned)((ty * HW2 + tx) * RS + kg * 16);
     }
     int slot_hy[NSLOT], slot_hx[NSLOT];
@@ -645,18 +651,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
     const unsigned lane16 = (unsigned)lane * 16;
     const char* wroot = reinterpret_cast<const char*>(wp);
     auto unit_w = [&](int nt, int c, int j) -> const char* {
-        const int cot = ((nt * 128 + wn * 64) >> 5) + j;
+        const int cot = THIN ? nt : nt * 4 + wn * 2 + j;
         return wroot + ((int64_t)cot * nch + c) * (18 * 1024);
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[NI][NJ];
 
     TilePos cur = tile_pos(0);
     load_halo(cur, 0);
-    frag_t bw[2][2];
-    const char* wcur[2] = {unit_w(cur.nt, 0, 0), unit_w(cur.nt, 0, 1)};
+    frag_t bw[NJ][2];
+    const char* wcur[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j) wcur[j] = unit_w(cur.nt, 0, j);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) bw[j][ks] = *reinterpret_cast<const frag_t*>(wcur[j] + ks * 1024 + lane16);
     store_halo(smem);
@@ -671,39 +679,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
         if (!has_next) { ntj = tj; nc = c; }                     // clamp: loads stay unconditional
         const TilePos nxt = (ntj == tj) ? cur : tile_pos(ntj);
         load_halo(nxt, nc);                                      // in flight during this unit's MFMAs
-        const char* wnxt[2] = {unit_w(nxt.nt, nc, 0), unit_w(nxt.nt, nc, 1)};
-        const char* lbase[4];
+        const char* wnxt[NJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lbase[i] = smem + boff + abase[i];
+        for (int j = 0; j < NJ; ++j) wnxt[j] = unit_w(nxt.nt, nc, j);
+        const char* lbase[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) lbase[i] = smem + boff + abase[i];
 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             constexpr int dummy = 0; (void)dummy;
             const int toff = ((tap / 3) * HW2 + (tap % 3)) * RS;        // compile-time after unrolling
-            frag_t a[2][4];
+            frag_t a[2][NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff);
+            for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
+            for (int i = 0; i < NI; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (tap == 0 && ks == 0 && c == 0) {             // first MFMA of a tile starts from C = 0: no
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll                                                   // accumulator clears in the epilogue
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < NJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks], a[ks][i], zero, 0, 0, 0);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < NJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks], a[ks][i], acc[i][j], 0, 0, 0);
                 }
                 // rolling prefetch of the same slot for the next tap (next unit after tap 8)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const char* src = (tap == 8) ? wnxt[j] + ks * 1024 : wcur[j] + ((tap + 1) * 2 + ks) * 1024;
                     bw[j][ks] = *reinterpret_cast<const frag_t*>(src + lane16);
                 }
@@ -711,19 +721,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
             }
         }
         if (c == nch - 1) {                                        // tile finished: epilogue, accumulators reset
-            const int n0 = cur.nt * 128;
+            const int n0 = cur.nt * COT;
             // Straight-line fast paths (no activation, unit gains, full cout tile): the epilogue runs on the same
             // SIMD as the MFMAs, so every branch / select per element is stolen from the matrix pipe.
             auto epi_plain = [&](auto has_bias, auto has_res) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     int ty, tx;
-                    if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
-                    else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+                    pix_of(i, ty, tx);
                     const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
                     const int64_t o0 = pix * g.cout + n0 + wn * 64 + 4 * kg;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
 #pragma unroll
                         for (int rq = 0; rq < 4; ++rq) {
                             const int cw = j * 32 + 8 * rq;
@@ -738,20 +747,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
             };
             typedef std::integral_constant<bool, true> yes_t;
             typedef std::integral_constant<bool, false> no_t;
-            const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
+            const bool plain = !THIN && act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
             if (plain && !bias && !res) epi_plain(no_t{}, no_t{});
             else if (plain && !bias) epi_plain(no_t{}, yes_t{});
             else if (plain && !res) epi_plain(yes_t{}, no_t{});
             else if (plain) epi_plain(yes_t{}, yes_t{});
             else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 int ty, tx;
-                if (TWLOG == 5) { ty = wm * 4 + i; tx = p; }
-                else { ty = wm * 8 + 2 * i + (p >> 4); tx = p & 15; }
+                pix_of(i, ty, tx);
                 const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         const int co = n0 + wn * 64 + j * 32 + 8 * rq + 4 * kg;
@@ -771,7 +779,124 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
         if (has_next) store_halo(smem + ((u + 1) & 1) * BUF);
         __syncthreads();
         cur = nxt; tj = ntj; c = nc;
-        wcur[0] = wnxt[0]; wcur[1] = wnxt[1];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wcur[j] = wnxt[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv with ONE 16-byte chunk of input channels (the 3-channel image padded to 8 bf16: the encoder's first conv,
+// autoencoder.py:114, and the dgrad of the decoder's last conv, :170).  HBM-write-bound: 16 B read, 2*Cout B written
+// per pixel.  A wave owns 32 consecutive pixels of an image row x (up to) 128 couts: K = 9 taps x 8 channels = 72
+// (padded to 80 = five 32x32x16 MFMAs per 32-cout tile), the im2col operand of k-step s is ONE 16-byte global load
+// per lane (tap 2s + lane/32; neighbours hit L1/L2), the weights live in registers for the whole kernel, and the
+// output tile is transposed through LDS so that every store instruction writes 1 KiB of consecutive bytes.
+// ------------------------------------------------------------------------------------------------
+template <int NJ>
+__global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(const bf16_raw* __restrict__ x,
+                                                                 const bf16_raw* __restrict__ wgt,
+                                                                 const float* __restrict__ bias,
+                                                                 bf16_raw* __restrict__ y, ConvGeom g, int act,
+                                                                 int cout_base) {
+    constexpr int RS = NJ * 64 + 8;                              // LDS row stride in bytes (payload NJ*32 couts * 2 B)
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* lds = smem + wave * (32 * RS);
+    const int p = lane & 31, kg = lane >> 5;
+
+    // weights: fragment (j, s) = w[cout_base + j*32 + p][tap 2s+kg][0..7]; tap 9 does not exist -> zero
+    bf16x8_t wf[NJ][5];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const int tap = 2 * s5 + kg, co = cout_base + j * 32 + p;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (tap < 9 && co < g.cout) v = *reinterpret_cast<const u32x4*>(wgt + ((int64_t)co * 9 + tap) * 8);
+            wf[j][s5] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    const int xb = g.w >> 5;                                     // 32-pixel segments per row
+    const int total = g.n * g.h * xb;
+    const int nw = (int)gridDim.x * 4;
+    const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && !bias;
+    auto load_a = [&](int t, bf16x8_t (&a)[5]) {
+        const int xs = t % xb;
+        const int row = t / xb;                                   // n * h + y
+        const int yy = row % g.h;
+        const int px = xs * 32 + p;
+        const bf16_raw* xrow = x + ((int64_t)row * g.w + px) * 8;
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const int tap = 2 * s5 + kg;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const bool ok = tap < 9 && (unsigned)(yy + dy) < (unsigned)g.h && (unsigned)(px + dx) < (unsigned)g.w;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(xrow + ((int64_t)dy * g.w + dx) * 8);
+            a[s5] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    };
+    int t = (int)blockIdx.x * 4 + wave;
+    if (t >= total) return;
+    bf16x8_t a[5], an[5];
+    load_a(t, a);
+    for (; t < total; t += nw) {
+        const int xs = t % xb;
+        const int row = t / xb;
+        const int tn = t + nw < total ? t + nw : t;              // next tile's operand in flight during this one
+        load_a(tn, an);
+        f32x16 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][0], a[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int s5 = 1; s5 < 5; ++s5) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][s5], a[s5], acc[j], 0, 0, 0);
+        }
+        // epilogue -> LDS (row = pixel, 4-cout pieces)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[j][4 * q + e];
+                    if (!plain) {
+                        const int co = cout_base + j * 32 + 8 * q + 4 * kg + e;
+                        const float bvv = (bias && co < g.cout) ? bias[co] : 0.0f;
+                        v[e] = epi_act(v[e] * g.acc_scale + bvv, act) * g.out_gain;
+                    }
+                }
+                const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(lds + p * RS + (j * 32 + 8 * q + 4 * kg) * 2) = o;
+            }
+        // LDS -> global: the wave's 32 pixels x NJ*64 B are consecutive rows of y
+        const int cout_blk = NJ * 32;
+        char* ybase = reinterpret_cast<char*>(y + ((int64_t)row * g.w + xs * 32) * g.cout + cout_base);
+        if (g.cout == cout_blk) {                                // rows are back to back: 1 KiB per store instruction
+#pragma unroll
+            for (int it = 0; it < NJ * 2; ++it) {
+                const int o = it * 1024 + lane * 16;
+                const int pr = o / (NJ * 64), pb = o - pr * (NJ * 64);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + pr * RS + pb);
+                *reinterpret_cast<u32x4*>(ybase + o) = v;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NJ * 2; ++it) {
+                const int o = it * 1024 + lane * 16;
+                const int pr = o / (NJ * 64), pb = o - pr * (NJ * 64);
+                if (cout_base + pb / 2 < g.cout) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(lds + pr * RS + pb);
+                    *reinterpret_cast<u32x4*>(ybase + (int64_t)pr * g.cout * 2 + pb) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) a[s5] = an[s5];
     }
 }
 
@@ -1218,20 +1343,43 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restri
     else pack_any<bf16_raw>(src, reinterpret_cast<bf16_raw*>(d[1]), cout, cin, ks * ks, tr, lay);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t rows, int c, float* __restrict__ out) {
-    // thread owns a column (grid.x covers columns), grid.y strides over rows
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rlane = threadIdx.x >> 6;
-    __shared__ float part[4][64];
-    float acc = 0.0f;
-    if (col < c)
-        for (int64_t r = (int64_t)blockIdx.y * 4 + rlane; r < rows; r += (int64_t)gridDim.y * 4)
-            acc += Elem<T>::ld(x + r * c + col);
-    part[rlane][threadIdx.x & 63] = acc;
+// out[c] += sum_rows x[row][c].  c*sizeof(T) a multiple of 16 (VEC): a thread owns one 16-byte channel slot and strides
+// over rows (the GroupNorm kernels' mapping); otherwise one column per thread.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t rows, int c, int64_t rows_per_block,
+                                                     float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sh = reinterpret_cast<float*>(smem);            // [c]
+    for (int i = threadIdx.x; i < c; i += 256) sh[i] = 0.f;
     __syncthreads();
-    if (rlane == 0 && col < c)
-        atomicAdd(out + col, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (VEC) {
+        constexpr int V = Vec16<T>::N;
+        const int vpp = c / V;                              // slots per row
+        const int slot = threadIdx.x % vpp, rlane = threadIdx.x / vpp, rstep = 256 / vpp;
+        if (rlane < rstep) {
+            float a[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) a[i] = 0.f;
+#pragma unroll 4
+            for (int64_t r = r0 + rlane; r < r1; r += rstep) {
+                float v[V];
+                Vec16<T>::load(x + r * c + slot * V, v);
+#pragma unroll
+                for (int i = 0; i < V; ++i) a[i] += v[i];
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) atomicAdd(&sh[slot * V + i], a[i]);
+        }
+    } else {
+        for (int col = threadIdx.x & 63; col < c; col += 64) {
+            float a = 0.f;
+            for (int64_t r = r0 + (threadIdx.x >> 6); r < r1; r += 4) a += Elem<T>::ld(x + r * c + col);
+            atomicAdd(&sh[col], a);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += 256) atomicAdd(out + i, sh[i]);
 }
 
 static int g_force_variant = -1;   // test hook: -1 auto, 0 im2col kernel only, 1 halo kernels when eligible
@@ -1255,11 +1403,20 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         static const int persist = getenv("VQK_STREAM_BLOCKS") ? atoi(getenv("VQK_STREAM_BLOCKS")) : 512;
         const dim3 grid((unsigned)(total < persist ? total : persist));
         constexpr int lds = 2 * 28 * 1024;
-        if (tw == 5)
-            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 5>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+        if (g.cout <= 32) {                                      // thin head: 32-wide cout tiles, waves split the pixels
+            ConvGeom gt = g;
+            gt.tiles_n = 1;
+            if (tw == 5)
+                hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 5, true>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+                                   bias, (const TO*)res, (TO*)y, (const char*)zeros, gt, act);
+            else
+                hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 4, true>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+                                   bias, (const TO*)res, (TO*)y, (const char*)zeros, gt, act);
+        } else if (tw == 5)
+            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 5, false>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
                                bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
         else
-            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 4>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 4, false>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
                                bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
         if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
         return VQK_OK;
@@ -1292,6 +1449,22 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
             (void)attr4;
             hipLaunchKernelGGL((conv3x3_halo_kernel<T, TO, 4>), grid, dim3(256), lds, st, (const T*)x, (const T*)w, bias,
                                (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+        }
+        if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+        return VQK_OK;
+    }
+    if (sizeof(T) == 2 && sizeof(TO) == 2 && wlayout == 0 && g.ks == 3 && g.cpt == 1 && !res && !g.ups && !g.zs &&
+        g.stride == 1 && g.pad == 1 && (g.w % 32) == 0 && (g.cout % 8) == 0 && g.vh == g.h && g.vw == g.w &&
+        g_force_variant != 0) {
+        const int total = g.n * g.h * (g.w >> 5);
+        int blocks = (total + 3) / 4; if (blocks > 1024) blocks = 1024;
+        for (int cb = 0; cb < g.cout; cb += 128) {
+            if (g.cout - cb > 64)
+                hipLaunchKernelGGL((conv3x3_thin_in_kernel<4>), dim3((unsigned)blocks), dim3(256), 4 * 32 * (4 * 64 + 8), st,
+                                   (const bf16_raw*)x, (const bf16_raw*)w, bias, (bf16_raw*)y, g, act, cb);
+            else
+                hipLaunchKernelGGL((conv3x3_thin_in_kernel<2>), dim3((unsigned)blocks), dim3(256), 4 * 32 * (2 * 64 + 8), st,
+                                   (const bf16_raw*)x, (const bf16_raw*)w, bias, (bf16_raw*)y, g, act, cb);
         }
         if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
         return VQK_OK;
@@ -1525,13 +1698,24 @@ int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw
 
 int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream) {
     VQK_REQUIRE(x && out, VQK_ERR_ARG);
-    VQK_REQUIRE(rows >= 0 && c > 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(rows >= 0 && c > 0 && c <= 8192, VQK_ERR_SHAPE);
+    VQK_REQUIRE(dtype == VQK_F32 || dtype == VQK_BF16, VQK_ERR_DTYPE);
     if (rows == 0) return VQK_OK;
-    int gy = (int)((rows + 255) / 256); if (gy > 1024) gy = 1024; if (gy < 1) gy = 1;
-    const dim3 grid((unsigned)((c + 63) / 64), (unsigned)gy);
-    if (dtype == VQK_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, rows, c, out);
-    else if (dtype == VQK_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)x, rows, c, out);
-    else return VQK_ERR_DTYPE;
+    const int v = dtype == VQK_F32 ? 4 : 8;
+    const bool vec = (c % v) == 0 && c / v <= 256 && vqk_aligned16(x);
+    int64_t blocks = (rows + 63) / 64; if (blocks > 1024) blocks = 1024;
+    const int64_t rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    const dim3 grid((unsigned)blocks);
+    const size_t lds = (size_t)c * 4;
+    hipStream_t st = vqk_stream(stream);
+    if (dtype == VQK_F32) {
+        if (vec) hipLaunchKernelGGL((colsum_kernel<float, true>), grid, dim3(256), lds, st, (const float*)x, rows, c, rpb, out);
+        else hipLaunchKernelGGL((colsum_kernel<float, false>), grid, dim3(256), lds, st, (const float*)x, rows, c, rpb, out);
+    } else {
+        if (vec) hipLaunchKernelGGL((colsum_kernel<bf16_raw, true>), grid, dim3(256), lds, st, (const bf16_raw*)x, rows, c, rpb, out);
+        else hipLaunchKernelGGL((colsum_kernel<bf16_raw, false>), grid, dim3(256), lds, st, (const bf16_raw*)x, rows, c, rpb, out);
+    }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

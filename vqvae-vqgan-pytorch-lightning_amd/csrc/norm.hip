@@ -121,27 +121,28 @@ __global__ __launch_bounds__(256) void gn_apply_fin_kernel(const T* __restrict__
     const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
     const int n = blockIdx.y, cpg = c / groups;
     const double m = (double)hw * cpg;
+    // finalize once per block: thread g turns the double sums of group g into (mean, rstd)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sh = reinterpret_cast<float*>(smem);            // [groups][2]
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        const double s_ = ws[((int64_t)n * groups + g) * 2], ss = ws[((int64_t)n * groups + g) * 2 + 1];
+        const double mean = s_ / m;
+        double var = (ss - s_ * mean) / (m - 1.0);          // unbiased (torch.var default)
+        if (var < 0.0) var = 0.0;
+        const float mean_f = (float)mean, rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+        sh[2 * g] = mean_f; sh[2 * g + 1] = rstd_f;
+        if (blockIdx.x == 0) {
+            stats[((int64_t)n * groups + g) * 2] = mean_f;
+            stats[((int64_t)n * groups + g) * 2 + 1] = rstd_f;
+        }
+    }
+    __syncthreads();
     float scale[V], shift[V];
-    int gprev = -1;
-    float mean_f = 0.f, rstd_f = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int ch = slot * V + i, g = ch / cpg;
-        if (g != gprev) {
-            const double s = ws[((int64_t)n * groups + g) * 2], ss = ws[((int64_t)n * groups + g) * 2 + 1];
-            const double mean = s / m;
-            double var = (ss - s * mean) / (m - 1.0);          // unbiased (torch.var default)
-            if (var < 0.0) var = 0.0;
-            mean_f = (float)mean;
-            rstd_f = (float)(1.0 / sqrt(var + (double)eps));
-            gprev = g;
-            if (blockIdx.x == 0 && prow == 0 && ch == g * cpg) {
-                stats[((int64_t)n * groups + g) * 2] = mean_f;
-                stats[((int64_t)n * groups + g) * 2 + 1] = rstd_f;
-            }
-        }
-        scale[i] = rstd_f * w[ch];
-        shift[i] = __fmaf_rn(-mean_f, scale[i], b[ch]);
+        scale[i] = sh[2 * g + 1] * w[ch];
+        shift[i] = __fmaf_rn(-sh[2 * g], scale[i], b[ch]);
     }
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
@@ -342,10 +343,10 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
     hipStream_t st = vqk_stream(stream);
     if (dtype == VQK_F32) {
         hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), lds, st, (const float*)x, hw, c, groups, ppb, ws);
-        hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps);
+        hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, grid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, ppb, ws);
-        hipLaunchKernelGGL(gn_apply_fin_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps);
+        hipLaunchKernelGGL(gn_apply_fin_kernel<bf16_raw>, grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps);
     }
     VQK_CHECK_LAUNCH();
     return VQK_OK;

@@ -111,11 +111,19 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
 // q = e[idx]; sum (q-z)^2; histogram.  One wavefront per row, float4 per lane.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ z, const float* __restrict__ e,
-                                                        const int64_t* __restrict__ idx, int64_t n, int d,
+                                                        const int64_t* __restrict__ idx, int64_t n, int k, int d,
                                                         float* __restrict__ q, bf16_raw* __restrict__ q_lo,
                                                         float* __restrict__ sse, int32_t* __restrict__ hist) {
+    // code histogram: block-local counts in LDS first (a collapsed codebook puts every row on a few codes -- one
+    // global atomic per row then serialises on those addresses), flushed as one global atomic per non-empty bin
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t* lh = reinterpret_cast<int32_t*>(smem);
     __shared__ float part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (hist) {
+        for (int i = threadIdx.x; i < k; i += 256) lh[i] = 0;
+        __syncthreads();
+    }
     float local = 0.0f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n; row += (int64_t)gridDim.x * 4) {
         const int64_t code = idx[row];
@@ -132,32 +140,84 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict_
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float t = ev[i] - zv[i]; local = __fmaf_rn(t, t, local); }
         }
-        if (hist && lane == 0) atomicAdd(hist + code, 1);
+        if (hist && lane == 0) atomicAdd(lh + code, 1);
     }
     local = wave_sum(local);
     if (lane == 0) part[wave] = local;
     __syncthreads();
     if (threadIdx.x == 0 && sse) atomicAdd(sse, part[0] + part[1] + part[2] + part[3]);
+    if (hist)
+        for (int i = threadIdx.x; i < k; i += 256) { const int32_t v = lh[i]; if (v) atomicAdd(hist + i, v); }
 }
 
-// dz = dq + cz (z - q);  de[idx] += ce (q - z)
 template <typename TDQ>
 __global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restrict__ z, const float* __restrict__ e,
                                                           const int64_t* __restrict__ idx, const TDQ* __restrict__ dq,
-                                                          int64_t n, int d, float cz, float ce,
-                                                          const float* __restrict__ gs,
-                                                          float* __restrict__ dz, float* __restrict__ de) {
+                                                          int64_t n, int d, float cz, const float* __restrict__ gs,
+                                                          float* __restrict__ dz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (gs) { const float s = *gs; cz *= s; ce *= s; }
+    if (gs) cz *= *gs;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n; row += (int64_t)gridDim.x * 4) {
         const int64_t code = idx[row];
         for (int c = lane; c < d; c += 64) {
             const float zv = z[row * d + c], qv = e[code * d + c];
             const float g = dq ? Elem<TDQ>::ld(dq + row * d + c) : 0.0f;
             dz[row * d + c] = __fmaf_rn(cz, zv - qv, g);
-            if (de) atomicAdd(de + code * d + c, ce * (qv - zv));
         }
     }
+}
+
+// dE[k] += ce * sum_{rows with idx == k} (e[k] - z[row]).  Block (k, s) scans rows [s*span, (s+1)*span) of idx (L2
+// resident), lists its matches in LDS and sums them channel-parallel: no atomic per (row, channel) -- a collapsed
+// codebook (all rows on a few codes, the state of a fresh model) made the scatter-add version 30x slower than the
+// stream -- only one atomic per (code, split, channel) at the end.
+__global__ __launch_bounds__(256) void vq_code_grad_kernel(const float* __restrict__ z, const float* __restrict__ e,
+                                                           const int64_t* __restrict__ idx, int64_t n, int d,
+                                                           int64_t span, float ce, const float* __restrict__ gs,
+                                                           float* __restrict__ de) {
+    constexpr int CAP = 2048;
+    __shared__ int rows[CAP];
+    __shared__ int nrows;
+    const int k = blockIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * span, r1 = min(n, r0 + span);
+    if (gs) ce *= *gs;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                 // channels threadIdx.x + 256*j
+    bool any = false;
+    for (int64_t base = r0; base < r1; base += CAP) {
+        if (threadIdx.x == 0) nrows = 0;
+        __syncthreads();
+        const int64_t lim = min(r1, base + CAP);
+        for (int64_t r = base + threadIdx.x; r < lim; r += 256)
+            if (idx[r] == k) rows[atomicAdd(&nrows, 1)] = (int)(r - r0);
+        __syncthreads();
+        const int cnt = nrows;
+        if (cnt) {
+            any = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = threadIdx.x + 256 * j;
+                if (c < d) {
+                    const float ev = e[(int64_t)k * d + c];
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;     // independent chains: the row loads overlap
+                    int i = 0;
+                    for (; i + 4 <= cnt; i += 4) {
+                        const float z0 = z[(r0 + rows[i]) * d + c], z1 = z[(r0 + rows[i + 1]) * d + c];
+                        const float z2 = z[(r0 + rows[i + 2]) * d + c], z3 = z[(r0 + rows[i + 3]) * d + c];
+                        a0 += ev - z0; a1 += ev - z1; a2 += ev - z2; a3 += ev - z3;
+                    }
+                    for (; i < cnt; ++i) a0 += ev - z[(r0 + rows[i]) * d + c];
+                    acc[j] += (a0 + a1) + (a2 + a3);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (any)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            if (c < d) atomicAdd(de + (int64_t)k * d + c, ce * acc[j]);
+        }
 }
 
 __global__ __launch_bounds__(256) void ema_stats_kernel(const float* __restrict__ z, const int64_t* __restrict__ idx,
@@ -244,8 +304,10 @@ int vqk_vq_gather_f32(const float* z, const float* e, const int64_t* idx, int64_
     VQK_REQUIRE(z && e && idx, VQK_ERR_ARG);
     VQK_REQUIRE(n >= 0 && k > 0 && d > 0 && (d % 4) == 0, VQK_ERR_SHAPE);
     if (n == 0) return VQK_OK;
-    hipLaunchKernelGGL(vq_gather_kernel, dim3(vqk_grid_1d(n, 4)), dim3(256), 0, vqk_stream(stream), z, e, idx, n, d, q,
-                       reinterpret_cast<bf16_raw*>(q_lo), sse, hist);
+    VQK_REQUIRE(!hist || k <= 16384, VQK_ERR_SHAPE);
+    const int blocks = vqk_grid_1d(n, 4 * 16, 512);          // >= 16 rows per wave: few histogram flushes
+    hipLaunchKernelGGL(vq_gather_kernel, dim3((unsigned)blocks), dim3(256), hist ? (size_t)k * 4 : 0, vqk_stream(stream), z, e,
+                       idx, n, k, d, q, reinterpret_cast<bf16_raw*>(q_lo), sse, hist);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }
@@ -255,12 +317,20 @@ int vqk_vq_backward_f32(const float* z, const float* e, const int64_t* idx, cons
     VQK_REQUIRE(z && e && idx && dz, VQK_ERR_ARG);
     VQK_REQUIRE(n >= 0 && k > 0 && d > 0, VQK_ERR_SHAPE);
     if (n == 0) return VQK_OK;
+    VQK_REQUIRE(!de || d <= 1024, VQK_ERR_SHAPE);
     const dim3 grid(vqk_grid_1d(n, 4));
     if (dq_dtype == VQK_F32)
-        hipLaunchKernelGGL(vq_backward_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), z, e, idx, (const float*)dq, n, d, cz, ce, gscale_dev, dz, de);
+        hipLaunchKernelGGL(vq_backward_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), z, e, idx, (const float*)dq, n, d, cz, gscale_dev, dz);
     else if (dq_dtype == VQK_BF16)
-        hipLaunchKernelGGL(vq_backward_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), z, e, idx, (const bf16_raw*)dq, n, d, cz, ce, gscale_dev, dz, de);
+        hipLaunchKernelGGL(vq_backward_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), z, e, idx, (const bf16_raw*)dq, n, d, cz, gscale_dev, dz);
     else return VQK_ERR_DTYPE;
+    if (de) {
+        int splits = (int)((n + 255) / 256);              // <= 256 rows per block even when every row hits one code
+        if (splits > 64) splits = 64;
+        const int64_t span = (n + splits - 1) / splits;
+        hipLaunchKernelGGL(vq_code_grad_kernel, dim3((unsigned)k, (unsigned)splits), dim3(256), 0, vqk_stream(stream), z, e,
+                           idx, n, d, span, ce, gscale_dev, de);
+    }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }
