@@ -589,7 +589,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
     const int tiles_x = g.w >> TWLOG, tiles_y = g.h / TH;
     const int total_tiles = g.n * tiles_y * tiles_x * g.tiles_n;
     const int nch = g.cpt >> 2;                                  // 32-channel chunks
-    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // consecutive virtual block ids sit on ONE XCD (hardware block b runs on XCD b % 8): the cout tiles of a patch and
+    // its neighbouring patches share that XCD's L2 instead of each fetching the halo from HBM
+    const int vbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int my_tiles = (total_tiles - vbid + (int)gridDim.x - 1) / (int)gridDim.x;
     const int units = my_tiles * nch;
     if (units <= 0) return;
 
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
 
     struct TilePos { int img, py0, px0, nt; };
     auto tile_pos = [&](int j) -> TilePos {
-        int t = (int)blockIdx.x + j * (int)gridDim.x;
+        int t = vbid + j * (int)gridDim.x;
         TilePos tp;
         tp.nt = t % g.tiles_n; t /= g.tiles_n;
         const int txi = t % tiles_x; t /= tiles_x;
@@ -724,24 +727,60 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
             const int n0 = cur.nt * COT;
             // Straight-line fast paths (no activation, unit gains, full cout tile): the epilogue runs on the same
             // SIMD as the MFMAs, so every branch / select per element is stolen from the matrix pipe.
+            // The MFMA result layout gives a lane 4 consecutive couts of its pixel; lanes l and l+32 hold the two
+            // halves of every 8-cout run.  One v_permlane32_swap per value pairs them up so that each lane owns 8
+            // consecutive couts = ONE 16-byte store / residual load instead of two 8-byte ones (the epilogue is
+            // store-issue bound).
             auto epi_plain = [&](auto has_bias, auto has_res) {
+                typedef __attribute__((ext_vector_type(4))) unsigned int u32x4e;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     int ty, tx;
                     pix_of(i, ty, tx);
                     const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
-                    const int64_t o0 = pix * g.cout + n0 + wn * 64 + 4 * kg;
+                    const int64_t o0 = pix * g.cout + n0 + wn * 64 + 8 * kg;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                        for (int rq = 0; rq < 4; ++rq) {
-                            const int cw = j * 32 + 8 * rq;
-                            float v[4];
+                        for (int qp = 0; qp < 2; ++qp) {
+                            const int cw = j * 32 + 16 * qp;
+                            float v[8];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rq + e];
-                            if constexpr (decltype(has_bias)::value) add4(bias + n0 + wn * 64 + 4 * kg + cw, v);
-                            if constexpr (decltype(has_res)::value) add4(res + o0 + cw, v);
-                            store4(y + o0 + cw, v);
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned lo = __float_as_uint(acc[i][j][8 * qp + e]);
+                                const unsigned hi = __float_as_uint(acc[i][j][8 * qp + 4 + e]);
+                                const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+                                v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+                            }
+                            if constexpr (decltype(has_bias)::value) {
+                                const float* bp = bias + n0 + wn * 64 + 8 * kg + cw;
+                                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                            }
+                            if constexpr (decltype(has_res)::value) {
+                                if constexpr (sizeof(TO) == 2) {
+                                    const u32x4e r = *reinterpret_cast<const u32x4e*>(res + o0 + cw);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        v[2 * e] += __uint_as_float(r[e] << 16);
+                                        v[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                                    }
+                                } else {
+                                    float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
+                                    add4(res + o0 + cw, v0); add4(res + o0 + cw + 4, v1);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                                }
+                            }
+                            if constexpr (sizeof(TO) == 2) {
+                                const u32x4e o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                  pack_bf16x2(v[6], v[7])};
+                                *reinterpret_cast<u32x4e*>(y + o0 + cw) = o;
+                            } else {
+                                const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
+                                store4(y + o0 + cw, v0); store4(y + o0 + cw + 4, v1);
+                            }
                         }
                 }
             };
