@@ -17,6 +17,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <math.h>
 
 namespace {
 
@@ -1205,11 +1206,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_ci = (g.cin + 63) >> 6;
-    const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
+    // the (co, ci) tiles of ONE pixel range sit on one XCD (consecutive virtual ids): every dy / x byte is needed by
+    // tiles_ci / tiles_co blocks, and only the first of them should have to go to HBM for it
+    const int vb = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int bx = vb % (int)gridDim.x, by = vb / (int)gridDim.x;
+    const int tco = bx / tiles_ci, tci = bx - tco * tiles_ci;
     const int co0 = tco * 64, ci0 = tci * 64;
     const int pw = g.w >> 3, ph = g.h >> 3;
     const int total_patches = g.n * ph * pw;
-    const int p_begin = blockIdx.y * patches_per_split;
+    const int p_begin = by * patches_per_split;
     const int p_end = min(total_patches, p_begin + patches_per_split);
     if (p_begin >= p_end) return;
 
@@ -1691,8 +1696,16 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     if (plain && dtype == VQK_BF16 && ksize == 3 && (g.h % 8) == 0 && (g.w % 8) == 0 && g_force_variant != 0) {
         const int tiles = ((cout + 63) / 64) * ((cin + 63) / 64);
         const int total_patches = g.n * (g.h / 8) * (g.w / 8);
-        static const int target = getenv("VQK_WGRAD_BLOCKS") ? atoi(getenv("VQK_WGRAD_BLOCKS")) : 512;
-        int splits = (target + tiles - 1) / tiles;
+        // split-K over pixel patches.  Cost model fitted on MI355X (tools/convbench.py sweeps): MFMA time falls with the
+        // number of resident blocks (up to 2 per CU) while every split adds one fp32 atomic pass over dW (~1.1 TB/s):
+        // t(s) = F / (R * min(1, tiles*s/512)) + s * |dW| / B  =>  s* = sqrt(0.16 * pixels / tiles) below the block cap.
+        static const int target = getenv("VQK_WGRAD_BLOCKS") ? atoi(getenv("VQK_WGRAD_BLOCKS")) : 0;
+        int splits;
+        if (target > 0) splits = (target + tiles - 1) / tiles;
+        else {
+            splits = (int)(sqrt(0.16 * (double)g.m / tiles) + 0.5);
+            if (splits > (512 + tiles - 1) / tiles) splits = (512 + tiles - 1) / tiles;
+        }
         if (splits > (total_patches + 3) / 4) splits = (total_patches + 3) / 4;     // >= 4 patches per block
         if (splits < 1) splits = 1;
         const int pps = (total_patches + splits - 1) / splits;
