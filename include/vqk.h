@@ -139,6 +139,10 @@ int vqk_conv_pack_multi(const int64_t* descs_dev, int ndesc, int blocks_per_desc
  * eligible, 2 halo kernel with LDS-staged weights (layout 0) instead of register weights, 3 one-tile-per-block
  * register-weight halo kernel instead of the persistent stream kernel (bf16) */
 int vqk_conv_set_variant(int variant);
+/* caps on the persistent grids of the 3x3 fprop/dgrad kernel and of the all-taps wgrad kernel (0 = default: two
+ * blocks per CU).  256 = one block per CU, leaving room for a kernel that runs concurrently on another stream
+ * (the host overlaps a layer's wgrad with its dgrad and GroupNorm backward). */
+int vqk_conv_set_block_caps(int stream_blocks, int wgrad_blocks);
 /* w [Cout][ks][ks][Cin] -> wt [Cin][ks][ks][Cout] with both taps flipped; src fp32, dst `dtype`. */
 int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, int ksize, void* stream);
 /* dw[Cout][ks][ks][Cin] (fp32) += sum_pix dy[pix][co] * x[pix (+) tap][ci].  dw must be pre-zeroed

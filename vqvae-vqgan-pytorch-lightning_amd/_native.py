@@ -17,7 +17,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
-_SO = os.path.join(_HERE, 'libvqk.so')
+_SO = os.environ.get('VQK_LIB') or os.path.join(_HERE, 'libvqk.so')     # VQK_LIB: A/B builds of the same ABI (tools/)
 _lib = None
 
 P = c_void_p
@@ -44,6 +44,7 @@ _PROTOS = {
     'vqk_conv_pack_weights': [P, P, I, I, I, I, I, I, P],
     'vqk_conv_pack_multi': [P, I, I, P],
     'vqk_conv_set_variant': [I],
+    'vqk_conv_set_block_caps': [I, I],
     'vqk_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
     'vqk_colsum': [I, P, L, I, P, P],

@@ -1427,6 +1427,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 }
 
 static int g_force_variant = -1;   // test hook: -1 auto, 0 im2col kernel only, 1 halo kernels when eligible
+static int g_stream_blocks = 0;    // persistent-grid caps (0 = default 2 blocks per CU): 256 leaves half of every CU to a
+static int g_wgrad_blocks = 0;     // kernel running concurrently on another stream (dgrad || wgrad || GroupNorm)
 
 // 0: not eligible for the halo kernels; 5 / 4: patch width log2 (8x32 / 16x16 pixel patches)
 inline int halo_twlog(const ConvGeom& g) {
@@ -1444,7 +1446,8 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         if (!tw) return VQK_ERR_SHAPE;
         const int th = 256 >> tw;
         const int total = g.n * (g.h / th) * (g.w >> tw) * g.tiles_n;
-        static const int persist = getenv("VQK_STREAM_BLOCKS") ? atoi(getenv("VQK_STREAM_BLOCKS")) : 512;
+        static const int persist_env = getenv("VQK_STREAM_BLOCKS") ? atoi(getenv("VQK_STREAM_BLOCKS")) : 512;
+        const int persist = g_stream_blocks > 0 ? g_stream_blocks : persist_env;
         const dim3 grid((unsigned)(total < persist ? total : persist));
         constexpr int lds = 2 * 28 * 1024;
         if (g.cout <= 32) {                                      // thin head: 32-wide cout tiles, waves split the pixels
@@ -1552,6 +1555,10 @@ extern "C" {
 
 /* test / tuning hook: -1 automatic choice, 0 force the im2col kernel, 1 prefer the halo kernel */
 int vqk_conv_set_variant(int v) { g_force_variant = v; return VQK_OK; }
+int vqk_conv_set_block_caps(int stream_blocks, int wgrad_blocks) {
+    g_stream_blocks = stream_blocks; g_wgrad_blocks = wgrad_blocks;
+    return VQK_OK;
+}
 
 static int conv_general(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                         int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int stride, int pad,
@@ -1700,11 +1707,12 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
         // number of resident blocks (up to 2 per CU) while every split adds one fp32 atomic pass over dW (~1.1 TB/s):
         // t(s) = F / (R * min(1, tiles*s/512)) + s * |dW| / B  =>  s* = sqrt(0.16 * pixels / tiles) below the block cap.
         static const int target = getenv("VQK_WGRAD_BLOCKS") ? atoi(getenv("VQK_WGRAD_BLOCKS")) : 0;
+        const int cap = g_wgrad_blocks > 0 ? g_wgrad_blocks : 512;
         int splits;
         if (target > 0) splits = (target + tiles - 1) / tiles;
         else {
             splits = (int)(sqrt(0.16 * (double)g.m / tiles) + 0.5);
-            if (splits > (512 + tiles - 1) / tiles) splits = (512 + tiles - 1) / tiles;
+            if (splits > (cap + tiles - 1) / tiles) splits = (cap + tiles - 1) / tiles;
         }
         if (splits > (total_patches + 3) / 4) splits = (total_patches + 3) / 4;     // >= 4 patches per block
         if (splits < 1) splits = 1;

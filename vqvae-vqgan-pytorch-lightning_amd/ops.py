@@ -7,6 +7,7 @@ Tensor convention: activations keep the reference's logical NCHW shape but are p
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -468,6 +469,20 @@ class GroupNormSiLUFn(torch.autograd.Function):
         return dx, dw.view(wshape), db.view(bshape), None, None, None
 
 
+OVERLAP_WGRAD = os.environ.get('VQK_OVERLAP_WGRAD', '1') == '1'
+OVERLAP_MODE = int(os.environ.get('VQK_OVERLAP_MODE', '3'))
+OVERLAP_STREAM_BLOCKS = int(os.environ.get('VQK_OVERLAP_STREAM_BLOCKS', '512'))
+OVERLAP_WGRAD_BLOCKS = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS', '384'))
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device) -> torch.cuda.Stream:
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 class ResBlockFn(torch.autograd.Function):
     """One pre-activation residual block (autoencoder.py:63-77) as a single autograd node:
     GN+SiLU -> 3x3 -> GN+SiLU -> 3x3 (+ skip, optionally through a 1x1), with a hand-scheduled backward whose last
@@ -511,12 +526,14 @@ class ResBlockFn(torch.autograd.Function):
         dout = nhwc(dout)
         n, _, h, w = x.shape
 
-        def conv_bwd(inp, dy, wparam, k, ci, co, need_dx=True):
+        def conv_bwd(inp, dy, wparam, k, ci, co, need_dx=True, need_dw=True):
             dx = None
             if need_dx:
                 lay = weight_layout(dt, n, h, w, co, ci, k, False)
                 wt = packed_weight(wparam, ci, co, dt, k, True, lay)
                 dx = raw_conv_fprop(dy, wt, None, None, k, False, 0, dt, ci, lay)
+            if not need_dw:
+                return dx, None
             tgt = direct_grad(wparam)
             dw = raw_conv_wgrad(inp, dy, k, False, out=tgt)
             return dx, (None if tgt is not None else dw)
@@ -530,6 +547,45 @@ class ResBlockFn(torch.autograd.Function):
                 return dx, None, None
             return dx, dw.view(wparam.shape), db.view(bparam.shape)
 
+        t1, t2 = direct_grad(c1w), direct_grad(c2w)
+        if OVERLAP_WGRAD and t1 is not None and t2 is not None:
+            # the two weight-gradient convs (MFMA-bound, results only needed by the optimizer) run on a side stream,
+            # one block per CU, next to the data-gradient convs and the memory-bound GroupNorm backward passes
+            main, side = torch.cuda.current_stream(), _side_stream(x.device)
+            lib = _native.lib()
+            lib.vqk_conv_set_block_caps(OVERLAP_STREAM_BLOCKS, OVERLAP_WGRAD_BLOCKS)
+            try:
+                if OVERLAP_MODE == 1:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        raw_conv_wgrad(a2, dout, 3, False, out=t2)
+                    d_a2, _ = conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)
+                else:                                    # wgrad starts behind the dgrad: it overlaps GroupNorm only
+                    d_a2, _ = conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        raw_conv_wgrad(a2, dout, 3, False, out=t2)
+                d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
+                if OVERLAP_MODE == 1:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                    d_a1, _ = conv_bwd(a1, d_r1, c1w, 3, cin, cout, need_dw=False)
+                else:
+                    if OVERLAP_MODE == 3:
+                        main.wait_stream(side)           # dgrad1 alone on the chip
+                    d_a1, _ = conv_bwd(a1, d_r1, c1w, 3, cin, cout, need_dw=False)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                dskip, dwsc = dout, None
+                if scw is not None:
+                    dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
+                dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip)
+                main.wait_stream(side)
+            finally:
+                lib.vqk_conv_set_block_caps(0, 0)
+            return dx, dn1w, dn1b, None, dn2w, dn2b, None, dwsc, None, None
         d_a2, dw2 = conv_bwd(a2, dout, c2w, 3, cout, cout)
         d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
         d_a1, dw1 = conv_bwd(a1, d_r1, c1w, 3, cin, cout)
