@@ -112,6 +112,69 @@ __global__ __launch_bounds__(256) void channel_affine_kernel(const T* __restrict
 }
 
 // one wavefront per pixel.  out[img] += (1/hw) sum_c w_c (fx_c/(|fx|+eps) - fy_c/(|fy|+eps))^2
+// segmented butterfly sum over groups of `width` consecutive lanes (width a power of two <= 64)
+__device__ __forceinline__ float seg_sum(float v, int width) {
+    for (int off = width >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Vectorised form: a lane owns one 16-byte channel slot of a pixel (c / V lanes per pixel, 64 / (c / V) pixels per wave
+// pass), both feature vectors are read ONCE into registers, the channel reductions are segmented shuffles, and the
+// per-image spatial mean is accumulated per wave and flushed with one atomic per (wave, image) -- the scalar version
+// issued one global atomic per PIXEL onto n addresses (3.5 ms per tap at 16 x 256^2).
+template <typename T>
+__global__ __launch_bounds__(256) void lpips_tap_fwd_vec_kernel(const T* __restrict__ fx, const T* __restrict__ fy,
+                                                                const float* __restrict__ lin, int64_t npix, int64_t hw,
+                                                                int c, int64_t pix_per_block, float* __restrict__ out) {
+    constexpr int V = Vec16<T>::N;
+    const int lpp = c / V;                                   // lanes per pixel
+    const int ppw = 64 / lpp;                                // pixels per wave pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / lpp, slot = lane - sub * lpp;
+    float lw[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) lw[i] = lin[slot * V + i];
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    int64_t cur_img = -1;
+    float img_acc = 0.f;
+    const float inv_hw = 1.0f / (float)hw;
+    for (int64_t base = p0 + (int64_t)wave * ppw; base < p1; base += 4 * ppw) {
+        const int64_t pix = base + sub;
+        const bool ok = pix < p1;
+        float a[V], b[V];
+        if (ok) { Vec16<T>::load(fx + pix * c + slot * V, a); Vec16<T>::load(fy + pix * c + slot * V, b); }
+        else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) { a[i] = 0.f; b[i] = 0.f; }
+        }
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { sx = __fmaf_rn(a[i], a[i], sx); sy = __fmaf_rn(b[i], b[i], sy); }
+        sx = seg_sum(sx, lpp); sy = seg_sum(sy, lpp);
+        const float rx = 1.0f / (sqrtf(sx) + 1e-10f), ry = 1.0f / (sqrtf(sy) + 1e-10f);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { const float d = a[i] * rx - b[i] * ry; acc = __fmaf_rn(lw[i] * d, d, acc); }
+        acc = seg_sum(acc, lpp);
+        if (ok && slot == 0) {
+            const int64_t img = pix / hw;
+            if (img != cur_img) {
+                if (cur_img >= 0) atomicAdd(out + cur_img, img_acc * inv_hw);
+                cur_img = img; img_acc = 0.f;
+            }
+            img_acc += acc;
+        }
+    }
+    // flush: normally the whole wave ended on one image -> one atomic per wave
+    const int64_t mine = slot == 0 ? cur_img : -2;
+    const int64_t first = __shfl(cur_img, 0, 64);
+    const bool uniform = __all(mine == -2 || mine == first || mine == -1);
+    if (uniform) {
+        const float tot = wave_sum((slot == 0 && cur_img >= 0) ? img_acc : 0.f);
+        if (lane == 0 && first >= 0) atomicAdd(out + first, tot * inv_hw);
+    } else if (slot == 0 && cur_img >= 0) atomicAdd(out + cur_img, img_acc * inv_hw);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const T* __restrict__ fx, const T* __restrict__ fy,
                                                             const float* __restrict__ lin, int64_t npix, int64_t hw, int c,
@@ -459,7 +522,16 @@ int vqk_lpips_tap(int dtype, const void* fx, const void* fy, const float* lin, i
         else if (dtype == VQK_BF16) hipLaunchKernelGGL(lpips_tap_bwd_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)fx, (const bf16_raw*)fy, lin, gout, gscale, npix, hw, c, (bf16_raw*)dfy);
         else return VQK_ERR_DTYPE;
     } else {
-        if (dtype == VQK_F32) hipLaunchKernelGGL(lpips_tap_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)fx, (const float*)fy, lin, npix, hw, c, out);
+        const int v = dtype == VQK_F32 ? 4 : 8;
+        const int lpp = (c % v) == 0 ? c / v : 0;
+        if (lpp >= 1 && lpp <= 64 && (lpp & (lpp - 1)) == 0 && vqk_aligned16(fx) && vqk_aligned16(fy)) {
+            int64_t blocks = (npix + 1023) / 1024; if (blocks > 2048) blocks = 2048;
+            const int64_t ppb = (npix + blocks - 1) / blocks;
+            const dim3 vgrid((unsigned)((npix + ppb - 1) / ppb));
+            if (dtype == VQK_F32) hipLaunchKernelGGL(lpips_tap_fwd_vec_kernel<float>, vgrid, dim3(256), 0, st, (const float*)fx, (const float*)fy, lin, npix, hw, c, ppb, out);
+            else if (dtype == VQK_BF16) hipLaunchKernelGGL(lpips_tap_fwd_vec_kernel<bf16_raw>, vgrid, dim3(256), 0, st, (const bf16_raw*)fx, (const bf16_raw*)fy, lin, npix, hw, c, ppb, out);
+            else return VQK_ERR_DTYPE;
+        } else if (dtype == VQK_F32) hipLaunchKernelGGL(lpips_tap_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)fx, (const float*)fy, lin, npix, hw, c, out);
         else if (dtype == VQK_BF16) hipLaunchKernelGGL(lpips_tap_fwd_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)fx, (const bf16_raw*)fy, lin, npix, hw, c, out);
         else return VQK_ERR_DTYPE;
     }
