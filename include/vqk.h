@@ -107,6 +107,14 @@ int vqk_ema_update_f32(float* ema_count, float* ema_weight, float* codebook, con
 int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                      int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int act,
                      int wlayout, const void* zeros, void* stream);
+/* The same conv with a 2x2 pooling of its output fused into the epilogue: y[N][H/2][W/2][Cout] = pool_scale * (sum over
+ * each 2x2 block of conv(x) + bias + residual) -- pool_scale 0.25: the avg_pool2d that follows a level's last ResBlock
+ * (autoencoder.py:89-91, residual = the block's skip input at full resolution); pool_scale 1: the backward of the nearest
+ * x2 upsample in front of an Upsample conv (:104-106).  bf16 only, fragment-major weights (layout 1), Cout % 128 == 0;
+ * VQK_ERR_SHAPE when the problem is not eligible (callers then use vqk_conv2d_fprop + vqk_pool2x2). */
+int vqk_conv2d_fprop_pooled(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                            int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, float pool_scale,
+                            const void* zeros, void* stream);
 /* General form (im2col kernel when not plain): stride in {1,2}, explicit zero padding `pad`, explicit output size;
  * mode 0: x as is, 1: nearest x2 upsample of x, 2: x zero-stuffed x2 (the dgrad of a stride-2 conv, with flipped /
  * transposed weights and pad = ks-1-pad_fwd).  Epilogue: y = out_gain * act(acc * acc_scale + bias) + residual, act 0

@@ -196,6 +196,9 @@ CONV_CASES = [
     (1, 8, 96, 5, 32, 3, False, True, False),
     (2, 128, 8, 8, 32, 3, False, True, False),
     (1, 64, 8, 16, 64, 3, False, False, False),
+    # nearest-x2 upsample convs whose dgrad pools in the epilogue (bf16, Cin % 128 == 0), both patch shapes
+    (2, 128, 128, 8, 16, 3, True, True, False),
+    (1, 128, 256, 8, 8, 3, True, False, False),
 ]
 
 
@@ -258,6 +261,44 @@ def test_conv_kernel_variants_agree(dtype):
     finally:
         native.lib().vqk_conv_set_variant(-1)
     assert rel_err(outs[1], outs[0]) < 1e-3 and rel_err(outs[2], outs[0]) < 1e-3
+
+
+@pytest.mark.parametrize('h,w', [(8, 32), (16, 16), (16, 64)])
+@pytest.mark.parametrize('has_b,has_r', [(False, False), (True, True), (False, True)])
+def test_conv_pooled_epilogue_matches_conv_then_pool(h, w, has_b, has_r):
+    """fused 2x2 pooling in the stream kernel's epilogue == conv kernel followed by the pool kernel (bf16)"""
+    g = torch.Generator().manual_seed(h * 100 + w + has_b)
+    dt = torch.bfloat16
+    x = dev(torch.randn(2, 64, h, w, generator=g), dt).contiguous(memory_format=torch.channels_last)
+    wt = dev(torch.randn(128, 3, 3, 64, generator=g) * 0.05).reshape(-1)
+    b = dev(torch.randn(128, generator=g)) if has_b else None
+    r = dev(torch.randn(2, 128, h, w, generator=g), dt).contiguous(memory_format=torch.channels_last) if has_r else None
+    layout = ops.weight_layout(dt, 2, h, w, 64, 128, 3, False)
+    assert layout == 1 and ops.can_pool_epilogue(dt, 128, layout)
+    wq = ops.pack_weights(wt, dt, 128, 64, 3, False, layout)
+    for scale in (0.25, 1.0):
+        fused = ops.raw_conv_fprop_pooled(x, wq, b, r, 3, False, 128, scale)
+        ref = ops.raw_pool(ops.raw_conv_fprop(x, wq, b, r, 3, False, 0, dt, 128, layout).float(), scale)
+        assert fused.shape == (2, 128, h // 2, w // 2)
+        assert rel_err(fused, ref) < 6e-3          # one bf16 rounding of the pooled value vs four of the full-res ones
+
+
+def test_res_block_with_fused_downsample_bf16():
+    """ResBlock(pool=True) == avg_pool2x2(ResBlock(x)), forward and every gradient (bf16 throughput mode)"""
+    g = torch.Generator().manual_seed(77)
+    blk = ae.ResBlock(128, 128).to(DEV)
+    x = dev(torch.randn(2, 128, 16, 32, generator=g), torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = dev(torch.randn(2, 128, 8, 16, generator=g), torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    params = list(blk.parameters())
+    xa = x.clone().requires_grad_(True)
+    ya = blk(xa, pool=True)
+    ga = torch.autograd.grad(ya, [xa] + params, dy)
+    xb = x.clone().requires_grad_(True)
+    yb = ops.avg_pool2x2(blk(xb))
+    gb = torch.autograd.grad(yb, [xb] + params, dy)
+    assert rel_err(ya, yb) < 6e-3
+    for a, b in zip(ga, gb):
+        assert rel_err(a, b) < 2e-2
 
 
 def test_conv_padded_edges_fp32():

@@ -38,6 +38,7 @@ _PROTOS = {
     'vqk_ema_stats_f32': [P, P, L, I, I, P, P, P],
     'vqk_ema_update_f32': [P, P, P, P, P, I, I, F, F, F, P],
     'vqk_conv2d_fprop': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
+    'vqk_conv2d_fprop_pooled': [I, P, P, P, P, P, I, I, I, I, I, I, I, F, P, P],
     'vqk_conv2d_general': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, I, P, P],
     'vqk_conv2d_wgrad_general': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P],
     'vqk_conv_weight_layout': [I, I, I, I, I, I, I, I],

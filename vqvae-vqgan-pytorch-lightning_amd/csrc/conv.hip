@@ -28,6 +28,8 @@ struct ConvGeom {
     // zs = 1: only even coordinates carry data -- the dgrad of a stride-2 conv); vh/vw = its extent.
     int stride, pad, zs, vh, vw;
     float acc_scale, out_gain;      // epilogue: y = out_gain * act(acc * acc_scale + bias) + residual
+    int pool;                       // stream kernel: y = pool_scale * (2x2 sum of the above), written at half resolution
+    float pool_scale;
     int m;          // n*h*w output pixels
     int cpt;        // 16-byte chunks per tap  (cin / elems-per-16B)
     int kchunks;    // ks*ks*cpt
@@ -732,8 +734,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
             // halves of every 8-cout run.  One v_permlane32_swap per value pairs them up so that each lane owns 8
             // consecutive couts = ONE 16-byte store / residual load instead of two 8-byte ones (the epilogue is
             // store-issue bound).
+            // The MFMA result layout gives a lane 4 consecutive couts of its pixel; lanes l and l+32 hold the two
+            // halves of every 8-cout run.  One v_permlane32_swap per value pairs them up so that each lane owns 8
+            // consecutive couts = ONE 16-byte store / residual load instead of two 8-byte ones (the epilogue is
+            // store-issue bound).
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4e;
+            auto epi_vals = [&](auto has_bias, auto has_res, int i, int j, int qp, int64_t o0, float (&v)[8]) {
+                const int cw = j * 32 + 16 * qp;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned lo = __float_as_uint(acc[i][j][8 * qp + e]);
+                    const unsigned hi = __float_as_uint(acc[i][j][8 * qp + 4 + e]);
+                    const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+                    v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+                }
+                if constexpr (decltype(has_bias)::value) {
+                    const float* bp = bias + n0 + wn * 64 + 8 * kg + cw;
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                if constexpr (decltype(has_res)::value) {
+                    if constexpr (sizeof(TO) == 2) {
+                        const u32x4e r = *reinterpret_cast<const u32x4e*>(res + o0 + cw);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += __uint_as_float(r[e] << 16);
+                            v[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                        }
+                    } else {
+                        float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
+                        add4(res + o0 + cw, v0); add4(res + o0 + cw + 4, v1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                    }
+                }
+            };
+            auto epi_store = [&](TO* dst, const float (&v)[8]) {
+                if constexpr (sizeof(TO) == 2) {
+                    const u32x4e o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                      pack_bf16x2(v[6], v[7])};
+                    *reinterpret_cast<u32x4e*>(dst) = o;
+                } else {
+                    const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
+                    store4(dst, v0); store4(dst + 4, v1);
+                }
+            };
             auto epi_plain = [&](auto has_bias, auto has_res) {
-                typedef __attribute__((ext_vector_type(4))) unsigned int u32x4e;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     int ty, tx;
@@ -744,51 +791,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
                     for (int j = 0; j < NJ; ++j)
 #pragma unroll
                         for (int qp = 0; qp < 2; ++qp) {
-                            const int cw = j * 32 + 16 * qp;
                             float v[8];
+                            epi_vals(has_bias, has_res, i, j, qp, o0, v);
+                            epi_store(y + o0 + j * 32 + 16 * qp, v);
+                        }
+                }
+            };
+            // 2x2 pooled output (avg-pool of a ResBlock output, autoencoder.py:89-91, or the sum-pool that is the
+            // backward of the nearest x2 upsample, :104-106): vertical partner = the next MFMA row tile (8x32 patches)
+            // or lane ^ 16 (16x16 patches), horizontal partner = lane ^ 1; even lanes store at half resolution.
+            auto epi_pool = [&](auto has_bias, auto has_res) {
+                const int hh = g.h >> 1, wh = g.w >> 1;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const unsigned lo = __float_as_uint(acc[i][j][8 * qp + e]);
-                                const unsigned hi = __float_as_uint(acc[i][j][8 * qp + 4 + e]);
-                                const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
-                                v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
-                            }
-                            if constexpr (decltype(has_bias)::value) {
-                                const float* bp = bias + n0 + wn * 64 + 8 * kg + cw;
-                                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                for (int i = 0; i < NI; i += (TWLOG == 5 ? 2 : 1)) {
+                    int ty, tx;
+                    pix_of(i, ty, tx);
+                    const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
+                    const int64_t o0 = pix * g.cout + n0 + wn * 64 + 8 * kg;
+                    const int64_t ppix = ((int64_t)cur.img * hh + ((cur.py0 + ty) >> 1)) * wh + ((cur.px0 + tx) >> 1);
+                    const bool writer = TWLOG == 5 ? (p & 1) == 0 : (p & 17) == 0;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                            }
-                            if constexpr (decltype(has_res)::value) {
-                                if constexpr (sizeof(TO) == 2) {
-                                    const u32x4e r = *reinterpret_cast<const u32x4e*>(res + o0 + cw);
+                    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        v[2 * e] += __uint_as_float(r[e] << 16);
-                                        v[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
-                                    }
-                                } else {
-                                    float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
-                                    add4(res + o0 + cw, v0); add4(res + o0 + cw + 4, v1);
+                        for (int qp = 0; qp < 2; ++qp) {
+                            float v[8];
+                            epi_vals(has_bias, has_res, i, j, qp, o0, v);
+                            if (TWLOG == 5) {
+                                float v2[8];
+                                epi_vals(has_bias, has_res, i + 1, j, qp, o0 + (int64_t)g.w * g.cout, v2);
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-                                }
-                            }
-                            if constexpr (sizeof(TO) == 2) {
-                                const u32x4e o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                                  pack_bf16x2(v[6], v[7])};
-                                *reinterpret_cast<u32x4e*>(y + o0 + cw) = o;
+                                for (int e = 0; e < 8; ++e) v[e] += v2[e];
                             } else {
-                                const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
-                                store4(y + o0 + cw, v0); store4(y + o0 + cw + 4, v1);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += __shfl_xor(v[e], 16, 64);
                             }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (v[e] + __shfl_xor(v[e], 1, 64)) * g.pool_scale;
+                            if (writer) epi_store(y + ppix * g.cout + n0 + wn * 64 + 8 * kg + j * 32 + 16 * qp, v);
                         }
                 }
             };
             typedef std::integral_constant<bool, true> yes_t;
             typedef std::integral_constant<bool, false> no_t;
             const bool plain = !THIN && act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
-            if (plain && !bias && !res) epi_plain(no_t{}, no_t{});
+            if (plain && g.pool) {
+                if (!bias && !res) epi_pool(no_t{}, no_t{});
+                else if (!bias) epi_pool(no_t{}, yes_t{});
+                else if (!res) epi_pool(yes_t{}, no_t{});
+                else epi_pool(yes_t{}, yes_t{});
+            } else if (plain && !bias && !res) epi_plain(no_t{}, no_t{});
             else if (plain && !bias) epi_plain(no_t{}, yes_t{});
             else if (plain && !res) epi_plain(yes_t{}, no_t{});
             else if (plain) epi_plain(yes_t{}, yes_t{});
@@ -1538,7 +1589,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.n = n; g.h_in = h_in; g.w_in = w_in; g.h = h_in << ups; g.w = w_in << ups;
     g.cin = cin; g.cout = cout; g.ks = ksize; g.ups = ups;
     g.stride = 1; g.pad = ksize >> 1; g.zs = 0; g.vh = g.h; g.vw = g.w;
-    g.acc_scale = 1.0f; g.out_gain = 1.0f;
+    g.acc_scale = 1.0f; g.out_gain = 1.0f; g.pool = 0; g.pool_scale = 1.0f;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
     g.m = (int)m;
@@ -1607,6 +1658,21 @@ int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias,
     VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
     return conv_general(dtype, x, w, bias, residual, y, out_dtype, n, h_in, w_in, cin, cout, ksize, 1, ksize >> 1, ups,
                         h_in << ups, w_in << ups, act, 1.0f, 1.0f, wlayout, zeros, stream);
+}
+
+int vqk_conv2d_fprop_pooled(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                            int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, float pool_scale,
+                            const void* zeros, void* stream) {
+    VQK_REQUIRE(x && w && y && zeros, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w) && vqk_aligned16(zeros) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    VQK_REQUIRE(dtype == VQK_BF16, VQK_ERR_DTYPE);
+    VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
+    ConvGeom g;
+    const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
+    if (rc) return rc;
+    VQK_REQUIRE(halo_twlog(g) && (cout % 128) == 0 && g_force_variant != 3 && g_force_variant != 2, VQK_ERR_SHAPE);
+    g.pool = 1; g.pool_scale = pool_scale;
+    return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, 0, 1, vqk_stream(stream));
 }
 
 int vqk_conv2d_general(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,

@@ -74,12 +74,13 @@ class ResBlock(nn.Module):
         self.norm2 = GroupNorm(32, out_channels, eps=1e-6)
         self.conv2 = Conv2d(out_channels, out_channels, 3, bias=False)
 
-    def forward(self, x):
-        # one fused autograd node: residual add in conv2's epilogue, skip-gradient add in norm1's backward sweep
+    def forward(self, x, pool: bool = False):
+        # one fused autograd node: residual add in conv2's epilogue, skip-gradient add in norm1's backward sweep;
+        # pool: the Downsample that follows the block rides in conv2's epilogue as well
         return ops.res_block(x, self.norm1.weight, self.norm1.bias, self.conv1.weight, self.norm2.weight,
                              self.norm2.bias, self.conv2.weight,
                              None if self.conv_shortcut is None else self.conv_shortcut.weight,
-                             self.norm1.num_groups, self.norm1.eps)
+                             self.norm1.num_groups, self.norm1.eps, pool)
 
 
 class Downsample(nn.Module):
@@ -135,7 +136,15 @@ class Encoder(nn.Module):
     def forward(self, x):
         x = _to_internal(x, self.compute_dtype)
         x = self.conv_in(x)
-        x = self.blocks(x)
+        mods = list(self.blocks)
+        i = 0
+        while i < len(mods):                                  # ResBlock + Downsample pairs run as one fused op
+            if isinstance(mods[i], ResBlock) and i + 1 < len(mods) and isinstance(mods[i + 1], Downsample):
+                x = mods[i](x, pool=True)
+                i += 2
+            else:
+                x = mods[i](x)
+                i += 1
         x = self.final_residual(x)
         x = self.norm(x, silu=True)
         return self.conv_out(x, out_dtype=torch.float32)      # the quantizer always sees fp32 latents

@@ -209,6 +209,30 @@ def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_d
     return y
 
 
+def can_pool_epilogue(dtype, cout: int, wlayout: int) -> bool:
+    """the fused 2x2-pooling epilogue exists on the bf16 stream kernel for whole 128-wide cout tiles"""
+    return dtype == torch.bfloat16 and wlayout == 1 and cout % 128 == 0
+
+
+def raw_conv_fprop_pooled(x, wq, bias, residual, ksize: int, ups: bool, cout: int, pool_scale: float):
+    """pool_scale * sum-pool2x2(conv(x) + bias + residual), written at half resolution (vqk_conv2d_fprop_pooled)"""
+    _require_gpu(x)
+    n, cin, h, w = x.shape
+    s = 2 if ups else 1
+    y = empty_nhwc(n, cout, h * s // 2, w * s // 2, x.dtype, x.device)
+    flops = 2.0 * n * h * s * w * s * cout * cin * ksize * ksize
+    nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size()
+              + (residual.numel() * residual.element_size() if residual is not None else 0)
+              + cout * cin * ksize * ksize * x.element_size())
+    st = _timed(_fprop_kernel_name(x.dtype, 1), flops,
+                lambda: _native.lib().vqk_conv2d_fprop_pooled(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias),
+                                                              _p(residual), y.data_ptr(), n, h, w, cin, cout, ksize,
+                                                              int(ups), float(pool_scale),
+                                                              zero_page(x.device).data_ptr(), _stream()), nbytes)
+    _native.check(st, 'conv2d_fprop_pooled')
+    return y
+
+
 _DIRECT_GRAD = True
 
 
@@ -418,9 +442,12 @@ class Conv2dFn(torch.autograd.Function):
             n_img, _, h_out, w_out = dyc.shape
             layout = weight_layout(dt, n_img, h_out, w_out, cout_pad, cin, k, False)
             wt = packed_weight(weight, cin, cout_pad, dt, k, True, layout)
-            dx = raw_conv_fprop(dyc, wt, None, None, k, False, 0, dt, cin, layout)
-            if ups:
-                dx = raw_pool(dx, 1.0)
+            if ups and can_pool_epilogue(dt, cin, layout):
+                dx = raw_conv_fprop_pooled(dyc, wt, None, None, k, False, cin, 1.0)      # sum-pool in the epilogue
+            else:
+                dx = raw_conv_fprop(dyc, wt, None, None, k, False, 0, dt, cin, layout)
+                if ups:
+                    dx = raw_pool(dx, 1.0)
         padded = cin != i or cout_pad != o
         if ctx.needs_input_grad[1]:
             tgt = None if padded else direct_grad(ctx.weight_ref)
@@ -490,7 +517,7 @@ class ResBlockFn(torch.autograd.Function):
     bookkeeping for eight intermediate nodes)."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups: int, eps: float):
+    def forward(ctx, x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups: int, eps: float, pool: bool = False):
         _require_gpu(x)
         x = nhwc(x)
         dt = x.dtype
@@ -510,20 +537,27 @@ class ResBlockFn(torch.autograd.Function):
             skip = raw_conv_fprop(x, packed_weight(scw, cin, cout, dt, 1, False, 0), None, None, 1,
                                   False, 0, dt, cout, 0)
         l2 = weight_layout(dt, n, h, w, cout, cout, 3, False)
-        out = raw_conv_fprop(a2, packed_weight(c2w, cout, cout, dt, 3, False, l2), None, skip, 3,
-                             False, 0, dt, cout, l2)
+        wq2 = packed_weight(c2w, cout, cout, dt, 3, False, l2)
+        if pool and can_pool_epilogue(dt, cout, l2):
+            out = raw_conv_fprop_pooled(a2, wq2, None, skip, 3, False, cout, 0.25)   # the level's avg-pool, fused
+        else:
+            out = raw_conv_fprop(a2, wq2, None, skip, 3, False, 0, dt, cout, l2)
+            if pool:
+                out = raw_pool(out, 0.25)
         ctx.save_for_backward(x, st1, a1, r1, st2, a2, w1, b1, w2, b2)
         ctx.params = (n1w, n1b, c1w, n2w, n2b, c2w, scw)
-        ctx.cfg = (groups, cin, cout)
+        ctx.cfg = (groups, cin, cout, pool)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, st1, a1, r1, st2, a2, w1, b1, w2, b2 = ctx.saved_tensors
         n1w, n1b, c1w, n2w, n2b, c2w, scw = ctx.params
-        groups, cin, cout = ctx.cfg
+        groups, cin, cout, pool = ctx.cfg
         dt = x.dtype
         dout = nhwc(dout)
+        if pool:
+            dout = raw_unpool(dout, 0.25)                   # backward of the fused avg-pool
         n, _, h, w = x.shape
 
         def conv_bwd(inp, dy, wparam, k, ci, co, need_dx=True, need_dw=True):
@@ -585,7 +619,7 @@ class ResBlockFn(torch.autograd.Function):
                 main.wait_stream(side)
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)
-            return dx, dn1w, dn1b, None, dn2w, dn2b, None, dwsc, None, None
+            return dx, dn1w, dn1b, None, dn2w, dn2b, None, dwsc, None, None, None
         d_a2, dw2 = conv_bwd(a2, dout, c2w, 3, cout, cout)
         d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
         d_a1, dw1 = conv_bwd(a1, d_r1, c1w, 3, cin, cout)
@@ -593,11 +627,12 @@ class ResBlockFn(torch.autograd.Function):
         if scw is not None:
             dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
         dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip)
-        return dx, dn1w, dn1b, dw1, dn2w, dn2b, dw2, dwsc, None, None
+        return dx, dn1w, dn1b, dw1, dn2w, dn2b, dw2, dwsc, None, None, None
 
 
-def res_block(x, n1w, n1b, c1w, n2w, n2b, c2w, scw=None, groups: int = 32, eps: float = 1e-6):
-    return ResBlockFn.apply(x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups, eps)
+def res_block(x, n1w, n1b, c1w, n2w, n2b, c2w, scw=None, groups: int = 32, eps: float = 1e-6, pool: bool = False):
+    """pool: also apply the 2x2 average pool that follows the block (the encoder's Downsample, autoencoder.py:89-91)"""
+    return ResBlockFn.apply(x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups, eps, pool)
 
 
 def group_norm_silu(x, weight, bias, groups: int = 32, eps: float = 1e-6, silu: bool = True):
