@@ -216,7 +216,7 @@ def main():
                                final_loss=round(float(loss.item()), 6)),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
