@@ -145,7 +145,8 @@ int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int ci
 int vqk_conv_pack_multi(const int64_t* descs_dev, int ndesc, int blocks_per_desc, void* stream);
 /* test / tuning hook for the fprop kernel choice: -1 automatic, 0 im2col kernel only, 1 halo kernels when
  * eligible, 2 halo kernel with LDS-staged weights (layout 0) instead of register weights, 3 one-tile-per-block
- * register-weight halo kernel instead of the persistent stream kernel (bf16) */
+ * register-weight halo kernel instead of the persistent stream kernel (bf16), 4 stream kernel without its half-tile
+ * (128-pixel) form for maps with fewer 256-pixel tiles than CUs */
 int vqk_conv_set_variant(int variant);
 /* caps on the persistent grids of the 3x3 fprop/dgrad kernel and of the all-taps wgrad kernel (0 = default: two
  * blocks per CU).  256 = one block per CU, leaving room for a kernel that runs concurrently on another stream

@@ -252,15 +252,15 @@ def test_conv_kernel_variants_agree(dtype):
     w = dev(torch.randn(160, 3, 3, 128, generator=g) * 0.03).reshape(-1)
     outs = []
     try:
-        for variant in (0, 2, 1):
+        for variant in (0, 2, 1, 4):          # 4: register-weight stream kernel with 256-pixel tiles only (no half tiles)
             native.lib().vqk_conv_set_variant(variant)
             layout = ops.weight_layout(dtype, 2, 16, 32, 128, 160, 3, False)
-            assert layout == (1 if variant == 1 else 0)
+            assert layout == (1 if variant in (1, 4) else 0)
             wq = ops.pack_weights(w, dtype, 160, 128, 3, False, layout)
             outs.append(ops.raw_conv_fprop(x, wq, None, None, 3, False, 0, dtype, 160, layout))
     finally:
         native.lib().vqk_conv_set_variant(-1)
-    assert rel_err(outs[1], outs[0]) < 1e-3 and rel_err(outs[2], outs[0]) < 1e-3
+    assert rel_err(outs[1], outs[0]) < 1e-3 and rel_err(outs[2], outs[0]) < 1e-3 and rel_err(outs[3], outs[0]) < 1e-3
 
 
 @pytest.mark.parametrize('h,w', [(8, 32), (16, 16), (16, 64)])

@@ -571,18 +571,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_breg_kernel(const T* __re
 // ------------------------------------------------------------------------------------------------
 // THIN: couts fit ONE 32-wide MFMA tile (the decoder's 3-channel head, autoencoder.py:170): the four waves split the
 // 256 pixels four ways (wave tile 64 pixels x 32 couts) instead of 2 x 2 (128 x 64), cout tiles are 32 wide.
-template <typename TO, int TWLOG, bool THIN>
+// MODE 2 (half tile): 128-pixel patches (4x32 / 8x16), wave tile 64 pixels x 64 couts -- twice as many tiles for the
+// 16^2 / 32^2 maps whose 256-pixel tiling leaves most CUs idle.
+template <typename TO, int TWLOG, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* __restrict__ x,
                                                                 const bf16_raw* __restrict__ wp,
                                                                 const float* __restrict__ bias,
                                                                 const TO* __restrict__ res, TO* __restrict__ y,
                                                                 const char* __restrict__ zeros, ConvGeom g, int act) {
-    constexpr int TW = 1 << TWLOG, TH = 256 / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr bool THIN = MODE == 1;
+    constexpr int PIX = MODE == 2 ? 128 : 256;                   // output pixels per tile
+    constexpr int TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
     constexpr int RS = 80;                                       // padded LDS row stride (64 B payload)
     constexpr int HALO_INSTR = (HROWS + 15) / 16;                // register pieces: 16 rows x 64 B per wave load
     constexpr int BUF = 28 * 1024;
     constexpr int NSLOT = (HALO_INSTR + 3) / 4;
-    constexpr int NI = THIN ? 2 : 4, NJ = THIN ? 1 : 2, COT = THIN ? 32 : 128;
+    constexpr int NI = MODE == 0 ? 4 : 2, NJ = THIN ? 1 : 2, COT = THIN ? 32 : 128;
     typedef bf16x8_t frag_t;
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1501,20 +1505,30 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         const int persist = g_stream_blocks > 0 ? g_stream_blocks : persist_env;
         const dim3 grid((unsigned)(total < persist ? total : persist));
         constexpr int lds = 2 * 28 * 1024;
+        const bool half_ok = tw == 5 ? (g.h % 4) == 0 : (g.h % 8) == 0;
         if (g.cout <= 32) {                                      // thin head: 32-wide cout tiles, waves split the pixels
             ConvGeom gt = g;
             gt.tiles_n = 1;
             if (tw == 5)
-                hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 5, true>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+                hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 5, 1>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
                                    bias, (const TO*)res, (TO*)y, (const char*)zeros, gt, act);
             else
-                hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 4, true>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+                hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 4, 1>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
                                    bias, (const TO*)res, (TO*)y, (const char*)zeros, gt, act);
+        } else if (total < 256 && half_ok && !g.pool && sizeof(TO) == 2 && g_force_variant != 4) {
+            // fewer 256-pixel tiles than CUs: 128-pixel tiles
+            const dim3 hgrid((unsigned)(2 * total < persist ? 2 * total : persist));
+            if (tw == 5)
+                hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 5, 2>), hgrid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+                                   bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
+            else
+                hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 4, 2>), hgrid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+                                   bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
         } else if (tw == 5)
-            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 5, false>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 5, 0>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
                                bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
         else
-            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 4, false>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
+            hipLaunchKernelGGL((conv3x3_stream_kernel<TO, 4, 0>), grid, dim3(256), lds, st, (const bf16_raw*)x, (const bf16_raw*)w,
                                bias, (const TO*)res, (TO*)y, (const char*)zeros, g, act);
         if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
         return VQK_OK;
