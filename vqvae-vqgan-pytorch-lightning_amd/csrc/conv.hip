@@ -1455,20 +1455,37 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     if (VEC) {
         constexpr int V = Vec16<T>::N;
         const int vpp = c / V;                              // slots per row
-        const int slot = threadIdx.x % vpp, rlane = threadIdx.x / vpp, rstep = 256 / vpp;
-        if (rlane < rstep) {
-            float a[V];
+        if (vpp <= 256) {
+            const int slot = threadIdx.x % vpp, rlane = threadIdx.x / vpp, rstep = 256 / vpp;
+            if (rlane < rstep) {
+                float a[V];
 #pragma unroll
-            for (int i = 0; i < V; ++i) a[i] = 0.f;
+                for (int i = 0; i < V; ++i) a[i] = 0.f;
 #pragma unroll 4
-            for (int64_t r = r0 + rlane; r < r1; r += rstep) {
-                float v[V];
-                Vec16<T>::load(x + r * c + slot * V, v);
+                for (int64_t r = r0 + rlane; r < r1; r += rstep) {
+                    float v[V];
+                    Vec16<T>::load(x + r * c + slot * V, v);
 #pragma unroll
-                for (int i = 0; i < V; ++i) a[i] += v[i];
+                    for (int i = 0; i < V; ++i) a[i] += v[i];
+                }
+#pragma unroll
+                for (int i = 0; i < V; ++i) atomicAdd(&sh[slot * V + i], a[i]);
             }
+        } else {                                            // wide rows (the [N, K] matrices of the quantizers)
+            for (int slot = threadIdx.x; slot < vpp; slot += 256) {
+                float a[V];
 #pragma unroll
-            for (int i = 0; i < V; ++i) atomicAdd(&sh[slot * V + i], a[i]);
+                for (int i = 0; i < V; ++i) a[i] = 0.f;
+#pragma unroll 4
+                for (int64_t r = r0; r < r1; ++r) {
+                    float v[V];
+                    Vec16<T>::load(x + r * c + slot * V, v);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) a[i] += v[i];
+                }
+#pragma unroll
+                for (int i = 0; i < V; ++i) sh[slot * V + i] = a[i];
+            }
         }
     } else {
         for (int col = threadIdx.x & 63; col < c; col += 64) {
@@ -1842,7 +1859,7 @@ int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* 
     VQK_REQUIRE(dtype == VQK_F32 || dtype == VQK_BF16, VQK_ERR_DTYPE);
     if (rows == 0) return VQK_OK;
     const int v = dtype == VQK_F32 ? 4 : 8;
-    const bool vec = (c % v) == 0 && c / v <= 256 && vqk_aligned16(x);
+    const bool vec = (c % v) == 0 && vqk_aligned16(x);
     int64_t blocks = (rows + 63) / 64; if (blocks > 1024) blocks = 1024;
     const int64_t rpb = (rows + blocks - 1) / blocks;
     blocks = (rows + rpb - 1) / rpb;
