@@ -199,6 +199,17 @@ def main():
                         all_kernels={k: dict(launches=v[0] // event_steps, ms_per_step=round(v[2] / event_steps * 1e3, 3),
                                              tflops=round(v[1] / v[2] / 1e12, 1)) for k, v in by_kernel.items()})
 
+    vq_kernel = None
+    if rank == 0 and not args.no_kernel_events:
+        # the other kernel BASELINE.json's north_star names: the VQ distance / argmin kernel at this config's (N, K, D)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import vqbench
+            vq_kernel = vqbench.bench(args.batch * (args.image_size // 16) ** 2, args.codebook, 256, iters=200)
+            vq_kernel['note'] = ('exact-fp32 MFMA (indices bit-exact vs the oracle): bound by the 157 TF fp32 matrix peak, '
+                                 'not by HBM; algorithmic bytes = z + codebook + q + idx')
+        except Exception as exc:
+            vq_kernel = dict(error=f'{type(exc).__name__}: {exc}')
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -214,7 +225,7 @@ def main():
                                global_batch=world * args.batch, parallelism=f'dp{world}',
                                launch=('hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
                                final_loss=round(float(loss.item()), 6)),
-                   roofline=roofline, cpu_baseline=cpu)
+                   roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -108,6 +108,108 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Register-resident form for D == DD (256 in every reference config): one wave per SIMD with up to 512 registers, so
+// the lane's slice of its z row (DD/2 floats) stays in registers for the whole kernel and the code fragments are
+// double-buffered half tiles (the loads of the next 64 MFMAs are in flight during the current 64).  Same MFMA
+// sequence, same k order, same comparisons as vq_assign_kernel => identical indices.
+// ------------------------------------------------------------------------------------------------
+template <int ASSOC, bool WRITE_D, int DD>
+__global__ __launch_bounds__(256) void vq_assign_reg_kernel(const float* __restrict__ z, const float* __restrict__ e,
+                                                            const float* __restrict__ z2, const float* __restrict__ e2,
+                                                            int64_t n, int k, int64_t* __restrict__ idx,
+                                                            float* __restrict__ dmat) {
+    constexpr int NF = DD / 8, HF = NF / 2;                      // float4 fragments per row slice / per half tile
+    __shared__ float red_d[128];
+    __shared__ int red_i[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * 32;
+    const int j = lane & 31, half = lane >> 5;
+    int64_t zrow = n0 + j; if (zrow >= n) zrow = n - 1;
+    const float zz = z2[zrow];
+    f32x4 zr[NF];
+    {
+        const float* zp = z + zrow * DD + 4 * half;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) zr[i] = *reinterpret_cast<const f32x4*>(zp + 8 * i);
+    }
+    const int tiles = (k + 31) >> 5;
+    const int per_wave = (tiles + 3) >> 2;
+    const int t_begin = wave * per_wave;
+    const int t_end = min(tiles, t_begin + per_wave);
+    auto code_ptr = [&](int t) -> const float* {
+        int code_row = t * 32 + j; if (code_row >= k) code_row = k - 1;
+        return e + (int64_t)code_row * DD + 4 * half;
+    };
+    f32x4 ab[2][HF];
+    if (t_begin < t_end) {
+        const float* ea = code_ptr(t_begin);
+#pragma unroll
+        for (int i = 0; i < HF; ++i) ab[0][i] = *reinterpret_cast<const f32x4*>(ea + 8 * i);
+    }
+    float best = INFINITY;
+    int best_i = 0x7fffffff;
+    for (int t = t_begin; t < t_end; ++t) {
+        const float* ea = code_ptr(t);
+        const float* en = code_ptr(t + 1 < t_end ? t + 1 : t);
+#pragma unroll
+        for (int i = 0; i < HF; ++i) ab[1][i] = *reinterpret_cast<const f32x4*>(ea + 8 * (HF + i));
+        float e2v[16];                                           // |e|^2 of this tile's codes, loaded under the MFMAs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            e2v[r] = e2[code < k ? code : k - 1];
+        }
+        f32x16 acc = {0};
+#pragma unroll
+        for (int i = 0; i < HF; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][0], zr[i][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][1], zr[i][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][2], zr[i][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][3], zr[i][3], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < HF; ++i) ab[0][i] = *reinterpret_cast<const f32x4*>(en + 8 * i);
+#pragma unroll
+        for (int i = 0; i < HF; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][0], zr[HF + i][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][1], zr[HF + i][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][2], zr[HF + i][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][3], zr[HF + i][3], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (code < k) {
+                const float ab2 = 2.0f * acc[r];
+                float dist;
+                if (ASSOC == 0) dist = __fsub_rn(__fadd_rn(zz, e2v[r]), ab2);
+                else            dist = __fadd_rn(__fsub_rn(zz, ab2), e2v[r]);
+                if (dist < best) { best = dist; best_i = code; }
+                if (WRITE_D && n0 + j < n) dmat[(n0 + j) * (int64_t)k + code] = dist;
+            }
+        }
+    }
+    {
+        const float od = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(best_i, 32, 64);
+        if (od < best || (od == best && oi < best_i)) { best = od; best_i = oi; }
+    }
+    if (half == 0) { red_d[wave * 32 + j] = best; red_i[wave * 32 + j] = best_i; }
+    __syncthreads();
+    if (tid < 32 && n0 + tid < n) {
+        float bd = red_d[tid]; int bi = red_i[tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float od = red_d[w * 32 + tid]; const int oi = red_i[w * 32 + tid];
+            if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+        }
+        idx[n0 + tid] = (bi == 0x7fffffff) ? 0 : (int64_t)bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // q = e[idx]; sum (q-z)^2; histogram.  One wavefront per row, float4 per lane.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ z, const float* __restrict__ e,
@@ -272,6 +374,12 @@ int vqk_vq_assign_f32(const float* z, const float* e, const float* z2, const flo
     const size_t lds = (size_t)32 * (d + 4) * 4 + 128 * 4 + 128 * 4;
     VQK_REQUIRE(lds <= 160 * 1024, VQK_ERR_SHAPE);
     const dim3 grid((unsigned)((n + 31) / 32));
+    if (d == 256) {
+        if (assoc == 0) hipLaunchKernelGGL((vq_assign_reg_kernel<0, false, 256>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, (float*)nullptr);
+        else hipLaunchKernelGGL((vq_assign_reg_kernel<1, false, 256>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, (float*)nullptr);
+        VQK_CHECK_LAUNCH();
+        return VQK_OK;
+    }
     if (assoc == 0) {
         if (lds > 64 * 1024) hipFuncSetAttribute((const void*)vq_assign_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((vq_assign_kernel<0, false>), grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx, (float*)nullptr);
@@ -293,6 +401,12 @@ int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const 
     const size_t lds = (size_t)32 * (d + 4) * 4 + 128 * 4 + 128 * 4;
     VQK_REQUIRE(lds <= 64 * 1024, VQK_ERR_SHAPE);
     const dim3 grid((unsigned)((n + 31) / 32));
+    if (d == 256) {
+        if (assoc == 0) hipLaunchKernelGGL((vq_assign_reg_kernel<0, true, 256>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat);
+        else hipLaunchKernelGGL((vq_assign_reg_kernel<1, true, 256>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat);
+        VQK_CHECK_LAUNCH();
+        return VQK_OK;
+    }
     if (assoc == 0) hipLaunchKernelGGL((vq_assign_kernel<0, true>), grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx, dmat);
     else hipLaunchKernelGGL((vq_assign_kernel<1, true>), grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx, dmat);
     VQK_CHECK_LAUNCH();
