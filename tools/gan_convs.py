@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Per-shape timing of every conv launch of one VQ-GAN step (eager, HIP events around each launcher call)."""
+import importlib, os, sys, collections
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
+model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
+trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
+import bench
+lib = native.lib()
+log = []
+
+
+def wrap(name, shape_fn):
+    orig = getattr(lib, name)
+
+    def f(*a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = orig(*a); e1.record()
+        log.append((name, shape_fn(a), e0, e1))
+        return r
+    setattr(lib, name, f)
+
+
+wrap('vqk_conv2d_general', lambda a: ('n%d %dx%d cin%d cout%d k%d s%d pad%d mode%d -> %dx%d lay%d' % (a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[21])))
+wrap('vqk_conv2d_fprop', lambda a: ('n%d %dx%d cin%d cout%d k%d ups%d lay%d' % (a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[15])))
+wrap('vqk_conv2d_wgrad_general', lambda a: ('n%d %dx%d cin%d cout%d k%d s%d pad%d -> %dx%d' % (a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[13], a[14])))
+wrap('vqk_conv2d_wgrad', lambda a: ('n%d %dx%d cin%d cout%d k%d ups%d' % (a[4], a[5], a[6], a[7], a[8], a[9], a[10])))
+wrap('vqk_upfirdn2d_nhwc', lambda a: 'upfirdn')
+
+dev = torch.device('cuda:0')
+torch.manual_seed(1234)
+l_conf = dict(l1_weight=0.8, l2_weight=0.2, perc_weight=1.0,
+              adversarial_params=dict(start_epoch=0, loss_type='non-saturating', g_weight=0.1, use_adaptive=False,
+                                      r1_reg_weight=None, r1_reg_every=16))
+m = model_mod.VQVAE(256, bench.AE_CONF, bench.q_conf('gumbel', 1024), l_conf, bench.T_CONF, compute_dtype=torch.bfloat16).to(dev)
+m.criterion.discriminator.compute_dtype = torch.bfloat16
+m.criterion.perceptual_loss.net.compute_dtype = torch.bfloat16
+m.train()
+tr = trainer_mod.MiniTrainer(num_training_batches=10)
+tr.attach(m)
+m.on_train_start()
+x = torch.rand(16, 3, 256, 256).to(dev)
+for i in range(3):
+    tr.train_batch(m, x, i)
+torch.cuda.synchronize()
+log.clear()
+tr.train_batch(m, x, 3)
+torch.cuda.synchronize()
+agg = collections.OrderedDict()
+for name, shape, e0, e1 in log:
+    k = (name, shape)
+    c, t = agg.get(k, (0, 0.0))
+    agg[k] = (c + 1, t + e0.elapsed_time(e1) * 1e3)
+tot = 0
+for (name, shape), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    tot += t
+    print(f'{t:9.1f} us  x{c:<3d} {name[4:]:22s} {shape}')
+print('total conv-ish us', tot)

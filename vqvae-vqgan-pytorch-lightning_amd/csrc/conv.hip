@@ -31,6 +31,11 @@ struct ConvGeom {
     int pool;                       // stream kernel: y = pool_scale * (2x2 sum of the above), written at half resolution
     float pool_scale;
     int m;          // n*h*w output pixels
+    // im2col kernel, zero-stuffed input (dgrad of a stride-2 conv): ONE output-parity class per launch.  Output pixels
+    // (2a + sub_py, 2b + sub_px), a < sub_h, b < sub_w, and only the taps that land on real (even) input positions:
+    // kh in khl[0..nkh), kw in kwl[0..nkw) -- a quarter of the MFMA work of multiplying the stuffed zeros.
+    int sub, sub_py, sub_px, sub_h, sub_w, nkh, nkw, khl[2], kwl[2];
+    int wrow_chunks;   // 16-byte chunks per weight row (= ks*ks*cpt; kchunks counts only the taps of the class)
     int cpt;        // 16-byte chunks per tap  (cin / elems-per-16B)
     int kchunks;    // ks*ks*cpt
     int tiles_m, tiles_n;
@@ -151,17 +156,26 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
         const int r = 8 * (4 * wave + t) + (lane >> 3);
         const int m = m0 + r;
         if (m < g.m) {
-            const int hw = g.h * g.w;
-            const int img = m / hw, rem = m - img * hw;
-            a_oh[t] = rem / g.w;
-            a_ow[t] = rem - a_oh[t] * g.w;
-            a_img[t] = x + (int64_t)img * g.h_in * g.w_in * g.cin;
+            if (g.sub) {
+                const int hw = g.sub_h * g.sub_w;
+                const int img = m / hw, rem = m - img * hw;
+                const int a = rem / g.sub_w;
+                a_oh[t] = 2 * a + g.sub_py;
+                a_ow[t] = 2 * (rem - a * g.sub_w) + g.sub_px;
+                a_img[t] = x + (int64_t)img * g.h_in * g.w_in * g.cin;
+            } else {
+                const int hw = g.h * g.w;
+                const int img = m / hw, rem = m - img * hw;
+                a_oh[t] = rem / g.w;
+                a_ow[t] = rem - a_oh[t] * g.w;
+                a_img[t] = x + (int64_t)img * g.h_in * g.w_in * g.cin;
+            }
         } else {
             a_oh[t] = -1000000; a_ow[t] = 0; a_img[t] = x;
         }
         const int co = n0 + r;
         b_ok[t] = co < g.cout;
-        b_row[t] = reinterpret_cast<const char*>(wgt) + (int64_t)(b_ok[t] ? co : 0) * g.kchunks * 16;
+        b_row[t] = reinterpret_cast<const char*>(wgt) + (int64_t)(b_ok[t] ? co : 0) * g.wrow_chunks * 16;
     }
     // logical chunk held by this lane's physical LDS slot (swizzle: phys = logical ^ ((row>>1)&7))
     lchunk[0] = (lane & 7) ^ ((lane >> 4) & 7);
@@ -196,7 +210,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
         int tap_u = 0, kh_u = 0, kw_u = 0, cbase_u = 0;
         if (FASTK) {
             tap_u = s / steps_per_tap;
-            kh_u = tap_u / g.ks; kw_u = tap_u - kh_u * g.ks;
+            if (g.sub) { const int q = tap_u / g.nkw; kh_u = g.khl[q]; kw_u = g.kwl[tap_u - q * g.nkw]; }
+            else { kh_u = tap_u / g.ks; kw_u = tap_u - kh_u * g.ks; }
             cbase_u = (s - tap_u * steps_per_tap) * 8;     // chunk offset inside the tap
         }
 #pragma unroll
@@ -210,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                 ok = gch < g.kchunks;
                 const int tap = gch / g.cpt;
                 coff = gch - tap * g.cpt;
-                kh = tap / g.ks; kw = tap - kh * g.ks;
+                if (g.sub) { const int q = ok ? tap / g.nkw : 0; kh = g.khl[q]; kw = g.kwl[ok ? tap - q * g.nkw : 0]; }
+                else { kh = tap / g.ks; kw = tap - kh * g.ks; }
             }
             const int ih = a_oh[t] * g.stride + kh - g.pad, iw = a_ow[t] * g.stride + kw - g.pad;
             ok = ok && ih >= 0 && ih < g.vh && iw >= 0 && iw < g.vw && !(g.zs && ((ih | iw) & 1));
@@ -218,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             const void* sa = ok ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(zeros);
             glds16(sa, lds_a + (4 * wave + t) * 1024);
             const bool okb = b_ok[t] && gch < g.kchunks;
-            const void* sb = okb ? reinterpret_cast<const void*>(b_row[t] + (int64_t)gch * 16)
+            const int wch = g.sub ? (kh * g.ks + kw) * g.cpt + coff : gch;       // chunk inside the full weight row
+            const void* sb = okb ? reinterpret_cast<const void*>(b_row[t] + (int64_t)wch * 16)
                                  : reinterpret_cast<const void*>(zeros);
             glds16(sb, lds_b + (4 * wave + t) * 1024);
         }
@@ -232,28 +249,45 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    Mma<T>::run(lds_a + fa[i] + poff, lds_b + fb[j] + poff, acc[i][j]);
+                    Mma<T>::run(lds_b + fb[j] + poff, lds_a + fa[i] + poff, acc[i][j]);   // D[cout][pixel]
         }
         __syncthreads();
     }
 
-    // ---------------- epilogue: bias, residual, activation, store
-    const int ocol = lane & 31, orow = 4 * (lane >> 5);
+    // ---------------- epilogue: bias, residual, activation, store.  D[cout][pixel]: a lane owns one pixel (column)
+    // and, per MFMA tile, four runs of 4 consecutive couts -> 8 / 16-byte stores
+    const int opix = lane & 31, okg = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = n0 + wn * 64 + j * 32 + ocol;
-        if (co >= g.cout) continue;
-        const float bv = bias ? bias[co] : 0.0f;
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + opix;
+        if (m >= g.m) continue;
+        int64_t orow = (int64_t)m * g.cout;
+        if (g.sub) {
+            const int hw = g.sub_h * g.sub_w;
+            const int img = m / hw, rem = m - img * hw;
+            const int a = rem / g.sub_w, b = rem - a * g.sub_w;
+            orow = (((int64_t)img * g.h + 2 * a + g.sub_py) * g.w + 2 * b + g.sub_px) * g.cout;
+        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + orow;
-                if (m < g.m) {
-                    const int64_t o = (int64_t)m * g.cout + co;
-                    float v = epi_act(acc[i][j][r] * g.acc_scale + bv, act) * g.out_gain;
-                    if (res) v += Elem<TO>::ld(res + o);
-                    Elem<TO>::st(y + o, v);
+            for (int rq = 0; rq < 4; ++rq) {
+                const int co = n0 + wn * 64 + j * 32 + 8 * rq + 4 * okg;
+                if (co >= g.cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = epi_act(acc[i][j][4 * rq + e] * g.acc_scale + ((bias && co + e < g.cout) ? bias[co + e] : 0.0f), act) * g.out_gain;
+                const int64_t o = orow + co;
+                if (co + 3 < g.cout && (g.cout & 3) == 0) {
+                    if (res) add4(res + o, v);
+                    store4(y + o, v);
+                } else {
+                    for (int e = 0; e < 4 && co + e < g.cout; ++e) {
+                        float t = v[e];
+                        if (res) t += Elem<TO>::ld(res + o + e);
+                        Elem<TO>::st(y + o + e, t);
+                    }
                 }
             }
     }
@@ -1626,6 +1660,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.m = (int)m;
     g.cpt = cin / epc;
     g.kchunks = ksize * ksize * g.cpt;
+    g.wrow_chunks = g.kchunks; g.sub = 0;
     g.tiles_m = (g.m + 127) / 128;
     g.tiles_n = (cout + 127) / 128;
     return VQK_OK;
@@ -1671,6 +1706,34 @@ static int conv_general(int dtype, const void* x, const void* w, const float* bi
     }
     g.acc_scale = acc_scale; g.out_gain = out_gain;
     hipStream_t st = vqk_stream(stream);
+    if (mode == 2 && stride == 1 && g_force_variant != 5) {
+        // zero-stuffed input: one launch per output-parity class, each visiting only the taps that hit real samples
+        const int saved = g_force_variant;
+        g_force_variant = 0;
+        int r = VQK_OK;
+        for (int py = 0; py < 2 && r == VQK_OK; ++py)
+            for (int px = 0; px < 2 && r == VQK_OK; ++px) {
+                ConvGeom gs = g;
+                gs.sub = 1; gs.sub_py = py; gs.sub_px = px;
+                gs.sub_h = (g.h - py + 1) / 2; gs.sub_w = (g.w - px + 1) / 2;
+                if (gs.sub_h <= 0 || gs.sub_w <= 0) continue;
+                gs.nkh = gs.nkw = 0;
+                for (int kk = 0; kk < ksize; ++kk) {
+                    if (((py + kk - pad) & 1) == 0) gs.khl[gs.nkh++] = kk;
+                    if (((px + kk - pad) & 1) == 0) gs.kwl[gs.nkw++] = kk;
+                }
+                if (gs.nkh == 0 || gs.nkw == 0) { gs.nkh = gs.nkw = 1; gs.khl[0] = gs.kwl[0] = 0; gs.kchunks = 0; }
+                else gs.kchunks = gs.nkh * gs.nkw * gs.cpt;
+                gs.m = n * gs.sub_h * gs.sub_w;
+                gs.tiles_m = (gs.m + 127) / 128;
+                if (dtype == VQK_F32 && out_dtype == VQK_F32) r = launch_fprop<float, float>(x, w, bias, residual, y, zeros, gs, act, 0, st);
+                else if (dtype == VQK_BF16 && out_dtype == VQK_BF16) r = launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, gs, act, 0, st);
+                else if (dtype == VQK_BF16 && out_dtype == VQK_F32) r = launch_fprop<bf16_raw, float>(x, w, bias, residual, y, zeros, gs, act, 0, st);
+                else r = VQK_ERR_DTYPE;
+            }
+        g_force_variant = saved;
+        return r;
+    }
     const int fv = plain ? -1 : 0;
     const int saved = g_force_variant;
     if (!plain) g_force_variant = 0;                        // force the general im2col kernel
