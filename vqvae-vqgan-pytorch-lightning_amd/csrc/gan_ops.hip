@@ -447,6 +447,72 @@ __global__ void gan_loss_kernel(const float* __restrict__ real, const float* __r
         else return VQK_ERR_DTYPE;                                                                           \
     } while (0)
 
+// Fast path of the discriminator's blurs (upfirdn2d.py:214-268 with up = 1, a 4x4 FIR, down in {1, 2}): a thread produces
+// FOUR consecutive output pixels of one 16-byte channel slot, so the (3*down + 4) input columns of each filter row are
+// loaded once and reused from registers (7-10 loads per output instead of 16, no per-tap integer division).
+template <typename T, int DOWN>
+__global__ __launch_bounds__(256) void upfirdn_fir4_kernel(const T* __restrict__ x, const float* __restrict__ f,
+                                                           T* __restrict__ y, int n, int h, int w, int c, int px0, int py0,
+                                                           int flip, float gain, int oh, int ow) {
+    constexpr int V = Vec16<T>::N, OUTX = 4, NC = (OUTX - 1) * DOWN + 4;
+    __shared__ float fs[16];
+    if (threadIdx.x < 16) {
+        const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
+        fs[threadIdx.x] = (flip ? f[ky * 4 + kx] : f[(3 - ky) * 4 + (3 - kx)]) * gain;
+    }
+    __syncthreads();
+    const int vpp = c / V;
+    const int owq = (ow + OUTX - 1) / OUTX;
+    const int64_t total = (int64_t)n * oh * owq * vpp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        // 32-bit index arithmetic (the launcher guarantees total < 2^31): 64-bit div/mod by run-time values costs more
+        // than the 512 FMAs of the iteration
+        const unsigned iu = (unsigned)i;
+        const unsigned pu = iu / (unsigned)vpp;
+        const int v = (int)(iu - pu * (unsigned)vpp);
+        const unsigned pv = pu / (unsigned)owq;
+        const int oxq = (int)(pu - pv * (unsigned)owq);
+        const unsigned pw = pv / (unsigned)oh;
+        const int oy = (int)(pv - pw * (unsigned)oh);
+        const int img = (int)pw;
+        const int ox0 = oxq * OUTX;
+        const int ix0 = ox0 * DOWN - px0, iy0 = oy * DOWN - py0;
+        float acc[OUTX][V];
+#pragma unroll
+        for (int o = 0; o < OUTX; ++o)
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[o][k] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int iy = iy0 + ky;
+            if (iy < 0 || iy >= h) continue;                     // rows outside the image are zero padding
+            const T* xrow = x + (((int64_t)img * h + iy) * w) * c + v * V;
+            float col[NC][V];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int ix = ix0 + q;
+                if (ix >= 0 && ix < w) Vec16<T>::load(xrow + (int64_t)ix * c, col[q]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) col[q][k] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < OUTX; ++o)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const float fv = fs[ky * 4 + kx];
+#pragma unroll
+                    for (int k = 0; k < V; ++k) acc[o][k] = __fmaf_rn(col[o * DOWN + kx][k], fv, acc[o][k]);
+                }
+        }
+        T* yrow = y + (((int64_t)img * oh + oy) * ow + ox0) * c + v * V;
+#pragma unroll
+        for (int o = 0; o < OUTX; ++o)
+            if (ox0 + o < ow) Vec16<T>::store(yrow + (int64_t)o * c, acc[o]);
+    }
+}
+
 extern "C" {
 
 int vqk_act_backward(int dtype, const void* dy, const void* y, void* dx, int64_t n, int act, float scale, void* stream) {
@@ -471,6 +537,21 @@ int vqk_upfirdn2d_nhwc(int dtype, const void* x, const float* f, void* y, int n,
     VQK_REQUIRE(out_w == (w * upx + padx0 + padx1 - fw + downx) / downx, VQK_ERR_SHAPE);
     VQK_REQUIRE(out_h == (h * upy + pady0 + pady1 - fh + downy) / downy, VQK_ERR_SHAPE);
     VQK_REQUIRE(out_w >= 1 && out_h >= 1, VQK_ERR_SHAPE);
+    const int64_t tot4 = (int64_t)n * out_h * ((out_w + 3) / 4) * (c / v);
+    if (upx == 1 && upy == 1 && fh == 4 && fw == 4 && downx == downy && (downx == 1 || downx == 2) && (dtype == VQK_F32 || dtype == VQK_BF16) &&
+        tot4 < 0x7fffffff) {
+        const dim3 g4(vqk_grid_1d(tot4, 256, 256 * 64));
+        hipStream_t st = vqk_stream(stream);
+        if (dtype == VQK_F32) {
+            if (downx == 1) hipLaunchKernelGGL((upfirdn_fir4_kernel<float, 1>), g4, dim3(256), 0, st, (const float*)x, f, (float*)y, n, h, w, c, padx0, pady0, flip, gain, out_h, out_w);
+            else hipLaunchKernelGGL((upfirdn_fir4_kernel<float, 2>), g4, dim3(256), 0, st, (const float*)x, f, (float*)y, n, h, w, c, padx0, pady0, flip, gain, out_h, out_w);
+        } else {
+            if (downx == 1) hipLaunchKernelGGL((upfirdn_fir4_kernel<bf16_raw, 1>), g4, dim3(256), 0, st, (const bf16_raw*)x, f, (bf16_raw*)y, n, h, w, c, padx0, pady0, flip, gain, out_h, out_w);
+            else hipLaunchKernelGGL((upfirdn_fir4_kernel<bf16_raw, 2>), g4, dim3(256), 0, st, (const bf16_raw*)x, f, (bf16_raw*)y, n, h, w, c, padx0, pady0, flip, gain, out_h, out_w);
+        }
+        VQK_CHECK_LAUNCH();
+        return VQK_OK;
+    }
     const int64_t total = (int64_t)n * out_h * out_w * (c / v);
     const dim3 grid(vqk_grid_1d(total, 256, 256 * 16));
     if (dtype == VQK_F32) hipLaunchKernelGGL(upfirdn_nhwc_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, f, (float*)y, n, h, w, c, fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain, out_h, out_w);
