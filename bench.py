@@ -165,9 +165,11 @@ def main():
         # shapes, same stream) in eager steps right after the timed region
         event_steps = 3
         ops.KERNEL_EVENTS = []
+        overlap, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, False     # one kernel at a time: per-kernel durations, not overlap
         for i in range(event_steps):
             trainer.train_batch(model, images, args.warmup + args.steps + i)
         barrier()
+        ops.OVERLAP_WGRAD = overlap
         events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
 
     roofline = None
@@ -195,7 +197,8 @@ def main():
                         launches_per_step=count // event_steps, avg_launch_us=round(secs / count * 1e6, 2),
                         avg_gflop_per_launch=round(flops / count / 1e9, 3),
                         kernel_time_frac_of_step=round((secs / event_steps) / (elapsed / args.steps), 3),
-                        event_pass=('eager steps after the timed region' if use_graph else 'timed region'),
+                        event_pass=('eager steps after the timed region, kernels serialised (no wgrad side stream)' if use_graph
+                                    else 'timed region'),
                         all_kernels={k: dict(launches=v[0] // event_steps, ms_per_step=round(v[2] / event_steps * 1e3, 3),
                                              tflops=round(v[1] / v[2] / 1e12, 1)) for k, v in by_kernel.items()})
 
