@@ -68,6 +68,16 @@ int vqk_entropy_forward_f32(const float* dmat, int64_t n, int k, float temperatu
 /* In place dmat <- dL_ent/dd (scaled by *gscale_dev): the cotangent that the two GEMMs turn into dz and dE. */
 int vqk_entropy_backward_f32(float* dmat, const float* lse, const float* hrow, const float* u, int64_t n, int k,
                              float temperature, float ratio, const float* gscale_dev, void* stream);
+/* ent_loss_type == 'argmax' (vector_quantizers.py:311-315): the targets are one_hot(argmax_k a) with the gradient of p
+ * (straight-through).  idx = the assignment of vqk_vq_distances_f32 (argmax a == argmin d, first wins), hist = its code
+ * histogram (vqk_vq_gather_f32).  Forward: lse / hrow as above, ssum += sum_i (lse_i - a_i[idx_i]), mbuf[k] scratch,
+ * u / avg_term from m = hist / N;  loss_ent = ratio * (ssum / N + avg_term).  Backward overwrites dmat with dL/dd. */
+int vqk_entropy_argmax_forward_f32(const float* dmat, const int64_t* idx, const int32_t* hist, int64_t n, int k,
+                                   float temperature, float* lse, float* hrow, float* hsum, float* ssum, float* mbuf,
+                                   float* u, float* avg_term, void* stream);
+int vqk_entropy_argmax_backward_f32(float* dmat, const int64_t* idx, const float* lse, const float* hrow, const float* u,
+                                    int64_t n, int k, float temperature, float ratio, const float* gscale_dev,
+                                    void* stream);
 /* out[r][c] += a * scale[r] * m[r][c] */
 int vqk_row_scale_add_f32(float* out, const float* m, const float* scale, int64_t rows, int c, float a, void* stream);
 /* Gumbel-softmax rows (vector_quantizers.py:232-243): y = softmax((logits - log(noise))/tau) [hard: one-hot of its

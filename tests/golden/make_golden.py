@@ -282,6 +282,29 @@ def gen_stylegan_ops():
     save('stylegan_ops', **out)
 
 
+def gen_vq_entropy_argmax():
+    """Entropy quantizer with ent_loss_type='argmax' (straight-through one-hot targets, vector_quantizers.py:311-315)."""
+    g = torch.Generator().manual_seed(4321)
+    out = {}
+    for tag, (n_img, d, hw, k, scale, temp) in {'a': (2, 16, 8, 64, 0.3, 0.01), 'b': (3, 32, 4, 128, 1.0, 0.5)}.items():
+        z, e = _vq_inputs(g, n_img, d, hw, k, scale)
+        q = EntropyVectorQuantizer(k, d, 0.1, temp, 'argmax', 0.25)
+        with torch.no_grad():
+            q.codebook.weight.copy_(e)
+        zz = z.clone().requires_grad_(True)
+        qz, idx, loss = q(zz)
+        dq = torch.randn(qz.shape, generator=g)
+        dz, de = torch.autograd.grad([qz, loss], [zz, q.codebook.weight], [dq, torch.tensor(1.0)])
+        out.update({f'{tag}.z': npy(z), f'{tag}.e': npy(e), f'{tag}.q': npy(qz), f'{tag}.idx': npy(idx),
+                    f'{tag}.loss': npy(loss), f'{tag}.dq': npy(dq), f'{tag}.dz': npy(dz), f'{tag}.de': npy(de),
+                    f'{tag}.temp': np.float32(temp)})
+    save('vq_entropy_argmax', **out)
+
+
+if __name__ == '__main__' and 'entropy_argmax' in sys.argv[1:]:
+    gen_vq_entropy_argmax()
+    sys.exit(0)
+
 if __name__ == '__main__' and 'gan' not in sys.argv[1:]:
     gen_ops()
     gen_vq()

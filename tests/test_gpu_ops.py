@@ -128,6 +128,25 @@ def test_vq_entropy_module_golden(golden):
     assert rel_err(de, T(g['ent.de'])) < 2e-4
 
 
+@pytest.mark.parametrize('tag,k,d', [('a', 64, 16), ('b', 128, 32)])
+def test_vq_entropy_argmax_module_golden(golden, tag, k, d):
+    """ent_loss_type='argmax': one-hot targets with the softmax gradient (vector_quantizers.py:311-315)"""
+    g = golden('vq_entropy_argmax')
+    q = vqm.EntropyVectorQuantizer(k, d, 0.1, float(g[f'{tag}.temp']), 'argmax', 0.25).to(DEV)
+    with torch.no_grad():
+        q.codebook.weight.copy_(dev(g[f'{tag}.e']))
+    z = dev(g[f'{tag}.z']).requires_grad_(True)
+    qz, idx, loss = q(z)
+    assert np.array_equal(idx.cpu().numpy(), g[f'{tag}.idx'])
+    close(qz, g[f'{tag}.q'], rtol=1e-5, atol=1e-6)
+    close(loss, g[f'{tag}.loss'], rtol=2e-5, atol=1e-7)
+    dz, de = torch.autograd.grad([qz, loss], [z, q.codebook.weight], [dev(g[f'{tag}.dq']), torch.ones((), device=DEV)])
+    assert rel_err(dz, T(g[f'{tag}.dz'])) < 2e-4
+    assert rel_err(de, T(g[f'{tag}.de'])) < 2e-4
+    with pytest.raises(ValueError):
+        vqm.EntropyVectorQuantizer(k, d, 0.1, 0.01, 'hardmax', 0.25).to(DEV)(z)
+
+
 def test_vq_gumbel_module_golden(golden):
     g = golden('vq')
     q = vqm.GumbelVectorQuantizer(32, 8, False, 0.7, 5e-4).to(DEV)

@@ -132,6 +132,20 @@ def test_vq_gumbel(golden):
         close(a, g[k], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_vq_entropy_argmax(golden, tag):
+    """ent_loss_type='argmax' (vector_quantizers.py:311-315), vectors from the reference's own module"""
+    g = golden('vq_entropy_argmax')
+    z = T(g[f'{tag}.z']).requires_grad_(True)
+    e = T(g[f'{tag}.e']).requires_grad_(True)
+    q, idx, loss = O.vq_entropy(z, e, 0.25, 0.1, float(g[f'{tag}.temp']), 'argmax')
+    assert np.array_equal(idx.numpy(), g[f'{tag}.idx'])
+    close(loss, g[f'{tag}.loss'], rtol=1e-5)
+    dz, de = torch.autograd.grad([q, loss], [z, e], [T(g[f'{tag}.dq']), torch.tensor(1.0)])
+    close(dz, g[f'{tag}.dz'], rtol=1e-4, atol=1e-6)
+    close(de, g[f'{tag}.de'], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize('tag,assoc', [('n1', 0), ('n036', 0), ('ent', 1)])
 def test_vq_large_indices_canonical_order(golden, tag, assoc):
     """BASELINE shape: the canonical-order C oracle reproduces every reference index."""

@@ -96,6 +96,49 @@ __global__ __launch_bounds__(256) void entropy_dd_kernel(float* __restrict__ dma
     }
 }
 
+// ---- ent_loss_type == 'argmax' (vector_quantizers.py:311-315): target = one_hot(argmax a) with the gradient of p.
+//   L = mean_i ( lse_i - a_i[c_i] ) + sum_k m_k log(m_k + 1e-5),  m_k = hist_k / N
+//   dL/da_ij = (1/N) [ p_ij ( -(log p_ij + h_i) + 1 + (u_j - ubar_i) ) - [j == c_i] ],  u from m as above
+// ssum += sum_i ( lse_i + d[i][c_i] / T )
+__global__ __launch_bounds__(256) void entropy_argmax_rows_kernel(const float* __restrict__ dmat, const int64_t* __restrict__ idx,
+                                                                  const float* __restrict__ lse, int64_t n, int k, float inv_t,
+                                                                  float* __restrict__ ssum) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256)
+        acc += lse[r] + dmat[r * k + idx[r]] * inv_t;
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(ssum, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__global__ __launch_bounds__(256) void hist_to_float_kernel(const int32_t* __restrict__ hist, int k, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < k) out[c] = (float)hist[c];
+}
+
+__global__ __launch_bounds__(256) void entropy_dd_argmax_kernel(float* __restrict__ dmat, const int64_t* __restrict__ idx,
+                                                                const float* __restrict__ lse, const float* __restrict__ hrow,
+                                                                const float* __restrict__ u, int64_t n, int k, float inv_t,
+                                                                float coef, const float* __restrict__ gs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    if (gs) coef *= *gs;
+    float* dr = dmat + row * k;
+    const float l = lse[row], h = hrow[row];
+    const int code = (int)idx[row];
+    float ub = 0.f;
+    for (int c = lane; c < k; c += 64) ub = __fmaf_rn(__expf(-dr[c] * inv_t - l), u[c], ub);
+    ub = wave_sum(ub);
+    for (int c = lane; c < k; c += 64) {
+        const float lp = -dr[c] * inv_t - l;
+        const float p = __expf(lp);
+        dr[c] = coef * (p * (-(lp + h) + 1.0f + (u[c] - ub)) - (c == code ? 1.0f : 0.0f));
+    }
+}
+
 // out[r][c] += a * scale[r] * m[r][c]
 __global__ __launch_bounds__(256) void row_scale_add_kernel(float* __restrict__ out, const float* __restrict__ m,
                                                             const float* __restrict__ scale, int64_t rows, int c,
@@ -131,6 +174,33 @@ int vqk_entropy_backward_f32(float* dmat, const float* lse, const float* hrow, c
     const float coef = -ratio / ((float)n * temperature);
     hipLaunchKernelGGL(entropy_dd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, vqk_stream(stream), dmat, lse, hrow, u,
                        n, k, 1.0f / temperature, coef, gscale_dev);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_entropy_argmax_forward_f32(const float* dmat, const int64_t* idx, const int32_t* hist, int64_t n, int k,
+                                   float temperature, float* lse, float* hrow, float* hsum, float* ssum, float* mbuf,
+                                   float* u, float* avg_term, void* stream) {
+    VQK_REQUIRE(dmat && idx && hist && lse && hrow && hsum && ssum && mbuf && u && avg_term, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && k > 0 && temperature > 0.f, VQK_ERR_SHAPE);
+    hipStream_t st = vqk_stream(stream);
+    const float inv_t = 1.0f / temperature;
+    hipLaunchKernelGGL(entropy_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, dmat, n, k, inv_t, lse, hrow, hsum);
+    hipLaunchKernelGGL(entropy_argmax_rows_kernel, dim3(vqk_grid_1d(n, 256, 256)), dim3(256), 0, st, dmat, idx, lse, n, k, inv_t, ssum);
+    hipLaunchKernelGGL(hist_to_float_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, hist, k, mbuf);
+    hipLaunchKernelGGL(entropy_finalize_kernel, dim3(vqk_grid_1d(k, 256, 64)), dim3(256), 0, st, mbuf, k, 1.0f / (float)n, u, avg_term);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_entropy_argmax_backward_f32(float* dmat, const int64_t* idx, const float* lse, const float* hrow, const float* u,
+                                    int64_t n, int k, float temperature, float ratio, const float* gscale_dev,
+                                    void* stream) {
+    VQK_REQUIRE(dmat && idx && lse && hrow && u, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && k > 0 && temperature > 0.f, VQK_ERR_SHAPE);
+    const float coef = -ratio / ((float)n * temperature);
+    hipLaunchKernelGGL(entropy_dd_argmax_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, vqk_stream(stream), dmat, idx, lse,
+                       hrow, u, n, k, 1.0f / temperature, coef, gscale_dev);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

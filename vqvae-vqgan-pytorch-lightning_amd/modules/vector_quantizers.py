@@ -71,9 +71,6 @@ class EntropyVectorQuantizer(BaseVectorQuantizer):
     def __init__(self, num_embeddings: int, embedding_dim: int, ent_loss_ratio: float = 0.1,
                  ent_temperature: float = 0.01, ent_loss_type: str = 'softmax', commitment_cost: float = 0.25):
         super().__init__(num_embeddings, embedding_dim)
-        if ent_loss_type != 'softmax':
-            raise NotImplementedError("ent_loss_type 'argmax' (straight-through one-hot targets) is not built; the "
-                                      "reference configs use 'softmax' (example_confs/entropy_vqvae.yaml)")
         self.ent_loss_ratio = ent_loss_ratio
         self.ent_temperature = ent_temperature
         self.ent_loss_type = ent_loss_type
@@ -81,7 +78,7 @@ class EntropyVectorQuantizer(BaseVectorQuantizer):
 
     def forward(self, x: torch.Tensor):
         q, idx, loss, hist = ops.EntropyVQFn.apply(x, self.codebook.weight, self.commitment_cost, self.ent_loss_ratio,
-                                                   self.ent_temperature, self.compute_dtype)
+                                                   self.ent_temperature, self.compute_dtype, self.ent_loss_type)
         self.last_hist = hist
         return q, idx, loss
 

@@ -768,8 +768,10 @@ class EntropyVQFn(torch.autograd.Function):
     reuse the 1x1 conv kernels.  Returns (q, idx [B,HW], loss, hist)."""
 
     @staticmethod
-    def forward(ctx, z, codebook, beta: float, ratio: float, temperature: float, out_dtype):
+    def forward(ctx, z, codebook, beta: float, ratio: float, temperature: float, out_dtype, loss_type: str = 'softmax'):
         _require_gpu(z)
+        if loss_type not in ('softmax', 'argmax'):
+            raise ValueError('Entropy loss {} not supported'.format(loss_type))      # vector_quantizers.py:317, at forward
         z = nhwc(z.to(torch.float32))
         b, d, h, w = z.shape
         n = b * h * w
@@ -795,20 +797,29 @@ class EntropyVQFn(torch.autograd.Function):
                                             _p(qlo), scal[0:1].data_ptr(), hist.data_ptr(), st), 'vq_gather')
         lse, hrow = torch.empty(n, **f32), torch.empty(n, **f32)
         psum, u = torch.zeros(k, **f32), torch.empty(k, **f32)
-        _native.check(lib.vqk_entropy_forward_f32(dmat.data_ptr(), n, k, temperature, lse.data_ptr(), hrow.data_ptr(),
-                                                  scal[1:2].data_ptr(), psum.data_ptr(), u.data_ptr(),
-                                                  scal[2:3].data_ptr(), st), 'entropy_forward')
+        if loss_type == 'softmax':
+            _native.check(lib.vqk_entropy_forward_f32(dmat.data_ptr(), n, k, temperature, lse.data_ptr(), hrow.data_ptr(),
+                                                      scal[1:2].data_ptr(), psum.data_ptr(), u.data_ptr(),
+                                                      scal[2:3].data_ptr(), st), 'entropy_forward')
+            ent = scal[1] / float(n) + scal[2]
+        else:                                                  # one-hot targets: sample term from the assigned code only
+            s2 = torch.zeros(2, **f32)                         # row-entropy sum (unused by the loss), sample-term sum
+            _native.check(lib.vqk_entropy_argmax_forward_f32(dmat.data_ptr(), idx.data_ptr(), hist.data_ptr(), n, k,
+                                                             temperature, lse.data_ptr(), hrow.data_ptr(),
+                                                             s2[0:1].data_ptr(), s2[1:2].data_ptr(), psum.data_ptr(),
+                                                             u.data_ptr(), scal[2:3].data_ptr(), st), 'entropy_argmax_forward')
+            ent = s2[1] / float(n) + scal[2]
         mse = scal[0] / float(n * d)
-        loss = beta * mse + mse + (scal[1] / float(n) + scal[2]) * ratio
+        loss = beta * mse + mse + ent * ratio
         ctx.save_for_backward(z, cb, idx, dmat, lse, hrow, u)
-        ctx.cfg = (beta, ratio, temperature, n, k, d)
+        ctx.cfg = (beta, ratio, temperature, n, k, d, loss_type)
         ctx.mark_non_differentiable(idx, hist)
         return (qlo if qlo is not None else q32), idx.view(b, h * w), loss, hist
 
     @staticmethod
     def backward(ctx, dq, _didx, dloss, _dhist):
         z, cb, idx, dmat, lse, hrow, u = ctx.saved_tensors
-        beta, ratio, temperature, n, k, d = ctx.cfg
+        beta, ratio, temperature, n, k, d, loss_type = ctx.cfg
         lib, st = _native.lib(), _stream()
         flat = z.permute(0, 2, 3, 1).reshape(n, d)
         gs = dloss.to(torch.float32).contiguous() if dloss is not None else None
@@ -820,10 +831,15 @@ class EntropyVQFn(torch.autograd.Function):
                                               dcode(dqc.dtype) if dqc is not None else F32, n, k, d, beta * scale, scale,
                                               _p(gs), dz.data_ptr(), de.data_ptr(), st), 'vq_backward')
         if gs is None:
-            return dz, de, None, None, None, None
+            return dz, de, None, None, None, None, None
         # dmat <- dL_ent/dd  (rows sum to zero)
-        _native.check(lib.vqk_entropy_backward_f32(dmat.data_ptr(), lse.data_ptr(), hrow.data_ptr(), u.data_ptr(), n, k,
-                                                   temperature, ratio, gs.data_ptr(), st), 'entropy_backward')
+        if loss_type == 'softmax':
+            _native.check(lib.vqk_entropy_backward_f32(dmat.data_ptr(), lse.data_ptr(), hrow.data_ptr(), u.data_ptr(), n, k,
+                                                       temperature, ratio, gs.data_ptr(), st), 'entropy_backward')
+        else:
+            _native.check(lib.vqk_entropy_argmax_backward_f32(dmat.data_ptr(), idx.data_ptr(), lse.data_ptr(), hrow.data_ptr(),
+                                                              u.data_ptr(), n, k, temperature, ratio, gs.data_ptr(), st),
+                          'entropy_argmax_backward')
         dd = dmat.view(1, n, 1, k).permute(0, 3, 1, 2)            # [1, K, N, 1] logical, [N][K] memory (NHWC)
         # dz += -2 dd @ E      (1x1 conv: pixels = rows of dd, Cin = K, Cout = D, weight [D][K] = E^T)
         et = cb.t().contiguous()
@@ -836,7 +852,7 @@ class EntropyVQFn(torch.autograd.Function):
         _native.check(lib.vqk_axpby(F32, g2.data_ptr(), de.data_ptr(), de.data_ptr(), -2.0, 1.0, k * d, st), 'axpby')
         cs = raw_colsum(n, k, dmat)
         _native.check(lib.vqk_row_scale_add_f32(de.data_ptr(), cb.data_ptr(), cs.data_ptr(), k, d, 2.0, st), 'row_scale_add')
-        return dz, de, None, None, None, None
+        return dz, de, None, None, None, None, None
 
 
 class GumbelVQFn(torch.autograd.Function):
