@@ -204,6 +204,12 @@ int vqk_unpool2x2(int dtype, const void* x, void* y, int n, int h, int w, int c,
  * written as `dtype` and (optionally) as an fp32 NHWC-3 target for the loss.  base_autoencoder.py:31-50. */
 int vqk_preprocess(const float* images, void* x_pad, int dtype, float* target, int n, int h, int w, int cpad,
                    void* stream);
+/* The same with the reference's training augmentation (base_autoencoder.py:20-22: RandomResizedCrop(scale .7-1, ratio 1)
+ * + RandomHorizontalFlip, per sample) fused in front: box[N][4] = {x0, y0, w, h} of the crop in source pixels (resampled
+ * to H x W, bilinear, corner-aligned), flip[N] != 0 mirrors the output.  The random draws are the caller's (device
+ * tensors: no host sync); the kornia generator itself is not in the reference tree, so its exact stream is unpinned. */
+int vqk_augment_preprocess(const float* images, const float* box, const int32_t* flip, void* x_pad, int dtype, float* target,
+                           int n, int h, int w, int cpad, void* stream);
 /* loss[0] += sum (recon - target)^2 over n elements (recon dtype given; target fp32). */
 int vqk_sse(int dtype, const void* recon, const float* target, int64_t n, float* loss, void* stream);
 /* d = s * gscale * 2 (recon - target) * (through_tanh ? 1 - recon^2 : 1), s = *gscale_dev (NULL = 1)

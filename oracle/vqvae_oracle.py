@@ -354,3 +354,29 @@ def upfirdn2d(x, f, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0), flip_filter: bool 
         k = k.flip([0, 1])
     y = F.conv2d(y, k[None, None].repeat(c, 1, 1, 1), groups=c)
     return y[:, :, ::downy, ::downx]
+
+
+def augment_crop_flip(images, box, flip):
+    """Training augmentation of base_autoencoder.py:20-22,44-48 as a pure function of the draws: per-sample crop
+    box = (x0, y0, w, h) resampled to the full size with corner-aligned bilinear interpolation (kornia's crop warp),
+    optional horizontal flip, then clamp + Normalize(0.5, 0.5).  kornia itself is not importable here: the
+    interpolation convention is restated, the random generator is unpinned."""
+    n, c, h, w = images.shape
+    img = torch.clamp(images, 0., 1.)
+    out = torch.empty_like(img)
+    for b in range(n):
+        x0, y0, bw, bh = [float(v) for v in box[b]]
+        xs = x0 + torch.arange(w, dtype=torch.float32) * ((bw - 1.0) / (w - 1) if w > 1 else 0.0)
+        ys = y0 + torch.arange(h, dtype=torch.float32) * ((bh - 1.0) / (h - 1) if h > 1 else 0.0)
+        if int(flip[b]):
+            xs = xs.flip(0)
+        xs, ys = xs.clamp(0, w - 1), ys.clamp(0, h - 1)
+        ix = xs.floor().long(); iy = ys.floor().long()
+        fx = (xs - ix).view(1, 1, w); fy = (ys - iy).view(1, h, 1)
+        ix1 = (ix + 1).clamp(max=w - 1); iy1 = (iy + 1).clamp(max=h - 1)
+        im = img[b]
+        c00 = im[:, iy][:, :, ix]; c01 = im[:, iy][:, :, ix1]
+        c10 = im[:, iy1][:, :, ix]; c11 = im[:, iy1][:, :, ix1]
+        top = c00 + fx * (c01 - c00); bot = c10 + fx * (c11 - c10)
+        out[b] = top + fy * (bot - top)
+    return (out - 0.5) / 0.5

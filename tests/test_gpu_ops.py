@@ -471,6 +471,50 @@ def test_upfirdn2d_golden(golden):
         close(torch.autograd.grad(y, x, dev(g[f'uf.{tag}.dy']))[0], g[f'uf.{tag}.dx'], rtol=1e-5, atol=1e-6)
 
 
+def test_augment_preprocess_vs_oracle_and_identity():
+    """fused RandomResizedCrop + HFlip + normalise kernel (base_autoencoder.py:20-22,44-48) for given draws"""
+    g = torch.Generator().manual_seed(21)
+    images = torch.rand(5, 3, 24, 40, generator=g) * 1.2 - 0.1          # also exercises the clamp
+    box = torch.tensor([[0, 0, 40, 24], [3, 2, 20, 20], [10.0, 0, 30, 24], [0, 4, 33, 17], [39, 23, 1, 1]], dtype=torch.float32)
+    flip = torch.tensor([0, 1, 0, 1, 1], dtype=torch.int32)
+    ref = O.augment_crop_flip(images, box, flip)
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 8e-3)):
+        x, tgt = ops.raw_augment_preprocess(dev(images), dev(box), dev(flip), dt, want_target=True)
+        assert x.shape == (5, ops.epc(dt), 24, 40) and float(x[:, 3:].abs().max()) == 0.0
+        close(tgt[:, :3], ref, rtol=1e-5, atol=1e-5)
+        close(x[:, :3].float(), ref, rtol=tol, atol=tol)
+    # the full-image box without flip is exactly the plain preprocess kernel
+    plain, _ = ops.raw_preprocess(dev(images[:1]), torch.float32, want_target=False)
+    augm, _ = ops.raw_augment_preprocess(dev(images[:1]), dev(box[:1]), dev(flip[:1]), torch.float32, want_target=False)
+    assert torch.equal(plain, augm)
+    # device-side draws: boxes inside the image, square (ratio 1), area fraction in [0.7, 1]
+    b, f = ops.random_crop_params(4096, 256, 256, torch.device(DEV))
+    b = b.cpu()
+    assert (b[:, 0] >= 0).all() and (b[:, 1] >= 0).all() and (b[:, 0] + b[:, 2] <= 256).all() and (b[:, 1] + b[:, 3] <= 256).all()
+    assert (b[:, 2] == b[:, 3]).all()
+    frac = (b[:, 2] * b[:, 3]) / 65536.0
+    assert 0.69 < float(frac.min()) and float(frac.max()) <= 1.0 and abs(float(frac.mean()) - 0.85) < 0.02
+    assert abs(float(f.float().mean()) - 0.5) < 0.05
+
+
+def test_training_step_with_augmentation_runs():
+    torch.manual_seed(0)
+    model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
+    trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
+    ae_c = dict(channels=32, num_res_blocks=1, channel_multipliers=(1, 2))
+    qc = dict(num_embeddings=64, embedding_dim=16, reinit_every_n_epochs=None, type='standard', params=dict(commitment_cost=0.25))
+    tc = dict(lr=1e-4, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
+    m = model_mod.VQVAE(32, ae_c, qc, None, tc, training_augmentation=True).to(DEV).train()
+    tr = trainer_mod.MiniTrainer(num_training_batches=2)
+    tr.attach(m)
+    x = torch.rand(4, 3, 32, 32, device=DEV)
+    l0 = float(tr.train_batch(m, x, 0))
+    l1 = float(tr.train_batch(m, x, 1))
+    assert np.isfinite(l0) and np.isfinite(l1)
+    aug = m.preprocess_batch(x, training=True)
+    assert aug.shape == x.shape and float(aug.min()) >= -1.0 and float(aug.max()) <= 1.0
+
+
 def test_native_library_is_loaded():
     native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
     assert native.lib().vqk_arch() == b'gfx950'

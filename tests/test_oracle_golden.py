@@ -235,3 +235,13 @@ def test_bias_act_and_upfirdn2d(golden):
         y = O.upfirdn2d(x, f, **kw)
         close(y, g[f'uf.{tag}.y'], rtol=1e-5, atol=1e-6)
         close(torch.autograd.grad(y, x, T(g[f'uf.{tag}.dy']))[0], g[f'uf.{tag}.dx'], rtol=1e-5, atol=1e-6)
+
+
+def test_augment_restatement_identity_and_flip():
+    """oracle.augment_crop_flip: the full-image box is the plain normalisation; a flipped full box mirrors it"""
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 9, 13, generator=g)
+    box = torch.tensor([[0, 0, 13, 9], [0, 0, 13, 9]], dtype=torch.float32)
+    out = O.augment_crop_flip(x, box, torch.tensor([0, 1]))
+    close(out[0], (x[0] - 0.5) / 0.5, rtol=1e-6, atol=1e-6)
+    close(out[1], ((x[1] - 0.5) / 0.5).flip(-1), rtol=1e-6, atol=1e-6)

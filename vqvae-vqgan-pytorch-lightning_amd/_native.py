@@ -59,6 +59,7 @@ _PROTOS = {
     'vqk_pool2x2': [I, P, P, I, I, I, I, F, P],
     'vqk_unpool2x2': [I, P, P, I, I, I, I, F, P],
     'vqk_preprocess': [P, P, I, P, I, I, I, I, P],
+    'vqk_augment_preprocess': [P, P, P, P, I, P, I, I, I, I, P],
     'vqk_sse': [I, P, P, L, P, P],
     'vqk_mse_tanh_backward': [I, P, P, L, F, P, I, P, P],
     'vqk_tanh_backward': [I, P, P, P, L, P],

@@ -68,6 +68,43 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
     }
 }
 
+// preprocess with the training augmentation of base_autoencoder.py:20-22,44-48 fused in: per-sample random resized crop
+// (box[b] = {x0, y0, w, h} in source pixels, resampled to the full H x W with bilinear interpolation, corner-aligned)
+// and horizontal flip (flip[b] != 0), then clamp / normalise / NHWC pad exactly as preprocess_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void augment_preprocess_kernel(const float* __restrict__ img, const float* __restrict__ box,
+                                                                 const int32_t* __restrict__ flip, T* __restrict__ xp,
+                                                                 float* __restrict__ target, int n, int h, int w, int cpad) {
+    const int64_t hw = (int64_t)h * w, total = (int64_t)n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / hw, p = i - b * hw;
+        const int oy = (int)(p / w);
+        int ox = (int)(p - (int64_t)oy * w);
+        if (flip[b]) ox = w - 1 - ox;
+        const float x0 = box[b * 4 + 0], y0 = box[b * 4 + 1], bw = box[b * 4 + 2], bh = box[b * 4 + 3];
+        float sx = x0 + (w > 1 ? (float)ox * (bw - 1.0f) / (float)(w - 1) : 0.0f);
+        float sy = y0 + (h > 1 ? (float)oy * (bh - 1.0f) / (float)(h - 1) : 0.0f);
+        sx = fminf(fmaxf(sx, 0.0f), (float)(w - 1));
+        sy = fminf(fmaxf(sy, 0.0f), (float)(h - 1));
+        const int ix = (int)sx, iy = (int)sy;                    // <= w-1 / h-1 after the clamp; weight 0 on the far tap there
+        const float fx = sx - (float)ix, fy = sy - (float)iy;
+        const int ix1 = min(ix + 1, w - 1), iy1 = min(iy + 1, h - 1);
+        for (int ch = 0; ch < cpad; ++ch) {
+            float v = 0.0f;
+            if (ch < 3) {
+                const float* pl = img + (b * 3 + ch) * hw;
+                const float c00 = fminf(fmaxf(pl[(int64_t)iy * w + ix], 0.f), 1.f), c01 = fminf(fmaxf(pl[(int64_t)iy * w + ix1], 0.f), 1.f);
+                const float c10 = fminf(fmaxf(pl[(int64_t)iy1 * w + ix], 0.f), 1.f), c11 = fminf(fmaxf(pl[(int64_t)iy1 * w + ix1], 0.f), 1.f);
+                const float top = c00 + fx * (c01 - c00), bot = c10 + fx * (c11 - c10);
+                v = top + fy * (bot - top);
+                v = (v - 0.5f) / 0.5f;
+            }
+            Elem<T>::st(xp + i * cpad + ch, v);
+            if (target) target[i * cpad + ch] = v;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sse_kernel(const T* __restrict__ r, const float* __restrict__ t, int64_t n,
                                                   float* __restrict__ loss) {
@@ -169,6 +206,18 @@ int vqk_preprocess(const float* images, void* x_pad, int dtype, float* target, i
     const dim3 grid(vqk_grid_1d((int64_t)n * h * w, 256, 256 * 16));
     if (dtype == VQK_F32) hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), images, (float*)x_pad, target, n, h, w, cpad);
     else if (dtype == VQK_BF16) hipLaunchKernelGGL(preprocess_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), images, (bf16_raw*)x_pad, target, n, h, w, cpad);
+    else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_augment_preprocess(const float* images, const float* box, const int32_t* flip, void* x_pad, int dtype, float* target,
+                           int n, int h, int w, int cpad, void* stream) {
+    VQK_REQUIRE(images && box && flip && x_pad, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && h > 0 && w > 0 && cpad >= 3, VQK_ERR_SHAPE);
+    const dim3 grid(vqk_grid_1d((int64_t)n * h * w, 256, 256 * 16));
+    if (dtype == VQK_F32) hipLaunchKernelGGL(augment_preprocess_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), images, box, flip, (float*)x_pad, target, n, h, w, cpad);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(augment_preprocess_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), images, box, flip, (bf16_raw*)x_pad, target, n, h, w, cpad);
     else return VQK_ERR_DTYPE;
     VQK_CHECK_LAUNCH();
     return VQK_OK;

@@ -58,9 +58,12 @@ class VQVAE(BaseVQVAE, _LightningBase):
 
     def __init__(self, image_size: int, ae_conf: dict, q_conf: dict, l_conf: dict | None, t_conf: dict | None,
                  init_cb: bool = True, load_loss: bool = True, compute_dtype: torch.dtype = torch.float32,
-                 optimizer_param_set: str = 'all'):
+                 optimizer_param_set: str = 'all', training_augmentation: bool = False):
         super().__init__(image_size=image_size)
         self.t_conf = t_conf
+        # True: the reference's training behaviour (random resized crop + flip before every training step,
+        # base_autoencoder.py:44-48); False (default): the identity the golden vectors and the benchmark are defined on
+        self.training_augmentation = training_augmentation
         self.cb_size = q_conf['num_embeddings']
         self.latent_dim = q_conf['embedding_dim']
         self.reinit_every_n_epochs = q_conf['reinit_every_n_epochs']
@@ -149,9 +152,18 @@ class VQVAE(BaseVQVAE, _LightningBase):
         self.log('gumbel_quantizer/kl_constant', this_kl, sync_dist=True)
 
     # ------------------------------------------------------------------ the step (model.py:232-295)
+    def _preprocess_train(self, images, training: bool):
+        """fused clamp / normalise / NHWC pad; with ``self.training_augmentation`` also the reference's RandomResizedCrop +
+        RandomHorizontalFlip (base_autoencoder.py:20-22,44-48) in the same kernel, drawn on the device"""
+        if training and self.training_augmentation:
+            n, _, h, w = images.shape
+            box, flip = ops.random_crop_params(n, h, w, images.device)
+            return ops.raw_augment_preprocess(images, box, flip, self.compute_dtype, want_target=True)
+        return ops.raw_preprocess(images, self.compute_dtype, want_target=True)
+
     def _step_losses(self, batch, training: bool):
         images = batch[0] if isinstance(batch, (tuple, list)) else batch
-        x_pad, target = ops.raw_preprocess(images, self.compute_dtype, want_target=True)   # clamp, normalise, NHWC
+        x_pad, target = self._preprocess_train(images, training)                          # clamp, normalise, NHWC
         z = self.encoder(x_pad)
         quantized, used_indices, q_loss = self.quantizer(z)
         recon_pad = self.decoder.forward_padded(quantized)
@@ -161,7 +173,7 @@ class VQVAE(BaseVQVAE, _LightningBase):
     def _gan_training_step(self, batch: Any, batch_index: int):
         """manual optimisation, model.py:244-264: AE step (nll + g_weight * g_loss + q_loss), then discriminator step"""
         images = batch[0] if isinstance(batch, (tuple, list)) else batch
-        x_pad, target = ops.raw_preprocess(images, self.compute_dtype, want_target=True)
+        x_pad, target = self._preprocess_train(images, True)
         z = self.encoder(x_pad)
         quantized, _, q_loss = self.quantizer(z)
         recon_pad = self.decoder.forward_padded(quantized)

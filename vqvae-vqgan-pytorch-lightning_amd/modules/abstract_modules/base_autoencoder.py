@@ -4,7 +4,9 @@
 The reference normalises with kornia's ``Normalize(0.5, 0.5)`` / ``Denormalize`` and, in training, applies
 kornia's RandomResizedCrop + RandomHorizontalFlip.  Here normalisation is the closed form
 ``clamp(x,0,1)*2-1`` (the train step itself uses the fused HIP ``vqk_preprocess`` kernel instead of this
-method); the random augmentation is the "next" row of SURVEY 8(f) and is NOT applied yet."""
+method).  The random augmentation (``training=True``) is one fused HIP kernel, ``vqk_augment_preprocess``: per-sample
+RandomResizedCrop(scale .7-1, ratio 1) + RandomHorizontalFlip with device-side draws (``ops.random_crop_params``);
+kornia is not in the reference tree, so its exact random stream is unpinned."""
 from abc import ABC, abstractmethod
 
 import torch
@@ -21,7 +23,13 @@ class BaseVQVAE(ABC):
 
     @torch.no_grad()
     def preprocess_batch(self, images: torch.Tensor, training: bool = False):
-        """images (B,C,H,W) in [0,1] -> (-1,1)"""
+        """images (B,C,H,W) in [0,1] -> (-1,1); training=True additionally applies the crop / flip augmentation"""
+        if training:
+            from ... import ops
+            n, c, h, w = images.shape
+            box, flip = ops.random_crop_params(n, h, w, images.device)
+            x, _ = ops.raw_augment_preprocess(images.float(), box, flip, torch.float32, want_target=False)
+            return x[:, :3].contiguous()
         return (torch.clamp(images, 0., 1.) - 0.5) / 0.5
 
     @torch.no_grad()

@@ -374,6 +374,38 @@ def raw_preprocess(images, dtype, want_target: bool):
     return xp, (xp if (want_target and tgt is None) else tgt)
 
 
+def random_crop_params(n: int, h: int, w: int, device, scale=(0.7, 1.0), generator=None):
+    """Per-sample draws of RandomResizedCrop(scale, ratio=(1,1)) + RandomHorizontalFlip(p=0.5)
+    (base_autoencoder.py:20-22), on the device: box [N,4] = (x0, y0, w, h) in pixels, flip [N] int32.
+    Area fraction ~ U(scale), square boxes (ratio 1), top-left corner uniform over the valid range."""
+    r = torch.rand(n, 4, device=device, generator=generator)
+    area = scale[0] + (scale[1] - scale[0]) * r[:, 0]
+    side = torch.sqrt(area)
+    bw = torch.clamp(torch.floor(side * w + 0.5), 1, w)
+    bh = torch.clamp(torch.floor(side * h + 0.5), 1, h)
+    x0 = torch.floor(r[:, 1] * (w - bw + 1)).clamp(max=w - 1)
+    y0 = torch.floor(r[:, 2] * (h - bh + 1)).clamp(max=h - 1)
+    box = torch.stack([x0, y0, bw, bh], dim=1).to(torch.float32).contiguous()
+    flip = (r[:, 3] < 0.5).to(torch.int32).contiguous()
+    return box, flip
+
+
+def raw_augment_preprocess(images, box, flip, dtype, want_target: bool):
+    """raw_preprocess with the crop / flip augmentation fused in front (vqk_augment_preprocess)"""
+    _require_gpu(images)
+    n, c, h, w = images.shape
+    if c != 3 or images.dtype != torch.float32:
+        raise RuntimeError('vqk: preprocess expects fp32 images of shape [N,3,H,W]')
+    images = images.contiguous()
+    cp = epc(dtype)
+    xp = empty_nhwc(n, cp, h, w, dtype, images.device)
+    tgt = empty_nhwc(n, cp, h, w, torch.float32, images.device) if (want_target and dtype != torch.float32) else None
+    st = _native.lib().vqk_augment_preprocess(images.data_ptr(), box.data_ptr(), flip.data_ptr(), xp.data_ptr(), dcode(dtype),
+                                              _p(tgt), n, h, w, cp, _stream())
+    _native.check(st, 'augment_preprocess')
+    return xp, (xp if (want_target and tgt is None) else tgt)
+
+
 # ------------------------------------------------------------------------------------------------------
 # autograd functions
 # ------------------------------------------------------------------------------------------------------
