@@ -772,10 +772,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
             // halves of every 8-cout run.  One v_permlane32_swap per value pairs them up so that each lane owns 8
             // consecutive couts = ONE 16-byte store / residual load instead of two 8-byte ones (the epilogue is
             // store-issue bound).
-            // The MFMA result layout gives a lane 4 consecutive couts of its pixel; lanes l and l+32 hold the two
-            // halves of every 8-cout run.  One v_permlane32_swap per value pairs them up so that each lane owns 8
-            // consecutive couts = ONE 16-byte store / residual load instead of two 8-byte ones (the epilogue is
-            // store-issue bound).
             typedef __attribute__((ext_vector_type(4))) unsigned int u32x4e;
             auto epi_vals = [&](auto has_bias, auto has_res, int i, int j, int qp, int64_t o0, float (&v)[8]) {
                 const int cw = j * 32 + 16 * qp;
