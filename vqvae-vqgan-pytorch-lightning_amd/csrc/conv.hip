@@ -1314,14 +1314,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
     //   q <  8 : dy, half = q >> 2, rows 16*(q&3) .. +15 ; q >= 8 : x halo, half = (q-8)/7, rows 16*((q-8)%7) ..
     int s_dy[NSLOT], s_dx[NSLOT], s_choff[NSLOT];
     unsigned s_dst[NSLOT];
-    bool s_isdy[NSLOT], s_ok[NSLOT];
+    bool s_ok[NSLOT];
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
         const int q = wave + 4 * sl;
         const bool isdy = q < 8;
         const int half = isdy ? (q >> 2) : (q - 8) / 7;
         const int row = (isdy ? (q & 3) : (q - 8) % 7) * 16 + (lane >> 2);
-        s_isdy[sl] = isdy;
         s_choff[sl] = half * 32 + (lane & 3) * 8;
         if (isdy) {
             s_dy[sl] = row >> 3; s_dx[sl] = row & 7;
@@ -1334,16 +1333,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
             s_dst[sl] = (unsigned)(2 * DY_HALF + half * X_HALF + ((q - 8) % 7) * 1024);
         }
     }
+    // Per-slot source pointers for patch (0, 0) of image 0: an interior patch (its halo inside the image, no upsample) is
+    // then `base + one scalar offset` per piece.  The piece issue rate -- not HBM, LDS reads or load latency -- bounds this
+    // kernel (timing-only builds at 128->128 @256^2: no loads 739 -> 458 us; no x-fragment LDS reads, a third LDS stage
+    // with counted vmcnt, or VGPR-staged loads instead of LDS-DMA: no gain / slower), so the per-piece address arithmetic
+    // and bounds tests are worth removing: -4...5 % on the large maps.
+    const char* s_base[NSLOT];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+        if (sl < 2) s_base[sl] = reinterpret_cast<const char*>(dy + ((int64_t)s_dy[sl] * g.w + s_dx[sl]) * g.cout + co0 + s_choff[sl]);
+        else s_base[sl] = reinterpret_cast<const char*>(x + ((int64_t)s_dy[sl] * g.w_in + s_dx[sl]) * g.cin + ci0 + s_choff[sl]);
+    }
     auto issue = [&](int patch, char* st) {
         const int img = patch / (ph * pw), rem = patch - img * (ph * pw);
         const int pyi = rem / pw, pxi = rem - pyi * pw;
         const int py0 = pyi * 8, px0 = pxi * 8;
+        const bool interior = !g.ups && py0 >= 1 && py0 + 8 < g.h && px0 >= 1 && px0 + 8 < g.w;
+        if (interior) {
+            const int64_t pix = ((int64_t)img * g.h + py0) * g.w + px0;
+            const int64_t off_dy = pix * g.cout * 2, off_x = pix * g.cin * 2;       // bytes (bf16)
+#pragma unroll
+            for (int sl = 0; sl < NSLOT; ++sl) {
+                if (wave + 4 * sl >= PIECES) continue;
+                const void* src = s_ok[sl] ? (const void*)(s_base[sl] + (sl < 2 ? off_dy : off_x)) : (const void*)zeros;
+                glds16(src, st + s_dst[sl]);
+            }
+            return;
+        }
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
             if (wave + 4 * sl >= PIECES) continue;
             const int iy = py0 + s_dy[sl], ix = px0 + s_dx[sl];
             const void* src = zeros;
-            if (s_isdy[sl]) {
+            if (sl < 2) {                                      // (pieces 0..7 = slots 0, 1 are the dy pieces)
                 if (s_ok[sl]) src = dy + (((int64_t)img * g.h + iy) * g.w + ix) * g.cout + co0 + s_choff[sl];
             } else if (s_ok[sl] && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w) {
                 src = x + (((int64_t)img * g.h_in + (iy >> g.ups)) * g.w_in + (ix >> g.ups)) * g.cin + ci0 + s_choff[sl];
