@@ -282,9 +282,12 @@ int check_gn(int dtype, int c, int groups) {
     return VQK_OK;
 }
 
-inline int pick_ppb(int n, int64_t hw) {
-    // ~2048 blocks in total, at least 64 pixels per block
-    int64_t blocks_per_sample = (2048 + n - 1) / n;
+// pixels per block.  The streaming (apply) passes want many blocks (~2048); the reducing passes (statistics, backward
+// sums) pay per-block LDS + global atomics for every channel / group, so they want fewer, fatter blocks (~768 total):
+// measured -8...27 % per reducing pass on the 64^2 / 128^2 maps, -2...5 % on 256^2 (sweep 256...4096 blocks).
+inline int pick_ppb(int n, int64_t hw, bool reducing = false) {
+    const int total = reducing ? 768 : 2048;
+    int64_t blocks_per_sample = (total + n - 1) / n;
     int64_t ppb = (hw + blocks_per_sample - 1) / blocks_per_sample;
     if (ppb < 64) ppb = 64;
     return (int)ppb;
@@ -301,7 +304,7 @@ int vqk_gn_stats(int dtype, const void* x, int n, int64_t hw, int c, int groups,
     const int rc = check_gn(dtype, c, groups);
     if (rc) return rc;
     VQK_REQUIRE(vqk_aligned16(x), VQK_ERR_ALIGN);
-    const int ppb = pick_ppb(n, hw);
+    const int ppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(double);
     hipStream_t st = vqk_stream(stream);
@@ -337,15 +340,15 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
     const int rc = check_gn(dtype, c, groups);
     if (rc) return rc;
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y), VQK_ERR_ALIGN);
-    const int ppb = pick_ppb(n, hw);
-    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
+    const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
+    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(double);
     hipStream_t st = vqk_stream(stream);
     if (dtype == VQK_F32) {
-        hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), lds, st, (const float*)x, hw, c, groups, ppb, ws);
+        hipLaunchKernelGGL(gn_stats_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, hw, c, groups, rppb, ws);
         hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps);
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, grid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, ppb, ws);
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, rppb, ws);
         hipLaunchKernelGGL(gn_apply_fin_kernel<bf16_raw>, grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps);
     }
     VQK_CHECK_LAUNCH();
@@ -360,15 +363,15 @@ int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w
     const int rc = check_gn(dtype, c, groups);
     if (rc) return rc;
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(dx), VQK_ERR_ALIGN);
-    const int ppb = pick_ppb(n, hw);
-    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
+    const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
+    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(float);
     hipStream_t st = vqk_stream(stream);
     if (dtype == VQK_F32) {
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, ppb);
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, rppb);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
     } else {
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_raw>, grid, dim3(256), lds, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, dw, db, red, hw, c, groups, silu, ppb);
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, dw, db, red, hw, c, groups, silu, rppb);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
     }
     VQK_CHECK_LAUNCH();
