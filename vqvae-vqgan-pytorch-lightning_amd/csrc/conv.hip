@@ -730,17 +730,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
 #pragma unroll
         for (int i = 0; i < NI; ++i) lbase[i] = smem + boff + abase[i];
 
+        // Pixel fragments run one (tap, k-substep) phase ahead of the MFMAs that consume them (the reads of phase p+1
+        // are requested at the head of phase p; hipcc then spreads them over the second half of phase p's MFMAs instead
+        // of issuing each read two MFMAs before its use): -1...6 % on the 16^2...128^2 maps, neutral on 256^2.  The
+        // thin-head form (one cout tile, four pixel tiles per wave) is faster with the reads at the head of each tap.
+        constexpr bool APIPE = !THIN;
+        frag_t a[2][NI];
+        if (APIPE) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i]);
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             constexpr int dummy = 0; (void)dummy;
             const int toff = ((tap / 3) * HW2 + (tap % 3)) * RS;        // compile-time after unrolling
-            frag_t a[2][NI];
+            if (!APIPE) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff);
+                for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
+                for (int i = 0; i < NI; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (APIPE) {
+                    if (ks == 0) {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
+                    } else if (tap < 8) {
+                        const int toff1 = (((tap + 1) / 3) * HW2 + ((tap + 1) % 3)) * RS;
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff1);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, NI, 0);      // the phase-ahead ds_reads first
+                }
                 if (tap == 0 && ks == 0 && c == 0) {             // first MFMA of a tile starts from C = 0: no
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll                                                   // accumulator clears in the epilogue
