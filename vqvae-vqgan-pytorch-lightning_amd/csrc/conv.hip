@@ -1301,14 +1301,20 @@ __device__ __forceinline__ bf16x8_t tr_frag2(const char* p) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// PW16: 8x16 pixel patches (dy 128 px, x halo 10x18) instead of 8x8 -- 72 MFMAs per wave between two block barriers
+// instead of 36, 1.41 instead of 1.56 halo pixels per output pixel; 2 x 40 KiB stages per block = exactly two blocks per CU.
+template <bool PW16>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_raw* __restrict__ x,
                                                                     const bf16_raw* __restrict__ dy,
                                                                     float* __restrict__ dw,
                                                                     const char* __restrict__ zeros, ConvGeom g,
                                                                     int patches_per_split) {
-    constexpr int DY_HALF = 64 * 64, X_ROWS = 112, X_HALF = X_ROWS * 64;       // bytes per half tile
-    constexpr int STAGE = 2 * DY_HALF + 2 * X_HALF;                           // 22528
-    constexpr int PIECES = 8 + 14, NSLOT = (PIECES + 3) / 4;
+    constexpr int PWD = PW16 ? 16 : 8, PIX = 8 * PWD, HWD = PWD + 2, HROWS = 10 * HWD;   // patch width, pixels, halo
+    constexpr int X_ROWS = (HROWS + 15) / 16 * 16;                            // 112 / 192
+    constexpr int DY_HALF = PIX * 64, X_HALF = X_ROWS * 64;                   // bytes per half tile
+    constexpr int STAGE = 2 * DY_HALF + 2 * X_HALF;                           // 22528 / 40960
+    constexpr int DYP = PIX / 16, XP = X_ROWS / 16;                           // 1 KiB pieces per half tile
+    constexpr int PIECES = 2 * DYP + 2 * XP, NSLOT = (PIECES + 3) / 4, DYSLOTS = 2 * DYP / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1319,7 +1325,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
     const int bx = vb % (int)gridDim.x, by = vb / (int)gridDim.x;
     const int tco = bx / tiles_ci, tci = bx - tco * tiles_ci;
     const int co0 = tco * 64, ci0 = tci * 64;
-    const int pw = g.w >> 3, ph = g.h >> 3;
+    const int pw = g.w / PWD, ph = g.h >> 3;
     const int total_patches = g.n * ph * pw;
     const int p_begin = by * patches_per_split;
     const int p_end = min(total_patches, p_begin + patches_per_split);
@@ -1333,26 +1339,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     // ---- per-lane load slots (fixed over the patch loop): piece q = wave + 4*s
-    //   q <  8 : dy, half = q >> 2, rows 16*(q&3) .. +15 ; q >= 8 : x halo, half = (q-8)/7, rows 16*((q-8)%7) ..
+    //   q < 2*DYP : dy, half = q / DYP, rows 16*(q % DYP) .. +15 ; else x halo, half = (q-2*DYP)/XP, rows 16*((q-2*DYP)%XP) ..
     int s_dy[NSLOT], s_dx[NSLOT], s_choff[NSLOT];
     unsigned s_dst[NSLOT];
     bool s_ok[NSLOT];
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
         const int q = wave + 4 * sl;
-        const bool isdy = q < 8;
-        const int half = isdy ? (q >> 2) : (q - 8) / 7;
-        const int row = (isdy ? (q & 3) : (q - 8) % 7) * 16 + (lane >> 2);
+        const bool isdy = q < 2 * DYP;
+        const int half = isdy ? q / DYP : (q - 2 * DYP) / XP;
+        const int prow = isdy ? q % DYP : (q - 2 * DYP) % XP;
+        const int row = prow * 16 + (lane >> 2);
         s_choff[sl] = half * 32 + (lane & 3) * 8;
         if (isdy) {
-            s_dy[sl] = row >> 3; s_dx[sl] = row & 7;
+            s_dy[sl] = row / PWD; s_dx[sl] = row % PWD;
             s_ok[sl] = (co0 + s_choff[sl]) < g.cout;
-            s_dst[sl] = (unsigned)(half * DY_HALF + (q & 3) * 1024);
+            s_dst[sl] = (unsigned)(half * DY_HALF + prow * 1024);
         } else {
-            const int hy = row / 10, hx = row - hy * 10;
+            const int hy = row / HWD, hx = row - hy * HWD;
             s_dy[sl] = hy - 1; s_dx[sl] = hx - 1;
-            s_ok[sl] = q < PIECES && row < 100 && (ci0 + s_choff[sl]) < g.cin;
-            s_dst[sl] = (unsigned)(2 * DY_HALF + half * X_HALF + ((q - 8) % 7) * 1024);
+            s_ok[sl] = q < PIECES && row < HROWS && (ci0 + s_choff[sl]) < g.cin;
+            s_dst[sl] = (unsigned)(2 * DY_HALF + half * X_HALF + prow * 1024);
         }
     }
     // Per-slot source pointers for patch (0, 0) of image 0: an interior patch (its halo inside the image, no upsample) is
@@ -1363,21 +1370,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
     const char* s_base[NSLOT];
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
-        if (sl < 2) s_base[sl] = reinterpret_cast<const char*>(dy + ((int64_t)s_dy[sl] * g.w + s_dx[sl]) * g.cout + co0 + s_choff[sl]);
+        if (sl < DYSLOTS) s_base[sl] = reinterpret_cast<const char*>(dy + ((int64_t)s_dy[sl] * g.w + s_dx[sl]) * g.cout + co0 + s_choff[sl]);
         else s_base[sl] = reinterpret_cast<const char*>(x + ((int64_t)s_dy[sl] * g.w_in + s_dx[sl]) * g.cin + ci0 + s_choff[sl]);
     }
     auto issue = [&](int patch, char* st) {
         const int img = patch / (ph * pw), rem = patch - img * (ph * pw);
         const int pyi = rem / pw, pxi = rem - pyi * pw;
-        const int py0 = pyi * 8, px0 = pxi * 8;
-        const bool interior = !g.ups && py0 >= 1 && py0 + 8 < g.h && px0 >= 1 && px0 + 8 < g.w;
+        const int py0 = pyi * 8, px0 = pxi * PWD;
+        const bool interior = !g.ups && py0 >= 1 && py0 + 8 < g.h && px0 >= 1 && px0 + PWD < g.w;
         if (interior) {
             const int64_t pix = ((int64_t)img * g.h + py0) * g.w + px0;
             const int64_t off_dy = pix * g.cout * 2, off_x = pix * g.cin * 2;       // bytes (bf16)
 #pragma unroll
             for (int sl = 0; sl < NSLOT; ++sl) {
                 if (wave + 4 * sl >= PIECES) continue;
-                const void* src = s_ok[sl] ? (const void*)(s_base[sl] + (sl < 2 ? off_dy : off_x)) : (const void*)zeros;
+                const void* src = s_ok[sl] ? (const void*)(s_base[sl] + (sl < DYSLOTS ? off_dy : off_x)) : (const void*)zeros;
                 glds16(src, st + s_dst[sl]);
             }
             return;
@@ -1387,7 +1394,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
             if (wave + 4 * sl >= PIECES) continue;
             const int iy = py0 + s_dy[sl], ix = px0 + s_dx[sl];
             const void* src = zeros;
-            if (sl < 2) {                                      // (pieces 0..7 = slots 0, 1 are the dy pieces)
+            if (sl < DYSLOTS) {                                // (the first 2*DYP pieces = DYSLOTS slots are the dy pieces)
                 if (s_ok[sl]) src = dy + (((int64_t)img * g.h + iy) * g.w + ix) * g.cout + co0 + s_choff[sl];
             } else if (s_ok[sl] && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w) {
                 src = x + (((int64_t)img * g.h_in + (iy >> g.ups)) * g.w_in + (ix >> g.ups)) * g.cin + ci0 + s_choff[sl];
@@ -1400,7 +1407,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
     const int li = lane & 15, grp = (lane >> 4) & 1, kgrp = lane >> 5;
     const unsigned frag_lane = (unsigned)((li >> 2) * 64 + 32 * grp + 8 * (li & 3));
     const unsigned a_lane = (unsigned)(wi * DY_HALF) + frag_lane + (unsigned)(kgrp * 8 * 64);
-    const unsigned b_lane = (unsigned)(2 * DY_HALF + wj * X_HALF) + frag_lane + (unsigned)(kgrp * 10 * 64);
+    // k-group 1 = pixels 8..15 of the MFMA's 16: the next patch row (8x8 patches: +HWD halo rows) or the same row's
+    // second half (8x16 patches: +8 halo rows)
+    const unsigned b_lane = (unsigned)(2 * DY_HALF + wj * X_HALF) + frag_lane + (unsigned)(kgrp * (PW16 ? 8 : HWD) * 64);
 
     issue(p_begin, smem);
     for (int pch = p_begin; pch < p_end; ++pch) {
@@ -1411,11 +1420,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
         const char* pa = smem + cur + a_lane;
         const char* pb = smem + cur + b_lane;
 #pragma unroll
-        for (int gk = 0; gk < 4; ++gk) {                       // 16 pixels = patch rows 2gk, 2gk+1
+        for (int gk = 0; gk < PIX / 16; ++gk) {                // 16 pixels = patch rows 2gk, 2gk+1 (8x8) / patch row gk (8x16)
             const bf16x8_t a = tr_frag2(pa + gk * 16 * 64);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const bf16x8_t b = tr_frag2(pb + ((2 * gk + t / 3) * 10 + (t % 3)) * 64);
+                const bf16x8_t b = tr_frag2(pb + (((PW16 ? gk : 2 * gk) + t / 3) * HWD + (t % 3)) * 64);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
             }
         }
@@ -1902,7 +1911,9 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     }
     if (plain && dtype == VQK_BF16 && ksize == 3 && (g.h % 8) == 0 && (g.w % 8) == 0 && g_force_variant != 0) {
         const int tiles = ((cout + 63) / 64) * ((cin + 63) / 64);
-        const int total_patches = g.n * (g.h / 8) * (g.w / 8);
+        static const bool no_pw16 = getenv("VQK_WGRAD_NO_PW16") != nullptr;
+        const bool pw16 = (g.w % 16) == 0 && !no_pw16;
+        const int total_patches = g.n * (g.h / 8) * (g.w / (pw16 ? 16 : 8));
         // split-K over pixel patches.  Cost model fitted on MI355X (tools/convbench.py sweeps): MFMA time falls with the
         // number of resident blocks (up to 2 per CU) while every split adds one fp32 atomic pass over dW (~1.1 TB/s):
         // t(s) = F / (R * min(1, tiles*s/512)) + s * |dW| / B  =>  s* = sqrt(0.16 * pixels / tiles) below the block cap.
@@ -1914,13 +1925,22 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
             splits = (int)(sqrt(0.16 * (double)g.m / tiles) + 0.5);
             if (splits > (cap + tiles - 1) / tiles) splits = (cap + tiles - 1) / tiles;
         }
-        if (splits > (total_patches + 3) / 4) splits = (total_patches + 3) / 4;     // >= 4 patches per block
+        const int minp = pw16 ? 2 : 4;                                              // >= 256 pixels per block
+        if (splits > (total_patches + minp - 1) / minp) splits = (total_patches + minp - 1) / minp;
         if (splits < 1) splits = 1;
         const int pps = (total_patches + splits - 1) / splits;
         splits = (total_patches + pps - 1) / pps;
         const dim3 grid((unsigned)tiles, (unsigned)splits);
-        hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, grid, dim3(256), 2 * 22528, vqk_stream(stream),
-                           (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+        if (pw16) {
+            static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_wgrad_halo_kernel<true>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 40960);
+            (void)attr;
+            hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel<true>, grid, dim3(256), 2 * 40960, vqk_stream(stream),
+                               (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+        } else {
+            hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel<false>, grid, dim3(256), 2 * 22528, vqk_stream(stream),
+                               (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+        }
         VQK_CHECK_LAUNCH();
         return VQK_OK;
     }
