@@ -1419,13 +1419,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
         if (pch + 1 < p_end) issue(pch + 1, smem + (STAGE - cur));
         const char* pa = smem + cur + a_lane;
         const char* pb = smem + cur + b_lane;
+        if constexpr (PW16) {
+            // 8x16 patches: the x fragment of (patch row gk, tap row ty, tap column tx) depends on gk + ty only, so a
+            // rolling window of three halo rows (9 fragments in registers) serves all nine taps and every patch row
+            // reads THREE new fragments instead of nine (2.5x fewer LDS reads; -0.7 % time: LDS reads do not bound it)
+            bf16x8_t bwin[3][3];
 #pragma unroll
-        for (int gk = 0; gk < PIX / 16; ++gk) {                // 16 pixels = patch rows 2gk, 2gk+1 (8x8) / patch row gk (8x16)
-            const bf16x8_t a = tr_frag2(pa + gk * 16 * 64);
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const bf16x8_t b = tr_frag2(pb + (((PW16 ? gk : 2 * gk) + t / 3) * HWD + (t % 3)) * 64);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                for (int tx = 0; tx < 3; ++tx) bwin[r][tx] = tr_frag2(pb + (r * HWD + tx) * 64);
+#pragma unroll
+            for (int gk = 0; gk < 8; ++gk) {
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) bwin[(gk + 2) % 3][tx] = tr_frag2(pb + ((gk + 2) * HWD + tx) * 64);
+                const bf16x8_t a = tr_frag2(pa + gk * 16 * 64);
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bwin[(gk + t / 3) % 3][t % 3], acc[t], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int gk = 0; gk < PIX / 16; ++gk) {            // 16 pixels = patch rows 2gk, 2gk+1
+                const bf16x8_t a = tr_frag2(pa + gk * 16 * 64);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const bf16x8_t b = tr_frag2(pb + ((2 * gk + t / 3) * HWD + (t % 3)) * 64);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                }
             }
         }
     }
