@@ -1461,6 +1461,153 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 8x16-patch wgrad for whole 64-channel tiles (Cin % 64 == 0, Cout % 64 == 0: every 3x3 conv of the model) with
+// lean piece addressing: the per-slot source state is ONE 32-bit lane offset per piece against a wave-uniform patch
+// base (`global_load_lds v_off, s[base]`), so an interior patch issues its ten pieces with no address arithmetic, no
+// bounds tests and no zero-page select; boundary patches recompute their coordinates from the lane id.  -3 % over the
+// step's launches against conv3x3_wgrad_halo_kernel<true> (-6 % at 128->128 @256^2).  Measured and NOT kept: the ten
+// pieces issued two per patch row BETWEEN the MFMA groups instead of ahead of them (+7...9 % on the 128^2 / 256^2
+// maps: an LDS-DMA piece issued among ds_reads costs more than one issued in a batch); three specialised copies of
+// the stage (last / interior / boundary patch) made hipcc duplicate the 144 accumulators across the merge and spill.
+// Same LDS image, fragment reads and MFMA order as conv3x3_wgrad_halo_kernel<true> => bit-identical partial sums.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(const bf16_raw* __restrict__ x,
+                                                                   const bf16_raw* __restrict__ dy,
+                                                                   float* __restrict__ dw,
+                                                                   const char* __restrict__ zeros, ConvGeom g,
+                                                                   int patches_per_split) {
+    constexpr int PWD = 16, PIX = 128, HWD = 18, HROWS = 180, X_ROWS = 192;
+    constexpr int DY_HALF = PIX * 64, X_HALF = X_ROWS * 64, STAGE = 2 * DY_HALF + 2 * X_HALF;     // 40960
+    constexpr int NDY = 4, NX = 6;                               // pieces per wave and stage: 16 dy + 24 x over 4 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_ci = g.cin >> 6;
+    const int vb = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int bx = vb % (int)gridDim.x, by = vb / (int)gridDim.x;
+    const int tco = bx / tiles_ci, tci = bx - tco * tiles_ci;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int pw = g.w >> 4, ph = g.h >> 3;
+    const int total_patches = g.n * ph * pw;
+    const int p_begin = by * patches_per_split;
+    const int p_end = min(total_patches, p_begin + patches_per_split);
+    if (p_begin >= p_end) return;
+
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // piece q = wave + 4*sl.  q < 16: dy, half = q >> 3, patch row = q & 7, lane>>2 = patch column, (lane&3)*8 channels;
+    // q >= 16: x halo, r = q - 16, half = r / 12, halo rows 16*(r % 12) + (lane >> 2) (rows 180..191 are padding that no
+    // fragment reads: those lanes fetch row 179 again).
+    const int lrow = lane >> 2, lch = (lane & 3) * 8;
+    unsigned dyoff[NDY], xoff[NX];                               // byte offsets against the patch bases (interior patches)
+#pragma unroll
+    for (int sl = 0; sl < NDY; ++sl) {
+        const int q = wave + 4 * sl, half = q >> 3, prow = q & 7;
+        dyoff[sl] = (unsigned)((((prow * g.w + lrow) * g.cout) + co0 + half * 32 + lch) * 2);
+    }
+#pragma unroll
+    for (int sl = 0; sl < NX; ++sl) {
+        const int r = wave + 4 * sl, half = r / 12, row = min((r % 12) * 16 + lrow, HROWS - 1);
+        const int hy = row / HWD, hx = row - hy * HWD;
+        xoff[sl] = (unsigned)((((hy * g.w_in + hx) * g.cin) + ci0 + half * 32 + lch) * 2);
+    }
+    struct PatchPos { int img, py0, px0; bool interior; const char* bdy; const char* bx; };
+    auto decode = [&](int patch) -> PatchPos {
+        PatchPos pp;
+        pp.img = patch / (ph * pw);
+        const int rem = patch - pp.img * (ph * pw);
+        const int pyi = rem / pw, pxi = rem - pyi * pw;
+        pp.py0 = pyi * 8; pp.px0 = pxi * PWD;
+        pp.interior = !g.ups && pp.py0 >= 1 && pp.py0 + 8 < g.h && pp.px0 >= 1 && pp.px0 + PWD < g.w;
+        const int64_t pix = ((int64_t)pp.img * g.h + pp.py0) * g.w + pp.px0;
+        pp.bdy = reinterpret_cast<const char*>(dy + pix * g.cout);
+        pp.bx = reinterpret_cast<const char*>(x + (pix - g.w - 1) * g.cin);         // halo origin (py0 - 1, px0 - 1)
+        return pp;
+    };
+    // one piece of the next stage; `sl` is a compile-time constant at every call site
+    auto piece = [&](bool interior, int sl, const PatchPos& pp, char* st) {
+        if (sl < NDY) {
+            const int q = wave + 4 * sl;
+            char* dst = st + (q >> 3) * DY_HALF + (q & 7) * 1024;
+            if (interior || true) {                              // dy pixels of a patch are always inside the image
+                glds16(pp.bdy + dyoff[sl], dst);
+            }
+        } else {
+            const int r = wave + 4 * (sl - NDY), half = r / 12, pr = r % 12;
+            char* dst = st + 2 * DY_HALF + half * X_HALF + pr * 1024;
+            if (interior) {
+                glds16(pp.bx + xoff[sl - NDY], dst);
+            } else {
+                const int row = min(pr * 16 + lrow, HROWS - 1);
+                const int hy = row / HWD, hx = row - hy * HWD;
+                const int iy = pp.py0 + hy - 1, ix = pp.px0 + hx - 1;
+                const void* src = zeros;
+                if (iy >= 0 && iy < g.h && ix >= 0 && ix < g.w)
+                    src = x + (((int64_t)pp.img * g.h_in + (iy >> g.ups)) * g.w_in + (ix >> g.ups)) * g.cin + ci0 + half * 32 + lch;
+                glds16(src, dst);
+            }
+        }
+    };
+
+    const int li = lane & 15, grp = (lane >> 4) & 1, kgrp = lane >> 5;
+    const unsigned frag_lane = (unsigned)((li >> 2) * 64 + 32 * grp + 8 * (li & 3));
+    const unsigned a_lane = (unsigned)(wi * DY_HALF) + frag_lane + (unsigned)(kgrp * 8 * 64);
+    const unsigned b_lane = (unsigned)(2 * DY_HALF + wj * X_HALF) + frag_lane + (unsigned)(kgrp * 8 * 64);
+
+    {
+        const PatchPos p0 = decode(p_begin);
+#pragma unroll
+        for (int sl = 0; sl < NDY + NX; ++sl) piece(p0.interior, sl, p0, smem);
+    }
+    for (int pch = p_begin; pch < p_end; ++pch) {
+        const unsigned cur = (unsigned)(((pch - p_begin) & 1) * STAGE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // stage `cur` landed; everyone left the other stage
+        const bool has_next = pch + 1 < p_end;
+        const PatchPos pp = decode(has_next ? pch + 1 : pch);
+        char* nst = smem + (STAGE - cur);
+        const char* pa = smem + cur + a_lane;
+        const char* pb = smem + cur + b_lane;
+        if (has_next) {
+            if (pp.interior) {
+#pragma unroll
+                for (int sl = 0; sl < NDY + NX; ++sl) piece(true, sl, pp, nst);
+            } else {
+#pragma unroll
+                for (int sl = 0; sl < NDY + NX; ++sl) piece(false, sl, pp, nst);
+            }
+        }
+        bf16x8_t bwin[3][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) bwin[r][tx] = tr_frag2(pb + (r * HWD + tx) * 64);
+#pragma unroll
+        for (int gk = 0; gk < 8; ++gk) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) bwin[(gk + 2) % 3][tx] = tr_frag2(pb + ((gk + 2) * HWD + tx) * 64);
+            const bf16x8_t a = tr_frag2(pa + gk * 16 * 64);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bwin[(gk + t / 3) % 3][t % 3], acc[t], 0, 0, 0);
+        }
+    }
+    const int ci = ci0 + wj * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+            atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r]);
+        }
+}
+
 // w [Cout][taps][Cin] fp32 -> wt [Cin][taps (flipped)][Cout] as TD
 template <typename TD>
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, TD* __restrict__ wt, int cout, int cin, int taps) {
@@ -1951,7 +2098,14 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
         const int pps = (total_patches + splits - 1) / splits;
         splits = (total_patches + pps - 1) / pps;
         const dim3 grid((unsigned)tiles, (unsigned)splits);
-        if (pw16) {
+        static const bool no_p16k = getenv("VQK_WGRAD_NO_P16K") != nullptr;
+        if (pw16 && (cin % 64) == 0 && (cout % 64) == 0 && !no_p16k) {
+            static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_wgrad_p16_kernel,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 40960);
+            (void)attr;
+            hipLaunchKernelGGL(conv3x3_wgrad_p16_kernel, grid, dim3(256), 2 * 40960, vqk_stream(stream),
+                               (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+        } else if (pw16) {
             static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_wgrad_halo_kernel<true>,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 40960);
             (void)attr;
