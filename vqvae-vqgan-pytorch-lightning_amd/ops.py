@@ -531,7 +531,7 @@ class GroupNormSiLUFn(torch.autograd.Function):
 OVERLAP_WGRAD = os.environ.get('VQK_OVERLAP_WGRAD', '1') == '1'
 OVERLAP_MODE = int(os.environ.get('VQK_OVERLAP_MODE', '3'))
 OVERLAP_STREAM_BLOCKS = int(os.environ.get('VQK_OVERLAP_STREAM_BLOCKS', '512'))
-OVERLAP_WGRAD_BLOCKS = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS', '384'))
+OVERLAP_WGRAD_BLOCKS = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS', '320'))   # swept 192...512 with the 8x16-patch wgrad: flat 224...320
 _SIDE_STREAMS: dict = {}
 
 
