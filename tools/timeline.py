@@ -59,6 +59,22 @@ def main(path, back=2, min_gap=3.0):
     print(f'{len(gaps)} idle gaps > {min_gap} us, {tot:.1f} us in total; largest:')
     for g, a, b in sorted(gaps, reverse=True)[:25]:
         print(f'  {g:8.1f} us  after {short(a)}  before {short(b)}')
+    # context of the largest gap: the kernels either side of it
+    if gaps:
+        g, a, b = max(gaps)
+        names = [short(n) for n, s_, e, q in step]
+        starts = [s_ for n, s_, e, q in step]
+        order2 = sorted(range(len(step)), key=lambda i: starts[i])
+        # index of the first kernel starting after the gap
+        ends = [e for n, s_, e, q in step]
+        for pos, i in enumerate(order2):
+            if pos and starts[i] - max(ends[j] for j in order2[:pos]) > (g - 0.5) * 1e3:
+                lo_, hi_ = max(0, pos - 8), min(len(order2), pos + 8)
+                print(f'around the largest gap ({g:.1f} us):')
+                for k in range(lo_, hi_):
+                    j = order2[k]
+                    print(f'   {"-->" if k == pos else "   "} q{step[j][3]} {names[j]:60s} {(ends[j] - starts[j]) / 1e3:8.1f} us')
+                break
     # per-kernel sums in this step
     agg = {}
     for n, s, e, q in step:
