@@ -118,12 +118,9 @@ def test_train_step_batch_split_invariance_and_indices():
     assert np.array_equal(idx, ref)
 
 
-def test_full_architecture_256_vs_cpu_oracle():
-    """The north-star parity statement at the REAL architecture and resolution (config 2: channels 128, mult (1,2,2,4),
-    2 ResBlocks per level, K=1024, D=256, 256x256), batch 2, fp32 parity mode, against the torch-CPU oracle on identical
-    inputs and weights: reconstructions and loss within fp32 tolerance, every parameter gradient within 2e-3 relative,
-    codebook indices equal except on near-ties of the two best codes (47 fp32 conv layers upstream of the argmin), and
-    the assignment kernel on the ORACLE's own latents bit-exact."""
+@pytest.fixture(scope='module')
+def oracle_256():
+    """config-2 architecture at 256x256, batch 2: one CPU-oracle train step (a few seconds) shared by the tests below"""
     from oracle import vqvae_oracle as O
     torch.manual_seed(4321)
     m = model_mod.VQVAE(256, AE, QC, None, TC, compute_dtype=torch.float32)          # CPU tensors: initialisation only
@@ -131,7 +128,19 @@ def test_full_architecture_256_vs_cpu_oracle():
     g = torch.Generator().manual_seed(4321)
     images = torch.rand(2, 3, 256, 256, generator=g)
     r = O.train_step_mse(images, params, 2, 4, 'standard', dict(commitment_cost=0.25))
+    return params, images, r
 
+
+def test_full_architecture_256_vs_cpu_oracle(oracle_256):
+    """The north-star parity statement at the REAL architecture and resolution (config 2: channels 128, mult (1,2,2,4),
+    2 ResBlocks per level, K=1024, D=256, 256x256), batch 2, fp32 parity mode, against the torch-CPU oracle on identical
+    inputs and weights: reconstructions and loss within fp32 tolerance, every parameter gradient within 2e-3 relative,
+    codebook indices equal except on near-ties of the two best codes (47 fp32 conv layers upstream of the argmin), and
+    the assignment kernel on the ORACLE's own latents bit-exact."""
+    from oracle import vqvae_oracle as O
+    params, images, r = oracle_256
+    m = model_mod.VQVAE(256, AE, QC, None, TC, compute_dtype=torch.float32)
+    m.load_state_dict(params, strict=True)
     m = m.to(DEV).train()
     tr = trainer_mod.MiniTrainer(num_training_batches=1)
     opt = tr.attach(m)[0]
@@ -168,3 +177,33 @@ def test_full_architecture_256_vs_cpu_oracle():
     assert checked >= 100, checked
     print(f'full-architecture parity: {len(mism)} of {len(idx_ref)} indices differ (near-ties), reconstruction rel err '
           f'{rec_err:.2e}, loss {loss.item():.6f} vs {r["loss"].item():.6f}, worst gradient rel err {worst:.2e} over {checked} tensors')
+
+
+def test_full_architecture_256_bf16_tracks_cpu_oracle(oracle_256):
+    """Throughput mode (bf16 activations / weight shadow, fp32 accumulation, statistics, VQ and optimizer) at the same
+    architecture and inputs: loss, reconstruction and gradient DIRECTION stay with the fp32 oracle."""
+    params, images, r = oracle_256
+    m = model_mod.VQVAE(256, AE, QC, None, TC, compute_dtype=BF)
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV).train()
+    tr = trainer_mod.MiniTrainer(num_training_batches=1)
+    opt = tr.attach(m)[0]
+    opt.zero_grad()
+    loss = m.training_step(images.to(DEV), 0)
+    loss.backward()
+    named = dict(m.named_parameters())
+    num = den_a = den_b = 0.0
+    for k, gr in r['grads'].items():
+        a = named[k].grad.detach().double().cpu().reshape(-1)
+        b = gr.double().reshape(-1)
+        num += (a * b).sum().item(); den_a += (a * a).sum().item(); den_b += (b * b).sum().item()
+    cos = num / (den_a * den_b) ** 0.5
+    with torch.no_grad():
+        recon, _, idx = m(m.preprocess_batch(images.to(DEV)))
+    rec_err = ((recon.float().cpu() - r['recon']).norm() / r['recon'].norm()).item()
+    same = (idx.cpu().numpy().reshape(-1) == r['idx'].numpy().reshape(-1)).mean()
+    print(f'bf16 mode vs fp32 oracle: loss {loss.item():.5f} vs {r["loss"].item():.5f}, reconstruction rel err {rec_err:.2e}, '
+          f'gradient cosine {cos:.5f}, norm ratio {(den_a / den_b) ** 0.5:.4f}, {same * 100:.1f} % of indices equal')
+    assert abs(loss.item() - r['loss'].item()) < 5e-3 * abs(r['loss'].item())
+    assert cos > 0.99 and 0.9 < (den_a / den_b) ** 0.5 < 1.1
+    assert rec_err < 8e-2 and same > 0.9
