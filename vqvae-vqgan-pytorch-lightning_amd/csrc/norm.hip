@@ -5,6 +5,7 @@
 // Thread mapping: a thread owns one 16-byte channel vector slot (fixed channels) and strides over pixels,
 // so per-channel affine terms / partial sums live in registers.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -273,6 +274,232 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     ws_release(red, gridDim.y, groups);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small maps (H*W <= 1024: the 16^2 / 32^2 levels, 21 of the model's 42 GroupNorms): ONE kernel per direction.  A block
+// owns (sample, 32-channel slice = whole groups) over ALL pixels, keeps its <= 16 pixels per thread in registers (raw 16-byte
+// vectors), reduces inside the block (no global atomics for the statistics, no workspace, no second read) and applies from
+// the registers.  The two-kernel form spent most of its 20-60 us per call on launches, global atomics and the round trip.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Raw16;
+template <> struct Raw16<float> {
+    typedef f32x4 type;
+    __device__ static __forceinline__ void unpack(const f32x4& v, float (&o)[4]) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+};
+template <> struct Raw16<bf16_raw> {
+    typedef u16x8 type;
+    __device__ static __forceinline__ void unpack(const u16x8& v, float (&o)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(v[i]);
+    }
+};
+
+template <typename T, int PPT>
+__global__ __launch_bounds__(256) void gn_small_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, T* __restrict__ y,
+                                                           float* __restrict__ stats, int c, int groups, int silu, float eps) {
+    constexpr int V = Vec16<T>::N, SLOTS = 32 / V, ROWS = 256 / SLOTS, HW = PPT * ROWS;
+    typedef typename Raw16<T>::type raw_t;
+    __shared__ double sh[2][32];                                 // per-channel sums of the slice
+    __shared__ float gstat[32][2];                               // (mean, rstd) per channel of the slice
+    const int slot = threadIdx.x % SLOTS, prow = threadIdx.x / SLOTS;
+    const int n = blockIdx.y, ch0 = blockIdx.x * 32, cpg = c / groups;
+    if (threadIdx.x < 64) sh[threadIdx.x >> 5][threadIdx.x & 31] = 0.0;
+    __syncthreads();
+    const int64_t off = (int64_t)n * HW * c + ch0 + slot * V;
+    raw_t r[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) r[k] = *reinterpret_cast<const raw_t*>(x + off + (int64_t)(prow + k * ROWS) * c);
+    float s[V], ss[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s[i] = 0.f; ss[i] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        float v[V];
+        Raw16<T>::unpack(r[k], v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) { s[i] += v[i]; ss[i] = __fmaf_rn(v[i], v[i], ss[i]); }
+    }
+    // keep the RAW vectors (not their fp32 expansion, twice the registers) alive across the reduction
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) asm volatile("" : "+v"(r[k]));
+    // the ROWS threads of a slot sit SLOTS lanes apart: fold the lanes of a wave first, then one LDS atomic per wave
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+#pragma unroll
+        for (int o = 32; o >= SLOTS; o >>= 1) { s[i] += __shfl_xor(s[i], o, 64); ss[i] += __shfl_xor(ss[i], o, 64); }
+    }
+    if ((threadIdx.x & 63) < SLOTS) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            atomicAdd(&sh[0][slot * V + i], (double)s[i]);
+            atomicAdd(&sh[1][slot * V + i], (double)ss[i]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {                                      // thread = channel of the slice: its group's moments
+        const int g0 = (threadIdx.x / cpg) * cpg;                // cpg divides 32
+        double a = 0.0, q = 0.0;
+        for (int i = 0; i < cpg; ++i) { a += sh[0][g0 + i]; q += sh[1][g0 + i]; }
+        const double m = (double)HW * cpg, mean = a / m;
+        double var = (q - a * mean) / (m - 1.0);                 // unbiased (torch.var default)
+        if (var < 0.0) var = 0.0;
+        const float mean_f = (float)mean, rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+        gstat[threadIdx.x][0] = mean_f; gstat[threadIdx.x][1] = rstd_f;
+        if (threadIdx.x == g0) {
+            const int g = (ch0 + g0) / cpg;
+            stats[((int64_t)n * groups + g) * 2] = mean_f;
+            stats[((int64_t)n * groups + g) * 2 + 1] = rstd_f;
+        }
+    }
+    __syncthreads();
+    float scale[V], shift[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int cl = slot * V + i;
+        scale[i] = gstat[cl][1] * w[ch0 + cl];
+        shift[i] = __fmaf_rn(-gstat[cl][0], scale[i], b[ch0 + cl]);
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        float v[V];
+        Raw16<T>::unpack(r[k], v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float t = __fmaf_rn(v[i], scale[i], shift[i]);
+            v[i] = silu ? silu_f(t) : t;
+        }
+        Vec16<T>::store(y + off + (int64_t)(prow + k * ROWS) * c, v);
+    }
+}
+
+// KEEP = false (16 pixels per thread, the 32^2 maps): x / dy do not fit the registers twice, the second pass re-reads the
+// block's own 128 KiB from L2 instead.
+template <typename T, int PPT, bool KEEP>
+__global__ __launch_bounds__(256) void gn_small_bwd_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           const T* __restrict__ dy, T* __restrict__ dx,
+                                                           const T* __restrict__ add, float* __restrict__ dw,
+                                                           float* __restrict__ db, int c, int groups, int silu,
+                                                           int accumulate) {
+    constexpr int V = Vec16<T>::N, SLOTS = 32 / V, ROWS = 256 / SLOTS, HW = PPT * ROWS;
+    typedef typename Raw16<T>::type raw_t;
+    __shared__ float sh[2][32];                                  // per-channel sums of g and g * xhat
+    __shared__ float kk[32][2];                                  // (k1, k2) of the channel's group
+    const int slot = threadIdx.x % SLOTS, prow = threadIdx.x / SLOTS;
+    const int n = blockIdx.y, ch0 = blockIdx.x * 32, cpg = c / groups;
+    if (threadIdx.x < 64) sh[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
+    __syncthreads();
+    const int64_t off = (int64_t)n * HW * c + ch0 + slot * V;
+    raw_t rx[KEEP ? PPT : 1], rg[KEEP ? PPT : 1];
+    if (KEEP) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            rx[k] = *reinterpret_cast<const raw_t*>(x + off + (int64_t)(prow + k * ROWS) * c);
+            rg[k] = *reinterpret_cast<const raw_t*>(dy + off + (int64_t)(prow + k * ROWS) * c);
+        }
+    }
+    float mean[V], rstd[V], wv[V], bv[V], a[V], bb[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = ch0 + slot * V + i, g = ch / cpg;
+        mean[i] = stats[((int64_t)n * groups + g) * 2]; rstd[i] = stats[((int64_t)n * groups + g) * 2 + 1];
+        wv[i] = w[ch]; bv[i] = b[ch]; a[i] = 0.f; bb[i] = 0.f;
+    }
+    auto pre = [&](float xv, float gv, int i, float& xh) -> float {      // dy before the SiLU, xhat
+        xh = (xv - mean[i]) * rstd[i];
+        if (silu) {
+            const float yv = __fmaf_rn(xh, wv[i], bv[i]);
+            const float sg = sigmoid_f(yv);
+            gv *= sg * (1.0f + yv * (1.0f - sg));
+        }
+        return gv;
+    };
+#pragma unroll 4
+    for (int k = 0; k < PPT; ++k) {
+        float xv[V], gv[V];
+        if (KEEP) {
+            Raw16<T>::unpack(rx[k], xv);
+            Raw16<T>::unpack(rg[k], gv);
+        } else {
+            Vec16<T>::load(x + off + (int64_t)(prow + k * ROWS) * c, xv);
+            Vec16<T>::load(dy + off + (int64_t)(prow + k * ROWS) * c, gv);
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float xh;
+            const float g = pre(xv[i], gv[i], i, xh);
+            a[i] += g;
+            bb[i] = __fmaf_rn(g, xh, bb[i]);
+        }
+    }
+    if (KEEP) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) { asm volatile("" : "+v"(rx[k])); asm volatile("" : "+v"(rg[k])); }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+#pragma unroll
+        for (int o = 32; o >= SLOTS; o >>= 1) { a[i] += __shfl_xor(a[i], o, 64); bb[i] += __shfl_xor(bb[i], o, 64); }
+    }
+    if ((threadIdx.x & 63) < SLOTS) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            atomicAdd(&sh[0][slot * V + i], a[i]);
+            atomicAdd(&sh[1][slot * V + i], bb[i]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int cl = threadIdx.x, ch = ch0 + cl;
+        atomicAdd(db + ch, sh[0][cl]);
+        atomicAdd(dw + ch, sh[1][cl]);
+        const int g0 = (cl / cpg) * cpg;
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < cpg; ++i) {
+            s1 += (double)sh[0][g0 + i] * (double)w[ch0 + g0 + i];
+            s2 += (double)sh[1][g0 + i] * (double)w[ch0 + g0 + i];
+        }
+        const double m = (double)HW * cpg;
+        kk[cl][0] = (float)(s1 / m); kk[cl][1] = (float)(s2 / (m - 1.0));
+    }
+    __syncthreads();
+    float k1[V], k2[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { k1[i] = kk[slot * V + i][0]; k2[i] = kk[slot * V + i][1]; }
+#pragma unroll 4
+    for (int k = 0; k < PPT; ++k) {
+        float xv[V], gv[V], ov[V];
+        const int64_t o = off + (int64_t)(prow + k * ROWS) * c;
+        if (KEEP) {
+            Raw16<T>::unpack(rx[k], xv);
+            Raw16<T>::unpack(rg[k], gv);
+        } else {
+            Vec16<T>::load(x + o, xv);
+            Vec16<T>::load(dy + o, gv);
+        }
+        if (accumulate) Vec16<T>::load((add ? add : dx) + o, ov);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float xh;
+            const float g = pre(xv[i], gv[i], i, xh);
+            const float r = (g * wv[i] - k1[i] - xh * k2[i]) * rstd[i];
+            ov[i] = accumulate ? ov[i] + r : r;
+        }
+        Vec16<T>::store(dx + o, ov);
+    }
+}
+
+// pixels per thread of the small-map form for this problem, or 0 when it does not apply
+inline int gn_small_ppt(int dtype, int64_t hw, int c, int groups, int max_ppt) {
+    static const bool off = getenv("VQK_GN_NO_SMALL") != nullptr;
+    if (off || c % 32 || (32 % (c / groups))) return 0;
+    const int rows = dtype == VQK_F32 ? 32 : 64;
+    if (hw % rows) return 0;
+    const int64_t ppt = hw / rows;
+    if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != 8 && ppt != 16) return 0;
+    return ppt <= max_ppt ? (int)ppt : 0;
+}
+
 int check_gn(int dtype, int c, int groups) {
     if (dtype != VQK_F32 && dtype != VQK_BF16) return VQK_ERR_DTYPE;
     const int v = dtype == VQK_F32 ? 4 : 8;
@@ -340,10 +567,21 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
     const int rc = check_gn(dtype, c, groups);
     if (rc) return rc;
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    hipStream_t st = vqk_stream(stream);
+    if (const int ppt = gn_small_ppt(dtype, hw, c, groups, 16)) {
+        const dim3 sgrid((unsigned)(c / 32), (unsigned)n);
+#define VQK_GN_SMALL_FWD(T, P) hipLaunchKernelGGL((gn_small_fwd_kernel<T, P>), sgrid, dim3(256), 0, st, (const T*)x, w, b, (T*)y, stats, c, groups, silu, eps)
+#define VQK_GN_SMALL_FWD_T(T) do { switch (ppt) { case 1: VQK_GN_SMALL_FWD(T, 1); break; case 2: VQK_GN_SMALL_FWD(T, 2); break; \
+        case 4: VQK_GN_SMALL_FWD(T, 4); break; case 8: VQK_GN_SMALL_FWD(T, 8); break; default: VQK_GN_SMALL_FWD(T, 16); } } while (0)
+        if (dtype == VQK_F32) VQK_GN_SMALL_FWD_T(float); else VQK_GN_SMALL_FWD_T(bf16_raw);
+#undef VQK_GN_SMALL_FWD_T
+#undef VQK_GN_SMALL_FWD
+        VQK_CHECK_LAUNCH();
+        return VQK_OK;
+    }
     const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(double);
-    hipStream_t st = vqk_stream(stream);
     if (dtype == VQK_F32) {
         hipLaunchKernelGGL(gn_stats_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, hw, c, groups, rppb, ws);
         hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps);
@@ -363,10 +601,22 @@ int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w
     const int rc = check_gn(dtype, c, groups);
     if (rc) return rc;
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(dx), VQK_ERR_ALIGN);
+    hipStream_t st = vqk_stream(stream);
+    if (const int ppt = gn_small_ppt(dtype, hw, c, groups, 16)) {
+        const dim3 sgrid((unsigned)(c / 32), (unsigned)n);
+        const int acc = (accumulate || add) ? 1 : 0;
+#define VQK_GN_SMALL_BWD(T, P) hipLaunchKernelGGL((gn_small_bwd_kernel<T, P, (P < 16)>), sgrid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, dw, db, c, groups, silu, acc)
+#define VQK_GN_SMALL_BWD_T(T) do { switch (ppt) { case 1: VQK_GN_SMALL_BWD(T, 1); break; case 2: VQK_GN_SMALL_BWD(T, 2); break; \
+        case 4: VQK_GN_SMALL_BWD(T, 4); break; case 8: VQK_GN_SMALL_BWD(T, 8); break; default: VQK_GN_SMALL_BWD(T, 16); } } while (0)
+        if (dtype == VQK_F32) VQK_GN_SMALL_BWD_T(float); else VQK_GN_SMALL_BWD_T(bf16_raw);
+#undef VQK_GN_SMALL_BWD_T
+#undef VQK_GN_SMALL_BWD
+        VQK_CHECK_LAUNCH();
+        return VQK_OK;
+    }
     const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(float);
-    hipStream_t st = vqk_stream(stream);
     if (dtype == VQK_F32) {
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, rppb);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
