@@ -9,16 +9,38 @@
 
 namespace {
 
+// Block-level reduction shared by the two reducing kernels: every thread parks its 2V partial sums in LDS (lane-linear,
+// 16-byte stores), then thread `col` adds up its column over the rows.  The previous form issued 2V LDS atomics per
+// thread onto c addresses (up to 64 threads per address): serialised, several microseconds per block, i.e. most of a
+// block's time on the 64^2 / 128^2 maps.
+template <int V>
+__device__ __forceinline__ void block_colsum(const float (&p0)[V], const float (&p1)[V], float* part, double* colsum, int c) {
+    const int vpp = c / V, rows = 256 / vpp;
+    float* mine = part + (size_t)threadIdx.x * 2 * V;            // thread id = prow * vpp + slot
+#pragma unroll
+    for (int i = 0; i < V; i += 4) {
+        *reinterpret_cast<f32x4*>(mine + i) = f32x4{p0[i], p0[i + 1], p0[i + 2], p0[i + 3]};
+        *reinterpret_cast<f32x4*>(mine + V + i) = f32x4{p1[i], p1[i + 1], p1[i + 2], p1[i + 3]};
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < 2 * c; col += 256) {       // col = slot * 2V + j,  j < V: first sum, else second
+        const int slot = col / (2 * V), j = col - slot * 2 * V;
+        double a = 0.0;
+        for (int r = 0; r < rows; ++r) a += (double)part[((size_t)r * vpp + slot) * 2 * V + j];
+        colsum[(j >= V ? c : 0) + slot * V + (j % V)] = a;
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int64_t hw, int c, int groups,
                                                        int pix_per_block, double* __restrict__ acc) {
     constexpr int V = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sh = reinterpret_cast<double*>(smem);          // [2][c]
+    double* sh = reinterpret_cast<double*>(smem);          // [2][c] column sums
+    float* part = reinterpret_cast<float*>(sh + 2 * c);    // [256][2V] per-thread partials
     const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
     const int n = blockIdx.y;
-    for (int i = threadIdx.x; i < 2 * c; i += 256) sh[i] = 0.0;
-    __syncthreads();
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     float s[V], ss[V];
@@ -32,12 +54,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < V; ++i) { s[i] += v[i]; ss[i] = __fmaf_rn(v[i], v[i], ss[i]); }
     }
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-        atomicAdd(&sh[slot * V + i], (double)s[i]);
-        atomicAdd(&sh[c + slot * V + i], (double)ss[i]);
-    }
-    __syncthreads();
+    block_colsum<V>(s, ss, part, sh, c);
     const int cpg = c / groups;
     for (int g = threadIdx.x; g < groups; g += 256) {
         double a = 0.0, b = 0.0;
@@ -173,11 +190,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
                                                             int pix_per_block) {
     constexpr int V = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sh = reinterpret_cast<float*>(smem);            // [2][c]
+    double* sh = reinterpret_cast<double*>(smem);          // [2][c] column sums
+    float* part = reinterpret_cast<float*>(sh + 2 * c);    // [256][2V] per-thread partials
     const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
     const int n = blockIdx.y, cpg = c / groups;
-    for (int i = threadIdx.x; i < 2 * c; i += 256) sh[i] = 0.f;
-    __syncthreads();
     float mean[V], rstd[V], wv[V], bv[V], a[V], bb[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -206,22 +222,17 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
             bb[i] = __fmaf_rn(g, xh, bb[i]);
         }
     }
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-        atomicAdd(&sh[slot * V + i], a[i]);
-        atomicAdd(&sh[c + slot * V + i], bb[i]);
-    }
-    __syncthreads();
+    block_colsum<V>(a, bb, part, sh, c);
     for (int ch = threadIdx.x; ch < c; ch += 256) {
-        atomicAdd(db + ch, sh[ch]);
-        atomicAdd(dw + ch, sh[c + ch]);
+        atomicAdd(db + ch, (float)sh[ch]);
+        atomicAdd(dw + ch, (float)sh[c + ch]);
     }
     for (int g = threadIdx.x; g < groups; g += 256) {
         double s1 = 0.0, s2 = 0.0;
         for (int i = 0; i < cpg; ++i) {
             const int ch = g * cpg + i;
-            s1 += (double)sh[ch] * (double)w[ch];
-            s2 += (double)sh[c + ch] * (double)w[ch];
+            s1 += sh[ch] * (double)w[ch];
+            s2 += sh[c + ch] * (double)w[ch];
         }
         atomicAdd(&red[((int64_t)n * groups + g) * 2 + 0], s1);
         atomicAdd(&red[((int64_t)n * groups + g) * 2 + 1], s2);
@@ -533,7 +544,7 @@ int vqk_gn_stats(int dtype, const void* x, int n, int64_t hw, int c, int groups,
     VQK_REQUIRE(vqk_aligned16(x), VQK_ERR_ALIGN);
     const int ppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
-    const size_t lds = (size_t)2 * c * sizeof(double);
+    const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
     hipStream_t st = vqk_stream(stream);
     if (dtype == VQK_F32) hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), lds, st, (const float*)x, hw, c, groups, ppb, acc);
     else hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, grid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, ppb, acc);
@@ -581,7 +592,7 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
     }
     const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
-    const size_t lds = (size_t)2 * c * sizeof(double);
+    const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
     if (dtype == VQK_F32) {
         hipLaunchKernelGGL(gn_stats_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, hw, c, groups, rppb, ws);
         hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps);
@@ -616,7 +627,7 @@ int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w
     }
     const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
-    const size_t lds = (size_t)2 * c * sizeof(float);
+    const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
     if (dtype == VQK_F32) {
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, rppb);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
