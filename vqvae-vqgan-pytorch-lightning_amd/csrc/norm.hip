@@ -613,7 +613,9 @@ int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w
     if (rc) return rc;
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(dx), VQK_ERR_ALIGN);
     hipStream_t st = vqk_stream(stream);
-    if (const int ppt = gn_small_ppt(dtype, hw, c, groups, 16)) {
+    // 16 pixels per thread (the 32^2 maps, re-read form) measured 106 us per call inside the step against 93 for the
+    // two-kernel form next to the weight-gradient kernels: the single-kernel backward is used up to 8 pixels per thread
+    if (const int ppt = gn_small_ppt(dtype, hw, c, groups, 8)) {
         const dim3 sgrid((unsigned)(c / 32), (unsigned)n);
         const int acc = (accumulate || add) ? 1 : 0;
 #define VQK_GN_SMALL_BWD(T, P) hipLaunchKernelGGL((gn_small_bwd_kernel<T, P, (P < 16)>), sgrid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, dw, db, c, groups, silu, acc)
