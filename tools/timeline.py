@@ -75,6 +75,23 @@ def main(path, back=2, min_gap=3.0):
                     j = order2[k]
                     print(f'   {"-->" if k == pos else "   "} q{step[j][3]} {names[j]:60s} {(ends[j] - starts[j]) / 1e3:8.1f} us')
                 break
+    # time the busiest queue (the main stream) sits idle while another queue runs: joins waiting on side-stream kernels
+    main_q = max(qs, key=lambda q: qs[q][1])
+    main_iv = sorted((s_, e) for n, s_, e, q in step if q == main_q)
+    side_iv = sorted((s_, e, n) for n, s_, e, q in step if q != main_q)
+    waits = {}
+    tot_wait = 0.0
+    for (s0, e0), (s1, e1) in zip(main_iv, main_iv[1:]):
+        if s1 - e0 <= 1500:
+            continue
+        for ss, se, n in side_iv:                              # side kernels overlapping the main-queue hole [e0, s1]
+            lo_, hi_ = max(ss, e0), min(se, s1)
+            if hi_ > lo_:
+                waits[short(n)] = waits.get(short(n), 0.0) + (hi_ - lo_) / 1e3
+                tot_wait += (hi_ - lo_) / 1e3
+    print(f'main queue {main_q} idle while another queue runs: {tot_wait:.1f} us in total')
+    for n, t in sorted(waits.items(), key=lambda kv: -kv[1])[:6]:
+        print(f'  waiting on {n:56s} {t:9.1f} us')
     # per-kernel sums in this step
     agg = {}
     for n, s, e, q in step:
