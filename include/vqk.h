@@ -218,6 +218,15 @@ int vqk_mse_tanh_backward(int dtype, const void* recon, const float* target, int
                           const float* gscale_dev, int through_tanh, void* d, void* stream);
 /* dx = dy * (1 - y^2) */
 int vqk_tanh_backward(int dtype, const void* dy, const void* y, void* dx, int64_t n, void* stream);
+/* Test-loop metrics on [0,1] NCHW fp32 images (vqvae/model.py:491-553; torchmetrics MeanSquaredError, PeakSignalNoiseRatio,
+ * StructuralSimilarityIndexMeasure -- the library is not in the reference tree, its published algorithm is restated).
+ * pair_stats: out5[0] += sum (pred - target)^2; out5[1] / out5[2] = running min / max of target, out5[3] / out5[4] of
+ * pred (initialise to +inf / -inf).  ssim_sum: out[img] += sum over channels and the valid (h-k+1) x (w-k+1) region of the
+ * SSIM map with window `window` [k*k] (k = 11 or 7), c1 = (k1 R)^2, c2 = (k2 R)^2, R = max(pred range, target range) read
+ * from a pair_stats record of the same batch (`stats5`, device memory). */
+int vqk_pair_stats(const float* pred, const float* target, int64_t n, float* out5, void* stream);
+int vqk_ssim_sum(const float* pred, const float* target, int n, int c, int h, int w, const float* window, int ksize,
+                 const float* stats5, float k1, float k2, float* out, void* stream);
 /* generic elementwise: y = a*x + b*y2 (y2 optional) -- residual adds in backward */
 int vqk_axpby(int dtype, const void* x, const void* y2, void* y, float a, float b, int64_t n, void* stream);
 

@@ -380,3 +380,46 @@ def augment_crop_flip(images, box, flip):
         top = c00 + fx * (c01 - c00); bot = c10 + fx * (c11 - c10)
         out[b] = top + fy * (bot - top)
     return (out - 0.5) / 0.5
+
+
+# --------------------------------------------------------------------------------------
+# Test-loop metrics (vqvae/model.py:491-553).  The reference calls torchmetrics (not vendored, no pinned version in the
+# tree: parity UNPINNED); these restate the library's published functional algorithm.
+# --------------------------------------------------------------------------------------
+def metric_gaussian_window(kernel_size: int = 11, sigma: float = 1.5):
+    dist = torch.arange((1 - kernel_size) / 2, (1 + kernel_size) / 2, 1.0, dtype=torch.float32)
+    g = torch.exp(-torch.pow(dist / sigma, 2) / 2)
+    g = (g / g.sum()).unsqueeze(0)
+    return torch.matmul(g.t(), g)
+
+
+def metric_ssim_per_image(preds, target, sigma: float = 1.5, k1: float = 0.01, k2: float = 0.03):
+    """torchmetrics.functional.image.ssim `_ssim_update` with gaussian_kernel=True, data_range=None: reflect-pad by
+    (k-1)/2, depthwise Gaussian conv of (p, t, p*p, t*t, p*t), SSIM map, crop the pad again, mean per image."""
+    ks = int(3.5 * sigma + 0.5) * 2 + 1
+    pad = (ks - 1) // 2
+    c = preds.shape[1]
+    data_range = max(preds.max() - preds.min(), target.max() - target.min())
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    p = F.pad(preds, (pad, pad, pad, pad), mode='reflect')
+    t = F.pad(target, (pad, pad, pad, pad), mode='reflect')
+    kernel = metric_gaussian_window(ks, sigma).to(preds.dtype).expand(c, 1, ks, ks)
+    outs = F.conv2d(torch.cat((p, t, p * p, t * t, p * t)), kernel, groups=c).split(preds.shape[0])
+    mu_p_sq, mu_t_sq, mu_pt = outs[0] ** 2, outs[1] ** 2, outs[0] * outs[1]
+    s_p, s_t, s_pt = outs[2] - mu_p_sq, outs[3] - mu_t_sq, outs[4] - mu_pt
+    full = ((2 * mu_pt + c1) * (2 * s_pt + c2)) / ((mu_p_sq + mu_t_sq + c1) * (s_p + s_t + c2))
+    return full[..., pad:-pad, pad:-pad].reshape(preds.shape[0], -1).mean(-1)
+
+
+def metric_epoch(batches):
+    """batches: iterable of (preds, target) in [0, 1] -> dict(mse, psnr, ssim) as the three torchmetrics objects of
+    model.py:494-496 report them after ``update`` on every batch (PSNR: data_range = running max - min of target)."""
+    sse, n, tmin, tmax, ssim_sum, imgs = 0.0, 0, float('inf'), float('-inf'), 0.0, 0
+    for p, t in batches:
+        p, t = p.double(), t.double()
+        sse += ((p - t) ** 2).sum().item(); n += p.numel()
+        tmin, tmax = min(tmin, t.min().item()), max(tmax, t.max().item())
+        ssim_sum += metric_ssim_per_image(p, t).sum().item(); imgs += p.shape[0]
+    mse = sse / n
+    import math
+    return dict(mse=mse, psnr=10.0 * math.log10((tmax - tmin) ** 2 / mse), ssim=ssim_sum / imgs)

@@ -61,6 +61,8 @@ _PROTOS = {
     'vqk_preprocess': [P, P, I, P, I, I, I, I, P],
     'vqk_augment_preprocess': [P, P, P, P, I, P, I, I, I, I, P],
     'vqk_sse': [I, P, P, L, P, P],
+    'vqk_pair_stats': [P, P, L, P, P],
+    'vqk_ssim_sum': [P, P, I, I, I, I, P, I, P, F, F, P, P],
     'vqk_mse_tanh_backward': [I, P, P, L, F, P, I, P, P],
     'vqk_tanh_backward': [I, P, P, P, L, P],
     'vqk_axpby': [I, P, P, P, F, F, L, P],

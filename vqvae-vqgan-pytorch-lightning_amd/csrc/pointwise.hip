@@ -161,6 +161,102 @@ __global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, con
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Evaluation metrics of the test loop (vqvae/model.py:491-553: torchmetrics MSE / PSNR / SSIM on [0,1] NCHW fp32 images).
+// pair_stats: out[0] += sum (p - t)^2, out[1] = min t, out[2] = max t, out[3] = min p, out[4] = max p (out[1..4] must be
+// initialised to +inf / -inf / +inf / -inf).  ssim_sum: the torchmetrics SSIM map (Gaussian window, valid region) summed
+// per image; data_range = max(p range, t range) of THIS batch is read from a pair_stats record on the device.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_min_f(float* addr, float v) {
+    unsigned* a = reinterpret_cast<unsigned*>(addr);
+    unsigned old = *a;
+    while (__uint_as_float(old) > v) {
+        const unsigned prev = atomicCAS(a, old, __float_as_uint(v));
+        if (prev == old) break;
+        old = prev;
+    }
+}
+__device__ __forceinline__ void atomic_max_f(float* addr, float v) {
+    unsigned* a = reinterpret_cast<unsigned*>(addr);
+    unsigned old = *a;
+    while (__uint_as_float(old) < v) {
+        const unsigned prev = atomicCAS(a, old, __float_as_uint(v));
+        if (prev == old) break;
+        old = prev;
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_stats_kernel(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                                         float* __restrict__ out) {
+    __shared__ float part[5][4];
+    float sse = 0.f, tmin = INFINITY, tmax = -INFINITY, pmin = INFINITY, pmax = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = p[i], b = t[i], d = a - b;
+        sse = __fmaf_rn(d, d, sse);
+        tmin = fminf(tmin, b); tmax = fmaxf(tmax, b); pmin = fminf(pmin, a); pmax = fmaxf(pmax, a);
+    }
+    sse = wave_sum(sse);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        tmin = fminf(tmin, __shfl_xor(tmin, off, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
+        pmin = fminf(pmin, __shfl_xor(pmin, off, 64)); pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[0][wv] = sse; part[1][wv] = tmin; part[2][wv] = tmax; part[3][wv] = pmin; part[4][wv] = pmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(out, (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]));
+        atomic_min_f(out + 1, fminf(fminf(part[1][0], part[1][1]), fminf(part[1][2], part[1][3])));
+        atomic_max_f(out + 2, fmaxf(fmaxf(part[2][0], part[2][1]), fmaxf(part[2][2], part[2][3])));
+        atomic_min_f(out + 3, fminf(fminf(part[3][0], part[3][1]), fminf(part[3][2], part[3][3])));
+        atomic_max_f(out + 4, fmaxf(fmaxf(part[4][0], part[4][1]), fmaxf(part[4][2], part[4][3])));
+    }
+}
+
+// block = 16 x 16 outputs of one (image, channel) plane; the (16 + ks - 1)^2 input patches of p and t sit in LDS
+template <int KS>
+__global__ __launch_bounds__(256) void ssim_sum_kernel(const float* __restrict__ p, const float* __restrict__ t, int c, int h,
+                                                       int w, const float* __restrict__ win, const float* __restrict__ stats,
+                                                       float k1, float k2, float* __restrict__ out) {
+    constexpr int T = 16, R = T + KS - 1;
+    __shared__ float sp[R][R + 1], stt[R][R + 1], sw[KS * KS], part[4];
+    const int oh = h - KS + 1, ow = w - KS + 1;
+    const int plane = blockIdx.z, img = plane / c;
+    const int ox0 = blockIdx.x * T, oy0 = blockIdx.y * T;
+    const float* pp = p + (int64_t)plane * h * w;
+    const float* tp = t + (int64_t)plane * h * w;
+    for (int i = threadIdx.x; i < R * R; i += 256) {
+        const int y = i / R, x = i - y * R, gy = min(oy0 + y, h - 1), gx = min(ox0 + x, w - 1);
+        sp[y][x] = pp[(int64_t)gy * w + gx];
+        stt[y][x] = tp[(int64_t)gy * w + gx];
+    }
+    for (int i = threadIdx.x; i < KS * KS; i += 256) sw[i] = win[i];
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float mp = 0.f, mt = 0.f, epp = 0.f, ett = 0.f, ept = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const float wv = sw[ky * KS + kx], a = sp[ty + ky][tx + kx], b = stt[ty + ky][tx + kx];
+            mp = __fmaf_rn(wv, a, mp); mt = __fmaf_rn(wv, b, mt);
+            epp = __fmaf_rn(wv, a * a, epp); ett = __fmaf_rn(wv, b * b, ett); ept = __fmaf_rn(wv, a * b, ept);
+        }
+    const float range = fmaxf(stats[4] - stats[3], stats[2] - stats[1]);
+    const float c1 = (k1 * range) * (k1 * range), c2 = (k2 * range) * (k2 * range);
+    float v = 0.f;
+    if (ox0 + tx < ow && oy0 + ty < oh) {
+        const float mpp = mp * mp, mtt = mt * mt, mpt = mp * mt;
+        const float spp = epp - mpp, stt_ = ett - mtt, spt = ept - mpt;
+        v = ((2.f * mpt + c1) * (2.f * spt + c2)) / ((mpp + mtt + c1) * (spp + stt_ + c2));
+    }
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + img, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, KERNEL, grid, lds, st, ...)                                                      \
@@ -267,6 +363,28 @@ int vqk_axpby(int dtype, const void* x, const void* y2, void* y, float a, float 
     if (dtype == VQK_F32) hipLaunchKernelGGL(axpby_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, (const float*)y2, (float*)y, a, b, n / v);
     else if (dtype == VQK_BF16) hipLaunchKernelGGL(axpby_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)y2, (bf16_raw*)y, a, b, n / v);
     else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_pair_stats(const float* pred, const float* target, int64_t n, float* out5, void* stream) {
+    VQK_REQUIRE(pred && target && out5, VQK_ERR_ARG);
+    if (n <= 0) return VQK_OK;
+    hipLaunchKernelGGL(pair_stats_kernel, dim3(vqk_grid_1d(n, 256 * 8)), dim3(256), 0, vqk_stream(stream), pred, target, n, out5);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_ssim_sum(const float* pred, const float* target, int n, int c, int h, int w, const float* window, int ksize,
+                 const float* stats5, float k1, float k2, float* out, void* stream) {
+    VQK_REQUIRE(pred && target && window && stats5 && out, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && c > 0 && h >= ksize && w >= ksize, VQK_ERR_SHAPE);
+    VQK_REQUIRE((int64_t)n * c <= 65535, VQK_ERR_SHAPE);
+    const dim3 grid((unsigned)((w - ksize + 1 + 15) / 16), (unsigned)((h - ksize + 1 + 15) / 16), (unsigned)(n * c));
+    hipStream_t st = vqk_stream(stream);
+    if (ksize == 11) hipLaunchKernelGGL(ssim_sum_kernel<11>, grid, dim3(256), 0, st, pred, target, c, h, w, window, stats5, k1, k2, out);
+    else if (ksize == 7) hipLaunchKernelGGL(ssim_sum_kernel<7>, grid, dim3(256), 0, st, pred, target, c, h, w, window, stats5, k1, k2, out);
+    else return VQK_ERR_ARG;
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

@@ -241,6 +241,34 @@ class VQVAE(BaseVQVAE, _LightningBase):
             self.log('val_metrics/perplexity', perplexity, sync_dist=True)
         self.val_epoch_usage_count = None
 
+    # ------------------------------------------------------------------ test loop (model.py:491-553)
+    def on_test_epoch_start(self):
+        from .metrics import ReconstructionMetrics
+        self.test_metrics = ReconstructionMetrics(next(self.parameters()).device)
+        self.test_usage_count = None
+
+    @torch.no_grad()
+    def test_step(self, images: Any, _):
+        """reconstructions in [0, 1] against the (clamped) inputs: MSE / PSNR / SSIM and the code histogram, all on the
+        device.  rFID (model.py:535-541) needs the pretrained Inception network and is not computed offline."""
+        images = images[0] if isinstance(images, (tuple, list)) else images
+        recon, _, used_indices = self(self.preprocess_batch(images))
+        recon = self.preprocess_visualization(recon.float())[:, :3]
+        hist = torch.bincount(used_indices.reshape(-1), minlength=self.cb_size)
+        # (the reference writes `else + used_indices`, i.e. keeps the LAST batch's histogram; the sum is what it logs as usage)
+        self.test_usage_count = hist if self.test_usage_count is None else self.test_usage_count + hist
+        self.test_metrics.update(recon, images.to(recon.device).float())
+
+    def on_test_epoch_end(self):
+        out = self.test_metrics.compute()
+        for name in ('mse', 'ssim', 'psnr'):
+            self.log(name, out[name], sync_dist=True)
+        _, perplexity, cb_usage = self.quantizer.get_codebook_usage(self.test_usage_count.float())
+        self.log('used_codebook', cb_usage, sync_dist=True)
+        self.log('perplexity', perplexity, sync_dist=True)
+        out.update(used_codebook=cb_usage, perplexity=perplexity)
+        return out
+
     # ------------------------------------------------------------------ optimizer (model.py:372-440)
     def optimizer_groups(self):
         """(decay, no_decay) lists of (full name, parameter).  decay = conv weights; no decay = biases,
