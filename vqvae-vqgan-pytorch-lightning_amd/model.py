@@ -53,6 +53,15 @@ except Exception:                                       # pragma: no cover - not
         def manual_backward(self, loss):
             loss.backward()
 
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = True, **kwargs):
+            """``pl.LightningModule.load_from_checkpoint`` as vqvae/train.py:106-111 and evaluate.py:49 call it: a
+            Lightning checkpoint is a ``torch.save``d dict with the weights under 'state_dict'"""
+            ckpt = torch.load(checkpoint_path, map_location=map_location or 'cpu', weights_only=False)
+            model = cls(**kwargs)
+            model.load_state_dict(ckpt['state_dict'] if 'state_dict' in ckpt else ckpt, strict=strict)
+            return model
+
 
 class VQVAE(BaseVQVAE, _LightningBase):
 

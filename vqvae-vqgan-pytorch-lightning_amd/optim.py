@@ -74,6 +74,59 @@ class FlatAdamW(torch.optim.Optimizer):
             self.shadow = self.flat_p.to(torch.bfloat16)
         return self.shadow
 
+    # ---- checkpoint format: the same layout ``torch.optim.AdamW.state_dict()`` produces (what Lightning stores under
+    # 'optimizer_states', vqvae/train.py:121-122), so optimizer states move between the reference and this build
+    def _params_in_order(self):
+        return [p for g in self.param_groups for p in g['params']]
+
+    def state_dict(self):
+        state, idx = {}, 0
+        groups = []
+        for g in self.param_groups:
+            ids = []
+            for p in g['params']:
+                off, n = self.offsets[id(p)], p.numel()
+                entry = {'step': torch.tensor(float(self.step_count)),
+                         'exp_avg_sq': self._logical(self.flat_v[off:off + n], p).clone()}
+                entry['exp_avg'] = (self._logical(self.flat_m[off:off + n], p).clone() if self.flat_m is not None
+                                    else torch.zeros_like(p, memory_format=torch.contiguous_format))
+                state[idx] = entry
+                ids.append(idx)
+                idx += 1
+            groups.append({**{k: v for k, v in g.items() if k != 'params'}, 'params': ids})
+        return {'state': state, 'param_groups': groups}
+
+    @staticmethod
+    def _logical(seg, p):
+        """arena segment (conv weights: [O][kh][kw][I] memory) -> contiguous tensor of the parameter's logical shape"""
+        if _is_channels_last_param(p):
+            o, i, kh, kw = p.shape
+            return seg.view(o, kh, kw, i).permute(0, 3, 1, 2).contiguous()
+        return seg.view(p.shape)
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        params = self._params_in_order()
+        if len(sd['state']) not in (0, len(params)):
+            raise ValueError('FlatAdamW.load_state_dict: optimizer state does not match the parameter list')
+        for g, gs in zip(self.param_groups, sd['param_groups']):
+            for k, v in gs.items():
+                if k != 'params':
+                    g[k] = tuple(v) if k == 'betas' else v
+        for idx, p in enumerate(params):
+            st = sd['state'].get(idx, sd['state'].get(str(idx)))
+            if st is None:
+                continue
+            off, n = self.offsets[id(p)], p.numel()
+            for name, buf in (('exp_avg_sq', self.flat_v), ('exp_avg', self.flat_m)):
+                if buf is None or name not in st:
+                    continue
+                src = st[name].to(buf.device, torch.float32)
+                if _is_channels_last_param(p):
+                    src = src.permute(0, 2, 3, 1)
+                buf[off:off + n].copy_(src.reshape(-1))
+            self.step_count = int(float(st['step']))
+
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
 

@@ -110,6 +110,38 @@ class MiniTrainer:
         self.global_step += 1
         return self._static_loss
 
+    # ------------------------------------------------------------------ checkpoints (vqvae/train.py:106-122)
+    def save_checkpoint(self, model, path: str) -> None:
+        """the keys of a Lightning checkpoint that the reference's resume path reads: 'state_dict' (plain contiguous
+        tensors under the LightningModule's own names), 'optimizer_states', 'epoch', 'global_step'"""
+        sd = {k: v.detach().clone(memory_format=torch.contiguous_format).cpu() for k, v in model.state_dict().items()}
+        opts = [{'state': {i: {k: (t.cpu() if torch.is_tensor(t) else t) for k, t in e.items()}
+                           for i, e in o.state_dict()['state'].items()},
+                 'param_groups': o.state_dict()['param_groups']} for o in self.optimizers]
+        torch.save({'epoch': int(getattr(model, 'current_epoch', 0)), 'global_step': int(self.global_step),
+                    'state_dict': sd, 'optimizer_states': opts}, path)
+
+    def load_checkpoint(self, model, path: str, strict: bool = True) -> dict:
+        """resume: weights, optimizer moments / step counts, epoch and global step (call after ``attach``)"""
+        ckpt = torch.load(path, map_location='cpu', weights_only=False)
+        with torch.no_grad():
+            own = model.state_dict()
+            missing = [k for k in own if k not in ckpt['state_dict']]
+            if strict and missing:
+                raise KeyError(f'checkpoint lacks {missing[:4]}...')
+            for k, v in ckpt['state_dict'].items():
+                if k in own:
+                    own[k].copy_(v.to(own[k].device))               # in place: parameters stay views of the flat arena
+        for o, s in zip(self.optimizers, ckpt.get('optimizer_states', [])):
+            o.load_state_dict(s)
+            o.generation += 1
+            ops.repack_owned(o)                                      # cached conv operands follow the loaded weights
+            if o.shadow is not None:
+                o.shadow.copy_(o.flat_p)
+        model.current_epoch = ckpt.get('epoch', 0)
+        self.global_step = ckpt.get('global_step', 0)
+        return ckpt
+
     def fit(self, model, batches: Iterable):
         batches = list(batches)
         if self.num_training_batches is None:
