@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 AE_CONF = dict(channels=128, num_res_blocks=2, channel_multipliers=(1, 2, 2, 4))
 T_CONF = dict(lr=1e-4, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
+HBM_PEAK_BPS = 8.0e12                                   # MI355X_MICROARCH.md: HBM3E peak (about 6.3e12 achievable)
 
 
 def q_conf(qtype: str, k: int):
@@ -181,7 +182,7 @@ def main():
             rec[1] += flops
             rec[2] += e0.elapsed_time(e1) * 1e-3
             rec[3] += nbytes
-        name, (count, flops, secs, nbytes) = max(by_kernel.items(), key=lambda kv: kv[1][2])
+        name, (count, flops, secs, nbytes) = max(((k, v) for k, v in by_kernel.items() if v[1] > 0), key=lambda kv: kv[1][2])
         traffic = None
         try:                                   # HBM bytes per launch from the committed rocprofv3 --pmc passes
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'round1_traffic.json')))
@@ -199,8 +200,12 @@ def main():
                         kernel_time_frac_of_step=round((secs / event_steps) / (elapsed / args.steps), 3),
                         event_pass=('eager steps after the timed region, kernels serialised (no wgrad side stream)' if use_graph
                                     else 'timed region'),
-                        all_kernels={k: dict(launches=v[0] // event_steps, ms_per_step=round(v[2] / event_steps * 1e3, 3),
-                                             tflops=round(v[1] / v[2] / 1e12, 1)) for k, v in by_kernel.items()})
+                        all_kernels={k: (dict(launches=v[0] // event_steps, ms_per_step=round(v[2] / event_steps * 1e3, 3),
+                                              tflops=round(v[1] / v[2] / 1e12, 1)) if v[1] > 0 else
+                                         dict(launches=v[0] // event_steps, ms_per_step=round(v[2] / event_steps * 1e3, 3),
+                                              algorithmic_tbps=round(v[3] / v[2] / 1e12, 2),
+                                              hbm_frac=round(v[3] / v[2] / HBM_PEAK_BPS, 3)))
+                                     for k, v in by_kernel.items()})
 
     vq_kernel = None
     if rank == 0 and not args.no_kernel_events:

@@ -326,8 +326,13 @@ def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool):
     y = torch.empty_like(x, memory_format=_CL)
     stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
     ws = _gn_ws(x.device, n * groups * 2 + n)
-    st = _native.lib().vqk_gn_forward(dcode(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
-                                      stats.data_ptr(), ws.data_ptr(), n, h * wd, c, groups, eps, int(silu), _stream())
+    nb = x.numel() * x.element_size()
+    # algorithmic bytes: x read for the statistics, x read + y written by the apply pass (one read, one write on the
+    # single-kernel path of the small maps)
+    st = _timed('group_norm_fwd (HBM)', 0.0,
+                lambda: _native.lib().vqk_gn_forward(dcode(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                                     stats.data_ptr(), ws.data_ptr(), n, h * wd, c, groups, eps, int(silu),
+                                                     _stream()), (2 if h * wd <= 1024 else 3) * nb)
     _native.check(st, 'gn_forward')
     return y, stats
 
@@ -338,9 +343,13 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
     dw = dw if dw is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     db = db if db is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     red = _gn_ws(x.device, n * groups * 2 + n)
-    st = _native.lib().vqk_gn_backward(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                       dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), red.data_ptr(), n,
-                                       h * wd, c, groups, int(silu), 0, _p(add), _stream())
+    nb = x.numel() * x.element_size()
+    passes = (3 if h * wd <= 512 else 5) + (1 if add is not None else 0)     # x, dy (twice on the two-kernel path), dx, skip
+    st = _timed('group_norm_bwd (HBM)', 0.0,
+                lambda: _native.lib().vqk_gn_backward(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
+                                                      b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                      db.data_ptr(), red.data_ptr(), n, h * wd, c, groups, int(silu), 0,
+                                                      _p(add), _stream()), passes * nb)
     _native.check(st, 'gn_backward')
     return dx, dw, db
 
