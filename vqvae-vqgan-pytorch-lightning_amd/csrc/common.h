@@ -48,6 +48,10 @@ template <> struct Vec16<float> {
         f32x4 v = {o[0], o[1], o[2], o[3]};
         *reinterpret_cast<f32x4*>(p) = v;
     }
+    __device__ static __forceinline__ void store_nt(float* p, const float (&o)[4]) {
+        f32x4 v = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    }
 };
 template <> struct Vec16<bf16_raw> {
     static constexpr int N = 8;
@@ -61,6 +65,13 @@ template <> struct Vec16<bf16_raw> {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = f32_to_bf16(o[i]);
         *reinterpret_cast<u16x8*>(p) = v;
+    }
+    // streaming store (nt): the line is not kept in L2 / Infinity Cache on its way to HBM
+    __device__ static __forceinline__ void store_nt(bf16_raw* p, const float (&o)[8]) {
+        u16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = f32_to_bf16(o[i]);
+        __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(p));
     }
 };
 
