@@ -44,6 +44,10 @@ template <> struct Vec16<float> {
         f32x4 v = *reinterpret_cast<const f32x4*>(p);
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
     }
+    __device__ static __forceinline__ void load_nt(const float* p, float (&o)[4]) {
+        f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
     __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
         f32x4 v = {o[0], o[1], o[2], o[3]};
         *reinterpret_cast<f32x4*>(p) = v;
@@ -57,6 +61,11 @@ template <> struct Vec16<bf16_raw> {
     static constexpr int N = 8;
     __device__ static __forceinline__ void load(const bf16_raw* p, float (&o)[8]) {
         u16x8 v = *reinterpret_cast<const u16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(v[i]);
+    }
+    __device__ static __forceinline__ void load_nt(const bf16_raw* p, float (&o)[8]) {
+        u16x8 v = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p));
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(v[i]);
     }

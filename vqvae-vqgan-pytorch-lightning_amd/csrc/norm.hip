@@ -247,7 +247,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-template <typename T>
+// NT: x and dy are read for the last time here; for tensors beyond the Infinity Cache (>= 192 MB) nontemporal loads keep
+// them from evicting what the next kernel reads (backward pair 530 -> 485 us at 128 ch @256^2, 272 -> 248 us at 256 ch
+// @128^2); for cache-sized tensors they are slower (127 -> 137 us at 128 ch @128^2), so the host picks.
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const T* __restrict__ dy, T* __restrict__ dx,
@@ -273,8 +276,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll GN_UNROLL
     for (int64_t p = p0 + prow; p < p1; p += pstep) {
         float xv[V], gv[V], ov[V];
-        Vec16<T>::load(x + off + p * c, xv);
-        Vec16<T>::load(dy + off + p * c, gv);
+        if (NT) { Vec16<T>::load_nt(x + off + p * c, xv); Vec16<T>::load_nt(dy + off + p * c, gv); }
+        else { Vec16<T>::load(x + off + p * c, xv); Vec16<T>::load(dy + off + p * c, gv); }
         if (accumulate) Vec16<T>::load((add ? add : dx) + off + p * c, ov);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -638,12 +641,15 @@ int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w
     const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
+    const bool nt = (int64_t)n * hw * c * (dtype == VQK_F32 ? 4 : 2) >= ((int64_t)192 << 20);
     if (dtype == VQK_F32) {
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, rppb);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
+        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
+        else hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
     } else {
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, dw, db, red, hw, c, groups, silu, rppb);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
+        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_raw, true>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
+        else hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_raw, false>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
     }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
