@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(const bf16_raw*
                 const int o = it * 1024 + lane * 16;
                 const int pr = o / (NJ * 64), pb = o - pr * (NJ * 64);
                 const u32x4 v = *reinterpret_cast<const u32x4*>(lds + pr * RS + pb);
-                *reinterpret_cast<u32x4*>(ybase + o) = v;
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(ybase + o));   // whole lines, written once: 146 -> 105 us
             }
         } else {
 #pragma unroll
