@@ -134,8 +134,8 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = not args.no_graph
-    if args.gan or (world > 1 and args.quantizer == 'ema'):
-        use_graph = False      # the EMA statistics all-reduce sits inside forward: keep collectives out of graph capture
+    if args.gan:
+        use_graph = False      # manual optimisation with two optimizers: eager (the step is kernel-bound)
     step_fn = trainer.train_batch
     if use_graph:
         try:

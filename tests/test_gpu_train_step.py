@@ -152,12 +152,15 @@ def test_multi_step_loss_decreases():
     assert loss.item() < first
 
 
-def test_graph_replay_matches_eager():
-    """hipGraph replay of fwd+bwd (MiniTrainer.capture) walks the same trajectory as eager launches"""
-    qc = dict(num_embeddings=64, embedding_dim=16, reinit_every_n_epochs=None, type='standard', params=QP['standard'])
+@pytest.mark.parametrize('qtype', ['standard', 'ema'])
+def test_graph_replay_matches_eager(qtype):
+    """hipGraph replay of fwd+bwd (MiniTrainer.capture) walks the same trajectory as eager launches.  EMA: the graph path
+    defers the statistics all-reduce + update kernel to after the replay (EMAVectorQuantizer.finish_update) -- the
+    codebook / EMA buffers must follow the inline update of the eager path."""
+    qc = dict(num_embeddings=64, embedding_dim=16, reinit_every_n_epochs=None, type=qtype, params=QP[qtype])
     tc = dict(TC, lr=1e-3)
     images = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(DEV)
-    losses = {}
+    losses, state = {}, {}
     for mode in ('eager', 'graph'):
         torch.manual_seed(0)
         m = model_mod.VQVAE(32, AE, qc, None, tc).to(DEV).train()
@@ -167,6 +170,7 @@ def test_graph_replay_matches_eager():
         out = []
         if mode == 'graph':
             tr.capture(m, images, warmup=2)
+            assert getattr(m.quantizer, 'defer_update', True)
             for i in range(4):
                 out.append(tr.train_batch_graphed(m, images, 2 + i).item())
         else:
@@ -174,4 +178,8 @@ def test_graph_replay_matches_eager():
                 out.append(tr.train_batch(m, images, i).item())
             out = out[2:]
         losses[mode] = out
+        state[mode] = {k: v.detach().float().cpu().clone() for k, v in m.quantizer.state_dict().items()}
     np.testing.assert_allclose(losses['graph'], losses['eager'], rtol=2e-3)
+    if qtype == 'ema':
+        for k in ('ema_count', 'ema_weight', 'codebook.weight'):
+            np.testing.assert_allclose(state['graph'][k].numpy(), state['eager'][k].numpy(), rtol=2e-3, atol=1e-5)

@@ -47,6 +47,13 @@ class EMAVectorQuantizer(BaseVectorQuantizer):
                                                                                                 1 / num_embeddings))
         self.decay = decay
         self.epsilon = epsilon
+        # The update only changes what the NEXT step looks up (this step's quantized vectors are already gathered and the
+        # backward uses the saved ones), so a trainer may take it out of the forward: with ``defer_update`` the forward
+        # leaves this rank's packed statistics in ``pending_stats`` and ``finish_update()`` -- the all-reduce over ranks
+        # and the update kernel -- runs after the step's captured graph, next to the gradient all-reduce.
+        self.defer_update = False
+        self.pending_stats = None
+        self._pending_batch = 0
 
     def forward(self, x: torch.Tensor):
         q, idx, loss, hist = ops.VQLookupFn.apply(x, self.codebook.weight, self.commitment_cost, False, 0,
@@ -54,12 +61,28 @@ class EMAVectorQuantizer(BaseVectorQuantizer):
         self.last_hist = hist
         if self.training:
             with torch.no_grad():
-                world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-                reduce_fn = (lambda buf: dist.all_reduce(buf, op=dist.ReduceOp.SUM)) if world > 1 else None
                 z = ops.nhwc(x.detach().to(torch.float32))
-                ops.ema_update(_flat_view(z), idx.reshape(-1), self.ema_count, self.ema_weight, self.codebook.weight.data,
-                               self.decay, self.epsilon, float(x.shape[0] * world), reduce_fn)
+                if self.defer_update:
+                    self.pending_stats = ops.ema_stats(_flat_view(z), idx.reshape(-1), self.num_embeddings,
+                                                       out=self.pending_stats)
+                    self._pending_batch = int(x.shape[0])
+                else:
+                    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+                    reduce_fn = (lambda buf: dist.all_reduce(buf, op=dist.ReduceOp.SUM)) if world > 1 else None
+                    ops.ema_update(_flat_view(z), idx.reshape(-1), self.ema_count, self.ema_weight,
+                                   self.codebook.weight.data, self.decay, self.epsilon, float(x.shape[0] * world), reduce_fn)
         return q, idx, loss
+
+    @torch.no_grad()
+    def finish_update(self, force_collective: bool = False) -> None:
+        """second half of a deferred update: ONE all-reduce of [counts | dw] over the ranks, then the EMA kernel"""
+        if self.pending_stats is None:
+            return
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world > 1 or (force_collective and dist.is_available() and dist.is_initialized()):
+            dist.all_reduce(self.pending_stats, op=dist.ReduceOp.SUM)
+        ops.ema_apply(self.pending_stats, self.ema_count, self.ema_weight, self.codebook.weight.data, self.decay,
+                      self.epsilon, float(self._pending_batch * world))
 
     @torch.no_grad()
     def vec_to_codes(self, x: torch.Tensor) -> torch.Tensor:

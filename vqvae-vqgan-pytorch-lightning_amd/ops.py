@@ -948,20 +948,32 @@ class GumbelVQFn(torch.autograd.Function):
         return dlogits, de, None, None, None, None, None
 
 
+def ema_stats(flat_z, idx, k: int, out=None) -> torch.Tensor:
+    """packed [counts(K) | dw(K*D)] of this rank's batch (vector_quantizers.py:159-163); ``out``: a persistent buffer
+    (zeroed here) so that a captured graph always writes the same memory"""
+    n, d = flat_z.shape
+    buf = out if out is not None else torch.empty(k + k * d, dtype=torch.float32, device=flat_z.device)
+    buf.zero_()
+    _native.check(_native.lib().vqk_ema_stats_f32(flat_z.data_ptr(), idx.data_ptr(), n, k, d, buf.data_ptr(),
+                                                  buf[k:].data_ptr(), _stream()), 'ema_stats')
+    return buf
+
+
+def ema_apply(buf, ema_count, ema_weight, codebook, decay: float, eps: float, batch: float) -> None:
+    """EMA update in place from the (all-reduced) packed statistics (vector_quantizers.py:164-169)"""
+    k, d = codebook.shape
+    _native.check(_native.lib().vqk_ema_update_f32(ema_count.data_ptr(), ema_weight.data_ptr(), codebook.data_ptr(),
+                                                   buf.data_ptr(), buf[k:].data_ptr(), k, d, decay, eps, batch, _stream()),
+                  'ema_update')
+
+
 def ema_update(flat_z, idx, ema_count, ema_weight, codebook, decay: float, eps: float, batch: float, reduce_fn=None):
     """EMA statistics + update in place (vector_quantizers.py:159-169).  ``reduce_fn(buf)`` sums the
     packed [counts | dw] buffer over ranks (one small all-reduce)."""
-    n, d = flat_z.shape
-    k = codebook.shape[0]
-    buf = torch.zeros(k + k * d, dtype=torch.float32, device=flat_z.device)
-    counts, dw = buf[:k], buf[k:]
-    lib = _native.lib()
-    _native.check(lib.vqk_ema_stats_f32(flat_z.data_ptr(), idx.data_ptr(), n, k, d, counts.data_ptr(), dw.data_ptr(),
-                                        _stream()), 'ema_stats')
+    buf = ema_stats(flat_z, idx, codebook.shape[0])
     if reduce_fn is not None:
         reduce_fn(buf)
-    _native.check(lib.vqk_ema_update_f32(ema_count.data_ptr(), ema_weight.data_ptr(), codebook.data_ptr(),
-                                         counts.data_ptr(), dw.data_ptr(), k, d, decay, eps, batch, _stream()), 'ema_update')
+    ema_apply(buf, ema_count, ema_weight, codebook, decay, eps, batch)
 
 
 # ------------------------------------------------------------------------------------------------------

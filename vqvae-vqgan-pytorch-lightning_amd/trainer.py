@@ -58,10 +58,17 @@ class MiniTrainer:
         opt.zero_grad()
         loss = model.training_step(batch, batch_index)
         loss.backward()
+        self._finish_deferred(model, opt)
         opt.all_reduce_grads()
         opt.step()
         self.global_step += 1
         return loss
+
+    @staticmethod
+    def _finish_deferred(model, opt):
+        q = getattr(model, 'quantizer', None)
+        if getattr(q, 'defer_update', False):                       # EMA statistics left pending by the forward
+            q.finish_update(force_collective=opt.force_collective)
 
     # ------------------------------------------------------------------ hipGraph replay of forward + backward
     def capture(self, model, example_batch, warmup: int = 3):
@@ -79,6 +86,11 @@ class MiniTrainer:
                 self._eager_step(model, self._static_in, i)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # EMA quantizer: its statistics all-reduce must not sit inside the captured graph -- the update is deferred and
+        # finished (collective + update kernel) after each replay
+        self._deferred_q = getattr(model, 'quantizer', None) if hasattr(getattr(model, 'quantizer', None), 'defer_update') else None
+        if self._deferred_q is not None:
+            self._deferred_q.defer_update = True
         self._graph = torch.cuda.CUDAGraph()
         # thread_local: the autograd worker thread and (multi-GPU) the RCCL watchdog thread issue runtime calls
         # of their own while this thread captures
@@ -94,6 +106,7 @@ class MiniTrainer:
         opt.zero_grad()
         loss = model.training_step(batch, batch_index)
         loss.backward()
+        self._finish_deferred(model, opt)
         opt.all_reduce_grads()
         opt.step()
         return loss
@@ -105,6 +118,7 @@ class MiniTrainer:
             self._static_in.copy_(batch, non_blocking=True)
         ops.repack_owned(None)               # operands of weights changed outside the optimizer (normally none)
         self._graph.replay()
+        self._finish_deferred(model, opt)
         opt.all_reduce_grads()
         opt.step()
         self.global_step += 1
