@@ -423,3 +423,59 @@ def metric_epoch(batches):
     mse = sse / n
     import math
     return dict(mse=mse, psnr=10.0 * math.log10((tmax - tmin) ** 2 / mse), ssim=ssim_sum / imgs)
+
+
+# --------------------------------------------------------------------------------------
+# Entropy quantizer at sizes where [N, K] does not fit comfortably: the same arithmetic as ``vq_entropy``
+# (vector_quantizers.py:290-356), evaluated in row chunks with the closed-form backward of SURVEY Appendix B.
+# Pinned against the reference's own output at K=8192, N=4096 (tests/golden/full_entropy.npz).
+# --------------------------------------------------------------------------------------
+def vq_entropy_chunked(z, codebook, beta: float, ratio: float, temperature: float, dq=None, chunk: int = 2048):
+    """-> dict(idx, loss, dz, de): loss = (1+beta) mse(q, z) + ratio (mean_i H(p_i) - H(mean_i p_i)), p = softmax(-d/T),
+    d = (|z|^2 - 2 z.e) + |e|^2 (:337-340).  dz / de are d(loss)/dz (+ the straight-through ``dq``) and d(loss)/dE.
+    Two sweeps over row chunks: (A) argmin, p-bar, sum_i H(p_i); (B) the cotangent of the distances."""
+    fz = _flat(z).contiguous()
+    n, d_ = fz.shape
+    k = codebook.shape[0]
+    e2 = torch.sum(codebook.t() ** 2, dim=0, keepdim=True)
+    idx = torch.empty(n, dtype=torch.int64)
+    pbar = torch.zeros(k, dtype=torch.float64)
+    hsum = 0.0
+    for s in range(0, n, chunk):
+        c = fz[s:s + chunk]
+        dist = torch.sum(c ** 2, dim=1, keepdim=True) - 2 * torch.matmul(c, codebook.t()) + e2
+        idx[s:s + chunk] = torch.argmin(dist, dim=1)
+        a = -dist / temperature
+        logp = F.log_softmax(a, dim=-1)
+        p = logp.exp()
+        pbar += p.double().sum(0)
+        hsum += -(p * logp).double().sum().item()
+    pbar = (pbar / n).float()
+    q = codebook[idx]
+    mse = torch.mean((q - fz) ** 2)
+    avg_entropy = -torch.sum(pbar * torch.log(pbar + 1e-5))
+    loss = (1.0 + beta) * mse + ratio * (hsum / n - avg_entropy)
+    # backward: d loss / d a_ik = ratio/N * p_ik * (-(l_ik + h_i) - (g_k - gbar_i)),  g_k = -(log(pbar+1e-5) + pbar/(pbar+1e-5))
+    g = -(torch.log(pbar + 1e-5) + pbar / (pbar + 1e-5))
+    dz = torch.zeros_like(fz)
+    de = torch.zeros_like(codebook)
+    nd = float(n * d_)
+    for s in range(0, n, chunk):
+        c = fz[s:s + chunk]
+        dist = torch.sum(c ** 2, dim=1, keepdim=True) - 2 * torch.matmul(c, codebook.t()) + e2
+        logp = F.log_softmax(-dist / temperature, dim=-1)
+        p = logp.exp()
+        h = -(p * logp).sum(1, keepdim=True)
+        gbar = (p * g).sum(1, keepdim=True)
+        da = (ratio / n) * p * (-(logp + h) - (g - gbar))
+        dd = -da / temperature
+        # d = |z|^2 - 2 z.e + |e|^2:  dz += 2 z rowsum(dd) - 2 dd @ E ; dE += -2 dd^T @ z + 2 E colsum(dd)
+        dz[s:s + chunk] += 2 * c * dd.sum(1, keepdim=True) - 2 * dd @ codebook
+        de += -2 * dd.t() @ c + 2 * codebook * dd.sum(0).unsqueeze(1)
+    qi = q
+    dz += beta * 2 * (fz - qi) / nd
+    de.index_add_(0, idx, 2 * (qi - fz) / nd)
+    dz = _unflat(dz, z.shape)
+    if dq is not None:
+        dz = dz + dq
+    return dict(idx=idx.reshape(z.shape[0], -1), loss=loss, dz=dz, de=de)

@@ -1,0 +1,261 @@
+"""Every BASELINE.json config at its REAL quantizer / discriminator / architecture size, HIP path vs what the reference's
+own modules produced on the same seed-regenerated inputs and weights (tests/golden/full_*.npz, model_gan_step.npz;
+generators: tests/golden/make_golden_full.py, make_golden_model.py).  fp32 parity mode; indices bit-exact.
+
+  config 1: standard_vqvae.yaml architecture at 64x64, bs=8: the whole train step + one AdamW step
+  config 3: EMA K=1024, D=256, N=8192: one training forward, EMA buffers after
+  config 4: Gumbel K=1024 N=4096 with injected noise; Discriminator(256) logits / gradients / R1;
+            the real VQ-GAN ``training_step`` (gumbel_vqgan.yaml at 64x64, both optimizers) fixed and adaptive g_weight
+  config 5: entropy K=8192, N=4096 fwd + bwd; N=16384 (BASELINE size) against the chunked oracle
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqvae_oracle as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+import seeded as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+vqm = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.vector_quantizers')
+disc = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.loss.discriminator')
+model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
+trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
+DEV = 'cuda:0'
+ONE = lambda: torch.ones((), device=DEV)
+TC = dict(lr=1e-4, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(a.detach().float().cpu().numpy(), b, rtol=rtol, atol=atol)
+
+
+def test_config3_ema_full_size(golden):
+    g, i = golden('full_ema'), S.ema_full_inputs()
+    q = vqm.EMAVectorQuantizer(1024, 256, i['beta'], i['decay'], i['eps']).to(DEV)
+    with torch.no_grad():
+        q.codebook.weight.copy_(dev(i['e']))
+        q.ema_count.copy_(dev(i['ema_count']))
+        q.ema_weight.copy_(dev(i['ema_weight']))
+    q.train()
+    z = dev(i['z']).requires_grad_(True)
+    qz, idx, loss = q(z)
+    assert np.array_equal(idx.cpu().numpy(), g['idx'].astype(np.int64))                       # bit-exact, all 8192 rows
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-5)
+    close(q.ema_count, g['count_after'], 1e-5, 1e-7)
+    close(q.ema_weight[::16], g['weight_after_rows'], 1e-5, 1e-6)
+    close(q.codebook.weight[::16], g['cb_after_rows'], 1e-4, 1e-6)
+    S.check_summary(q.ema_weight, g['weight_after_sum'], 'ema.weight', 1e-5)
+    S.check_summary(q.codebook.weight, g['cb_after_sum'], 'ema.cb', 1e-5)
+    S.check_summary(qz, g['q_sum'], 'ema.q', 1e-5)
+    dz, = torch.autograd.grad([qz, loss], [z], [dev(i['dq']), ONE()])
+    S.check_summary(dz, g['dz_sum'], 'ema.dz', 1e-5)
+
+
+@pytest.mark.parametrize('tag,temp', [('t001', 0.01), ('t1', 1.0)])
+def test_config5_entropy_k8192(golden, tag, temp):
+    g, i = golden('full_entropy'), S.entropy_full_inputs(temp)
+    q = vqm.EntropyVectorQuantizer(8192, 256, i['ratio'], temp, 'softmax', i['beta']).to(DEV)
+    with torch.no_grad():
+        q.codebook.weight.copy_(dev(i['e']))
+    z = dev(i['z']).requires_grad_(True)
+    qz, idx, loss = q(z)
+    assert np.array_equal(idx.cpu().numpy(), g[f'{tag}.idx'].astype(np.int64))
+    assert np.array_equal(q.vec_to_codes(z.detach()).cpu().numpy(), g[f'{tag}.idx'].astype(np.int64))
+    np.testing.assert_allclose(loss.item(), g[f'{tag}.loss'], rtol=2e-5)
+    dz, de = torch.autograd.grad([qz, loss], [z, q.codebook.weight], [dev(i['dq']), ONE()])
+    S.check_summary(dz, g[f'{tag}.dz_sum'], f'ent.{tag}.dz', 2e-4)
+    S.check_summary(de, g[f'{tag}.de_sum'], f'ent.{tag}.de', 2e-4)
+    close(dz[:, :, ::8, ::8], g[f'{tag}.dz_rows'], 5e-3, 1e-7)
+    close(de[::64], g[f'{tag}.de_rows'], 5e-3, 1e-8)
+
+
+def test_config5_entropy_baseline_size_vs_chunked_oracle():
+    """N = 16,384 (bs=64), K = 8192: loss, indices and both gradients against the chunked CPU oracle (which
+    test_oracle_full.py pins to the reference at N = 4096); the cotangent of the distances sums to zero per row, so
+    dz carries no |z|^2 term beyond the oracle's"""
+    i = S.entropy_full_inputs(0.05, n_img=64)
+    r = O.vq_entropy_chunked(i['z'], i['e'], i['beta'], i['ratio'], 0.05, dq=i['dq'], chunk=2048)
+    q = vqm.EntropyVectorQuantizer(8192, 256, i['ratio'], 0.05, 'softmax', i['beta']).to(DEV)
+    with torch.no_grad():
+        q.codebook.weight.copy_(dev(i['e']))
+    z = dev(i['z']).requires_grad_(True)
+    qz, idx, loss = q(z)
+    assert np.array_equal(idx.cpu().numpy(), r['idx'].numpy())
+    np.testing.assert_allclose(loss.item(), r['loss'].item(), rtol=2e-5)
+    dz, de = torch.autograd.grad([qz, loss], [z, q.codebook.weight], [dev(i['dq']), ONE()])
+    for got, ref, name in ((dz, r['dz'], 'dz'), (de, r['de'], 'de')):
+        err = ((got.float().cpu().double() - ref.double()).norm() / ref.double().norm()).item()
+        assert err < 5e-4, (name, err)
+
+
+def test_config4_gumbel_k1024(golden):
+    g, i = golden('full_gumbel'), S.gumbel_full_inputs()
+    q = vqm.GumbelVectorQuantizer(1024, 256, False, i['tau'], i['kl_cost']).to(DEV)
+    with torch.no_grad():
+        q.codebook.weight.copy_(dev(i['e']))
+        q.x_to_logits.weight.copy_(dev(i['w']))
+        q.x_to_logits.bias.copy_(dev(i['b']))
+    q.train()
+    x = dev(i['x']).requires_grad_(True)
+    qz, idx, loss = q(x, exp_noise=dev(i['noise']))
+    # argmax of softmax((logits + g) / tau): logits come from a K=1024 contraction, so a near-tie may flip
+    mism = int((idx.cpu().numpy() != g['idx'].astype(np.int64)).sum())
+    assert mism <= 2, mism
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-4)
+    close(qz[:, :, ::8, ::8], g['q_rows'], 1e-3, 1e-7)
+    S.check_summary(qz, g['q_sum'], 'gum.q', 1e-4)
+    gr = torch.autograd.grad([qz, loss], [x, q.codebook.weight, q.x_to_logits.weight, q.x_to_logits.bias],
+                             [dev(i['dq']), ONE()])
+    for t, name in zip(gr[:3], ('dx', 'de', 'dw')):
+        S.check_summary(t, g[f'{name}_sum'], f'gum.{name}', 2e-4)
+    close(gr[1][::32], g['de_rows'], 2e-3, 1e-6)
+    close(gr[3], g['db'], 2e-3, 1e-8)
+
+
+@pytest.fixture(scope='module')
+def disc256():
+    i = S.disc256_inputs()
+    d = disc.Discriminator(256)
+    S.fill_named(list(d.named_parameters()), i['seed'], 'discriminator')
+    return d.to(DEV), i
+
+
+def test_config4_discriminator_256(golden, disc256):
+    """Discriminator(256) (28.9 M parameters) on [4,3,256,256]: logits, input gradient and every parameter gradient"""
+    g = golden('full_disc256')
+    d, i = disc256
+    assert sum(p.numel() for p in d.parameters()) == int(g['n_params'])
+    x = dev(i['x']).requires_grad_(True)
+    logits = d(x)
+    close(logits, g['logits'], 2e-4, 2e-5)
+    named = list(d.named_parameters())
+    grads = torch.autograd.grad((logits * dev(i['r'])).sum(), [x] + [p for _, p in named])
+    S.check_summary(grads[0], g['dx_sum'], 'd256.dx', 1e-3)
+    close(grads[0][:, :, ::16, ::16], g['dx_rows'], 1e-2, 1e-6 * float(g['dx_sum'][1]))
+    for (n, _), gr in zip(named, grads[1:]):
+        S.check_summary(gr, g['g.' + n], 'd256.g.' + n, 1e-3)
+
+
+def test_config4_discriminator_256_r1(golden, disc256):
+    """R1 at the real size: value, the image gradient it is built from, d(R1)/d(theta) for every parameter"""
+    g = golden('full_disc256')
+    d, i = disc256
+    x = dev(i['x']).requires_grad_(True)
+    logits = d(x)
+    gimg, = torch.autograd.grad(logits.sum(), x, create_graph=True)
+    S.check_summary(gimg, g['r1.gimg_sum'], 'd256.gimg', 1e-3)
+    r1 = 10.0 * ops.SumSqFn.apply(gimg) / gimg.shape[0]
+    np.testing.assert_allclose(r1.item(), g['r1.value'], rtol=2e-3)
+    named = [(n, p) for n, p in d.named_parameters() if 'r1g.' + n in g]
+    grads = torch.autograd.grad(r1, [p for _, p in named], allow_unused=True)
+    for (n, _), gr in zip(named, grads):
+        assert gr is not None, n
+        S.check_summary(gr, g['r1g.' + n], 'd256.r1g.' + n, 5e-3)
+
+
+def test_config1_standard_architecture_64(golden):
+    """standard_vqvae.yaml (channels 128, mult (1,2,2,4), 2 ResBlocks, K=1024, D=256) at 64x64, bs=8: indices, losses, all
+    144 parameter gradients and the parameters after one AdamW step, against the reference modules' own results"""
+    g, i = golden('full_config1'), S.config1_inputs()
+    qc = dict(num_embeddings=1024, embedding_dim=256, reinit_every_n_epochs=None, type='standard',
+              params=dict(commitment_cost=0.25))
+    m = model_mod.VQVAE(64, S.AE_FULL, qc, None, TC)
+    S.fill_named(list(m.named_parameters()), i['seed'])
+    with torch.no_grad():
+        m.quantizer.codebook.weight.copy_(i['codebook'])
+    m = m.to(DEV).train()
+    tr = trainer_mod.MiniTrainer(num_training_batches=1)
+    opt = tr.attach(m)[0]
+    images = dev(i['images'])
+    recon, q_loss, idx = m(m.preprocess_batch(images))
+    mism = int((idx.cpu().numpy() != g['idx'].astype(np.int64)).sum())
+    assert mism == 0, mism
+    np.testing.assert_allclose(q_loss.item(), g['q_loss'], rtol=1e-4)
+    S.check_summary(recon.float(), g['recon_sum'], 'c1.recon', 2e-4)
+    close(recon[:, :, ::8, ::8], g['recon_rows'], 2e-3, 2e-5)
+    opt.zero_grad()
+    loss = m.training_step(images, 0)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-4)
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in g:
+        if k.startswith('g.'):
+            worst = max(worst, S.check_summary(named[k[2:]].grad, g[k], 'c1.' + k, 1e-3))
+    opt.step()
+    torch.cuda.synchronize()
+    for k in g:
+        if k.startswith('p.'):
+            # beta1 = 0: the first step moves every element by ~lr * sign(g); a sign flip where |g| ~ 1e-8 moves it 2 lr
+            ref = g[k]
+            got = S.summary(named[k[2:]], 'c1.' + k)
+            n = named[k[2:]].numel()
+            assert np.abs(got[2:] - ref[2:]).max() <= 3.0 * (2e-4 * np.sqrt(n) * 0.02 + 1e-5 * ref[1]), k
+    print(f'config 1: worst gradient projection error {worst:.2e}')
+
+
+@pytest.mark.parametrize('tag,adaptive,gw', [('fixed', False, 0.1), ('adaptive', True, 0.8)])
+def test_config4_vqgan_training_step_vs_reference(golden, tag, adaptive, gw):
+    """A13/A16 GAN branch: the reference's REAL ``VQVAE.training_step`` (model.py:244-264; loss.py:80-164) on
+    gumbel_vqgan.yaml at 64x64, bs=4, start_epoch 0, R1 every step, injected Gumbel noise, seeded weights: all logged
+    scalars, g_weight, R1, the gradients both backward passes leave behind and the parameters after both optimizer
+    steps.  ``optimizer_param_set='reference'``: the reference's AE optimizer holds 93 of its 146 tensors."""
+    g = golden('model_gan_step')
+    seed, size, bs = 7007, 64, 4
+    gen = torch.Generator().manual_seed(seed)
+    images = torch.rand(bs, 3, size, size, generator=gen)
+    noise = torch.empty(bs, 1024, size // 16, size // 16).exponential_(generator=gen)
+    assert np.array_equal(images.numpy(), g['images'])
+    qc = dict(num_embeddings=1024, embedding_dim=256, reinit_every_n_epochs=None, type='gumbel',
+              params=dict(straight_through=False, temp=1.0, kl_cost=0.00859375, kl_warmup_epochs=0.48,
+                          temp_decay_epochs=15, temp_final=0.0625))
+    lc = dict(l1_weight=0.8, l2_weight=0.2, perc_weight=1.0,
+              adversarial_params=dict(start_epoch=0, loss_type='non-saturating', g_weight=gw, use_adaptive=adaptive,
+                                      r1_reg_weight=10., r1_reg_every=1))
+    tc = dict(TC, decay_epochs=250)
+    m = model_mod.VQVAE(size, S.AE_FULL, qc, lc, tc, optimizer_param_set='reference')
+    S.fill_vqgan(m, seed)
+    m = m.to(DEV).train()
+    tr = trainer_mod.MiniTrainer(num_training_batches=10)
+    opts = tr.attach(m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert [names[id(p)] for grp in opts[0].param_groups for p in grp['params']] == g[f'{tag}.ae_opt'].tolist()
+    noise_dev = dev(noise)
+    orig = torch.Tensor.exponential_
+    torch.Tensor.exponential_ = lambda self, *a, **k: self.copy_(noise_dev)
+    try:
+        m.training_step(dev(images), 0)
+    finally:
+        torch.Tensor.exponential_ = orig
+    torch.cuda.synchronize()
+    log = {k: float(v) for k, v in m.logged.items()}
+    for k in ('train/loss', 'train/l1_loss', 'train/l2_loss', 'train/quant_loss', 'train/perc_loss', 'train/gen_loss',
+              'train/disc_loss', 'g_weight', 'r1_penalty'):
+        np.testing.assert_allclose(log[k], float(g[f'{tag}.log.{k}']), rtol=2e-3, err_msg=k)
+    named = dict(m.named_parameters())
+    checked = 0
+    for k in g:
+        if k.startswith(f'{tag}.grad.'):
+            n = k[len(tag) + 6:]
+            p = named[n]
+            assert p.grad is not None, n
+            S.check_summary(p.grad, g[k], f'gan.{k}', 5e-3)
+            checked += 1
+    assert checked >= 140, checked
+    for k in g:
+        if k.startswith(f'{tag}.after.'):
+            n = k[len(tag) + 7:]
+            ref, got = g[k], S.summary(named[n], f'gan.{k}')
+            assert np.abs(got[2:] - ref[2:]).max() <= 3.0 * (2e-4 * np.sqrt(named[n].numel()) * 0.02 + 1e-5 * ref[1]), n

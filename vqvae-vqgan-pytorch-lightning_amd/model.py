@@ -201,6 +201,8 @@ class VQVAE(BaseVQVAE, _LightningBase):
             self.manual_backward(loss)
             disc_opt.all_reduce_grads()
             disc_opt.step()
+        for name, value in (('g_weight', g_weight), ('r1_penalty', r1_penalty)):          # model.py:277-278
+            self.log(name, value.detach() if torch.is_tensor(value) else value, sync_dist=True, on_step=False, on_epoch=True)
         for name, value in (('train/loss', ae_loss), ('train/l1_loss', l1_loss), ('train/l2_loss', l2_loss),
                             ('train/quant_loss', q_loss), ('train/perc_loss', p_loss), ('train/gen_loss', g_loss),
                             ('train/disc_loss', d_loss)):
@@ -280,21 +282,24 @@ class VQVAE(BaseVQVAE, _LightningBase):
 
     # ------------------------------------------------------------------ optimizer (model.py:372-440)
     def optimizer_groups(self):
-        """(decay, no_decay) lists of (full name, parameter).  decay = conv weights; no decay = biases,
-        GroupNorm affine, codebook (model.py:388-396, :424-425)."""
-        decay, no_decay = [], []
+        """(decay, no_decay) lists of (full name, parameter) IN OPTIMIZER ORDER.  decay = conv weights; no decay =
+        biases, GroupNorm affine, codebook (model.py:388-396, :424-425).  The reference keys its sets by the name
+        relative to encoder / decoder / quantizer and sorts by that key (model.py:384-410): with
+        ``optimizer_param_set='reference'`` the later sub-module shadows an earlier one of the same relative name (91 of
+        144 tensors survive) and the order is the sorted relative names -- what a reference 'optimizer_states' checkpoint
+        is indexed by.  'all' keeps every tensor, sorted by full name."""
         seen = {}
         for prefix, sub in (('encoder', self.encoder), ('decoder', self.decoder), ('quantizer', self.quantizer)):
             for mn, m in sub.named_modules():
                 for pn, p in m.named_parameters(recurse=False):
-                    if not p.requires_grad:
-                        continue
+                    if not p.requires_grad and self.optimizer_param_set != 'reference':
+                        continue              # (the reference hands the frozen EMA codebook to AdamW too: it never gets a grad)
                     rel = f'{mn}.{pn}' if mn else pn
                     is_decay = pn.endswith('weight') and isinstance(m, Conv2d)
                     key = rel if self.optimizer_param_set == 'reference' else f'{prefix}.{rel}'
                     seen[key] = (f'{prefix}.{rel}', p, is_decay)      # 'reference': later sub-modules shadow earlier ones
-        for full, p, is_decay in seen.values():
-            (decay if is_decay else no_decay).append((full, p))
+        decay = [(full, p) for key, (full, p, d) in sorted(seen.items()) if d]
+        no_decay = [(full, p) for key, (full, p, d) in sorted(seen.items()) if not d]
         return decay, no_decay
 
     def configure_optimizers(self):
@@ -302,8 +307,8 @@ class VQVAE(BaseVQVAE, _LightningBase):
         betas = [float(b) for b in self.t_conf['betas']]
         eps, wd = float(self.t_conf['eps']), float(self.t_conf['weight_decay'])
         decay, no_decay = self.optimizer_groups()
-        groups = [{'params': [p for _, p in sorted(decay, key=lambda t: t[0])], 'weight_decay': wd},
-                  {'params': [p for _, p in sorted(no_decay, key=lambda t: t[0])], 'weight_decay': 0.0}]
+        groups = [{'params': [p for _, p in decay], 'weight_decay': wd},
+                  {'params': [p for _, p in no_decay], 'weight_decay': 0.0}]
         ae_optimizer = FlatAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd)
         if isinstance(self.criterion, VQLPIPSWithDiscriminator):                      # model.py:431-438
             disc_optimizer = FlatAdamW(list(self.criterion.discriminator.parameters()), lr=lr, betas=betas, eps=eps,

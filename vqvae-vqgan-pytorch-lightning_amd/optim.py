@@ -122,6 +122,10 @@ class FlatAdamW(torch.optim.Optimizer):
                 if buf is None or name not in st:
                     continue
                 src = st[name].to(buf.device, torch.float32)
+                if tuple(src.shape) != tuple(p.shape):
+                    raise ValueError(f'FlatAdamW.load_state_dict: state {idx} ({name}) has shape {tuple(src.shape)}, '
+                                     f'parameter {idx} has {tuple(p.shape)} -- the parameter ORDER of the saved optimizer '
+                                     f'differs (reference checkpoints need optimizer_param_set="reference")')
                 if _is_channels_last_param(p):
                     src = src.permute(0, 2, 3, 1)
                 buf[off:off + n].copy_(src.reshape(-1))
