@@ -25,27 +25,35 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-AE_CONF = dict(channels=128, num_res_blocks=2, channel_multipliers=(1, 2, 2, 4))
-T_CONF = dict(lr=1e-4, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
+CONFIG_OF = {'standard': 'standard_vqvae.yaml', 'ema': 'ema_vqvae.yaml', 'entropy': 'entropy_vqvae.yaml',
+             'gumbel': 'gumbel_vqgan.yaml'}
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
 HBM_PEAK_BPS = 8.0e12                                   # MI355X_MICROARCH.md: HBM3E peak (about 6.3e12 achievable)
 
 
-def q_conf(qtype: str, k: int):
-    params = {'standard': dict(commitment_cost=0.25),
-              'ema': dict(commitment_cost=0.25, decay=0.95, epsilon=1e-5),
-              'entropy': dict(commitment_cost=0.25, ent_loss_ratio=0.1, ent_temperature=0.01, ent_loss_type='softmax'),
-              'gumbel': dict(straight_through=False, temp=1.0, kl_cost=0.00859375, kl_warmup_epochs=None,
-                             temp_decay_epochs=None, temp_final=None)}[qtype]
-    return dict(num_embeddings=k, embedding_dim=256, reinit_every_n_epochs=None, type=qtype, params=params)
+def run_config(args, world: int):
+    """(run dict, yaml path, overrides): the YAML through train.py's derivation rules (vqvae/train.py:55-103), with the
+    per-GPU batch of the benchmark (cumulative_bs = batch * world -> lr = base_lr * sqrt(cumulative_bs / 256)) and
+    BASELINE.json's overrides (codebook size; VQ-GAN: adversarial phase on from epoch 0)"""
+    train_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.train')
+    path = args.config or os.path.join(ROOT, 'example_confs', CONFIG_OF[args.quantizer])
+    conf = train_mod.get_model_conf(path)
+    over = {'training.cumulative_bs': args.batch * world, 'image_size': args.image_size}
+    if args.codebook is not None:
+        over['quantizer.num_embeddings'] = args.codebook
+    if 'loss' in conf and not args.gan:
+        conf.pop('loss')                                         # plain VQ-VAE step on a VQ-GAN yaml (MSE criterion)
+    if 'loss' in conf:
+        over['loss.adversarial_params.start_epoch'] = 0          # SURVEY 8(d) config 4: discriminator + R1 exercised
+    return train_mod.derive_run_config(conf, world, over), path, over
 
 
-def cpu_baseline(image_size: int, batch: int, steps: int):
+def cpu_baseline(run: dict, image_size: int, batch: int, steps: int):
     """CPU oracle train step (fwd + bwd + AdamW), fp32, all host cores."""
     from oracle import vqvae_oracle as O
     model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
     torch.manual_seed(1234)
-    m = model_mod.VQVAE(image_size, AE_CONF, q_conf('standard', 1024), None, T_CONF)     # CPU tensors: init only
+    m = model_mod.VQVAE(image_size, run['ae_conf'], run['q_conf'], None, run['t_conf'])   # CPU tensors: init only
     params = {k: v.detach().clone().contiguous() for k, v in m.state_dict().items()}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     try:                                       # honour a cgroup CPU quota (containers often expose every host CPU)
@@ -63,13 +71,14 @@ def cpu_baseline(image_size: int, batch: int, steps: int):
     times = []
     budget_t0 = time.perf_counter()
     for s in range(steps + 1):
-        if s >= 2 and time.perf_counter() - budget_t0 > 40.0:      # keep the default run within minutes
+        if s >= 2 and time.perf_counter() - budget_t0 > 60.0:      # keep the default run within minutes
             steps = s - 1
             break
         t0 = time.perf_counter()
-        r = O.train_step_mse(images, params, 2, 4, 'standard', dict(commitment_cost=0.25))
+        r = O.train_step_mse(images, params, run['ae_conf']['num_res_blocks'], len(run['ae_conf']['channel_multipliers']),
+                             'standard', dict(commitment_cost=0.25))
         for k_, gr in r['grads'].items():
-            params[k_], _, v[k_] = O.adamw_step(params[k_], gr, v[k_], s + 1, 1e-4, 0.0, 0.99, 1e-8,
+            params[k_], _, v[k_] = O.adamw_step(params[k_], gr, v[k_], s + 1, run['t_conf']['lr'], 0.0, 0.99, 1e-8,
                                                 1e-4 if k_ in decay else 0.0)
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / steps
@@ -81,17 +90,18 @@ def cpu_baseline(image_size: int, batch: int, steps: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--config', type=str, default=None, help='example_confs-schema YAML (default: the one of --quantizer)')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--image-size', type=int, default=256)
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
     ap.add_argument('--quantizer', choices=['standard', 'ema', 'entropy', 'gumbel'], default='standard')
-    ap.add_argument('--gan', action='store_true', help='VQ-GAN criterion (LPIPS + StyleGAN2 discriminator, hinge, no R1)')
-    ap.add_argument('--codebook', type=int, default=1024)
+    ap.add_argument('--gan', action='store_true', help='VQ-GAN criterion of gumbel_vqgan.yaml (LPIPS + StyleGAN2 discriminator, non-saturating, R1 every 16 steps)')
+    ap.add_argument('--codebook', type=int, default=None, help='override quantizer.num_embeddings of the YAML')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=2)
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-batch', type=int, default=4)
+    ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel eagerly instead of replaying a hipGraph')
     args = ap.parse_args()
@@ -109,13 +119,13 @@ def main():
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
 
     torch.manual_seed(1234)                                   # identical replicas on every rank
-    l_conf = None
     if args.gan:
-        l_conf = dict(l1_weight=0.8, l2_weight=0.2, perc_weight=1.0,
-                      adversarial_params=dict(start_epoch=0, loss_type='non-saturating', g_weight=0.1, use_adaptive=False,
-                                              r1_reg_weight=None, r1_reg_every=16))
-    model = model_mod.VQVAE(args.image_size, AE_CONF, q_conf(args.quantizer, args.codebook), l_conf, T_CONF,
+        args.quantizer = 'gumbel' if args.config is None else args.quantizer
+    run, conf_path, conf_over = run_config(args, world)
+    qtype, codebook = run['q_conf']['type'], run['q_conf']['num_embeddings']
+    model = model_mod.VQVAE(run['image_size'], run['ae_conf'], run['q_conf'], run['l_conf'], run['t_conf'],
                             compute_dtype=dtype).to(device)
+    args.gan = run['use_adversarial']
     if args.gan:
         model.criterion.discriminator.compute_dtype = dtype
         model.criterion.perceptual_loss.net.compute_dtype = dtype
@@ -213,7 +223,7 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import vqbench
-            vq_kernel = vqbench.bench(args.batch * (args.image_size // 16) ** 2, args.codebook, 256, iters=200)
+            vq_kernel = vqbench.bench(args.batch * (args.image_size // 16) ** 2, codebook, run['q_conf']['embedding_dim'], iters=200)
             vq_kernel['note'] = ('exact-fp32 MFMA (indices bit-exact vs the oracle): bound by the 157 TF fp32 matrix peak, '
                                  'not by HBM; algorithmic bytes = z + codebook + q + idx')
         except Exception as exc:
@@ -221,15 +231,17 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.image_size, args.cpu_batch, args.cpu_steps)
+            cpu = cpu_baseline(run, args.image_size, args.cpu_batch, args.cpu_steps)
         value = world * args.batch * args.steps / elapsed
         out = dict(metric='images/sec/node (256x256 bs=32/GPU) VQ-VAE train step', value=round(value, 2),
                    unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype=args.dtype, data='synthetic',
-                   config=dict(workload=f'{args.quantizer}_{"vqgan" if args.gan else "vqvae"} cb={args.codebook}, '
+                   config=dict(workload=f'{qtype}_{"vqgan" if args.gan else "vqvae"} cb={codebook}, '
                                         f'{args.image_size}x{args.image_size} bs={args.batch}/GPU (encoder+VQ+decoder '
-                                        f'{"+LPIPS+discriminator " if args.gan else ""}fwd/bwd + AdamW)',
+                                        f'{"+LPIPS+discriminator+R1 " if args.gan else ""}fwd/bwd + AdamW)',
+                               yaml=os.path.relpath(conf_path, ROOT), yaml_overrides=conf_over,
+                               learning_rate=run['learning_rate'],
                                global_batch=world * args.batch, parallelism=f'dp{world}',
                                launch=('hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
                                final_loss=round(float(loss.item()), 6)),

@@ -178,7 +178,28 @@ def gen_config1():
     save('full_config1', **out)
 
 
+def gen_utils():
+    """BaseVectorQuantizer utilities (base_quantizer.py:54-102): usage statistics, dead-code re-initialisation under a fixed
+    CPU seed, codes_to_vec"""
+    g = torch.Generator().manual_seed(808)
+    k, d = 64, 16
+    count = torch.randint(0, 40, (k,), generator=g).float()
+    count[torch.randperm(k, generator=g)[:20]] = 0.0
+    q = VectorQuantizer(k, d, 0.25)
+    with torch.no_grad():
+        q.codebook.weight.copy_(torch.randn(k, d, generator=g))
+    cb0 = npy(q.codebook.weight)
+    p, perplexity, used = q.get_codebook_usage(count)
+    codes = torch.randint(0, k, (3, 7), generator=g)
+    vec = q.codes_to_vec(codes)
+    torch.manual_seed(4242)
+    q.reinit_unused_codes(p)
+    save('quantizer_utils', count=npy(count), p=npy(p), perplexity=np.float64(perplexity), used=np.float64(used),
+         cb0=cb0, cb1=npy(q.codebook.weight), codes=npy(codes), vec=npy(vec), reinit_seed=np.int64(4242))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ema', 'entropy', 'gumbel', 'disc', 'config1']
+    which = sys.argv[1:] or ['ema', 'entropy', 'gumbel', 'disc', 'config1', 'utils']
     for w in which:
-        {'ema': gen_ema, 'entropy': gen_entropy, 'gumbel': gen_gumbel, 'disc': gen_disc, 'config1': gen_config1}[w]()
+        {'ema': gen_ema, 'entropy': gen_entropy, 'gumbel': gen_gumbel, 'disc': gen_disc, 'config1': gen_config1,
+         'utils': gen_utils}[w]()

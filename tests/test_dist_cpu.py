@@ -56,20 +56,53 @@ def _ema_worker(rank, world, port, out):
     z = z_all[rank * b:(rank + 1) * b]
     fz = O._flat(z)
     idx = torch.argmin(O.distances_std(fz, cb), dim=1)
-    # what every rank contributes: packed [counts | dw], summed by ONE all-reduce (ops.ema_update's reduce_fn)
+    # what every rank contributes: packed [counts | dw] (the layout ops.ema_stats writes on the GPU), summed by the
+    # PRODUCT's collective: the same reduce_ema_stats that EMAVectorQuantizer.forward / finish_update call
+    vqm = importlib.import_module(PKG + '.modules.vector_quantizers')
     buf = torch.zeros(k + k * d)
     buf[:k] = torch.bincount(idx, minlength=k).float()
     buf[k:] = torch.zeros(k, d).index_add_(0, idx, fz).reshape(-1)
-    dist.all_reduce(buf)
+    batch = vqm.reduce_ema_stats(buf, b)
+    assert batch == float(world * b)                                  # smoothing constant = GLOBAL batch
     n_k, dw = buf[:k], buf[k:].view(k, d)
     c = cnt * 0.95 + 0.05 * n_k
-    new_cnt = (c + 1e-5) / (world * b + k * 1e-5) * (world * b)       # smoothing constant = GLOBAL batch
+    new_cnt = (c + 1e-5) / (batch + k * 1e-5) * batch                 # vector_quantizers.py:164 (what vqk_ema_update does)
     new_w = w * 0.95 + 0.05 * dw
     if rank == 0:
         _, _, _, rc, rw, rcb = O.vq_ema(z_all, cb, cnt, w, 0.25, 0.95, 1e-5)   # single process, concatenated batch
         torch.testing.assert_close(new_cnt, rc, rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(new_w, rw, rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(new_w / new_cnt[:, None], rcb, rtol=1e-5, atol=1e-6)
+        out.put('ok')
+    dist.destroy_process_group()
+
+
+def _reinit_worker(rank, world, port, out):
+    """dead-code re-initialisation under data parallelism: usage all-reduced, the multinomial draw broadcast from rank 0
+    -> identical codebooks on every rank although the ranks' RNG streams and local histograms differ"""
+    _init(rank, world, port)
+    model_mod = importlib.import_module(PKG + '.model')
+    torch.manual_seed(0)
+    ae = dict(channels=32, num_res_blocks=1, channel_multipliers=(1,))
+    qc = dict(num_embeddings=32, embedding_dim=8, reinit_every_n_epochs=1, type='standard', params=dict(commitment_cost=0.25))
+    tc = dict(lr=1e-4, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
+    m = model_mod.VQVAE(16, ae, qc, None, tc)
+    cb0 = m.quantizer.codebook.weight.detach().clone()
+    torch.manual_seed(100 + rank)                                     # ranks diverge in RNG state from here on
+    hist = torch.zeros(32, dtype=torch.int32)
+    hist[rank * 4:rank * 4 + 6] = torch.randint(1, 9, (6,), dtype=torch.int32)   # rank 0 uses codes 0..5, rank 1 codes 4..9
+    m.accumulate_usage(hist)
+    m.current_epoch = 1
+    m.on_train_epoch_end()
+    cb = m.quantizer.codebook.weight.detach()
+    both = [torch.zeros_like(cb) for _ in range(world)]
+    dist.all_gather(both, cb)
+    if rank == 0:
+        assert torch.equal(both[0], both[1])
+        assert torch.equal(cb[:10], cb0[:10])                         # codes used by EITHER rank are untouched
+        live = {tuple(r.tolist()) for r in cb0[:10]}
+        assert all(tuple(r.tolist()) in live for r in cb[10:])        # every dead row is now a copy of a live row
+        assert m.train_epoch_usage_count is None
         out.put('ok')
     dist.destroy_process_group()
 
@@ -92,3 +125,7 @@ def test_flat_gradient_allreduce_equals_big_batch():
 
 def test_ema_statistics_allreduce_equals_single_process():
     _run(_ema_worker, 29612)
+
+
+def test_dead_code_reinit_is_identical_on_every_rank():
+    _run(_reinit_worker, 29613)

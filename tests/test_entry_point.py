@@ -1,0 +1,80 @@
+"""B2: the config surface.  ``train.derive_run_config`` reproduces what the reference's ``vqvae/train.py:55-103,139-140``
+derives from an ``example_confs``-schema YAML and the device count; the shipped YAMLs carry the reference's values."""
+import importlib
+import math
+import os
+
+import pytest
+
+train = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.train')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONFS = os.path.join(ROOT, 'example_confs')
+
+# the values of the reference's example_confs/*.yaml (quantizer type, K, cumulative_bs, base_lr, decay_epochs, max_epochs)
+EXPECT = {'standard_vqvae.yaml': ('standard', 1024, None), 'standard_vqvae_reinit.yaml': ('standard', 1024, 10),
+          'ema_vqvae.yaml': ('ema', 4096, None), 'entropy_vqvae.yaml': ('entropy', 1024, None),
+          'gumbel_vqgan.yaml': ('gumbel', 1024, None)}
+
+
+@pytest.mark.parametrize('name', sorted(EXPECT))
+def test_yaml_schema_and_values(name):
+    conf = train.get_model_conf(os.path.join(CONFS, name))
+    qtype, k, reinit = EXPECT[name]
+    assert conf['image_size'] == 256
+    assert conf['autoencoder'] == dict(channels=128, num_res_blocks=2, channel_multipliers=[1, 2, 2, 4])
+    q = conf['quantizer']
+    assert (q['type'], q['num_embeddings'], q['embedding_dim'], q['reinit_every_n_epochs']) == (qtype, k, 256, reinit)
+    t = conf['training']
+    assert (t['cumulative_bs'], float(t['base_lr']), t['betas'], float(t['eps']), float(t['weight_decay']),
+            t['decay_epochs'], t['max_epochs']) == (256, 1e-4, [0.0, 0.99], 1e-8, 1e-4, 250, 300)
+    if name == 'gumbel_vqgan.yaml':
+        assert q['params'] == dict(straight_through=False, temp=1.0, kl_cost=0.00859375, kl_warmup_epochs=0.48,
+                                   temp_decay_epochs=15, temp_final=0.0625)
+        assert conf['loss'] == dict(l1_weight=0.8, l2_weight=0.2, perc_weight=1.0,
+                                    adversarial_params=dict(start_epoch=100, loss_type='non-saturating', g_weight=0.1,
+                                                            use_adaptive=False, r1_reg_weight=10., r1_reg_every=16))
+    else:
+        assert 'loss' not in conf
+
+
+@pytest.mark.parametrize('world,bs', [(1, 256), (8, 32), (16, 16)])
+def test_derived_hyper_parameters(world, bs):
+    """train.py:59-63, :86-98"""
+    conf = train.get_model_conf(os.path.join(CONFS, 'standard_vqvae.yaml'))
+    run = train.derive_run_config(conf, world)
+    assert run['batch_size_per_device'] == bs and run['cumulative_batch_size'] == 256
+    assert run['learning_rate'] == 1e-4 * math.sqrt(256 / 256)
+    tc = run['t_conf']            # (YAML 1.1 reads '1e-8' as a string; VQVAE converts with float(), as the reference does)
+    assert (tc['lr'], tc['betas'], float(tc['eps']), float(tc['weight_decay']), tc['warmup_epochs'], tc['decay_epochs']) == \
+        (1e-4, [0.0, 0.99], 1e-8, 1e-4, None, 250)
+    assert run['l_conf'] is None and not run['use_adversarial'] and run['max_epochs'] == 300
+    run = train.derive_run_config(conf, world, {'training.cumulative_bs': 1024, 'quantizer.num_embeddings': 8192,
+                                                'training.warmup_epochs': 5})
+    assert run['learning_rate'] == 1e-4 * math.sqrt(1024 / 256) == 2e-4
+    assert run['batch_size_per_device'] == 1024 // world and run['q_conf']['num_embeddings'] == 8192
+    assert run['t_conf']['warmup_epochs'] == 5
+    assert conf['training']['cumulative_bs'] == 256                      # overrides never touch the loaded file
+
+
+def test_adversarial_batch_guard():
+    """train.py:139-140: the StyleGAN2 minibatch-stddev layer groups 4 samples"""
+    conf = train.get_model_conf(os.path.join(CONFS, 'gumbel_vqgan.yaml'))
+    run = train.derive_run_config(conf, 8)
+    assert run['use_adversarial'] and run['batch_size_per_device'] == 32
+    with pytest.raises(RuntimeError, match='divisible by 4'):
+        train.derive_run_config(conf, 8, {'training.cumulative_bs': 48})           # 6 per device
+    train.derive_run_config(conf, 8, {'training.cumulative_bs': 128})                  # 16 per device: BASELINE config 4
+    ablation = train.derive_run_config(conf, 8, {'training.cumulative_bs': 48, 'loss.adversarial_params': None})
+    assert not ablation['use_adversarial']
+
+
+def test_model_builds_from_every_yaml():
+    model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
+    for name in ('standard_vqvae.yaml', 'ema_vqvae.yaml', 'entropy_vqvae.yaml'):
+        run = train.derive_run_config(train.get_model_conf(os.path.join(CONFS, name)), 8,
+                                      {'autoencoder.channels': 32, 'quantizer.num_embeddings': 64})
+        m = model_mod.VQVAE(run['image_size'], run['ae_conf'], run['q_conf'], run['l_conf'], run['t_conf'])
+        assert m.quantizer.num_embeddings == 64 and type(m.criterion).__name__ == 'MSELoss'
+    args = train.parse_args(['--params_file', 'x.yaml', '--seed', '3', '--set', 'quantizer.num_embeddings=8192',
+                             '--set', 'loss.adversarial_params.start_epoch=0'])
+    assert train.parse_overrides(args.set) == {'quantizer.num_embeddings': 8192, 'loss.adversarial_params.start_epoch': 0}

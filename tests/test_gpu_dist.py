@@ -1,0 +1,146 @@
+"""RCCL in the GPU suite (A22 / SURVEY 8(e)).  (1) one process, world size 1, backend nccl (= RCCL): the product's two
+collectives -- the flat-gradient all-reduce (FlatAdamW.all_reduce_grads) and the EMA statistics all-reduce
+(EMAVectorQuantizer.finish_update -> reduce_ema_stats) -- really issued on the device next to a hipGraph replay, and the
+trajectory must equal the one without them.  (2) two processes on two GPUs (skipped on a 1-GPU box): data-parallel
+gradients == big-batch gradients, EMA buffers == the single-process oracle on the concatenated batch with the global
+batch as the smoothing constant."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+PKG = 'vqvae-vqgan-pytorch-lightning_amd'
+AE = dict(channels=32, num_res_blocks=1, channel_multipliers=(1, 2))
+TC = dict(lr=1e-3, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
+QP = {'standard': dict(commitment_cost=0.25), 'ema': dict(commitment_cost=0.25, decay=0.95, epsilon=1e-5)}
+
+
+def _qc(qtype):
+    return dict(num_embeddings=64, embedding_dim=16, reinit_every_n_epochs=None, type=qtype, params=QP[qtype])
+
+
+def _env(rank, world, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY='0')
+
+
+def _trajectory(qtype, force, steps=4):
+    model_mod = importlib.import_module(PKG + '.model')
+    trainer_mod = importlib.import_module(PKG + '.trainer')
+    torch.manual_seed(0)
+    m = model_mod.VQVAE(32, AE, _qc(qtype), None, TC).to('cuda').train()
+    with torch.no_grad():
+        m.quantizer.codebook.weight.mul_(32.0)
+    tr = trainer_mod.MiniTrainer(num_training_batches=100)
+    opt = tr.attach(m)[0]
+    opt.force_collective = force
+    m.on_train_start()
+    images = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+    tr.capture(m, images, warmup=2)
+    losses = [tr.train_batch_graphed(m, images, 2 + i).item() for i in range(steps)]
+    state = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+    return losses, state
+
+
+def _world1_worker(rank, port, out):
+    _env(0, 1, port)
+    os.environ['VQK_FORCE_DIST'] = '1'
+    trainer_mod = importlib.import_module(PKG + '.trainer')
+    r, local, world = trainer_mod.init_distributed('nccl')
+    assert dist.is_initialized() and dist.get_backend() == 'nccl' and world == 1
+    calls = {'n': 0}
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        assert t.is_cuda
+        calls['n'] += 1
+        return real(t, *a, **k)
+    dist.all_reduce = counting
+    res = {}
+    for qtype in ('standard', 'ema'):
+        before = calls['n']
+        l1, s1 = _trajectory(qtype, force=True)
+        issued = calls['n'] - before
+        # 2 eager warm-up steps + 4 replays: one gradient all-reduce each; the 4 replays also finish the deferred EMA update
+        # with its statistics all-reduce (the eager warm-up steps update inline: world size 1 needs no collective there)
+        assert issued == (10 if qtype == 'ema' else 6), (qtype, issued)
+        before = calls['n']
+        l0, s0 = _trajectory(qtype, force=False)
+        assert calls['n'] == before
+        np.testing.assert_allclose(l1, l0, rtol=1e-5)
+        for k in s0:
+            np.testing.assert_allclose(s1[k].numpy(), s0[k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+        res[qtype] = l1
+    dist.destroy_process_group()
+    out.put(res)
+
+
+def test_rccl_collectives_world1_graph_replay():
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    p = ctx.Process(target=_world1_worker, args=(0, 29641, out))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    res = out.get()
+    assert set(res) == {'standard', 'ema'} and all(np.isfinite(v).all() for v in res.values())
+
+
+def _world2_worker(rank, port, out):
+    _env(rank, 2, port)
+    from oracle import vqvae_oracle as O
+    trainer_mod = importlib.import_module(PKG + '.trainer')
+    model_mod = importlib.import_module(PKG + '.model')
+    trainer_mod.init_distributed('nccl')
+    dev = torch.device('cuda', rank)
+    torch.manual_seed(0)
+    b = 2
+    m = model_mod.VQVAE(32, AE, _qc('ema'), None, TC)
+    with torch.no_grad():
+        m.quantizer.codebook.weight.mul_(32.0)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    all_images = torch.rand(2 * b, 3, 32, 32, generator=torch.Generator().manual_seed(11))
+    m = m.to(dev).train()
+    tr = trainer_mod.MiniTrainer(num_training_batches=1)
+    opt = tr.attach(m)[0]
+    opt.zero_grad()
+    loss = m.training_step(all_images[rank * b:(rank + 1) * b].to(dev), 0)
+    loss.backward()
+    opt.all_reduce_grads()
+    torch.cuda.synchronize()
+    assert opt.grad_scale == 0.5
+    if rank == 0:
+        buffers = dict(ema_count=params['quantizer.ema_count'], ema_weight=params['quantizer.ema_weight'])
+        ref = O.train_step_mse(all_images, params, 1, 2, 'ema', dict(QP['ema'], global_batch=2 * b), buffers)
+        named = dict(m.named_parameters())
+        for k, gr in ref['grads'].items():
+            got = named[k].grad.detach().float().cpu() * opt.grad_scale
+            err = ((got - gr).norm() / (gr.norm() + 1e-7 * gr.numel() ** 0.5)).item()
+            assert err < 2e-3, (k, err)
+        q = m.quantizer
+        np.testing.assert_allclose(q.ema_count.cpu().numpy(), ref['extra']['ema_count'].numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(q.ema_weight.cpu().numpy(), ref['extra']['ema_weight'].numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(q.codebook.weight.detach().cpu().numpy(), ref['extra']['codebook'].numpy(), rtol=1e-4,
+                                   atol=1e-6)
+        out.put('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the driver runs it on the 8-GPU node)')
+def test_rccl_two_ranks_equal_big_batch():
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_world2_worker, args=(r, 29642, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert out.get() == 'ok'

@@ -41,6 +41,22 @@ def close(a, b, rtol, atol):
     np.testing.assert_allclose(a.detach().float().cpu().numpy(), b, rtol=rtol, atol=atol)
 
 
+def close_norm(a, b, tol):
+    """||a - b|| / ||b|| of a stored slice (gradient slices span many orders of magnitude: element-wise rtol is the wrong
+    yardstick for values that are sums of cancelling terms)"""
+    a, b = a.detach().double().cpu(), torch.from_numpy(np.asarray(b)).double()
+    err = ((a - b).norm() / b.norm()).item()
+    assert err < tol, err
+
+
+def stepped_ok(p, ref, name):
+    """parameters after one beta1 = 0 AdamW step: every element moves by ~lr * sign(g), so the only error is a sign flip
+    where |g| ~ 1e-8 (2 lr per flipped element): allow a handful (or 0.04 %) of flips"""
+    got = S.summary(p, name)
+    flips = max(4.0, 4e-4 * p.numel())
+    assert np.abs(got[2:] - ref[2:]).max() <= 3.0 * (2e-4 * np.sqrt(flips) + 1e-5 * ref[1]), name
+
+
 def test_config3_ema_full_size(golden):
     g, i = golden('full_ema'), S.ema_full_inputs()
     q = vqm.EMAVectorQuantizer(1024, 256, i['beta'], i['decay'], i['eps']).to(DEV)
@@ -77,8 +93,8 @@ def test_config5_entropy_k8192(golden, tag, temp):
     dz, de = torch.autograd.grad([qz, loss], [z, q.codebook.weight], [dev(i['dq']), ONE()])
     S.check_summary(dz, g[f'{tag}.dz_sum'], f'ent.{tag}.dz', 2e-4)
     S.check_summary(de, g[f'{tag}.de_sum'], f'ent.{tag}.de', 2e-4)
-    close(dz[:, :, ::8, ::8], g[f'{tag}.dz_rows'], 5e-3, 1e-7)
-    close(de[::64], g[f'{tag}.de_rows'], 5e-3, 1e-8)
+    close_norm(dz[:, :, ::8, ::8], g[f'{tag}.dz_rows'], 1e-3)
+    close_norm(de[::64], g[f'{tag}.de_rows'], 1e-3)
 
 
 def test_config5_entropy_baseline_size_vs_chunked_oracle():
@@ -120,8 +136,8 @@ def test_config4_gumbel_k1024(golden):
                              [dev(i['dq']), ONE()])
     for t, name in zip(gr[:3], ('dx', 'de', 'dw')):
         S.check_summary(t, g[f'{name}_sum'], f'gum.{name}', 2e-4)
-    close(gr[1][::32], g['de_rows'], 2e-3, 1e-6)
-    close(gr[3], g['db'], 2e-3, 1e-8)
+    close_norm(gr[1][::32], g['de_rows'], 1e-3)
+    close_norm(gr[3], g['db'], 1e-3)
 
 
 @pytest.fixture(scope='module')
@@ -143,7 +159,7 @@ def test_config4_discriminator_256(golden, disc256):
     named = list(d.named_parameters())
     grads = torch.autograd.grad((logits * dev(i['r'])).sum(), [x] + [p for _, p in named])
     S.check_summary(grads[0], g['dx_sum'], 'd256.dx', 1e-3)
-    close(grads[0][:, :, ::16, ::16], g['dx_rows'], 1e-2, 1e-6 * float(g['dx_sum'][1]))
+    close_norm(grads[0][:, :, ::16, ::16], g['dx_rows'], 2e-3)
     for (n, _), gr in zip(named, grads[1:]):
         S.check_summary(gr, g['g.' + n], 'd256.g.' + n, 1e-3)
 
@@ -199,10 +215,7 @@ def test_config1_standard_architecture_64(golden):
     for k in g:
         if k.startswith('p.'):
             # beta1 = 0: the first step moves every element by ~lr * sign(g); a sign flip where |g| ~ 1e-8 moves it 2 lr
-            ref = g[k]
-            got = S.summary(named[k[2:]], 'c1.' + k)
-            n = named[k[2:]].numel()
-            assert np.abs(got[2:] - ref[2:]).max() <= 3.0 * (2e-4 * np.sqrt(n) * 0.02 + 1e-5 * ref[1]), k
+            stepped_ok(named[k[2:]], g[k], 'c1.' + k)
     print(f'config 1: worst gradient projection error {worst:.2e}')
 
 
@@ -257,5 +270,4 @@ def test_config4_vqgan_training_step_vs_reference(golden, tag, adaptive, gw):
     for k in g:
         if k.startswith(f'{tag}.after.'):
             n = k[len(tag) + 7:]
-            ref, got = g[k], S.summary(named[n], f'gan.{k}')
-            assert np.abs(got[2:] - ref[2:]).max() <= 3.0 * (2e-4 * np.sqrt(named[n].numel()) * 0.02 + 1e-5 * ref[1]), n
+            stepped_ok(named[n], g[k], f'gan.{k}')

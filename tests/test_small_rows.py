@@ -1,0 +1,207 @@
+"""The small rows of SURVEY 8: quantizer-base utilities (A7), schedules and their wiring ((f)3), the inference API ((f)4),
+the epoch usage count under hipGraph replay.  CPU tests pin the plain-torch host logic against
+tests/golden/quantizer_utils.npz (captured from the reference's BaseVectorQuantizer); ``gpu`` tests go through the kernels."""
+import importlib
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqvae_oracle as O
+
+model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
+trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
+vqm = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.vector_quantizers')
+sched = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.schedulers')
+T = torch.from_numpy
+DEV = 'cuda:0'
+AE = dict(channels=32, num_res_blocks=1, channel_multipliers=(1, 2))
+TC = dict(lr=1e-4, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
+
+
+def qconf(qtype='standard', reinit=None, **extra):
+    params = {'standard': dict(commitment_cost=0.25),
+              'gumbel': dict(straight_through=False, temp=1.0, kl_cost=5e-4, kl_warmup_epochs=None, temp_decay_epochs=None,
+                             temp_final=None)}[qtype]
+    params.update(extra)
+    return dict(num_embeddings=64, embedding_dim=16, reinit_every_n_epochs=reinit, type=qtype, params=params)
+
+
+# ------------------------------------------------------------------------------------------ A7 (CPU: host logic)
+def test_codebook_usage_and_codes_to_vec_vs_reference(golden):
+    g = golden('quantizer_utils')
+    q = vqm.VectorQuantizer(64, 16, 0.25)
+    with torch.no_grad():
+        q.codebook.weight.copy_(T(g['cb0']))
+    p, perplexity, used = q.get_codebook_usage(T(g['count']))
+    np.testing.assert_allclose(p.numpy(), g['p'], rtol=1e-6)
+    np.testing.assert_allclose(perplexity, float(g['perplexity']), rtol=1e-6)
+    assert used == float(g['used'])
+    po, pero, usedo = O.codebook_usage(T(g['count']))                     # the oracle restatement, same fixture
+    np.testing.assert_allclose(po.numpy(), g['p'], rtol=1e-6)
+    assert abs(pero - float(g['perplexity'])) < 1e-4 and usedo == float(g['used'])
+    vec = q.codes_to_vec(T(g['codes']))
+    assert vec.shape == (3, 7, 16) and np.array_equal(vec.numpy(), g['vec'])
+
+
+def test_reinit_unused_codes_vs_reference(golden):
+    """same CPU seed, same draw: the codebook after re-initialisation equals the reference's row for row"""
+    g = golden('quantizer_utils')
+    q = vqm.VectorQuantizer(64, 16, 0.25)
+    with torch.no_grad():
+        q.codebook.weight.copy_(T(g['cb0']))
+    torch.manual_seed(int(g['reinit_seed']))
+    q.reinit_unused_codes(T(g['p']))
+    assert np.array_equal(q.codebook.weight.detach().numpy(), g['cb1'])
+    dead = g['p'] == 0
+    assert dead.sum() >= 20 and np.array_equal(g['cb1'][~dead], g['cb0'][~dead])
+
+
+# ------------------------------------------------------------------------------------------ (f)3 schedules (CPU)
+def test_scheduler_endpoints_and_monotonicity():
+    lin = sched.LinearScheduler(0, 100, 1e-20, 1e-3)
+    assert lin.step(0) == 1e-20 and lin.step(100) == 1e-3 and lin.step(1000) == 1e-3
+    assert abs(lin.step(50) - 5e-4) < 1e-12
+    cos = sched.CosineScheduler(0, 200, 1e-3, 5e-4)
+    vals = [cos.step(i) for i in range(0, 260, 10)]
+    assert vals[0] == 1e-3 and vals[-1] == 5e-4 and all(a >= b for a, b in zip(vals, vals[1:]))
+    assert abs(cos.step(100) - 7.5e-4) < 1e-12                             # half-way of a half-cosine
+    assert abs(cos.step(100) - O.cosine_lr(100, 0, 200, 1e-3, 5e-4)) < 1e-15
+    lc = sched.LinearCosineScheduler(0, 300, 1e-3, 5e-4, 100)
+    up = [lc.step(i) for i in range(0, 101, 10)]
+    down = [lc.step(i) for i in range(100, 301, 10)]
+    assert all(a <= b for a, b in zip(up, up[1:])) and all(a >= b for a, b in zip(down, down[1:]))
+    assert lc.step(100) == 1e-3 and lc.step(300) == 5e-4 and lc.step(10 ** 6) == 5e-4
+    lin.destroy(); cos.destroy(); lc.destroy()
+
+
+@pytest.mark.parametrize('wu,de,kind', [(None, None, None), (2, None, 'LinearScheduler'), (None, 5, 'CosineScheduler'),
+                                        (2, 5, 'LinearCosineScheduler')])
+def test_on_train_start_wires_the_lr_schedule(wu, de, kind):
+    """model.py:163-187 / :202-216: which schedule is built from (warmup_epochs, decay_epochs) and that every param group
+    of every optimizer receives the step's value"""
+    m = model_mod.VQVAE(32, AE, qconf(), None, dict(TC, warmup_epochs=wu, decay_epochs=de))
+    groups = [{'lr': 0.0}, {'lr': 0.0}]
+    m.trainer = types.SimpleNamespace(num_training_batches=10, optimizers=[types.SimpleNamespace(param_groups=groups)])
+    m.on_train_start()
+    assert (m.scheduler is None) if kind is None else type(m.scheduler).__name__ == kind
+    m.current_epoch = 1
+    m.on_train_batch_start(None, 3)                                        # step 13
+    if kind is None:
+        want = 1e-4
+    elif kind == 'LinearScheduler':
+        want = 1e-20 + (1e-4 - 1e-20) * 13 / 20
+    elif kind == 'CosineScheduler':
+        want = 5e-5 + 0.5 * 5e-5 * (1 + math.cos(math.pi * 13 / 50))
+    else:
+        want = 1e-20 + (1e-4 - 1e-20) * 13 / 20
+    assert all(abs(g['lr'] - want) < 1e-12 for g in groups)
+    assert m.logged['gumbel_quantizer/temperature'] == 0.0
+
+
+def test_gumbel_schedules_are_wired():
+    """model.py:189-200, :218-225: KL warm-up 0 -> kl_cost and temperature decay temp -> temp_final, pushed via set_consts"""
+    qc = qconf('gumbel', kl_warmup_epochs=0.5, temp_decay_epochs=2, temp_final=0.0625)
+    m = model_mod.VQVAE(32, AE, qc, None, TC)
+    m.trainer = types.SimpleNamespace(num_training_batches=10, optimizers=[])
+    m.on_train_start()
+    m.current_epoch = 0
+    m.on_train_batch_start(None, 0)
+    assert m.quantizer.get_consts() == (1.0, 0.0)
+    m.current_epoch = 1
+    m.on_train_batch_start(None, 0)                                        # step 10: warm-up over, decay half-way
+    temp, kl = m.quantizer.get_consts()
+    assert kl == 5e-4 and abs(temp - (0.0625 + 0.5 * (1 - 0.0625) * (1 + math.cos(math.pi * 0.5)))) < 1e-12
+    m.current_epoch = 5
+    m.on_train_batch_start(None, 0)
+    assert m.quantizer.get_consts() == (0.0625, 5e-4)
+    tr = trainer_mod.MiniTrainer(num_training_batches=10)
+    tr.optimizers = [types.SimpleNamespace()]
+    with pytest.raises(RuntimeError, match='schedule'):                    # scheduled kernel arguments cannot be replayed
+        tr.capture(m, torch.zeros(1, 3, 32, 32))
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _golden_model(golden, **kw):
+    base = golden('train_step_standard')
+    m = model_mod.VQVAE(32, AE, qconf(**kw), None, TC)
+    sd = {k: T(v) for k, v in base.items() if k.startswith(('encoder.', 'decoder.', 'quantizer.'))}
+    m.load_state_dict(sd, strict=True)
+    return base, m.to(DEV)
+
+
+@pytest.mark.gpu
+def test_inference_api_vs_reference_outputs(golden):
+    """model.py:458-489: get_tokens == the reference's indices; quantize == codebook rows; reconstruct == its clipped,
+    de-normalised reconstruction; reconstruct_from_tokens(get_tokens(x)) == reconstruct(x)"""
+    base, m = _golden_model(golden)
+    m.eval()
+    images = T(base['images']).to(DEV)
+    tokens = m.get_tokens(images)
+    assert tokens.dtype == torch.int64 and np.array_equal(tokens.cpu().numpy(), base['out.idx'])
+    qv = m.quantize(images)
+    cb = T(base['quantizer.codebook.weight'])
+    assert qv.shape == (4, 64, 16) and torch.equal(qv.cpu(), cb[T(base['out.idx'])])
+    want = O.postprocess(T(base['out.recon']))
+    rec = m.reconstruct(images)
+    assert rec.shape == (4, 3, 32, 32) and float(rec.min()) >= 0.0 and float(rec.max()) <= 1.0
+    np.testing.assert_allclose(rec.cpu().numpy(), want.numpy(), rtol=1e-3, atol=2e-5)
+    rec2 = m.reconstruct_from_tokens(tokens)
+    np.testing.assert_allclose(rec2.cpu().numpy(), want.numpy(), rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_reinit_unused_codes_on_device():
+    q = vqm.VectorQuantizer(64, 16, 0.25).to(DEV)
+    q.init_codebook()
+    cb0 = q.codebook.weight.detach().clone()
+    count = torch.zeros(64, device=DEV)
+    count[:24] = torch.arange(1, 25, device=DEV).float()
+    p, perplexity, used = q.get_codebook_usage(count)
+    assert used == 37.5 and 1.0 < perplexity <= 24.0
+    q.reinit_unused_codes(p)
+    cb1 = q.codebook.weight.detach()
+    assert torch.equal(cb1[:24], cb0[:24])
+    live = {tuple(r.tolist()) for r in cb0[:24].cpu()}
+    assert all(tuple(r.tolist()) in live for r in cb1[24:].cpu())
+
+
+@pytest.mark.gpu
+def test_graph_replay_accumulates_epoch_usage_and_reinit_matches_eager():
+    """under hipGraph replay the epoch histogram must be the SUM of every step's histogram (the captured add
+    would re-read its capture-time operand) and must survive the epoch boundary; dead-code re-init then sees the same
+    distribution as the eager run"""
+    images = [torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(s)).to(DEV) for s in range(3)]
+    counts, after = {}, {}
+    for mode in ('eager', 'graph'):
+        torch.manual_seed(0)
+        m = model_mod.VQVAE(32, AE, qconf(reinit=1), None, dict(TC, lr=1e-3)).to(DEV).train()
+        with torch.no_grad():
+            m.quantizer.codebook.weight.mul_(32.0)
+        tr = trainer_mod.MiniTrainer(num_training_batches=3)
+        tr.attach(m)
+        m.on_train_start()
+        if mode == 'graph':
+            tr.capture(m, images[0], warmup=1)          # one eager step on images[0] (counts), then capture
+            step = tr.train_batch_graphed
+        else:
+            tr.train_batch(m, images[0], 0)
+            step = tr.train_batch
+        per_epoch = []
+        for epoch in range(2):
+            m.current_epoch = epoch
+            for i, im in enumerate(images):
+                step(m, im, i)
+            per_epoch.append(m.train_epoch_usage_count.clone().cpu())
+            torch.manual_seed(77)                       # same multinomial draw in both modes
+            m.on_train_epoch_end()
+            assert m.train_epoch_usage_count is None
+        counts[mode] = per_epoch
+        after[mode] = m.quantizer.codebook.weight.detach().cpu().clone()
+    # epoch 0 holds the warm-up step + 3 steps, epoch 1 holds 3 steps: 64 latents per image, 4 images per step
+    assert int(counts['graph'][0].sum()) == 4 * 4 * 64 and int(counts['graph'][1].sum()) == 3 * 4 * 64
+    for e in range(2):
+        assert torch.equal(counts['graph'][e], counts['eager'][e]), e
+    np.testing.assert_allclose(after['graph'].numpy(), after['eager'].numpy(), rtol=1e-3, atol=1e-5)

@@ -19,6 +19,7 @@ from __future__ import annotations
 from typing import Any
 
 import torch
+import torch.distributed as dist
 from torch import nn
 
 from . import ops
@@ -77,6 +78,7 @@ class VQVAE(BaseVQVAE, _LightningBase):
         self.latent_dim = q_conf['embedding_dim']
         self.reinit_every_n_epochs = q_conf['reinit_every_n_epochs']
         self.optimizer_param_set = optimizer_param_set
+        self.defer_usage_accumulation = False
         self.kl_warmup_epochs = self.temp_decay_epochs = self.temp_final = None
 
         qt, qp = q_conf['type'], q_conf['params']
@@ -207,9 +209,7 @@ class VQVAE(BaseVQVAE, _LightningBase):
                             ('train/quant_loss', q_loss), ('train/perc_loss', p_loss), ('train/gen_loss', g_loss),
                             ('train/disc_loss', d_loss)):
             self.log(name, value.detach(), sync_dist=True, on_step=False, on_epoch=True)
-        hist = self.quantizer.last_hist
-        self.train_epoch_usage_count = hist.clone() if self.train_epoch_usage_count is None \
-            else self.train_epoch_usage_count + hist
+        self.accumulate_usage(self.quantizer.last_hist)
         return ae_loss
 
     def training_step(self, batch: Any, batch_index: int):
@@ -219,15 +219,26 @@ class VQVAE(BaseVQVAE, _LightningBase):
         ae_loss = q_loss + l2_loss
         for name, value in (('train/loss', ae_loss), ('train/l2_loss', l2_loss), ('train/quant_loss', q_loss)):
             self.log(name, value.detach(), sync_dist=True, on_step=False, on_epoch=True)      # device scalars: no sync
-        hist = self.quantizer.last_hist
+        self.accumulate_usage(self.quantizer.last_hist)
+        return ae_loss
+
+    def accumulate_usage(self, hist: torch.Tensor) -> None:
+        """epoch code histogram += this step's (model.py:289-293; the reference's ``else + used_indices`` keeps only the
+        last batch).  Inside a hipGraph capture this must not run: a captured ``a = a + hist`` would re-read the
+        capture-time tensor on every replay, so the trainer sets ``defer_usage_accumulation`` while capturing and calls
+        this itself after each replay with the graph's static histogram."""
+        if self.defer_usage_accumulation:
+            return
         self.train_epoch_usage_count = hist.clone() if self.train_epoch_usage_count is None \
             else self.train_epoch_usage_count + hist
-        return ae_loss
 
     def on_train_epoch_end(self):
         if (self.reinit_every_n_epochs is not None and self.current_epoch % self.reinit_every_n_epochs == 0
                 and self.current_epoch > 0 and self.train_epoch_usage_count is not None):
-            usage = self.quantizer.get_codebook_usage(self.train_epoch_usage_count.float())[0]
+            count = self.train_epoch_usage_count.float()
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(count, op=dist.ReduceOp.SUM)       # every replica re-initialises from the GLOBAL usage
+            usage = self.quantizer.get_codebook_usage(count)[0]
             self.quantizer.reinit_unused_codes(usage)
         self.train_epoch_usage_count = None
 

@@ -5,6 +5,7 @@ re-initialisation.  Sub-classes implement ``forward`` / ``vec_to_codes`` on the 
 from abc import ABC, abstractmethod
 
 import torch
+import torch.distributed as dist
 from torch import nn
 
 
@@ -49,9 +50,13 @@ class BaseVectorQuantizer(ABC, nn.Module):
 
     @torch.no_grad()
     def reinit_unused_codes(self, codebook_usage: torch.Tensor):
-        """codes never used (p == 0) are overwritten with codes sampled in proportion to p"""
+        """codes never used (p == 0) are overwritten with codes sampled in proportion to p (base_quantizer.py:82-102).
+        Data parallel: the draw is made on rank 0 and broadcast, so that every replica rewrites the same rows with the same
+        codes (the caller all-reduces the usage histogram first) -- replicas never re-synchronise their parameters."""
         unused = torch.nonzero(codebook_usage == 0).squeeze(1)
         if unused.numel() == 0:
             return
         picks = torch.multinomial(codebook_usage.float(), unused.numel(), replacement=True)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(picks, src=0)
         self.codebook.weight[unused] = self.codebook.weight[picks]

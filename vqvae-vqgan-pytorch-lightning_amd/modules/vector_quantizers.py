@@ -14,6 +14,17 @@ from .abstract_modules.base_quantizer import BaseVectorQuantizer
 from .autoencoder import Conv2d
 
 
+def reduce_ema_stats(stats: torch.Tensor, local_batch: int, force_collective: bool = False) -> float:
+    """Collective #2: sum the packed ``[counts(K) | dw(K*D)]`` statistics of every data-parallel rank with
+    ONE all-reduce, in place; returns the Laplace-smoothing constant of vector_quantizers.py:164 for the reduced
+    statistics = the GLOBAL batch (world * per-rank batch), so that the update equals the reference's single-process EMA
+    on the rank-concatenated batch.  Host logic only (no kernel): callable on CPU tensors under gloo."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world > 1 or (force_collective and dist.is_available() and dist.is_initialized()):
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    return float(local_batch * world)
+
+
 def _flat_view(z: torch.Tensor):
     b, d, h, w = z.shape
     return z.permute(0, 2, 3, 1).reshape(b * h * w, d)
@@ -67,10 +78,10 @@ class EMAVectorQuantizer(BaseVectorQuantizer):
                                                        out=self.pending_stats)
                     self._pending_batch = int(x.shape[0])
                 else:
-                    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-                    reduce_fn = (lambda buf: dist.all_reduce(buf, op=dist.ReduceOp.SUM)) if world > 1 else None
-                    ops.ema_update(_flat_view(z), idx.reshape(-1), self.ema_count, self.ema_weight,
-                                   self.codebook.weight.data, self.decay, self.epsilon, float(x.shape[0] * world), reduce_fn)
+                    stats = ops.ema_stats(_flat_view(z), idx.reshape(-1), self.num_embeddings)
+                    batch = reduce_ema_stats(stats, int(x.shape[0]))
+                    ops.ema_apply(stats, self.ema_count, self.ema_weight, self.codebook.weight.data, self.decay,
+                                  self.epsilon, batch)
         return q, idx, loss
 
     @torch.no_grad()
@@ -78,11 +89,9 @@ class EMAVectorQuantizer(BaseVectorQuantizer):
         """second half of a deferred update: ONE all-reduce of [counts | dw] over the ranks, then the EMA kernel"""
         if self.pending_stats is None:
             return
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if world > 1 or (force_collective and dist.is_available() and dist.is_initialized()):
-            dist.all_reduce(self.pending_stats, op=dist.ReduceOp.SUM)
+        batch = reduce_ema_stats(self.pending_stats, self._pending_batch, force_collective)
         ops.ema_apply(self.pending_stats, self.ema_count, self.ema_weight, self.codebook.weight.data, self.decay,
-                      self.epsilon, float(self._pending_batch * world))
+                      self.epsilon, batch)
 
     @torch.no_grad()
     def vec_to_codes(self, x: torch.Tensor) -> torch.Tensor:

@@ -967,15 +967,6 @@ def ema_apply(buf, ema_count, ema_weight, codebook, decay: float, eps: float, ba
                   'ema_update')
 
 
-def ema_update(flat_z, idx, ema_count, ema_weight, codebook, decay: float, eps: float, batch: float, reduce_fn=None):
-    """EMA statistics + update in place (vector_quantizers.py:159-169).  ``reduce_fn(buf)`` sums the
-    packed [counts | dw] buffer over ranks (one small all-reduce)."""
-    buf = ema_stats(flat_z, idx, codebook.shape[0])
-    if reduce_fn is not None:
-        reduce_fn(buf)
-    ema_apply(buf, ema_count, ema_weight, codebook, decay, eps, batch)
-
-
 # ------------------------------------------------------------------------------------------------------
 # StyleGAN2 plugin ops (same call surface as the reference's python wrappers)
 # ------------------------------------------------------------------------------------------------------

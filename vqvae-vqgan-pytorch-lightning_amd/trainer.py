@@ -78,6 +78,11 @@ class MiniTrainer:
         each), so schedules (lr) remain ordinary host scalars.  ``warmup`` eager steps run first (they DO
         update the model) so that every lazy allocation / kernel attribute is settled before capture."""
         opt = self.optimizers[0]
+        q = getattr(model, 'quantizer', None)
+        if getattr(q, 'kl_warmup', None) is not None or getattr(q, 'temp_decay', None) is not None:
+            # the Gumbel temperature / KL weight are kernel ARGUMENTS: a replay would keep their capture-time values
+            raise RuntimeError('MiniTrainer.capture: Gumbel quantizer with a temperature / KL schedule cannot be replayed '
+                               'from a hipGraph (scheduled scalars are baked at capture); run it eagerly')
         self._static_in = example_batch.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -94,11 +99,15 @@ class MiniTrainer:
         self._graph = torch.cuda.CUDAGraph()
         # thread_local: the autograd worker thread and (multi-GPU) the RCCL watchdog thread issue runtime calls
         # of their own while this thread captures
-        with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
-            opt.zero_grad()
-            self._static_loss = model.training_step(self._static_in, 0)
-            self._static_loss.backward()
-        self._static_hist = model.quantizer.last_hist
+        model.defer_usage_accumulation = True      # host-side bookkeeping stays out of the captured region
+        try:
+            with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
+                opt.zero_grad()
+                self._static_loss = model.training_step(self._static_in, 0)
+                self._static_loss.backward()
+        finally:
+            model.defer_usage_accumulation = False
+        self._static_hist = model.quantizer.last_hist          # rewritten by every replay
         return self._graph
 
     def _eager_step(self, model, batch, batch_index):
@@ -118,6 +127,7 @@ class MiniTrainer:
             self._static_in.copy_(batch, non_blocking=True)
         ops.repack_owned(None)               # operands of weights changed outside the optimizer (normally none)
         self._graph.replay()
+        model.accumulate_usage(self._static_hist)          # epoch code histogram: eager add of the replay's histogram
         self._finish_deferred(model, opt)
         opt.all_reduce_grads()
         opt.step()
@@ -126,14 +136,27 @@ class MiniTrainer:
 
     # ------------------------------------------------------------------ checkpoints (vqvae/train.py:106-122)
     def save_checkpoint(self, model, path: str) -> None:
-        """the keys of a Lightning checkpoint that the reference's resume path reads: 'state_dict' (plain contiguous
-        tensors under the LightningModule's own names), 'optimizer_states', 'epoch', 'global_step'"""
-        sd = {k: v.detach().clone(memory_format=torch.contiguous_format).cpu() for k, v in model.state_dict().items()}
-        opts = [{'state': {i: {k: (t.cpu() if torch.is_tensor(t) else t) for k, t in e.items()}
-                           for i, e in o.state_dict()['state'].items()},
-                 'param_groups': o.state_dict()['param_groups']} for o in self.optimizers]
-        torch.save({'epoch': int(getattr(model, 'current_epoch', 0)), 'global_step': int(self.global_step),
-                    'state_dict': sd, 'optimizer_states': opts}, path)
+        """the keys of a Lightning checkpoint that the reference's ``load_from_checkpoint`` / ``state_dict`` consumers
+        read: 'state_dict' (plain contiguous tensors under the LightningModule's own names), 'optimizer_states' (loadable
+        by ``torch.optim.AdamW``), 'epoch', 'global_step'.  NOT a full Lightning resume file ('loops', 'callbacks',
+        'lr_schedulers' and the version stamp are absent: ``Trainer.fit(ckpt_path=...)`` of real Lightning needs those).
+        Rank 0 writes (temporary file + rename), every rank waits."""
+        import torch.distributed as dist
+        distributed = dist.is_available() and dist.is_initialized()
+        if not distributed or dist.get_rank() == 0:
+            sd = {k: v.detach().clone(memory_format=torch.contiguous_format).cpu() for k, v in model.state_dict().items()}
+            adamw_defaults = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                                  fused=None, decoupled_weight_decay=True)
+            opts = [{'state': {i: {k: (t.cpu() if torch.is_tensor(t) else t) for k, t in e.items()}
+                               for i, e in o.state_dict()['state'].items()},
+                     'param_groups': [{**adamw_defaults, **g} for g in o.state_dict()['param_groups']]}
+                    for o in self.optimizers]
+            tmp = f'{path}.tmp.{os.getpid()}'
+            torch.save({'epoch': int(getattr(model, 'current_epoch', 0)), 'global_step': int(self.global_step),
+                        'state_dict': sd, 'optimizer_states': opts}, tmp)
+            os.replace(tmp, path)
+        if distributed:
+            dist.barrier()
 
     def load_checkpoint(self, model, path: str, strict: bool = True) -> dict:
         """resume: weights, optimizer moments / step counts, epoch and global step (call after ``attach``)"""
