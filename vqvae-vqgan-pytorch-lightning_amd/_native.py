@@ -97,7 +97,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with open(lock_path, 'w') as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(('.hip', '.cpp', '.h'))]
+            srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(('.hip', '.cpp', '.h', '.inc'))]
             srcs.append(os.path.join(_HERE, '..', 'include', 'vqk.h'))
             stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
             if force or stale:

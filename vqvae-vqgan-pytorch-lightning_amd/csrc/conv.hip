@@ -722,7 +722,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
         const bool has_next = u + 1 < units;
         if (!has_next) { ntj = tj; nc = c; }                     // clamp: loads stay unconditional
         const TilePos nxt = (ntj == tj) ? cur : tile_pos(ntj);
+#ifndef VQK_ABL_NOHALO
         load_halo(nxt, nc);                                      // in flight during this unit's MFMAs
+#endif
         const char* wnxt[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) wnxt[j] = unit_w(nxt.nt, nc, j);
@@ -786,7 +788,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#ifdef VQK_ABL_NOEPI
+        if (c == nch - 1 && g.n < 0) {                             // timing-only ablation: the epilogue is never executed
+#else
         if (c == nch - 1) {                                        // tile finished: epilogue, accumulators reset
+#endif
             const int n0 = cur.nt * COT;
             // Straight-line fast paths (no activation, unit gains, full cout tile): the epilogue runs on the same
             // SIMD as the MFMAs, so every branch / select per element is stolen from the matrix pipe.
@@ -923,13 +929,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
             }
             }
         }
+#ifndef VQK_ABL_NOHALO
         if (has_next) store_halo(smem + ((u + 1) & 1) * BUF);
+#endif
         __syncthreads();
         cur = nxt; tj = ntj; c = nc;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) wcur[j] = wnxt[j];
     }
 }
+
+#include "conv_mx.inc"
 
 // ------------------------------------------------------------------------------------------------
 // 3x3 conv with ONE 16-byte chunk of input channels (the 3-channel image padded to 8 bf16: the encoder's first conv,
@@ -1748,7 +1758,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     for (int i = threadIdx.x; i < c; i += 256) atomicAdd(out + i, sh[i]);
 }
 
-static int g_force_variant = -1;   // test hook: -1 auto, 0 im2col kernel only, 1 halo kernels when eligible
+static int g_force_variant = -1;   // test hook: -1 auto, 0 im2col kernel only, 1 halo kernels when eligible,
+                                   // 5 never the matrix/auxiliary-wave kernel, 6 that kernel whenever it is eligible
 static int g_stream_blocks = 0;    // persistent-grid caps (0 = default 2 blocks per CU): 256 leaves half of every CU to a
 static int g_wgrad_blocks = 0;     // kernel running concurrently on another stream (dgrad || wgrad || GroupNorm)
 
@@ -1773,6 +1784,28 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         const dim3 grid((unsigned)(total < persist ? total : persist));
         constexpr int lds = 2 * 28 * 1024;
         const bool half_ok = tw == 5 ? (g.h % 4) == 0 : (g.h % 8) == 0;
+        if constexpr (sizeof(TO) == 2) {
+            // matrix-wave / auxiliary-wave kernel (conv_mx.inc): whole 128-cout tiles, plain epilogue (bias / residual /
+            // pooling), at least two tiles per CU so that the auxiliary waves always have a next halo to fetch
+            static const int mx_on = getenv("VQK_MX") ? atoi(getenv("VQK_MX")) : 1;
+            static const int mx_min = getenv("VQK_MX_MIN_TILES") ? atoi(getenv("VQK_MX_MIN_TILES")) : 512;
+            const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
+            const bool fits32 = (int64_t)g.n * g.h_in * g.w_in * g.cin * 2 < 0x7fffffffLL && (int64_t)g.m * g.cout * 2 < 0x7fffffffLL;
+            if (mx_on && g_force_variant != 5 && plain && fits32 && (g.cpt >> 2) >= 2 && (total >= mx_min || g_force_variant == 6)) {
+                constexpr int mx_lds = 2 * 28 * 1024 + 256 * 272;
+                const dim3 mgrid((unsigned)(total < 256 ? total : 256));
+                auto launch_mx = [&](auto kern) {
+                    static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, mx_lds);
+                    (void)attr;
+                    hipLaunchKernelGGL(kern, mgrid, dim3(512), mx_lds, st, (const bf16_raw*)x, (const bf16_raw*)w, bias,
+                                       (const bf16_raw*)res, (bf16_raw*)y, (const char*)zeros, g);
+                };
+                if (tw == 5) { if (g.pool) launch_mx(conv3x3_mx_kernel<5, true>); else launch_mx(conv3x3_mx_kernel<5, false>); }
+                else { if (g.pool) launch_mx(conv3x3_mx_kernel<4, true>); else launch_mx(conv3x3_mx_kernel<4, false>); }
+                if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+                return VQK_OK;
+            }
+        }
         if (g.cout <= 32) {                                      // thin head: 32-wide cout tiles, waves split the pixels
             ConvGeom gt = g;
             gt.tiles_n = 1;
