@@ -49,6 +49,8 @@ def main():
         hin = hw >> ups
         x = torch.randn(n, cin, hin, hin, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
         w = (torch.randn(cout, k, k, cin, device='cuda') * 0.05).to(dt)
+        if os.environ.get('VQK_ZERO') == '1':      # DVFS probe: zero operands draw less power, the clock stays up
+            x.zero_(); w.zero_()
         dy = torch.randn(n, cout, hw, hw, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
         fl = 2.0 * n * hw * hw * cin * cout * k * k
         layout = ops.weight_layout(dt, n, hin, hin, cin, cout, k, bool(ups))

@@ -14,32 +14,16 @@
 //   both operands are pixel-major in LDS and the bf16 fragments come from ds_read_b64_tr_b16
 //   (hardware transpose read); fp32 fragments are plain ds_read_b32.  Split-K over pixel ranges,
 //   partials combined with fp32 atomics.
-#include "common.h"
+#include "conv_geom.h"
 #include <type_traits>
 #include <stdlib.h>
 #include <math.h>
 
 namespace {
 
-struct ConvGeom {
-    int n, h_in, w_in, h, w, cin, cout, ks, ups;
-    // general (im2col kernels only): output pixel (oh, ow) reads virtual-input pixel (oh*stride + kh - pad, ...);
-    // the virtual input is x itself (ups = 0), its nearest x2 upsample (ups = 1) or x zero-stuffed x2 (ups = 1,
-    // zs = 1: only even coordinates carry data -- the dgrad of a stride-2 conv); vh/vw = its extent.
-    int stride, pad, zs, vh, vw;
-    float acc_scale, out_gain;      // epilogue: y = out_gain * act(acc * acc_scale + bias) + residual
-    int pool;                       // stream kernel: y = pool_scale * (2x2 sum of the above), written at half resolution
-    float pool_scale;
-    int m;          // n*h*w output pixels
-    // im2col kernel, zero-stuffed input (dgrad of a stride-2 conv): ONE output-parity class per launch.  Output pixels
-    // (2a + sub_py, 2b + sub_px), a < sub_h, b < sub_w, and only the taps that land on real (even) input positions:
-    // kh in khl[0..nkh), kw in kwl[0..nkw) -- a quarter of the MFMA work of multiplying the stuffed zeros.
-    int sub, sub_py, sub_px, sub_h, sub_w, nkh, nkw, khl[2], kwl[2];
-    int wrow_chunks;   // 16-byte chunks per weight row (= ks*ks*cpt; kchunks counts only the taps of the class)
-    int cpt;        // 16-byte chunks per tap  (cin / elems-per-16B)
-    int kchunks;    // ks*ks*cpt
-    int tiles_m, tiles_n;
-};
+using vqkd::ConvGeom;
+using vqkd::xcd_remap;
+using vqkd::pack_bf16x2;
 
 // epilogue activations: 0 none, 1 tanh, 2 relu, 3 leaky relu (slope 0.2)
 __device__ __forceinline__ float epi_act(float v, int act) {
@@ -49,11 +33,6 @@ __device__ __forceinline__ float epi_act(float v, int act) {
     return v;
 }
 
-__device__ __forceinline__ int xcd_remap(int bid, int total) {
-    // contiguous chunk of tiles per XCD (block b runs on XCD b % 8); bijective for any total
-    const int q = total >> 3, r = total & 7, xcd = bid & 7, k = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_raw> {
@@ -96,13 +75,6 @@ template <> struct Frag<float> {
 __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
     f32x4 o = {v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p) = o;
-}
-// two fp32 -> packed bf16 pair (v_cvt_pk_bf16_f32: hardware round-to-nearest-even)
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void store4(bf16_raw* p, const float (&v)[4]) {
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -938,8 +910,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
         for (int j = 0; j < NJ; ++j) wcur[j] = wnxt[j];
     }
 }
-
-#include "conv_mx.inc"
 
 // ------------------------------------------------------------------------------------------------
 // 3x3 conv with ONE 16-byte chunk of input channels (the 3-channel image padded to 8 bf16: the encoder's first conv,
@@ -1792,18 +1762,7 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
             const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
             const bool fits32 = (int64_t)g.n * g.h_in * g.w_in * g.cin * 2 < 0x7fffffffLL && (int64_t)g.m * g.cout * 2 < 0x7fffffffLL;
             if (mx_on && g_force_variant != 5 && plain && fits32 && (g.cpt >> 2) >= 2 && (total >= mx_min || g_force_variant == 6)) {
-                constexpr int mx_lds = 2 * 28 * 1024 + 256 * 272;
-                const dim3 mgrid((unsigned)(total < 256 ? total : 256));
-                auto launch_mx = [&](auto kern) {
-                    static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, mx_lds);
-                    (void)attr;
-                    hipLaunchKernelGGL(kern, mgrid, dim3(512), mx_lds, st, (const bf16_raw*)x, (const bf16_raw*)w, bias,
-                                       (const bf16_raw*)res, (bf16_raw*)y, (const char*)zeros, g);
-                };
-                if (tw == 5) { if (g.pool) launch_mx(conv3x3_mx_kernel<5, true>); else launch_mx(conv3x3_mx_kernel<5, false>); }
-                else { if (g.pool) launch_mx(conv3x3_mx_kernel<4, true>); else launch_mx(conv3x3_mx_kernel<4, false>); }
-                if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
-                return VQK_OK;
+                return vqkd::launch_conv3x3_mx(x, w, bias, res, y, zeros, g, tw, st);
             }
         }
         if (g.cout <= 32) {                                      // thin head: 32-wide cout tiles, waves split the pixels

@@ -1,0 +1,45 @@
+// Geometry descriptor and small device helpers shared by the conv translation units (conv.hip, conv_mx.hip).
+#pragma once
+#include "common.h"
+
+namespace vqkd {
+
+struct ConvGeom {
+    int n, h_in, w_in, h, w, cin, cout, ks, ups;
+    // general (im2col kernels only): output pixel (oh, ow) reads virtual-input pixel (oh*stride + kh - pad, ...);
+    // the virtual input is x itself (ups = 0), its nearest x2 upsample (ups = 1) or x zero-stuffed x2 (ups = 1,
+    // zs = 1: only even coordinates carry data -- the dgrad of a stride-2 conv); vh/vw = its extent.
+    int stride, pad, zs, vh, vw;
+    float acc_scale, out_gain;      // epilogue: y = out_gain * act(acc * acc_scale + bias) + residual
+    int pool;                       // stream kernel: y = pool_scale * (2x2 sum of the above), written at half resolution
+    float pool_scale;
+    int m;          // n*h*w output pixels
+    // im2col kernel, zero-stuffed input (dgrad of a stride-2 conv): ONE output-parity class per launch.  Output pixels
+    // (2a + sub_py, 2b + sub_px), a < sub_h, b < sub_w, and only the taps that land on real (even) input positions:
+    // kh in khl[0..nkh), kw in kwl[0..nkw) -- a quarter of the MFMA work of multiplying the stuffed zeros.
+    int sub, sub_py, sub_px, sub_h, sub_w, nkh, nkw, khl[2], kwl[2];
+    int wrow_chunks;   // 16-byte chunks per weight row (= ks*ks*cpt; kchunks counts only the taps of the class)
+    int cpt;        // 16-byte chunks per tap  (cin / elems-per-16B)
+    int kchunks;    // ks*ks*cpt
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+    // contiguous chunk of tiles per XCD (block b runs on XCD b % 8); bijective for any total
+    const int q = total >> 3, r = total & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// two fp32 -> packed bf16 pair (v_cvt_pk_bf16_f32: hardware round-to-nearest-even)
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// matrix-wave / auxiliary-wave 3x3 kernel (conv_mx.hip): bf16, whole 128-cout tiles, 256-pixel patches of width 1 << twlog
+int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
+                      const ConvGeom& g, int twlog, hipStream_t st);
+
+}  // namespace vqkd

@@ -1,0 +1,402 @@
+// ------------------------------------------------------------------------------------------------
+// conv3x3_mx_kernel: the 3x3 stream convolution (fprop / dgrad, bf16, NHWC) split into MATRIX waves and AUXILIARY waves.
+// Replaces the F.conv2d calls of vqvae/modules/autoencoder.py:57-60, :102-105, :132, :153 on the large maps.
+//
+// Why (measured on the single-role stream kernel, tools/ab_conv.py + tools/ab_mx.sh, round 2): its MFMA loop alone runs at
+// 1.25-1.45 PF, the halo loads (HBM latency in the same in-order vector-memory queue as the weight stream) and the epilogue
+// (unpack / pack / residual loads / stores on the SIMD that issues the MFMAs) cost 13 % + 11 % on top, and hipcc schedules
+// the loop's ds_reads just-in-time (each phase opened with an exposed LDS round trip).  So:
+//
+//   block = 512 threads, one block per CU (persistent over (patch, cout-tile) tiles x 32-channel chunks = "units"):
+//     waves 0-3  "M": ds_read_b128 pixel fragments (80-byte padded halo rows, conflict-free), weight fragments straight
+//                from L2 by buffer loads with scalar offsets (ring three taps deep), 144 MFMAs per unit in 18 phases whose
+//                instruction order is pinned (sched_group_barrier): the NEXT phase's four fragment reads are issued
+//                between the first MFMAs of a phase, the two weight loads behind its last MFMA.  At the end of a tile the
+//                128 accumulators are rounded to bf16 and parked in an LDS staging tile.
+//     waves 4-7  "X": everything that touches HBM.  The (TH+2)x(TW+2) halo of unit u+2 is fetched by LDS-DMA
+//                (buffer_load_dwordx4 ... lds) into one of THREE halo buffers while unit u is computed -- no staging
+//                registers, no ds_write; the padded row layout is produced by the per-lane SOURCE address (every fifth
+//                16-byte slot is a pad: its lane reads out of range, which fetches nothing).  Image borders are
+//                out-of-range buffer offsets as well (zeros, no zero page, no branch).  The finished tile is drained from
+//                the staging tile: bias / residual add, optional 2x2 pooling, 16-byte stores of whole 256-byte pixel rows.
+//   One s_barrier per unit joins the two groups.  Each SIMD hosts one M and one X wave.
+//
+// LDS: 3 halo buffers (27 KiB) + the staging tile (256 pixels x 272 bytes) = 149 KiB.
+// Numerics: the convolution sum is rounded to bf16 ONCE more than in the stream kernel when a bias / residual / pooling
+// follows (the epilogue arithmetic runs on the parked bf16 values, in fp32).
+// ------------------------------------------------------------------------------------------------
+#include "conv_geom.h"
+
+namespace {
+using vqkd::ConvGeom;
+using vqkd::pack_bf16x2;
+using vqkd::xcd_remap;
+
+#ifndef VQK_MXABL
+#define VQK_MXABL 0          // timing-only ablation bits (tools/ab_build.sh): never set in the shipped build
+#endif
+#ifndef VQK_MX_RD
+#define VQK_MX_RD 6          // weight ring depth in phases ((tap, k-substep) pairs; divides 18)
+#endif
+#ifndef VQK_MX_NT
+#define VQK_MX_NT 2          // output stores: 0 default policy, 2 nontemporal
+#endif
+#ifndef VQK_MX_PRIO
+#define VQK_MX_PRIO 0        // s_setprio of the matrix waves
+#endif
+#ifndef VQK_MX_PIN
+#define VQK_MX_PIN 1         // pinned instruction order inside a phase
+#endif
+
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+template <int TWLOG, bool POOL>
+__global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ wp,
+                                                            const float* __restrict__ bias,
+                                                            const bf16_raw* __restrict__ res, bf16_raw* __restrict__ y,
+                                                            ConvGeom g) {
+    constexpr int PIX = 256, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr int RS = 80;                                       // bytes per halo pixel: 64 data + 16 pad
+    constexpr int PIECES = (HROWS * 5 + 63) / 64;                // 1-KiB LDS-DMA pieces per halo
+    constexpr int BUF = PIECES * 1024, STG = 3 * BUF, SPITCH = 272;
+    constexpr int NI = 4, NJ = 2;
+    constexpr int XS = (PIECES + 3) / 4;                         // pieces per X wave
+    constexpr int OOB = (int)0x80000000;
+    typedef bf16x8_t frag_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = g.w >> TWLOG, tiles_y = g.h / TH;
+    const int total_tiles = g.n * tiles_y * tiles_x * g.tiles_n;
+    const int nch = g.cpt >> 2;                                  // 32-channel chunks per tile
+    const int vbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int my_tiles = (total_tiles - vbid + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int units = my_tiles * nch;
+    if (units <= 0) return;
+
+    struct TilePos { int img, py0, px0, nt; };
+    auto tile_pos = [&](int j) -> TilePos {
+        int t = vbid + j * (int)gridDim.x;
+        TilePos tp;
+        tp.nt = t % g.tiles_n; t /= g.tiles_n;
+        const int txi = t % tiles_x; t /= tiles_x;
+        const int tyi = t % tiles_y;
+        tp.img = t / tiles_y; tp.py0 = tyi * TH; tp.px0 = txi * TW;
+        return tp;
+    };
+    auto unit_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    if (wave < 4) {
+        // ================================================================= M waves: MFMA only
+        if (VQK_MX_PRIO) __builtin_amdgcn_s_setprio(VQK_MX_PRIO);
+        const int wm = wave >> 1, wn = wave & 1;
+        const int p = lane & 31, kg = lane >> 5;
+        unsigned abase[NI], sbase[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int ty, tx;
+            if (TWLOG == 5) { ty = wm * NI + i; tx = p; }
+            else { ty = wm * 2 * NI + 2 * i + (p >> 4); tx = p & 15; }
+            abase[i] = (unsigned)((ty * HW2 + tx) * RS + kg * 16);
+            sbase[i] = (unsigned)(STG + (ty * TW + tx) * SPITCH + (wn * 64 + 4 * kg) * 2);
+        }
+        const int lane16 = lane * 16;
+        const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_raw*>(wp), 0, (g.cout >> 5) * nch * (18 * 1024), 0x00020000);
+        auto unit_w = [&](int nt, int c, int j) -> int { return ((nt * 4 + wn * 2 + j) * nch + c) * (18 * 1024); };
+        auto tile_nt = [&](int j) -> int { return (vbid + j * (int)gridDim.x) % g.tiles_n; };
+        auto wload = [&](int soff) -> frag_t {
+            return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, soff, 0));
+        };
+
+        constexpr int RD = VQK_MX_RD;
+        static_assert(18 % RD == 0, "weight ring depth must divide the eighteen phases");
+        f32x16 acc[NI][NJ];
+        frag_t bw[RD][NJ];
+        int wcur[NJ];
+        int cur_nt = tile_nt(0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wcur[j] = unit_w(cur_nt, 0, j);
+#pragma unroll
+        for (int d = 0; d < RD; ++d)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bw[d][j] = wload(wcur[j] + d * 1024);
+        unit_barrier();                                          // the halo of unit 0 has landed
+
+        int tj = 0, c = 0, bi = 0;
+        for (int u = 0; u < units; ++u) {
+            int ntj = tj, nc = c + 1;
+            if (nc == nch) { nc = 0; ntj = tj + 1; }
+            if (u + 1 >= units) { ntj = tj; nc = c; }            // clamp: the weight prefetch stays unconditional
+            const int nxt_nt = (ntj == tj) ? cur_nt : tile_nt(ntj);
+            int wnxt[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wnxt[j] = unit_w(nxt_nt, nc, j);
+            const char* lbase[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) lbase[i] = smem + bi * BUF + abase[i];
+
+            frag_t a[2][NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = ((tap / 3) * HW2 + (tap % 3)) * RS;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bool reads = ks == 0 || tap < 8;
+                    const int ph = tap * 2 + ks;
+                    if (ks == 0) {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
+                    } else if (tap < 8) {
+                        const int toff1 = (((tap + 1) / 3) * HW2 + ((tap + 1) % 3)) * RS;
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff1);
+                    }
+                    if (tap == 0 && ks == 0 && c == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[ph % RD][j], a[ks][i], zero, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[ph % RD][j], a[ks][i], acc[i][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int soff = (ph + RD >= 18) ? wnxt[j] + (ph + RD - 18) * 1024 : wcur[j] + (ph + RD) * 1024;
+                        bw[ph % RD][j] = wload(soff);
+                    }
+                    if (VQK_MX_PIN) {
+                        if (reads) {
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) { SGB(0x008, 1); SGB(0x100, 1); }
+                            SGB(0x008, NI * NJ - NI);
+                        } else {
+                            SGB(0x008, NI * NJ);
+                        }
+                        SGB(0x020, NJ);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (c == nch - 1 && !((VQK_MXABL & 4) && g.n > 0)) {
+                // park the tile: lane (pixel p, half kg) holds couts j*32 + 8*rq + 4*kg + e of its wave's 64 -> 8-byte pieces
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const u32x2 o = {pack_bf16x2(acc[i][j][4 * rq], acc[i][j][4 * rq + 1]),
+                                             pack_bf16x2(acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3])};
+                            *reinterpret_cast<u32x2*>(smem + sbase[i] + (j * 32 + 8 * rq) * 2) = o;
+                        }
+            }
+            unit_barrier();
+            cur_nt = nxt_nt; tj = ntj; c = nc;
+            bi = bi == 2 ? 0 : bi + 1;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wcur[j] = wnxt[j];
+        }
+        return;
+    }
+
+    // ===================================================================== X waves: HBM traffic only
+    const int xt = tid - 256, xw = wave - 4;
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_raw*>(x), 0, (int)((int64_t)g.n * g.h_in * g.w_in * g.cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_raw*>(res), 0, res ? (int)((int64_t)g.m * g.cout * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
+        y, 0, (int)(((int64_t)g.m * g.cout * 2) >> (POOL ? 2 : 0)), 0x00020000);
+
+    // halo pieces of this wave: piece xw + 4*sl, lane -> 16-byte slot s = piece*64 + lane = halo pixel s/5, chunk s%5
+    // (chunk 4 = pad).  rel = byte offset against the tile origin (input resolution), flg = border classes of the pixel
+    // (1 top row, 2 bottom row, 4 left column, 8 right column of the halo; 16 = pad / beyond the halo: never fetched)
+    int rel[XS], flg[XS];
+#pragma unroll
+    for (int sl = 0; sl < XS; ++sl) {
+        const int s = (xw + 4 * sl) * 64 + lane;
+        const int hp = s / 5, cp = s - hp * 5;
+        const int hy = hp / HW2, hx = hp - hy * HW2;
+        rel[sl] = ((((hy - 1) >> g.ups) * g.w_in + ((hx - 1) >> g.ups)) * g.cin + cp * 8) * 2;
+        flg[sl] = (hy == 0 ? 1 : 0) | (hy == TH + 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == TW + 1 ? 8 : 0) |
+                  ((cp == 4 || hp >= HROWS) ? 16 : 0);
+    }
+    auto issue_halo = [&](const TilePos& tp, int c, int bufi) {
+        const int base = (((tp.img * g.h_in + (tp.py0 >> g.ups)) * g.w_in + (tp.px0 >> g.ups)) * g.cin + c * 32) * 2;
+        const int tb = (tp.py0 == 0 ? 1 : 0) | (tp.py0 + TH == g.h ? 2 : 0) | (tp.px0 == 0 ? 4 : 0) | (tp.px0 + TW == g.w ? 8 : 0) | 16;
+#pragma unroll
+        for (int sl = 0; sl < XS; ++sl) {
+            if (xw + 4 * sl < PIECES) {                          // wave-uniform
+                const int off = (flg[sl] & tb) ? OOB : base + rel[sl];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    xsrd, (VQK_LDS void*)(smem + bufi * BUF + (xw + 4 * sl) * 1024), 16,
+                    (VQK_MXABL & 8) ? (off & 0x8003fff0) : off, 0, 0, 0);
+            }
+        }
+    };
+    auto unpack8 = [&](const u32x4& r, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(r[e] << 16); v[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+    };
+    auto pack8 = [&](const float (&v)[8]) -> u32x4 {
+        const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        return o;
+    };
+    const int slot = xt & 15;                                    // 8 couts = one 16-byte piece of the 256-byte pixel row
+    constexpr int NP = POOL ? 4 : 16;                            // output pieces per thread and tile
+    constexpr int NR = 16;                                       // residual pieces per thread and tile
+    struct OutPos { int pix0, ppix0, co; };
+    auto out_pos = [&](const TilePos& tp) -> OutPos {
+        OutPos o;
+        o.pix0 = (tp.img * g.h + tp.py0) * g.w + tp.px0;
+        o.ppix0 = (tp.img * (g.h >> 1) + (tp.py0 >> 1)) * (g.w >> 1) + (tp.px0 >> 1);
+        o.co = tp.nt * 128 + slot * 8;
+        return o;
+    };
+    auto res_off = [&](const OutPos& o, int k) -> int {          // byte offset of residual piece k (un-pooled resolution)
+        int ty, tx;
+        if constexpr (!POOL) { const int pp = k * 16 + (xt >> 4); ty = pp >> TWLOG; tx = pp & (TW - 1); }
+        else { const int opp = (k >> 2) * 16 + (xt >> 4); ty = 2 * (opp >> (TWLOG - 1)) + ((k >> 1) & 1); tx = 2 * (opp & (TW / 2 - 1)) + (k & 1); }
+        return ((o.pix0 + ty * g.w + tx) * g.cout + o.co) * 2;
+    };
+    auto load_res = [&](const OutPos& o, u32x4 (&rv)[NR]) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            rv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, res_off(o, k), 0, 0));
+    };
+    auto drain = [&](const OutPos& o, const u32x4 (&rv)[NR]) {
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + o.co), b1 = *reinterpret_cast<const f32x4*>(bias + o.co + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+        }
+        u32x4 t[16];                                             // the thread's 16 staging pieces, all requested up front
+        if constexpr (!POOL) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                t[k] = *reinterpret_cast<const u32x4*>(smem + STG + (k * 16 + (xt >> 4)) * SPITCH + slot * 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int opp = (k >> 2) * 16 + (xt >> 4);
+                const int ty = 2 * (opp >> (TWLOG - 1)) + ((k >> 1) & 1), tx = 2 * (opp & (TW / 2 - 1)) + (k & 1);
+                t[k] = *reinterpret_cast<const u32x4*>(smem + STG + (ty * TW + tx) * SPITCH + slot * 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!POOL) {
+            if (!bias && !res) {                                 // plain copy (wave-uniform)
+#pragma unroll
+                for (int k = 0; k < NP; ++k) __builtin_amdgcn_raw_buffer_store_b128(t[k], ysrd, res_off(o, k), 0, VQK_MX_NT);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    float f[8], r[8];
+                    unpack8(t[k], f);
+                    unpack8(rv[k], r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = f[e] + bv[e] + r[e];
+                    __builtin_amdgcn_raw_buffer_store_b128(pack8(f), ysrd, res_off(o, k), 0, VQK_MX_NT);
+                }
+            }
+        } else {
+            // y = pool_scale * sum over the 2x2 window of (conv + bias + residual), written at half resolution
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int opp = k * 16 + (xt >> 4);              // pooled pixel 0..63 of the (TH/2) x (TW/2) output patch
+                const int oty = opp >> (TWLOG - 1), otx = opp & (TW / 2 - 1);
+                float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    float f[8], r[8];
+                    unpack8(t[4 * k + d], f);
+                    unpack8(rv[4 * k + d], r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[e] += f[e] + r[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] = (s[e] + 4.0f * bv[e]) * g.pool_scale;
+                __builtin_amdgcn_raw_buffer_store_b128(pack8(s), ysrd, ((o.ppix0 + oty * (g.w >> 1) + otx) * g.cout + o.co) * 2, 0, VQK_MX_NT);
+            }
+        }
+    };
+
+    // position of the unit whose halo is requested next (two units ahead of the M waves)
+    int ltj = 0, lc = 0, lbuf = 0;
+    TilePos ltp = tile_pos(0);
+    auto advance = [&]() {
+        if (++lc == nch) { lc = 0; ++ltj; ltp = tile_pos(ltj < my_tiles ? ltj : my_tiles - 1); }
+        lbuf = lbuf == 2 ? 0 : lbuf + 1;
+    };
+    issue_halo(ltp, lc, lbuf); advance();                        // unit 0
+    issue_halo(ltp, lc, lbuf); advance();                        // unit 1 (nch >= 2: it exists)
+    int tj = 0, c = 0;
+    TilePos cur = tile_pos(0);
+    OutPos done = out_pos(cur);
+    bool pending = false;
+    u32x4 rv[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rv[k] = u32x4{0u, 0u, 0u, 0u};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unit_barrier();
+
+    for (int u = 0; u < units; ++u) {
+        // every vector-memory operation of the previous interval has completed: the halo of unit u+1 is in LDS (published
+        // to the M waves by the barrier that ends this interval), the residual pieces are in registers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (pending && !((VQK_MXABL & 2) && g.n > 0)) drain(done, rv);                       // tile parked during unit u-1
+        pending = (c == nch - 1);                                // unit u ends a tile: its residual is requested now,
+        if (pending) {                                           // the tile itself is drained in the next interval
+            done = out_pos(cur);
+            if (res) load_res(done, rv);
+        }
+        if (u + 2 < units && !((VQK_MXABL & 1) && g.n > 0)) issue_halo(ltp, lc, lbuf);      // unit u+2
+        advance();
+        unit_barrier();
+        if (++c == nch) { c = 0; ++tj; if (tj < my_tiles) cur = tile_pos(tj); }
+    }
+    if (pending) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        drain(done, rv);
+    }
+}
+
+}  // namespace
+
+namespace vqkd {
+
+int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
+                      const ConvGeom& g, int twlog, hipStream_t st) {
+    (void)zeros;
+    const int th = 256 >> twlog;
+    const int total = g.n * (g.h / th) * (g.w >> twlog) * g.tiles_n;
+    const dim3 grid((unsigned)(total < 256 ? total : 256));
+    auto launch = [&](auto kern, int lds) {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)attr;
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_raw*)x, (const bf16_raw*)w, bias,
+                           (const bf16_raw*)res, (bf16_raw*)y, g);
+    };
+    constexpr int lds5 = 3 * (((256 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 256 * 272;
+    constexpr int lds4 = 3 * (((256 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 256 * 272;
+    if (twlog == 5) { if (g.pool) launch(conv3x3_mx_kernel<5, true>, lds5); else launch(conv3x3_mx_kernel<5, false>, lds5); }
+    else { if (g.pool) launch(conv3x3_mx_kernel<4, true>, lds4); else launch(conv3x3_mx_kernel<4, false>, lds4); }
+    if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+    return VQK_OK;
+}
+
+}  // namespace vqkd
