@@ -125,6 +125,15 @@ int vqk_conv2d_fprop(int dtype, const void* x, const void* w, const float* bias,
 int vqk_conv2d_fprop_pooled(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                             int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, float pool_scale,
                             const void* zeros, void* stream);
+/* The 3x3 conv (optionally with the fused 2x2 pooling) that ALSO accumulates the GroupNorm statistics of its output: the
+ * per-(sample, group) sums of y and y*y (y as stored: rounded to bf16) are added to gn_ws[n][group][2] (doubles), the
+ * workspace of vqk_gn_forward -- the consumer then calls vqk_gn_forward_presummed and the statistics pass over y
+ * (autoencoder.py:25-39 re-reads its input once for mean / variance) disappears.  bf16, fragment-major weights, Cout % 128
+ * == 0, (Cout / groups) % 4 == 0; VQK_ERR_SHAPE when the problem is not served by the matrix/auxiliary-wave kernel
+ * (nothing has been launched: callers fall back to vqk_conv2d_fprop[_pooled] + vqk_gn_forward). */
+int vqk_conv2d_fprop_gnstats(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                             int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int pool, float pool_scale,
+                             double* gn_ws, int groups, const void* zeros, void* stream);
 /* General form (im2col kernel when not plain): stride in {1,2}, explicit zero padding `pad`, explicit output size;
  * mode 0: x as is, 1: nearest x2 upsample of x, 2: x zero-stuffed x2 (the dgrad of a stride-2 conv, with flipped /
  * transposed weights and pad = ks-1-pad_fwd).  Epilogue: y = out_gain * act(acc * acc_scale + bias) + residual, act 0
@@ -187,6 +196,9 @@ int vqk_gn_apply(int dtype, const void* x, const float* stats, const float* w, c
  * with no memset in between. */
 int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, void* y, float* stats, double* ws, int n,
                    int64_t hw, int c, int groups, float eps, int silu, void* stream);
+/* the same when the sums of x are already in ws (vqk_conv2d_fprop_gnstats of the producing conv): one launch */
+int vqk_gn_forward_presummed(int dtype, const void* x, const float* w, const float* b, void* y, float* stats, double* ws,
+                             int n, int64_t hw, int c, int groups, float eps, int silu, void* stream);
 /* backward of y = act(GN(x)): needs x, stats, w, b and dy.  red = N*G*2+N doubles scratch with the vqk_gn_forward
  * workspace protocol (zero on entry, zero again on exit); dw/db [C] fp32 pre-zeroed (accumulated into).  accumulate != 0: dx += result; add != NULL: dx = result + add (the residual-branch
  * gradient of a ResBlock, fused instead of a separate add pass). */

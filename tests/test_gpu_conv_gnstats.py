@@ -1,0 +1,58 @@
+"""GroupNorm statistics fused into the drain of the matrix/auxiliary-wave 3x3 kernel (vqk_conv2d_fprop_gnstats) against the
+separate statistics pass it replaces (vqk_gn_forward), which the golden tests pin to the reference's GroupNorm
+(autoencoder.py:25-39): same conv output bit for bit, (mean, rstd) equal to fp32 rounding, workspace left zero."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+DEV, BF, CL = 'cuda:0', torch.bfloat16, torch.channels_last
+
+# n, cin, cout, h, w, ups, bias, residual, pool   (every case has >= 512 tiles: served by the fused kernel)
+CASES = [(8, 128, 128, 128, 128, 0, 0, 0, 0), (4, 64, 256, 128, 128, 0, 1, 1, 0), (2, 64, 512, 128, 128, 0, 0, 1, 0),
+         (8, 128, 128, 128, 128, 0, 0, 1, 1), (8, 128, 128, 64, 64, 1, 1, 0, 0), (6, 128, 256, 96, 128, 0, 0, 0, 0)]
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,ups,hb,hr,pool', CASES)
+def test_fused_stats_match_separate_pass(n, cin, cout, h, w, ups, hb, hr, pool):
+    g = torch.Generator(device=DEV).manual_seed(cin + cout + h + 3 * ups + hb + 2 * hr + 4 * pool)
+    x = (torch.randn(n, cin, h, w, device=DEV, generator=g) + 0.3).to(BF).contiguous(memory_format=CL)
+    wt = (torch.randn(cout, 3, 3, cin, device=DEV, generator=g) / (3 * cin ** 0.5)).reshape(-1)
+    s = 2 if ups else 1
+    ho, wo = h * s, w * s
+    bias = torch.randn(cout, device=DEV, generator=g) if hb else None
+    res = torch.randn(n, cout, ho, wo, device=DEV, generator=g).to(BF).contiguous(memory_format=CL) if hr else None
+    layout = ops.weight_layout(BF, n, h, w, cin, cout, 3, bool(ups))
+    assert layout == 1
+    wq = ops.pack_weights(wt, BF, cout, cin, 3, False, layout)
+    gw = torch.randn(cout, device=DEV, generator=g)
+    gb = torch.randn(cout, device=DEV, generator=g)
+    if pool:
+        y_ref = ops.raw_conv_fprop_pooled(x, wq, bias, res, 3, bool(ups), cout, 0.25)
+    else:
+        y_ref = ops.raw_conv_fprop(x, wq, bias, res, 3, bool(ups), 0, BF, cout, layout)
+    a_ref, st_ref = ops.raw_gn_forward(y_ref, gw, gb, 32, 1e-6, True)
+    y = ops.raw_conv_fprop_gnstats(x, wq, bias, res, bool(ups), cout, 32, pool=bool(pool), pool_scale=0.25)
+    assert y is not None, 'the fused kernel must serve this shape'
+    a, st = ops.raw_gn_forward(y, gw, gb, 32, 1e-6, True, presummed=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    # mean / rstd: the same sums in a different order (fp32 partials per tile, fp64 across tiles)
+    torch.testing.assert_close(st.view(-1, 2)[:, 0], st_ref.view(-1, 2)[:, 0], rtol=0, atol=2e-5)
+    torch.testing.assert_close(st.view(-1, 2)[:, 1], st_ref.view(-1, 2)[:, 1], rtol=2e-5, atol=0)
+    assert float((a.float() - a_ref.float()).abs().max()) <= 2.0 ** -6        # at most one bf16 step on O(1) values
+    assert float((a.float() - a_ref.float()).norm() / a_ref.float().norm()) < 1e-4
+    ws = ops._gn_ws(x.device, n * 32 * 2 + n)
+    assert float(ws.abs().max()) == 0.0, 'the GroupNorm workspace must be left zero'
+
+
+def test_not_served_returns_none():
+    x = torch.randn(1, 128, 32, 32, device=DEV).to(BF).contiguous(memory_format=CL)     # 4 tiles: stream kernel territory
+    wq = ops.pack_weights(torch.randn(128 * 9 * 128, device=DEV) * 0.03, BF, 128, 128, 3, False, 1)
+    assert ops.raw_conv_fprop_gnstats(x, wq, None, None, False, 128, 32) is None
+    ws = ops._gn_ws(x.device, 128)
+    torch.cuda.synchronize()
+    assert float(ws.abs().max()) == 0.0

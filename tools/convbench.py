@@ -55,7 +55,13 @@ def main():
         fl = 2.0 * n * hw * hw * cin * cout * k * k
         layout = ops.weight_layout(dt, n, hin, hin, cin, cout, k, bool(ups))
         wq = ops.pack_weights(w.float().reshape(-1), dt, cout, cin, k, False, layout)
-        tf = 1.0 if skip_f else timeit(lambda: ops.raw_conv_fprop(x, wq, None, None, k, bool(ups), 0, dt, cout, layout), iters)
+        if os.environ.get('VQK_GNSTATS') == '1' and k == 3 and layout == 1 and cout % 128 == 0:      # fused GroupNorm sums
+            fn = lambda: ops.raw_conv_fprop_gnstats(x, wq, None, None, bool(ups), cout, 32)
+            if fn() is None:
+                fn = lambda: ops.raw_conv_fprop(x, wq, None, None, k, bool(ups), 0, dt, cout, layout)
+        else:
+            fn = lambda: ops.raw_conv_fprop(x, wq, None, None, k, bool(ups), 0, dt, cout, layout)
+        tf = 1.0 if skip_f else timeit(fn, iters)
         tw = 1.0 if skip_w else timeit(lambda: ops.raw_conv_wgrad(x, dy, k, bool(ups)), iters)
         tot_f += tf * cnt
         tot_w += tw * cnt

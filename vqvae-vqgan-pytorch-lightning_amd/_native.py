@@ -41,6 +41,7 @@ _PROTOS = {
     'vqk_ema_update_f32': [P, P, P, P, P, I, I, F, F, F, P],
     'vqk_conv2d_fprop': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     'vqk_conv2d_fprop_pooled': [I, P, P, P, P, P, I, I, I, I, I, I, I, F, P, P],
+    'vqk_conv2d_fprop_gnstats': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, I, P, P],
     'vqk_conv2d_general': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, I, P, P],
     'vqk_conv2d_wgrad_general': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P],
     'vqk_conv_weight_layout': [I, I, I, I, I, I, I, I],
@@ -55,6 +56,7 @@ _PROTOS = {
     'vqk_gn_stats': [I, P, I, L, I, I, F, P, P, P],
     'vqk_gn_apply': [I, P, P, P, P, P, I, L, I, I, I, P],
     'vqk_gn_forward': [I, P, P, P, P, P, P, I, L, I, I, F, I, P],
+    'vqk_gn_forward_presummed': [I, P, P, P, P, P, P, I, L, I, I, F, I, P],
     'vqk_gn_backward': [I, P, P, P, P, P, P, P, P, P, I, L, I, I, I, I, P, P],
     'vqk_pool2x2': [I, P, P, I, I, I, I, F, P],
     'vqk_unpool2x2': [I, P, P, I, I, I, I, F, P],
@@ -130,6 +132,9 @@ def lib() -> ctypes.CDLL:
         fn.argtypes = args
     _lib = cdll
     return _lib
+
+
+ERR_SHAPE = -1          # VQK_ERR_SHAPE (include/vqk.h)
 
 
 def check(status: int, what: str) -> None:

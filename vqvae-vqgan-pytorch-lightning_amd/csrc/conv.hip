@@ -1765,6 +1765,7 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
                 return vqkd::launch_conv3x3_mx(x, w, bias, res, y, zeros, g, tw, st);
             }
         }
+        if (g.gn_ws) return VQK_ERR_SHAPE;                       // fused statistics exist on the matrix/auxiliary-wave kernel only
         if (g.cout <= 32) {                                      // thin head: 32-wide cout tiles, waves split the pixels
             ConvGeom gt = g;
             gt.tiles_n = 1;
@@ -1863,6 +1864,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.cin = cin; g.cout = cout; g.ks = ksize; g.ups = ups;
     g.stride = 1; g.pad = ksize >> 1; g.zs = 0; g.vh = g.h; g.vw = g.w;
     g.acc_scale = 1.0f; g.out_gain = 1.0f; g.pool = 0; g.pool_scale = 1.0f;
+    g.gn_ws = nullptr; g.gn_cpg = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
     g.m = (int)m;
@@ -1974,6 +1976,23 @@ int vqk_conv2d_fprop_pooled(int dtype, const void* x, const void* w, const float
     if (rc) return rc;
     VQK_REQUIRE(halo_twlog(g) && (cout % 128) == 0 && g_force_variant != 3 && g_force_variant != 2, VQK_ERR_SHAPE);
     g.pool = 1; g.pool_scale = pool_scale;
+    return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, 0, 1, vqk_stream(stream));
+}
+
+int vqk_conv2d_fprop_gnstats(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                             int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int pool, float pool_scale,
+                             double* gn_ws, int groups, const void* zeros, void* stream) {
+    VQK_REQUIRE(x && w && y && zeros && gn_ws, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w) && vqk_aligned16(zeros) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    VQK_REQUIRE(dtype == VQK_BF16, VQK_ERR_DTYPE);
+    VQK_REQUIRE((ups == 0 || ups == 1) && (pool == 0 || pool == 1), VQK_ERR_ARG);
+    VQK_REQUIRE(ksize == 3 && groups > 0 && cout % groups == 0 && (cout / groups) % 4 == 0, VQK_ERR_SHAPE);
+    ConvGeom g;
+    const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
+    if (rc) return rc;
+    VQK_REQUIRE(halo_twlog(g) && (cout % 128) == 0 && g_force_variant != 3 && g_force_variant != 2, VQK_ERR_SHAPE);
+    g.pool = pool; g.pool_scale = pool ? pool_scale : 1.0f;
+    g.gn_ws = gn_ws; g.gn_cpg = cout / groups;
     return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, 0, 1, vqk_stream(stream));
 }
 

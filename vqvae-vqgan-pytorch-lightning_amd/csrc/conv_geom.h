@@ -22,6 +22,10 @@ struct ConvGeom {
     int cpt;        // 16-byte chunks per tap  (cin / elems-per-16B)
     int kchunks;    // ks*ks*cpt
     int tiles_m, tiles_n;
+    // matrix/auxiliary-wave kernel only: GroupNorm statistics of the OUTPUT fused into the drain -- the per-(sample, group)
+    // sums of y and y*y (y as stored, i.e. rounded to bf16) are added to gn_ws[n][group][2] (vqk_gn_forward's workspace)
+    double* gn_ws;
+    int gn_cpg;     // channels per group (cout / groups): a multiple of 4
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {

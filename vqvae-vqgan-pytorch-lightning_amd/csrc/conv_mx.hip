@@ -21,7 +21,7 @@
 //                the staging tile: bias / residual add, optional 2x2 pooling, 16-byte stores of whole 256-byte pixel rows.
 //   One s_barrier per unit joins the two groups.  Each SIMD hosts one M and one X wave.
 //
-// LDS: 3 halo buffers (27 KiB) + the staging tile (256 pixels x 272 bytes) = 149 KiB.
+// LDS: 3 halo buffers (27 KiB) + the staging tile (256 pixels x 272 bytes) + 1 KiB of statistics partials = 150 KiB.
 // Numerics: the convolution sum is rounded to bf16 ONCE more than in the stream kernel when a bias / residual / pooling
 // follows (the epilogue arithmetic runs on the parked bf16 values, in fp32).
 // ------------------------------------------------------------------------------------------------
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     constexpr int PIX = 256, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
     constexpr int RS = 80;                                       // bytes per halo pixel: 64 data + 16 pad
     constexpr int PIECES = (HROWS * 5 + 63) / 64;                // 1-KiB LDS-DMA pieces per halo
-    constexpr int BUF = PIECES * 1024, STG = 3 * BUF, SPITCH = 272;
+    constexpr int BUF = PIECES * 1024, STG = 3 * BUF, SPITCH = 272, SCR = STG + PIX * SPITCH;   // SCR: 1 KiB of statistics partials
     constexpr int NI = 4, NJ = 2;
     constexpr int XS = (PIECES + 3) / 4;                         // pieces per X wave
     constexpr int OOB = (int)0x80000000;
@@ -258,12 +258,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     const int slot = xt & 15;                                    // 8 couts = one 16-byte piece of the 256-byte pixel row
     constexpr int NP = POOL ? 4 : 16;                            // output pieces per thread and tile
     constexpr int NR = 16;                                       // residual pieces per thread and tile
-    struct OutPos { int pix0, ppix0, co; };
+    struct OutPos { int pix0, ppix0, co, img; };
     auto out_pos = [&](const TilePos& tp) -> OutPos {
         OutPos o;
         o.pix0 = (tp.img * g.h + tp.py0) * g.w + tp.px0;
         o.ppix0 = (tp.img * (g.h >> 1) + (tp.py0 >> 1)) * (g.w >> 1) + (tp.px0 >> 1);
         o.co = tp.nt * 128 + slot * 8;
+        o.img = tp.img;
         return o;
     };
     auto res_off = [&](const OutPos& o, int k) -> int {          // byte offset of residual piece k (un-pooled resolution)
@@ -277,6 +278,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         for (int k = 0; k < NR; ++k)
             rv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, res_off(o, k), 0, 0));
     };
+    int stat_idx = -1;                                           // workspace slot of this lane's statistic (drained tile)
+    auto flush_stats = [&]() {                                   // first X wave, one barrier after the drain that parked them
+        if (xw == 0) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v += *reinterpret_cast<const float*>(smem + SCR + (k * 64 + lane) * 4);
+            if (stat_idx >= 0) atomicAdd(g.gn_ws + stat_idx, (double)v);
+        }
+    };
     auto drain = [&](const OutPos& o, const u32x4 (&rv)[NR]) {
         float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (bias) {
@@ -284,6 +294,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
 #pragma unroll
             for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
         }
+        // GroupNorm statistics of the stored output (wave-uniform switch): channel sums over this thread's pieces
+        const bool want_stats = g.gn_ws != nullptr;
+        float gs[8], gq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+        auto tally = [&](const u32x4& o) {
+            float v[8];
+            unpack8(o, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] = __fmaf_rn(v[e], v[e], gq[e]); }
+        };
         u32x4 t[16];                                             // the thread's 16 staging pieces, all requested up front
         if constexpr (!POOL) {
 #pragma unroll
@@ -301,7 +322,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         if constexpr (!POOL) {
             if (!bias && !res) {                                 // plain copy (wave-uniform)
 #pragma unroll
-                for (int k = 0; k < NP; ++k) __builtin_amdgcn_raw_buffer_store_b128(t[k], ysrd, res_off(o, k), 0, VQK_MX_NT);
+                for (int k = 0; k < NP; ++k) {
+                    __builtin_amdgcn_raw_buffer_store_b128(t[k], ysrd, res_off(o, k), 0, VQK_MX_NT);
+                    if (want_stats) tally(t[k]);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
@@ -310,7 +334,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                     unpack8(rv[k], r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = f[e] + bv[e] + r[e];
-                    __builtin_amdgcn_raw_buffer_store_b128(pack8(f), ysrd, res_off(o, k), 0, VQK_MX_NT);
+                    const u32x4 ov = pack8(f);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, ysrd, res_off(o, k), 0, VQK_MX_NT);
+                    if (want_stats) tally(ov);
                 }
             }
         } else {
@@ -330,8 +356,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s[e] = (s[e] + 4.0f * bv[e]) * g.pool_scale;
-                __builtin_amdgcn_raw_buffer_store_b128(pack8(s), ysrd, ((o.ppix0 + oty * (g.w >> 1) + otx) * g.cout + o.co) * 2, 0, VQK_MX_NT);
+                const u32x4 ov = pack8(s);
+                __builtin_amdgcn_raw_buffer_store_b128(ov, ysrd, ((o.ppix0 + oty * (g.w >> 1) + otx) * g.cout + o.co) * 2, 0, VQK_MX_NT);
+                if (want_stats) tally(ov);
             }
+        }
+        if (want_stats) {
+            // thread: 8 channels = two 4-channel halves (one group each when cpg == 4, the same group otherwise); the four
+            // lanes l, l+16, l+32, l+48 of a wave own the same channels -> sum over them, then copy q = lane >> 4 of a slot
+            // keeps ONE of the (up to) four values.  The four X waves' 64 values are parked in LDS and combined by the first
+            // X wave after the next barrier (flush_stats): ONE wave-wide fp64 atomic instruction per tile -- with one per
+            // wave the 256 CUs, which all work on the same image at a time, queued up on that image's four cache lines.
+            float ga = (gs[0] + gs[1]) + (gs[2] + gs[3]), gb = (gs[4] + gs[5]) + (gs[6] + gs[7]);
+            float qa = (gq[0] + gq[1]) + (gq[2] + gq[3]), qb = (gq[4] + gq[5]) + (gq[6] + gq[7]);
+            const bool split = g.gn_cpg == 4;
+            if (!split) { ga += gb; qa += qb; }
+            ga += __shfl_xor(ga, 16, 64); ga += __shfl_xor(ga, 32, 64);
+            qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
+            if (split) {
+                gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
+                qb += __shfl_xor(qb, 16, 64); qb += __shfl_xor(qb, 32, 64);
+            }
+            const int q = (xt >> 4) & 3;
+            const float val = q == 0 ? ga : q == 1 ? qa : q == 2 ? gb : qb;
+            *reinterpret_cast<float*>(smem + SCR + (xw * 64 + lane) * 4) = val;
+            const int grp = (o.co + (q >> 1) * 4) / g.gn_cpg;
+            stat_idx = (split || q < 2) ? ((o.img * (g.cout / g.gn_cpg) + grp) * 2 + (q & 1)) : -1;
         }
     };
 
@@ -347,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     int tj = 0, c = 0;
     TilePos cur = tile_pos(0);
     OutPos done = out_pos(cur);
-    bool pending = false;
+    bool pending = false, flush = false;
     u32x4 rv[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) rv[k] = u32x4{0u, 0u, 0u, 0u};
@@ -358,7 +408,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         // every vector-memory operation of the previous interval has completed: the halo of unit u+1 is in LDS (published
         // to the M waves by the barrier that ends this interval), the residual pieces are in registers
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (pending && !((VQK_MXABL & 2) && g.n > 0)) drain(done, rv);                       // tile parked during unit u-1
+        if (flush) { flush_stats(); flush = false; }
+        if (pending && !((VQK_MXABL & 2) && g.n > 0)) { drain(done, rv); flush = g.gn_ws != nullptr; }   // tile parked during unit u-1
         pending = (c == nch - 1);                                // unit u ends a tile: its residual is requested now,
         if (pending) {                                           // the tile itself is drained in the next interval
             done = out_pos(cur);
@@ -369,9 +420,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         unit_barrier();
         if (++c == nch) { c = 0; ++tj; if (tj < my_tiles) cur = tile_pos(tj); }
     }
+    if (flush) flush_stats();
     if (pending) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         drain(done, rv);
+        if (g.gn_ws) {
+            unit_barrier();                                      // the M waves have ended: this joins the X waves only
+            flush_stats();
+        }
     }
 }
 
@@ -391,8 +447,8 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_raw*)x, (const bf16_raw*)w, bias,
                            (const bf16_raw*)res, (bf16_raw*)y, g);
     };
-    constexpr int lds5 = 3 * (((256 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 256 * 272;
-    constexpr int lds4 = 3 * (((256 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 256 * 272;
+    constexpr int lds5 = 3 * (((256 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
+    constexpr int lds4 = 3 * (((256 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
     if (twlog == 5) { if (g.pool) launch(conv3x3_mx_kernel<5, true>, lds5); else launch(conv3x3_mx_kernel<5, false>, lds5); }
     else { if (g.pool) launch(conv3x3_mx_kernel<4, true>, lds4); else launch(conv3x3_mx_kernel<4, false>, lds4); }
     if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;

@@ -615,6 +615,24 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
     return VQK_OK;
 }
 
+int vqk_gn_forward_presummed(int dtype, const void* x, const float* w, const float* b, void* y, float* stats, double* ws,
+                             int n, int64_t hw, int c, int groups, float eps, int silu, void* stream) {
+    VQK_REQUIRE(x && w && b && y && stats && ws, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
+    const int rc = check_gn(dtype, c, groups);
+    if (rc) return rc;
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    hipStream_t st = vqk_stream(stream);
+    const int ppb = pick_ppb(n, hw);
+    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
+    if (dtype == VQK_F32)
+        hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps);
+    else
+        hipLaunchKernelGGL(gn_apply_fin_kernel<bf16_raw>, grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
 int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy, void* dx,
                     float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu, int accumulate,
                     const void* add, void* stream) {

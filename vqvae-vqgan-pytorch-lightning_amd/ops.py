@@ -233,6 +233,36 @@ def raw_conv_fprop_pooled(x, wq, bias, residual, ksize: int, ups: bool, cout: in
     return y
 
 
+FUSE_GN_STATS = os.environ.get('VQK_FUSE_GN_STATS', '1') != '0'
+
+
+def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: int, pool: bool = False,
+                           pool_scale: float = 0.25):
+    """3x3 conv (+ fused 2x2 pooling) whose drain also leaves the GroupNorm sums of its OUTPUT in the stream's GroupNorm
+    workspace (vqk_conv2d_fprop_gnstats).  Returns y, or None when the problem is not served by the fused kernel
+    (nothing launched): the caller runs the plain conv, and the next ``raw_gn_forward`` its own statistics pass."""
+    _require_gpu(x)
+    n, cin, h, w = x.shape
+    s = 2 if ups else 1
+    ho, wo = (h * s // 2, w * s // 2) if pool else (h * s, w * s)
+    if not FUSE_GN_STATS or x.dtype != torch.bfloat16 or ho * wo <= 1024:
+        return None
+    y = empty_nhwc(n, cout, ho, wo, x.dtype, x.device)
+    ws = _gn_ws(x.device, n * groups * 2 + n)
+    flops = 2.0 * n * h * s * w * s * cout * cin * 9
+    nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size()
+              + (residual.numel() * residual.element_size() if residual is not None else 0) + cout * cin * 9 * x.element_size())
+    st = _timed(_fprop_kernel_name(x.dtype, 1), flops,
+                lambda: _native.lib().vqk_conv2d_fprop_gnstats(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias),
+                                                               _p(residual), y.data_ptr(), n, h, w, cin, cout, 3, int(ups),
+                                                               int(pool), float(pool_scale), ws.data_ptr(), groups,
+                                                               zero_page(x.device).data_ptr(), _stream()), nbytes)
+    if st == _native.ERR_SHAPE:
+        return None
+    _native.check(st, 'conv2d_fprop_gnstats')
+    return y
+
+
 _DIRECT_GRAD = True
 
 
@@ -320,13 +350,21 @@ def raw_gn_apply(x, stats, w, b, groups: int, silu: bool) -> torch.Tensor:
     return y
 
 
-def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool):
-    """(y, stats): sums kernel + finalize-and-apply kernel on the persistent workspace"""
+def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool = False):
+    """(y, stats): sums kernel + finalize-and-apply kernel on the persistent workspace; ``presummed``: the sums of x were
+    left in the workspace by the conv that produced x (``raw_conv_fprop_gnstats``), only the apply pass runs"""
     n, c, h, wd = x.shape
     y = torch.empty_like(x, memory_format=_CL)
     stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
     ws = _gn_ws(x.device, n * groups * 2 + n)
     nb = x.numel() * x.element_size()
+    if presummed:
+        st = _timed('group_norm_fwd (HBM)', 0.0,
+                    lambda: _native.lib().vqk_gn_forward_presummed(dcode(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                                   y.data_ptr(), stats.data_ptr(), ws.data_ptr(), n, h * wd, c,
+                                                                   groups, eps, int(silu), _stream()), 2 * nb)
+        _native.check(st, 'gn_forward_presummed')
+        return y, stats
     # algorithmic bytes: x read for the statistics, x read + y written by the apply pass (one read, one write on the
     # single-kernel path of the small maps)
     st = _timed('group_norm_fwd (HBM)', 0.0,
@@ -570,9 +608,13 @@ class ResBlockFn(torch.autograd.Function):
         w2 = n2w.detach().reshape(-1).contiguous(); b2 = n2b.detach().reshape(-1).contiguous()
         a1, st1 = raw_gn_forward(x, w1, b1, groups, eps, True)
         l1 = weight_layout(dt, n, h, w, cin, cout, 3, False)
-        r1 = raw_conv_fprop(a1, packed_weight(c1w, cin, cout, dt, 3, False, l1), None, None, 3,
-                            False, 0, dt, cout, l1)
-        a2, st2 = raw_gn_forward(r1, w2, b2, groups, eps, True)
+        wq1 = packed_weight(c1w, cin, cout, dt, 3, False, l1)
+        # the first conv's drain also sums its output for the second GroupNorm (no statistics pass over r1)
+        r1 = raw_conv_fprop_gnstats(a1, wq1, None, None, False, cout, groups) if l1 == 1 and cout % 128 == 0 else None
+        fused = r1 is not None
+        if not fused:
+            r1 = raw_conv_fprop(a1, wq1, None, None, 3, False, 0, dt, cout, l1)
+        a2, st2 = raw_gn_forward(r1, w2, b2, groups, eps, True, presummed=fused)
         skip = x
         if scw is not None:
             skip = raw_conv_fprop(x, packed_weight(scw, cin, cout, dt, 1, False, 0), None, None, 1,
