@@ -11,8 +11,11 @@ pytestmark = pytest.mark.gpu
 ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
 DEV, BF, CL = 'cuda:0', torch.bfloat16, torch.channels_last
 
-# n, cin, cout, h, w, ups, bias, residual, pool   (every case has >= 512 tiles: served by the fused kernel)
-CASES = [(8, 128, 128, 128, 128, 0, 0, 0, 0), (4, 64, 256, 128, 128, 0, 1, 1, 0), (2, 64, 512, 128, 128, 0, 0, 1, 0),
+# n, cin, cout, h, w, ups, bias, residual, pool   (every case has >= 64 tiles: served by the fused kernel; the short ones
+# give a block ONE tile, or some blocks one and some two)
+CASES = [(4, 128, 128, 128, 128, 0, 0, 0, 0), (2, 128, 128, 128, 128, 0, 0, 1, 0), (4, 256, 256, 64, 64, 0, 0, 1, 0),
+         (3, 128, 128, 128, 128, 0, 1, 0, 0), (5, 128, 256, 64, 64, 0, 0, 0, 0), (4, 128, 128, 128, 128, 0, 0, 1, 1),
+         (8, 128, 128, 128, 128, 0, 0, 0, 0), (4, 64, 256, 128, 128, 0, 1, 1, 0), (2, 64, 512, 128, 128, 0, 0, 1, 0),
          (8, 128, 128, 128, 128, 0, 0, 1, 1), (8, 128, 128, 64, 64, 1, 1, 0, 0), (6, 128, 256, 96, 128, 0, 0, 0, 0)]
 
 
@@ -43,7 +46,8 @@ def test_fused_stats_match_separate_pass(n, cin, cout, h, w, ups, hb, hr, pool):
     # mean / rstd: the same sums in a different order (fp32 partials per tile, fp64 across tiles)
     torch.testing.assert_close(st.view(-1, 2)[:, 0], st_ref.view(-1, 2)[:, 0], rtol=0, atol=2e-5)
     torch.testing.assert_close(st.view(-1, 2)[:, 1], st_ref.view(-1, 2)[:, 1], rtol=2e-5, atol=0)
-    assert float((a.float() - a_ref.float()).abs().max()) <= 2.0 ** -6        # at most one bf16 step on O(1) values
+    # the output may differ by ONE bf16 step where the fp32 value sits on a rounding boundary
+    assert float(((a.float() - a_ref.float()).abs() / (a_ref.float().abs() + 1.0)).max()) <= 2.0 ** -7
     assert float((a.float() - a_ref.float()).norm() / a_ref.float().norm()) < 1e-4
     ws = ops._gn_ws(x.device, n * 32 * 2 + n)
     assert float(ws.abs().max()) == 0.0, 'the GroupNorm workspace must be left zero'
@@ -56,3 +60,33 @@ def test_not_served_returns_none():
     ws = ops._gn_ws(x.device, 128)
     torch.cuda.synchronize()
     assert float(ws.abs().max()) == 0.0
+
+
+def test_unclaimed_sums_do_not_leak_into_the_next_groupnorm():
+    """a producer told ``next_gn`` whose consumer turns out NOT to be a GroupNorm (the decoder's ResBlock -> Upsample conv)
+    leaves sums nobody claims: the next producer / GroupNorm must clear them instead of adding to them"""
+    ae = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.autoencoder')
+    torch.manual_seed(3)
+    c1 = ae.Conv2d(128, 128, 3, bias=True).to(DEV)
+    up = ae.Upsample(128).to(DEV)
+    gn = ae.GroupNorm(32, 128).to(DEV)
+    x = torch.randn(4, 128, 64, 64, device=DEV).to(BF).contiguous(memory_format=CL)
+    with torch.no_grad():
+        saved, ops.FUSE_GN_STATS = ops.FUSE_GN_STATS, False
+        ref = gn(up(c1(x)), silu=True)
+        ops.FUSE_GN_STATS = True
+        try:
+            t = c1(x, next_gn=32)                 # sums of t are parked ... and never claimed
+            assert ops._PENDING_GN is not None
+            got = gn(up(t, next_gn=32), silu=True)
+            t2 = c1(x, next_gn=32)                # parked again; the next consumer is a GroupNorm of ANOTHER tensor
+            got2 = gn(ref.to(BF), silu=False)
+            ref2 = None
+            ops.FUSE_GN_STATS = False
+            ref2 = gn(ref.to(BF), silu=False)
+        finally:
+            ops.FUSE_GN_STATS = saved
+    torch.cuda.synchronize()
+    assert float((got.float() - ref.float()).norm() / ref.float().norm()) < 1e-3
+    assert float((got2.float() - ref2.float()).norm() / ref2.float().norm()) < 1e-3
+    assert float(ops._gn_ws(x.device, 4 * 64 + 4).abs().max()) == 0.0 and ops._PENDING_GN is None

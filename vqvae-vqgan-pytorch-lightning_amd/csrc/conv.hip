@@ -1758,7 +1758,7 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
             // matrix-wave / auxiliary-wave kernel (conv_mx.inc): whole 128-cout tiles, plain epilogue (bias / residual /
             // pooling), at least two tiles per CU so that the auxiliary waves always have a next halo to fetch
             static const int mx_on = getenv("VQK_MX") ? atoi(getenv("VQK_MX")) : 1;
-            static const int mx_min = getenv("VQK_MX_MIN_TILES") ? atoi(getenv("VQK_MX_MIN_TILES")) : 512;
+            static const int mx_min = getenv("VQK_MX_MIN_TILES") ? atoi(getenv("VQK_MX_MIN_TILES")) : 64;
             const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
             const bool fits32 = (int64_t)g.n * g.h_in * g.w_in * g.cin * 2 < 0x7fffffffLL && (int64_t)g.m * g.cout * 2 < 0x7fffffffLL;
             if (mx_on && g_force_variant != 5 && plain && fits32 && (g.cpt >> 2) >= 2 && (total >= mx_min || g_force_variant == 6)) {

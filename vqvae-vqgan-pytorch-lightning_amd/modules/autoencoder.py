@@ -44,8 +44,8 @@ class Conv2d(nn.Module):
         else:
             self.register_parameter('bias', None)
 
-    def forward(self, x, residual=None, ups: bool = False, act: int = 0, out_dtype=None):
-        return ops.conv2d(x, self.weight, self.bias, residual, ups, act, out_dtype)
+    def forward(self, x, residual=None, ups: bool = False, act: int = 0, out_dtype=None, next_gn: int = 0):
+        return ops.conv2d(x, self.weight, self.bias, residual, ups, act, out_dtype, next_gn)
 
 
 class GroupNorm(nn.Module):
@@ -74,13 +74,14 @@ class ResBlock(nn.Module):
         self.norm2 = GroupNorm(32, out_channels, eps=1e-6)
         self.conv2 = Conv2d(out_channels, out_channels, 3, bias=False)
 
-    def forward(self, x, pool: bool = False):
+    def forward(self, x, pool: bool = False, next_gn: int = 0):
         # one fused autograd node: residual add in conv2's epilogue, skip-gradient add in norm1's backward sweep;
-        # pool: the Downsample that follows the block rides in conv2's epilogue as well
+        # pool: the Downsample that follows the block rides in conv2's epilogue as well; next_gn: the GroupNorm that
+        # reads the result next has that many groups (its statistics ride in conv2's drain on the large maps)
         return ops.res_block(x, self.norm1.weight, self.norm1.bias, self.conv1.weight, self.norm2.weight,
                              self.norm2.bias, self.conv2.weight,
                              None if self.conv_shortcut is None else self.conv_shortcut.weight,
-                             self.norm1.num_groups, self.norm1.eps, pool)
+                             self.norm1.num_groups, self.norm1.eps, pool, next_gn)
 
 
 class Downsample(nn.Module):
@@ -102,8 +103,8 @@ class Upsample(nn.Module):
         self.scale_factor, self.mode = scale_factor, mode
         self.conv = Conv2d(channels, channels, 3, bias=True)
 
-    def forward(self, x):
-        return self.conv(x, ups=True)
+    def forward(self, x, next_gn: int = 0):
+        return self.conv(x, ups=True, next_gn=next_gn)
 
 
 def _to_internal(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -138,14 +139,20 @@ class Encoder(nn.Module):
         x = self.conv_in(x)
         mods = list(self.blocks)
         i = 0
+        # every ResBlock / pooled output is read next by a 32-group GroupNorm (the next block's norm1, finally self.norm)
+        gn = self.norm.num_groups
         while i < len(mods):                                  # ResBlock + Downsample pairs run as one fused op
             if isinstance(mods[i], ResBlock) and i + 1 < len(mods) and isinstance(mods[i + 1], Downsample):
-                x = mods[i](x, pool=True)
+                x = mods[i](x, pool=True, next_gn=gn)
                 i += 2
+            elif isinstance(mods[i], ResBlock):
+                x = mods[i](x, next_gn=gn)
+                i += 1
             else:
                 x = mods[i](x)
                 i += 1
-        x = self.final_residual(x)
+        for blk in self.final_residual:
+            x = blk(x, next_gn=gn)
         x = self.norm(x, silu=True)
         return self.conv_out(x, out_dtype=torch.float32)      # the quantizer always sees fp32 latents
 
@@ -172,8 +179,13 @@ class Decoder(nn.Module):
         """reconstruction with its zero pad channels ([N, 4 or 8, H, W], NHWC) -- what the fused loss reads"""
         x = _to_internal(x, self.compute_dtype)
         x = self.conv_in(x)
-        x = self.initial_residual(x)
-        x = self.blocks(x)
+        # a ResBlock / Upsample output is read next by a 32-group GroupNorm (the next block's norm1, finally self.norm)
+        # unless an Upsample conv follows it
+        gn = self.norm.num_groups
+        mods = list(self.initial_residual) + list(self.blocks)
+        for i, blk in enumerate(mods):
+            to_conv = i + 1 < len(mods) and isinstance(mods[i + 1], Upsample)
+            x = blk(x, next_gn=0 if to_conv else gn)
         x = self.norm(x, silu=True)
         return self.conv_out(x, act=1)                        # tanh in the epilogue
 

@@ -247,6 +247,8 @@ def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: 
     ho, wo = (h * s // 2, w * s // 2) if pool else (h * s, w * s)
     if not FUSE_GN_STATS or x.dtype != torch.bfloat16 or ho * wo <= 1024:
         return None
+    if _PENDING_GN is not None:                                  # sums nobody claimed (the consumer was not a GroupNorm)
+        _claim_presummed(x, -1)
     y = empty_nhwc(n, cout, ho, wo, x.dtype, x.device)
     ws = _gn_ws(x.device, n * groups * 2 + n)
     flops = 2.0 * n * h * s * w * s * cout * cin * 9
@@ -331,6 +333,31 @@ def _gn_ws(device, n_doubles: int) -> torch.Tensor:
     return ws
 
 
+# A conv that was told "a GroupNorm with `groups` groups reads my output next" (``next_gn``) leaves the sums of its output
+# in the stream's workspace (vqk_conv2d_fprop_gnstats) and notes the tensor here; the next ``raw_gn_forward`` on exactly
+# that tensor claims them and skips its statistics pass.  Anything else arriving first finds the workspace dirty: it is
+# cleared and the note dropped (the unfused sequence runs), so a changed call order costs a memset, never a wrong result.
+_PENDING_GN = None
+
+
+def _note_presummed(y, groups: int) -> None:
+    global _PENDING_GN
+    _PENDING_GN = (y.data_ptr(), tuple(y.shape), groups, _stream())
+
+
+def _claim_presummed(x, groups: int) -> bool:
+    global _PENDING_GN
+    p = _PENDING_GN
+    if p is None:
+        return False
+    _PENDING_GN = None
+    if p == (x.data_ptr(), tuple(x.shape), groups, _stream()):
+        return True
+    for ws in _GN_WS.values():
+        ws.zero_()
+    return False
+
+
 def raw_gn_stats(x, groups: int, eps: float) -> torch.Tensor:
     n, c, h, w = x.shape
     acc = torch.zeros(n * groups * 2, dtype=torch.float64, device=x.device)
@@ -358,6 +385,7 @@ def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool
     stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
     ws = _gn_ws(x.device, n * groups * 2 + n)
     nb = x.numel() * x.element_size()
+    presummed = presummed or _claim_presummed(x, groups)
     if presummed:
         st = _timed('group_norm_fwd (HBM)', 0.0,
                     lambda: _native.lib().vqk_gn_forward_presummed(dcode(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(),
@@ -380,6 +408,7 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
     dx = torch.empty_like(x, memory_format=_CL)
     dw = dw if dw is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     db = db if db is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
+    _claim_presummed(x, -1)                                      # (clears a stale note + workspace; never matches)
     red = _gn_ws(x.device, n * groups * 2 + n)
     nb = x.numel() * x.element_size()
     passes = (3 if h * wd <= 512 else 5) + (1 if add is not None else 0)     # x, dy (twice on the two-kernel path), dx, skip
@@ -477,7 +506,7 @@ class Conv2dFn(torch.autograd.Function):
     identically zero."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, ups: bool, act: int, out_dtype):
+    def forward(ctx, x, weight, bias, residual, ups: bool, act: int, out_dtype, next_gn: int = 0):
         _require_gpu(x)
         x = nhwc(x)
         dt = x.dtype
@@ -498,7 +527,13 @@ class Conv2dFn(torch.autograd.Function):
                 b32 = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
                 b32[:o] = bias.detach()
         res = nhwc(residual) if residual is not None else None
-        y = raw_conv_fprop(x, wq, b32, res, k, ups, act, out_dtype, cout_pad, layout)
+        y = None
+        if next_gn and k == 3 and act == 0 and layout == 1 and out_dtype == dt and cout_pad % 128 == 0 and cout_pad == o:
+            y = raw_conv_fprop_gnstats(x, wq, b32, res, ups, cout_pad, next_gn)
+            if y is not None:
+                _note_presummed(y, next_gn)
+        if y is None:
+            y = raw_conv_fprop(x, wq, b32, res, k, ups, act, out_dtype, cout_pad, layout)
         ctx.save_for_backward(x, weight, y if act == 1 else None)
         ctx.bias_ref, ctx.weight_ref = bias, weight
         ctx.cfg = (k, ups, act, o, i, cin, cout_pad, bias is not None, residual is not None, dt)
@@ -540,11 +575,11 @@ class Conv2dFn(torch.autograd.Function):
             tgt = None if padded else direct_grad(ctx.bias_ref)
             db = raw_colsum(n * h * w, c, dyc, out=tgt)
             db = None if tgt is not None else db[:o]
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, residual=None, ups: bool = False, act: int = 0, out_dtype=None):
-    return Conv2dFn.apply(x, weight, bias, residual, ups, act, out_dtype)
+def conv2d(x, weight, bias=None, residual=None, ups: bool = False, act: int = 0, out_dtype=None, next_gn: int = 0):
+    return Conv2dFn.apply(x, weight, bias, residual, ups, act, out_dtype, next_gn)
 
 
 class GroupNormSiLUFn(torch.autograd.Function):
@@ -596,7 +631,7 @@ class ResBlockFn(torch.autograd.Function):
     bookkeeping for eight intermediate nodes)."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups: int, eps: float, pool: bool = False):
+    def forward(ctx, x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups: int, eps: float, pool: bool = False, next_gn: int = 0):
         _require_gpu(x)
         x = nhwc(x)
         dt = x.dtype
@@ -621,7 +656,14 @@ class ResBlockFn(torch.autograd.Function):
                                   False, 0, dt, cout, 0)
         l2 = weight_layout(dt, n, h, w, cout, cout, 3, False)
         wq2 = packed_weight(c2w, cout, cout, dt, 3, False, l2)
-        if pool and can_pool_epilogue(dt, cout, l2):
+        out = None
+        if next_gn and l2 == 1 and cout % 128 == 0:              # the sums for the GroupNorm that reads `out` next
+            out = raw_conv_fprop_gnstats(a2, wq2, None, skip, False, cout, next_gn, pool=pool, pool_scale=0.25)
+            if out is not None:
+                _note_presummed(out, next_gn)
+        if out is not None:
+            pass
+        elif pool and can_pool_epilogue(dt, cout, l2):
             out = raw_conv_fprop_pooled(a2, wq2, None, skip, 3, False, cout, 0.25)   # the level's avg-pool, fused
         else:
             out = raw_conv_fprop(a2, wq2, None, skip, 3, False, 0, dt, cout, l2)
@@ -702,7 +744,7 @@ class ResBlockFn(torch.autograd.Function):
                 main.wait_stream(side)
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)
-            return dx, dn1w, dn1b, None, dn2w, dn2b, None, dwsc, None, None, None
+            return dx, dn1w, dn1b, None, dn2w, dn2b, None, dwsc, None, None, None, None
         d_a2, dw2 = conv_bwd(a2, dout, c2w, 3, cout, cout)
         d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
         d_a1, dw1 = conv_bwd(a1, d_r1, c1w, 3, cin, cout)
@@ -710,12 +752,14 @@ class ResBlockFn(torch.autograd.Function):
         if scw is not None:
             dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
         dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip)
-        return dx, dn1w, dn1b, dw1, dn2w, dn2b, dw2, dwsc, None, None, None
+        return dx, dn1w, dn1b, dw1, dn2w, dn2b, dw2, dwsc, None, None, None, None
 
 
-def res_block(x, n1w, n1b, c1w, n2w, n2b, c2w, scw=None, groups: int = 32, eps: float = 1e-6, pool: bool = False):
-    """pool: also apply the 2x2 average pool that follows the block (the encoder's Downsample, autoencoder.py:89-91)"""
-    return ResBlockFn.apply(x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups, eps, pool)
+def res_block(x, n1w, n1b, c1w, n2w, n2b, c2w, scw=None, groups: int = 32, eps: float = 1e-6, pool: bool = False,
+              next_gn: int = 0):
+    """pool: also apply the 2x2 average pool that follows the block (the encoder's Downsample, autoencoder.py:89-91);
+    next_gn: a GroupNorm with that many groups is the NEXT consumer of the result (its sums ride in conv2's drain)"""
+    return ResBlockFn.apply(x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups, eps, pool, next_gn)
 
 
 def group_norm_silu(x, weight, bias, groups: int = 32, eps: float = 1e-6, silu: bool = True):
