@@ -2110,6 +2110,20 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
         splits = (total_patches + pps - 1) / pps;
         const dim3 grid((unsigned)tiles, (unsigned)splits);
         static const bool no_p16k = getenv("VQK_WGRAD_NO_P16K") != nullptr;
+        static const int wgmx = getenv("VQK_WGMX") ? atoi(getenv("VQK_WGMX")) : 1;
+        if (pw16 && (cin % 64) == 0 && (cout % 64) == 0 && wgmx && target == 0) {
+            // matrix/auxiliary-wave form: ONE 512-thread block per CU, so half as many resident blocks as the cost model
+            // above assumes: s* = sqrt(0.08 * pixels / tiles) under half the block cap
+            static const double coef = getenv("VQK_WGMX_COEF") ? atof(getenv("VQK_WGMX_COEF")) : 0.08;
+            const int capm = cap / 2 > tiles ? cap / 2 : tiles;
+            int sm = (int)(sqrt(coef * (double)g.m / tiles) + 0.5);
+            if (sm > (capm + tiles - 1) / tiles) sm = (capm + tiles - 1) / tiles;
+            if (sm > (total_patches + 3) / 4) sm = (total_patches + 3) / 4;          // >= 4 patches per block
+            if (sm < 1) sm = 1;
+            const int ppm = (total_patches + sm - 1) / sm;
+            sm = (total_patches + ppm - 1) / ppm;
+            return vqkd::launch_conv3x3_wgrad_mx(x, dy, dw, zeros, g, tiles, sm, ppm, vqk_stream(stream));
+        }
         if (pw16 && (cin % 64) == 0 && (cout % 64) == 0 && !no_p16k) {
             static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_wgrad_p16_kernel,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 40960);

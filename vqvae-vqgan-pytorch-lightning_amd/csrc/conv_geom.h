@@ -46,4 +46,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                       const ConvGeom& g, int twlog, hipStream_t st);
 
+// matrix-wave / auxiliary-wave 3x3 weight-gradient kernel (conv_wgmx.hip): bf16, Cin % 64 == 0, Cout % 64 == 0, W % 16 == 0;
+// grid = tiles x splits blocks of 512 threads, `pps` 8x16-pixel patches per split
+int launch_conv3x3_wgrad_mx(const void* x, const void* dy, float* dw, const void* zeros, const ConvGeom& g, int tiles,
+                            int splits, int pps, hipStream_t st);
+
 }  // namespace vqkd
