@@ -195,9 +195,13 @@ def main():
         name, (count, flops, secs, nbytes) = max(((k, v) for k, v in by_kernel.items() if v[1] > 0), key=lambda kv: kv[1][2])
         traffic = None
         try:                                   # HBM bytes per launch from the committed rocprofv3 --pmc passes
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'round1_traffic.json')))
-            if tj['kernel'].startswith(name.split('<')[0]):
-                traffic = tj['hbm_bytes_per_launch']
+            for tag in ('round2', 'round1'):
+                tp = os.path.join(ROOT, 'profiles', f'{tag}_traffic.json')
+                if os.path.exists(tp):
+                    tj = json.load(open(tp))
+                    if tj['kernel'].startswith(name.split('<')[0]):
+                        traffic = tj['hbm_bytes_per_launch']
+                        break
         except Exception:
             pass
         peak = MFMA_PEAK_TFLOPS[args.dtype]

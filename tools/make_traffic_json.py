@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Combine the FETCH_SIZE / WRITE_SIZE summaries written by tools/collect_profiles.sh into profiles/<tag>_traffic.json
-(launch-weighted average over every conv3x3_stream_kernel variant; FETCH_SIZE doubled per the gfx950 note in
-MI355X_MICROARCH.md).  usage: make_traffic_json.py gpurun_out/<tag>_fetch.txt gpurun_out/<tag>_write.txt out.json"""
+(launch-weighted average over every variant of the summarised kernel; FETCH_SIZE doubled per the gfx950 note in
+MI355X_MICROARCH.md).  usage: make_traffic_json.py gpurun_out/<tag>_fetch.txt gpurun_out/<tag>_write.txt out.json [kernel label]"""
 import json, re, sys
 
 
@@ -17,7 +17,8 @@ def parse(path, ctr):
 
 f, nf = parse(sys.argv[1], 'FETCH_SIZE')
 w, nw = parse(sys.argv[2], 'WRITE_SIZE')
-out = dict(kernel='conv3x3_stream_kernel<bf16> (all variants / patch shapes)', launches_sampled=nf,
+kname = sys.argv[4] if len(sys.argv) > 4 else 'conv3x3_stream_kernel<bf16>'
+out = dict(kernel=f'{kname} (all variants / patch shapes)', launches_sampled=nf,
            fetch_size_kb_per_launch=round(f, 1), write_size_kb_per_launch=round(w, 1),
            correction='FETCH_SIZE doubled (gfx950: wide coalesced reads are tallied at half, MI355X_MICROARCH.md HBM '
                       'section); WRITE_SIZE as reported',

@@ -79,10 +79,23 @@ def _timed(name: str, flops: float, launch, nbytes: float = 0.0):
     return st
 
 
-def _fprop_kernel_name(dtype, wlayout: int) -> str:
-    """the kernel symbol the launcher picks (csrc/conv.hip::launch_fprop), for the per-kernel event statistics"""
+_MX_ON = os.environ.get('VQK_MX', '1') != '0'
+_MX_MIN_TILES = int(os.environ.get('VQK_MX_MIN_TILES', '64'))
+_WGMX_ON = os.environ.get('VQK_WGMX', '1') != '0'
+
+
+def _fprop_kernel_name(dtype, wlayout: int, shape=None) -> str:
+    """the kernel symbol the launcher picks (csrc/conv.hip::launch_fprop), for the per-kernel event statistics;
+    shape = (n, h_out, w_out, cin, cout, act, out_dtype) lets it tell the matrix/auxiliary-wave kernel from the stream kernel"""
     if wlayout == 1:
-        return 'conv3x3_stream_kernel<bf16>' if dtype == torch.bfloat16 else 'conv3x3_halo_breg_kernel<f32>'
+        if dtype != torch.bfloat16:
+            return 'conv3x3_halo_breg_kernel<f32>'
+        if shape is not None and _MX_ON:
+            n, ho, wo, cin, cout, act, odt = shape
+            if (act == 0 and odt == torch.bfloat16 and cout % 128 == 0 and cin >= 64
+                    and n * ho * wo // 256 * (cout // 128) >= _MX_MIN_TILES):
+                return 'conv3x3_mx_kernel<bf16>'
+        return 'conv3x3_stream_kernel<bf16>'
     return f'conv_fprop_kernel<{"f32" if dtype == torch.float32 else "bf16"}>'
 
 
@@ -200,7 +213,7 @@ def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_d
     flops = 2.0 * n * h * s * w * s * cout * cin * ksize * ksize
     nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size() * (2 if residual is not None else 1)
               + cout * cin * ksize * ksize * x.element_size())
-    st = _timed(_fprop_kernel_name(x.dtype, wlayout), flops,
+    st = _timed(_fprop_kernel_name(x.dtype, wlayout, (n, h * s, w * s, cin, cout, act, out_dtype)), flops,
                 lambda: _native.lib().vqk_conv2d_fprop(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias),
                                                        _p(residual), y.data_ptr(), dcode(out_dtype), n, h, w, cin,
                                                        cout, ksize, int(ups), act, wlayout,
@@ -224,7 +237,7 @@ def raw_conv_fprop_pooled(x, wq, bias, residual, ksize: int, ups: bool, cout: in
     nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size()
               + (residual.numel() * residual.element_size() if residual is not None else 0)
               + cout * cin * ksize * ksize * x.element_size())
-    st = _timed(_fprop_kernel_name(x.dtype, 1), flops,
+    st = _timed(_fprop_kernel_name(x.dtype, 1, (n, h * s, w * s, cin, cout, 0, x.dtype)), flops,
                 lambda: _native.lib().vqk_conv2d_fprop_pooled(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias),
                                                               _p(residual), y.data_ptr(), n, h, w, cin, cout, ksize,
                                                               int(ups), float(pool_scale),
@@ -254,7 +267,7 @@ def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: 
     flops = 2.0 * n * h * s * w * s * cout * cin * 9
     nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size()
               + (residual.numel() * residual.element_size() if residual is not None else 0) + cout * cin * 9 * x.element_size())
-    st = _timed(_fprop_kernel_name(x.dtype, 1), flops,
+    st = _timed(_fprop_kernel_name(x.dtype, 1, (n, h * s, w * s, cin, cout, 0, x.dtype)), flops,
                 lambda: _native.lib().vqk_conv2d_fprop_gnstats(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias),
                                                                _p(residual), y.data_ptr(), n, h, w, cin, cout, 3, int(ups),
                                                                int(pool), float(pool_scale), ws.data_ptr(), groups,
@@ -297,7 +310,9 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None) -> torch.Tensor:
     dw = out if out is not None else \
         torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
     flops = 2.0 * n * dy.shape[2] * dy.shape[3] * cout * cin * ksize * ksize
-    st = _timed(f'conv_wgrad_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
+    mxw = (_WGMX_ON and x.dtype == torch.bfloat16 and ksize == 3 and cin % 64 == 0 and cout % 64 == 0
+           and dy.shape[3] % 16 == 0 and dy.shape[2] % 8 == 0)
+    st = _timed('conv3x3_wgrad_mx_kernel<bf16>' if mxw else f'conv_wgrad_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
                 lambda: _native.lib().vqk_conv2d_wgrad(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h,
                                                        w, cin, cout, ksize, int(ups),
                                                        zero_page(x.device).data_ptr(), _stream()))
