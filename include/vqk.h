@@ -279,8 +279,8 @@ int vqk_maxpool2x2(int dtype, const void* x, const void* dy, void* out, int n, i
 int vqk_channel_affine(int dtype, const void* x, const float* scale, const float* shift, void* y, int64_t npix, int c,
                        void* stream);
 /* LPIPS tap (lpips.py:31-38, utils.py:6-8): dfy == NULL: out[n] += (1/hw) sum_pix sum_c lin[c] (fx/(|fx|+1e-10) -
- * fy/(|fy|+1e-10))^2 (out pre-zeroed);  dfy != NULL: gradient w.r.t. fy for upstream gscale * gout[0] / n-independent
- * (the batch mean is folded into gscale by the caller). */
+ * fy/(|fy|+1e-10))^2 (out pre-zeroed);  dfy != NULL: gradient w.r.t. fy for the upstream gradient gscale * gout[image]
+ * (gout: n floats, one per image; NULL = 1). */
 int vqk_lpips_tap(int dtype, const void* fx, const void* fy, const float* lin, int n, int64_t hw, int c, float* out,
                   const float* gout, float gscale, void* dfy, void* stream);
 /* minibatch-stddev layer (discriminator.py:271-293), F = 1 feature: forward writes out[N][hw][cpad] = [x | stat | 0..]

@@ -44,6 +44,9 @@ using vqkd::xcd_remap;
 #ifndef VQK_MX_PRIO
 #define VQK_MX_PRIO 0        // s_setprio of the matrix waves
 #endif
+#ifndef VQK_MX_JOUTER
+#define VQK_MX_JOUTER 0      // MFMA order inside a phase: 0 pixel-fragment-major, 1 weight-fragment-major
+#endif
 #ifndef VQK_MX_PIN
 #define VQK_MX_PIN 1         // pinned instruction order inside a phase
 #endif
@@ -165,6 +168,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
 #pragma unroll
                             for (int j = 0; j < NJ; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[ph % RD][j], a[ks][i], zero, 0, 0, 0);
+                    } else if (VQK_MX_JOUTER) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int i = 0; i < NI; ++i)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[ph % RD][j], a[ks][i], acc[i][j], 0, 0, 0);
                     } else {
 #pragma unroll
                         for (int i = 0; i < NI; ++i)
@@ -296,14 +305,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         }
         // GroupNorm statistics of the stored output (wave-uniform switch): channel sums over this thread's pieces
         const bool want_stats = g.gn_ws != nullptr;
-        float gs[8], gq[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+        // (v_dot2c_f32_bf16 sums a packed pair -- against (1, 1) for the sum, against itself for the squares -- straight
+        // from the stored bf16 words: 8 VALU per 16-byte piece instead of 24 for unpack / add / fma; every X-wave VALU
+        // instruction competes with the matrix wave of its SIMD for the issue port)
+        // (inline asm: with __builtin_amdgcn_fdot2_f32_bf16 on the elements of a 16-byte vector hipcc 7.2 folded all four
+        // dwords of a piece onto the first register)
+        const unsigned ones2 = 0x3f803f80u;
+        float ga = 0.f, qa = 0.f, gb = 0.f, qb = 0.f;            // channels 0-3 / 4-7 of the thread's eight
+        auto dot2 = [](float& acc, unsigned a, unsigned b) { asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); };
         auto tally = [&](const u32x4& o) {
-            float v[8];
-            unpack8(o, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] = __fmaf_rn(v[e], v[e], gq[e]); }
+            const unsigned d0 = o[0], d1 = o[1], d2 = o[2], d3 = o[3];
+            dot2(ga, d0, ones2); dot2(ga, d1, ones2); dot2(qa, d0, d0); dot2(qa, d1, d1);
+            dot2(gb, d2, ones2); dot2(gb, d3, ones2); dot2(qb, d2, d2); dot2(qb, d3, d3);
         };
         u32x4 t[16];                                             // the thread's 16 staging pieces, all requested up front
         if constexpr (!POOL) {
@@ -367,8 +380,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             // keeps ONE of the (up to) four values.  The four X waves' 64 values are parked in LDS and combined by the first
             // X wave after the next barrier (flush_stats): ONE wave-wide fp64 atomic instruction per tile -- with one per
             // wave the 256 CUs, which all work on the same image at a time, queued up on that image's four cache lines.
-            float ga = (gs[0] + gs[1]) + (gs[2] + gs[3]), gb = (gs[4] + gs[5]) + (gs[6] + gs[7]);
-            float qa = (gq[0] + gq[1]) + (gq[2] + gq[3]), qb = (gq[4] + gq[5]) + (gq[6] + gq[7]);
             const bool split = g.gn_cpg == 4;
             if (!split) { ga += gb; qa += qb; }
             ga += __shfl_xor(ga, 16, 64); ga += __shfl_xor(ga, 32, 64);

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const T* __restrict_
     for (int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (int64_t)gridDim.x * 4) {
         const T* px = fx + pix * c;
         const T* py = fy + pix * c;
-        const float g = gscale * (gout ? gout[0] : 1.0f) / (float)hw;
+        const float g = gscale * (gout ? gout[pix / hw] : 1.0f) / (float)hw;     // upstream gradient of THIS pixel's image
         float sx = 0.f, sy = 0.f;
         for (int k = lane; k < c; k += 64) {
             const float a = Elem<T>::ld(px + k), b = Elem<T>::ld(py + k);

@@ -1461,17 +1461,12 @@ class LpipsTapFn(torch.autograd.Function):
     def backward(ctx, dout):
         fx, fy, lin = ctx.saved_tensors
         n, c, h, w = fx.shape
-        # dout is [n]; the reference reduces with a batch mean, so every entry is the same scalar: use per-image scale
+        # dout is [n]: the kernel scales every image by its own upstream gradient (no host-side test of the values, which
+        # would be a device -> host sync in the middle of the backward)
         dfy = torch.empty_like(fy, memory_format=_CL)
-        if bool((dout != dout[0]).any()):                      # general upstream: one launch per image
-            for b in range(n):
-                _native.check(_native.lib().vqk_lpips_tap(dcode(fx.dtype), fx[b:b + 1].data_ptr(), fy[b:b + 1].data_ptr(),
-                                                          lin.data_ptr(), 1, h * w, c, 0, dout[b:b + 1].contiguous().data_ptr(),
-                                                          1.0, dfy[b:b + 1].data_ptr(), _stream()), 'lpips_tap_backward')
-        else:
-            _native.check(_native.lib().vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
-                                                      0, dout[0:1].contiguous().data_ptr(), 1.0, dfy.data_ptr(), _stream()),
-                          'lpips_tap_backward')
+        _native.check(_native.lib().vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
+                                                  0, dout.contiguous().float().data_ptr(), 1.0, dfy.data_ptr(), _stream()),
+                      'lpips_tap_backward')
         return None, dfy, None
 
 
