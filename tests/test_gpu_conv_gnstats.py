@@ -15,6 +15,7 @@ DEV, BF, CL = 'cuda:0', torch.bfloat16, torch.channels_last
 # give a block ONE tile, or some blocks one and some two)
 CASES = [(4, 128, 128, 128, 128, 0, 0, 0, 0), (2, 128, 128, 128, 128, 0, 0, 1, 0), (4, 256, 256, 64, 64, 0, 0, 1, 0),
          (3, 128, 128, 128, 128, 0, 1, 0, 0), (5, 128, 256, 64, 64, 0, 0, 0, 0), (4, 128, 128, 128, 128, 0, 0, 1, 1),
+         (4, 256, 256, 128, 128, 0, 0, 1, 1), (4, 128, 256, 128, 128, 0, 0, 0, 1), (2, 128, 512, 128, 128, 0, 1, 1, 1),
          (8, 128, 128, 128, 128, 0, 0, 0, 0), (4, 64, 256, 128, 128, 0, 1, 1, 0), (2, 64, 512, 128, 128, 0, 0, 1, 0),
          (8, 128, 128, 128, 128, 0, 0, 1, 1), (8, 128, 128, 64, 64, 1, 1, 0, 0), (6, 128, 256, 96, 128, 0, 0, 0, 0)]
 
@@ -54,7 +55,7 @@ def test_fused_stats_match_separate_pass(n, cin, cout, h, w, ups, hb, hr, pool):
 
 
 def test_not_served_returns_none():
-    x = torch.randn(1, 128, 32, 32, device=DEV).to(BF).contiguous(memory_format=CL)     # 4 tiles: stream kernel territory
+    x = torch.randn(1, 128, 32, 32, device=DEV).to(BF).contiguous(memory_format=CL)     # 32x32 map: single-kernel GroupNorm territory
     wq = ops.pack_weights(torch.randn(128 * 9 * 128, device=DEV) * 0.03, BF, 128, 128, 3, False, 1)
     assert ops.raw_conv_fprop_gnstats(x, wq, None, None, False, 128, 32) is None
     ws = ops._gn_ws(x.device, 128)

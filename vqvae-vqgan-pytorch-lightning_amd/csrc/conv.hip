@@ -1755,10 +1755,11 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         constexpr int lds = 2 * 28 * 1024;
         const bool half_ok = tw == 5 ? (g.h % 4) == 0 : (g.h % 8) == 0;
         if constexpr (sizeof(TO) == 2) {
-            // matrix-wave / auxiliary-wave kernel (conv_mx.inc): whole 128-cout tiles, plain epilogue (bias / residual /
-            // pooling), at least two tiles per CU so that the auxiliary waves always have a next halo to fetch
+            // matrix-wave / auxiliary-wave kernel (conv_mx.hip): whole 128-cout tiles, plain epilogue (bias / residual /
+            // pooling).  The choice must not depend on the batch size (a step on B images has to equal the mean of the steps
+            // on its halves to bf16 noise -- the two kernels round differently), hence no tile-count threshold by default
             static const int mx_on = getenv("VQK_MX") ? atoi(getenv("VQK_MX")) : 1;
-            static const int mx_min = getenv("VQK_MX_MIN_TILES") ? atoi(getenv("VQK_MX_MIN_TILES")) : 64;
+            static const int mx_min = getenv("VQK_MX_MIN_TILES") ? atoi(getenv("VQK_MX_MIN_TILES")) : 1;
             const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
             const bool fits32 = (int64_t)g.n * g.h_in * g.w_in * g.cin * 2 < 0x7fffffffLL && (int64_t)g.m * g.cout * 2 < 0x7fffffffLL;
             if (mx_on && g_force_variant != 5 && plain && fits32 && (g.cpt >> 2) >= 2 && (total >= mx_min || g_force_variant == 6)) {

@@ -309,15 +309,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         // from the stored bf16 words: 8 VALU per 16-byte piece instead of 24 for unpack / add / fma; every X-wave VALU
         // instruction competes with the matrix wave of its SIMD for the issue port)
         // (inline asm: with __builtin_amdgcn_fdot2_f32_bf16 on the elements of a 16-byte vector hipcc 7.2 folded all four
-        // dwords of a piece onto the first register)
+        // dwords of a piece onto the first register.  hipcc pads no hazards for asm: a DOT result needs 3 wait states before
+        // a different VALU instruction reads it and 1 before the same opcode accumulates into it again -- the eight dot
+        // products of a piece go out as ONE statement with the four accumulators interleaved, and `settle` closes the
+        // chain before the sums are read; without it the last products of a tile were dropped now and then)
         const unsigned ones2 = 0x3f803f80u;
         float ga = 0.f, qa = 0.f, gb = 0.f, qb = 0.f;            // channels 0-3 / 4-7 of the thread's eight
-        auto dot2 = [](float& acc, unsigned a, unsigned b) { asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); };
         auto tally = [&](const u32x4& o) {
             const unsigned d0 = o[0], d1 = o[1], d2 = o[2], d3 = o[3];
-            dot2(ga, d0, ones2); dot2(ga, d1, ones2); dot2(qa, d0, d0); dot2(qa, d1, d1);
-            dot2(gb, d2, ones2); dot2(gb, d3, ones2); dot2(qb, d2, d2); dot2(qb, d3, d3);
+            asm("v_dot2c_f32_bf16 %0, %4, %8\n\tv_dot2c_f32_bf16 %1, %4, %4\n\tv_dot2c_f32_bf16 %2, %6, %8\n\t"
+                "v_dot2c_f32_bf16 %3, %6, %6\n\tv_dot2c_f32_bf16 %0, %5, %8\n\tv_dot2c_f32_bf16 %1, %5, %5\n\t"
+                "v_dot2c_f32_bf16 %2, %7, %8\n\tv_dot2c_f32_bf16 %3, %7, %7\n\ts_nop 0"
+                : "+v"(ga), "+v"(qa), "+v"(gb), "+v"(qb) : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(ones2));
         };
+        auto settle = [&]() { asm volatile("s_nop 3" : "+v"(ga), "+v"(qa), "+v"(gb), "+v"(qb)); };
         u32x4 t[16];                                             // the thread's 16 staging pieces, all requested up front
         if constexpr (!POOL) {
 #pragma unroll
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             // keeps ONE of the (up to) four values.  The four X waves' 64 values are parked in LDS and combined by the first
             // X wave after the next barrier (flush_stats): ONE wave-wide fp64 atomic instruction per tile -- with one per
             // wave the 256 CUs, which all work on the same image at a time, queued up on that image's four cache lines.
+            settle();
             const bool split = g.gn_cpg == 4;
             if (!split) { ga += gb; qa += qb; }
             ga += __shfl_xor(ga, 16, 64); ga += __shfl_xor(ga, 32, 64);

@@ -80,7 +80,7 @@ def _timed(name: str, flops: float, launch, nbytes: float = 0.0):
 
 
 _MX_ON = os.environ.get('VQK_MX', '1') != '0'
-_MX_MIN_TILES = int(os.environ.get('VQK_MX_MIN_TILES', '64'))
+_MX_MIN_TILES = int(os.environ.get('VQK_MX_MIN_TILES', '1'))
 _WGMX_ON = os.environ.get('VQK_WGMX', '1') != '0'
 
 
