@@ -134,6 +134,15 @@ int vqk_conv2d_fprop_pooled(int dtype, const void* x, const void* w, const float
 int vqk_conv2d_fprop_gnstats(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                              int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int pool, float pool_scale,
                              double* gn_ws, int groups, const void* zeros, void* stream);
+/* The nearest-x2 upsample + 3x3 conv of autoencoder.py:104-106 in PHASE form: output pixel (2i+a, 2j+b) only sees a 2x2
+ * window of the low-resolution input with pre-summed weights, so the conv runs as four 2x2-tap launches (4/9 of the
+ * multiply-adds).  w4: the operand of vqk_conv_pack_weights(..., layout 2) -- transpose = 0 for backward = 0 (x [N][h][w][Cin]
+ * -> y [N][2h][2w][Cout] (+ bias; gn_ws as in vqk_conv2d_fprop_gnstats, or NULL)), transpose = 1 for backward = 1 (x = dy
+ * [N][2h][2w][Cin := conv's Cout] -> y = dx [N][h][w][Cout := conv's Cin], the four phases accumulate in place).  bf16,
+ * Cout % 128 == 0, Cin % 64 == 0; VQK_ERR_SHAPE when the matrix/auxiliary-wave kernel does not serve the problem (nothing
+ * launched: callers use vqk_conv2d_fprop with ups = 1 / the pooled data gradient). */
+int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w,
+                         int cin, int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream);
 /* General form (im2col kernel when not plain): stride in {1,2}, explicit zero padding `pad`, explicit output size;
  * mode 0: x as is, 1: nearest x2 upsample of x, 2: x zero-stuffed x2 (the dgrad of a stride-2 conv, with flipped /
  * transposed weights and pad = ks-1-pad_fwd).  Epilogue: y = out_gain * act(acc * acc_scale + bias) + residual, act 0
@@ -152,7 +161,10 @@ int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw
  * fragment is one coalesced 1 KiB load and the 18 fragments of a (cout tile, chunk) are contiguous.  vqk_conv_weight_layout() returns the layout the fprop launcher wants for
  * a problem (>= 0) or a negative status; vqk_conv_packed_elems() the element count of the packed buffer;
  * vqk_conv_pack_weights() builds it from the fp32 [Cout][ks][ks][Cin] master (transpose = 1: the dgrad operand,
- * i.e. Cin/Cout swapped and both taps flipped). */
+ * i.e. Cin/Cout swapped and both taps flipped).  2: the upsample-phase operand of vqk_conv2d_ups_phase (bf16, 3x3): four
+ * phases (a, b) of fragment-major blocks with FOUR taps each, tap (r, s) of a phase = the sum of the 3x3 taps that fall
+ * on the same low-resolution pixel (rows {0},{1,2} for a = 0 and {0,1},{2} for a = 1; columns alike); transpose = 1:
+ * channels swapped and the 2x2 taps mirrored. */
 int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups);
 int64_t vqk_conv_packed_elems(int cout, int cin, int ksize, int layout);
 int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int cin, int ksize, int transpose,

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 PKG = 'vqvae-vqgan-pytorch-lightning_amd'
 AE = dict(channels=32, num_res_blocks=1, channel_multipliers=(1, 2))
 TC = dict(lr=1e-3, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
+TRAJ_LR = 1e-5
 QP = {'standard': dict(commitment_cost=0.25), 'ema': dict(commitment_cost=0.25, decay=0.95, epsilon=1e-5)}
 
 
@@ -34,7 +35,10 @@ def _trajectory(qtype, force, steps=4):
     model_mod = importlib.import_module(PKG + '.model')
     trainer_mod = importlib.import_module(PKG + '.trainer')
     torch.manual_seed(0)
-    m = model_mod.VQVAE(32, AE, _qc(qtype), None, TC).to('cuda').train()
+    # a SMALL learning rate: with beta1 = 0 every step moves each weight by ~lr * sign(g), and run-to-run atomics order flips
+    # the sign of ~1e-9 gradient elements -- at lr = 1e-3 two identical runs drift apart by > 1 % in the loss within six
+    # steps (1 run in 6), which says nothing about the collectives this test is about
+    m = model_mod.VQVAE(32, AE, _qc(qtype), None, dict(TC, lr=TRAJ_LR)).to('cuda').train()
     with torch.no_grad():
         m.quantizer.codebook.weight.mul_(32.0)
     tr = trainer_mod.MiniTrainer(num_training_batches=100)
@@ -76,11 +80,10 @@ def _world1_worker(rank, port, out):
         # two runs of the same step are not bit-identical (split-K weight gradients accumulate with fp32 atomics) and with
         # beta1 = 0 a sign flip of a ~1e-9 gradient element moves that weight by 2 lr per step: same yardstick as
         # test_graph_replay_matches_eager
-        # (1 run in 8 exceeded 2e-3 on the loss of the last replay: the yardstick is the drift of two UNFORCED runs, ~5e-3)
-        np.testing.assert_allclose(l1, l0, rtol=1e-2)
+        np.testing.assert_allclose(l1, l0, rtol=2e-3)
         bad = total = 0
         for k in s0:
-            assert (s1[k] - s0[k]).abs().max().item() <= 6 * 2.1e-3, k
+            assert (s1[k] - s0[k]).abs().max().item() <= 6 * 2.1 * TRAJ_LR + 1e-6 * s0[k].abs().max().item(), k
             bad += (~torch.isclose(s1[k], s0[k], rtol=2e-3, atol=1e-5)).sum().item()
             total += s0[k].numel()
         assert bad <= 0.02 * total, (qtype, bad, total)

@@ -1629,6 +1629,51 @@ __device__ __forceinline__ void pack_any(const float* __restrict__ w, TD* __rest
         }
         return;
     }
+    if (layout == 2) {
+        // upsample-phase form (conv_mx.hip, ConvGeom::ntap == 4): four phases (a, b) x fragment-major blocks of FOUR taps
+        // (r, s); the tap of phase (a, b) is the SUM of the 3x3 taps that land on the same low-resolution pixel:
+        // rows R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}, columns alike.  transpose: the data-gradient
+        // form (output channels = ci, input = co, taps mirrored: tap (r', s') carries W_ab[1-r'][1-s']).
+        const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
+        const int cot_tiles = ((dcout + 127) / 128) * 4;
+        const int ncc = dcin / (4 * E);
+        const int64_t per_phase = (int64_t)cot_tiles * ncc * 4 * 2 * 64;
+        for (int64_t o = tid; o < 4 * per_phase; o += nthr) {
+            int64_t r = o;
+            const int co32 = (int)(r & 31); r >>= 5;
+            const int kg = (int)(r & 1); r >>= 1;
+            const int ks = (int)(r & 1); r >>= 1;
+            int tap = (int)(r & 3); r >>= 2;
+            const int cc = (int)(r % ncc); r /= ncc;
+            const int cot = (int)(r % cot_tiles);
+            const int ph = (int)(r / cot_tiles), pa = ph >> 1, pb = ph & 1;
+            const int co = cot * 32 + co32;
+            const int ci = ((cc * 2 + ks) * 2 + kg) * E;
+            if (transpose) tap = 3 - tap;
+            const int tr = tap >> 1, ts = tap & 1;
+            const int ky0 = pa == 0 ? (tr == 0 ? 0 : 1) : (tr == 0 ? 0 : 2), ky1 = pa == 0 ? (tr == 0 ? 0 : 2) : (tr == 0 ? 1 : 2);
+            const int kx0 = pb == 0 ? (ts == 0 ? 0 : 1) : (ts == 0 ? 0 : 2), kx1 = pb == 0 ? (ts == 0 ? 0 : 2) : (ts == 0 ? 1 : 2);
+            float v[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = 0.0f;
+            if (co < dcout) {
+                for (int ky = ky0; ky <= ky1; ++ky)
+                    for (int kx = kx0; kx <= kx1; ++kx) {
+                        if (!transpose) {
+                            const float* src = w + ((int64_t)co * 9 + ky * 3 + kx) * cin + ci;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) v[e] += src[e];
+                        } else {
+                            const float* src = w + ((int64_t)ci * 9 + ky * 3 + kx) * cin + co;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) v[e] += src[(int64_t)e * 9 * cin];
+                        }
+                    }
+            }
+            Vec16<TD>::store(out + o * E, v);
+        }
+        return;
+    }
     // fragment-major: one thread builds one 16-byte piece (E consecutive input channels of one output channel)
     const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
     const int cot_tiles = ((dcout + 127) / 128) * 4;
@@ -1866,6 +1911,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.stride = 1; g.pad = ksize >> 1; g.zs = 0; g.vh = g.h; g.vw = g.w;
     g.acc_scale = 1.0f; g.out_gain = 1.0f; g.pool = 0; g.pool_scale = 1.0f;
     g.gn_ws = nullptr; g.gn_cpg = 0;
+    g.ntap = 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
     g.m = (int)m;
@@ -1997,6 +2043,45 @@ int vqk_conv2d_fprop_gnstats(int dtype, const void* x, const void* w, const floa
     return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, 0, 1, vqk_stream(stream));
 }
 
+int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w,
+                         int cin, int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream) {
+    VQK_REQUIRE(x && w4 && y && zeros, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w4) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    VQK_REQUIRE(dtype == VQK_BF16, VQK_ERR_DTYPE);
+    VQK_REQUIRE(backward == 0 || backward == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(!gn_ws || (!backward && groups > 0 && cout % groups == 0 && (cout / groups) % 4 == 0), VQK_ERR_SHAPE);
+    ConvGeom g;
+    const int rc = make_geom(g, dtype, n, h, w, cin, cout, 3, 0);            // tiles over the LOW-resolution h x w grid
+    if (rc) return rc;
+    const int tw = halo_twlog(g);
+    static const int mx_on = getenv("VQK_MX") ? atoi(getenv("VQK_MX")) : 1;
+    static const int ph_on = getenv("VQK_UPS_PHASE") ? atoi(getenv("VQK_UPS_PHASE")) : 1;
+    VQK_REQUIRE(tw && mx_on && ph_on && (cout % 128) == 0 && (g.cpt >> 2) >= 2 && g_force_variant != 5, VQK_ERR_SHAPE);
+    VQK_REQUIRE((int64_t)4 * g.m * (backward ? cin : cout) * 2 < 0x7fffffffLL && (int64_t)g.m * (backward ? cout : cin) * 2 < 0x7fffffffLL,
+                VQK_ERR_SHAPE);
+    g.ntap = 4;
+    const int64_t phase_elems = (int64_t)((cout + 127) / 128) * 128 * cin * 4;
+    hipStream_t st = vqk_stream(stream);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1;
+        ConvGeom gp = g;
+        const void* res = nullptr;
+        if (!backward) {                                     // y[2i+a][2j+b] = 2x2 window of x at rows i+a-1.., columns j+b-1..
+            gp.tap_oy = a; gp.tap_ox = b;
+            gp.dst_s = 2; gp.dst_a = a; gp.dst_b = b;
+            gp.gn_ws = gn_ws; gp.gn_cpg = gn_ws ? cout / groups : 0;
+        } else {                                             // dx[i][j] += mirrored 2x2 window of the phase (a, b) of dy
+            gp.tap_oy = 1 - a; gp.tap_ox = 1 - b;
+            gp.src_s = 2; gp.src_a = a; gp.src_b = b;
+            gp.h_in = 2 * h; gp.w_in = 2 * w;                // the source tensor is dy at full resolution
+            res = ph ? y : nullptr;                          // later phases accumulate in place
+        }
+        const int r = vqkd::launch_conv3x3_mx(x, (const bf16_raw*)w4 + ph * phase_elems, backward ? nullptr : bias, res, y, zeros, gp, tw, st);
+        if (r != VQK_OK) return r;
+    }
+    return VQK_OK;
+}
+
 int vqk_conv2d_general(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                        int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int stride, int pad,
                        int mode, int h_out, int w_out, int act, float acc_scale, float out_gain, int wlayout,
@@ -2014,6 +2099,7 @@ int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int co
 
 int64_t vqk_conv_packed_elems(int cout, int cin, int ksize, int layout) {
     if (layout == 0) return (int64_t)cout * cin * ksize * ksize;
+    if (layout == 2) return (int64_t)4 * ((cout + 127) / 128) * 128 * cin * 4;      // four phases x four taps
     return (int64_t)((cout + 127) / 128) * 128 * cin * ksize * ksize;
 }
 
@@ -2043,6 +2129,17 @@ int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int ci
         const dim3 grid(vqk_grid_1d(total, 256));
         if (dtype == VQK_F32) hipLaunchKernelGGL(pack_frag_kernel<float>, grid, dim3(256), 0, st, w, (float*)out, cout, cin, taps, transpose, cot_tiles);
         else hipLaunchKernelGGL(pack_frag_kernel<bf16_raw>, grid, dim3(256), 0, st, w, (bf16_raw*)out, cout, cin, taps, transpose, cot_tiles);
+    } else if (layout == 2) {
+        const int dcin = transpose ? cout : cin;
+        VQK_REQUIRE(ksize == 3 && dtype == VQK_BF16 && dcin % 64 == 0, VQK_ERR_SHAPE);
+        // one descriptor through the multi-tensor kernel (it holds the only copy of the phase packing)
+        int64_t h[8] = {(int64_t)(uintptr_t)w, (int64_t)(uintptr_t)out, dtype, cout, cin, ksize, transpose, layout};
+        int64_t* d = nullptr;
+        if (hipMallocAsync((void**)&d, sizeof(h), st) != hipSuccess) return VQK_ERR_WORKSPACE;
+        hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, st);
+        hipStreamSynchronize(st);                              // h lives on this stack frame
+        hipLaunchKernelGGL(pack_multi_kernel, dim3(32, 1), dim3(256), 0, st, d);
+        hipFreeAsync(d, st);
     } else return VQK_ERR_ARG;
     VQK_CHECK_LAUNCH();
     return VQK_OK;

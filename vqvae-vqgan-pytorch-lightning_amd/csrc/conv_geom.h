@@ -26,6 +26,13 @@ struct ConvGeom {
     // sums of y and y*y (y as stored, i.e. rounded to bf16) are added to gn_ws[n][group][2] (vqk_gn_forward's workspace)
     double* gn_ws;
     int gn_cpg;     // channels per group (cout / groups): a multiple of 4
+    // matrix/auxiliary-wave kernel, nearest-x2 upsample convs in PHASE form (conv_mx.hip): output pixel (2i+a, 2j+b) of a 3x3
+    // conv over the upsampled image sees only a 2x2 window of the low-resolution input, with pre-summed weights -- four
+    // 2x2-tap launches (16 tap-GEMMs per low-resolution pixel instead of 36).  ntap = 4: the taps (r, s), r, s in {0, 1},
+    // sit at halo rows tap_oy + r / columns tap_ox + s of the ordinary (TH+2)x(TW+2) halo; the output is written at
+    // pixel (dst_s*i + dst_a, dst_s*j + dst_b) of a (dst_s*h) x (dst_s*w) tensor (fprop: dst_s = 2); the input is read at
+    // pixel (src_s*i + src_a, src_s*j + src_b) of an h_in x w_in tensor (the data gradient reads the phase of dy: src_s = 2).
+    int ntap, tap_oy, tap_ox, src_s, src_a, src_b, dst_s, dst_a, dst_b;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {

@@ -53,7 +53,7 @@ using vqkd::xcd_remap;
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
-template <int TWLOG, bool POOL>
+template <int TWLOG, bool POOL, int NTAP>
 __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ wp,
                                                             const float* __restrict__ bias,
                                                             const bf16_raw* __restrict__ res, bf16_raw* __restrict__ y,
@@ -63,6 +63,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     constexpr int PIECES = (HROWS * 5 + 63) / 64;                // 1-KiB LDS-DMA pieces per halo
     constexpr int BUF = PIECES * 1024, STG = 3 * BUF, SPITCH = 272, SCR = STG + PIX * SPITCH;   // SCR: 1 KiB of statistics partials
     constexpr int NI = 4, NJ = 2;
+    constexpr int NPH = NTAP * 2;                                // phases ((tap, k-substep) pairs) and weight fragments per unit
+    static_assert(NTAP == 9 || (NTAP == 4 && !POOL), "3x3 taps, or the 2x2 taps of an upsample phase");
     constexpr int XS = (PIECES + 3) / 4;                         // pieces per X wave
     constexpr int OOB = (int)0x80000000;
     typedef bf16x8_t frag_t;
@@ -103,20 +105,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             int ty, tx;
             if (TWLOG == 5) { ty = wm * NI + i; tx = p; }
             else { ty = wm * 2 * NI + 2 * i + (p >> 4); tx = p & 15; }
-            abase[i] = (unsigned)((ty * HW2 + tx) * RS + kg * 16);
+            abase[i] = (unsigned)(((ty + g.tap_oy) * HW2 + tx + g.tap_ox) * RS + kg * 16);
             sbase[i] = (unsigned)(STG + (ty * TW + tx) * SPITCH + (wn * 64 + 4 * kg) * 2);
         }
         const int lane16 = lane * 16;
         const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_raw*>(wp), 0, (g.cout >> 5) * nch * (18 * 1024), 0x00020000);
-        auto unit_w = [&](int nt, int c, int j) -> int { return ((nt * 4 + wn * 2 + j) * nch + c) * (18 * 1024); };
+            const_cast<bf16_raw*>(wp), 0, (g.cout >> 5) * nch * (NPH * 1024), 0x00020000);
+        auto unit_w = [&](int nt, int c, int j) -> int { return ((nt * 4 + wn * 2 + j) * nch + c) * (NPH * 1024); };
         auto tile_nt = [&](int j) -> int { return (vbid + j * (int)gridDim.x) % g.tiles_n; };
         auto wload = [&](int soff) -> frag_t {
             return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, soff, 0));
         };
 
-        constexpr int RD = VQK_MX_RD;
-        static_assert(18 % RD == 0, "weight ring depth must divide the eighteen phases");
+        constexpr int RD = NTAP == 9 ? VQK_MX_RD : 4;
+        static_assert(NPH % RD == 0, "weight ring depth must divide the phases of a unit");
         f32x16 acc[NI][NJ];
         frag_t bw[RD][NJ];
         int wcur[NJ];
@@ -147,17 +149,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int toff = ((tap / 3) * HW2 + (tap % 3)) * RS;
+            for (int tap = 0; tap < NTAP; ++tap) {
+                constexpr int TWD = NTAP == 9 ? 3 : 2;           // taps per window row
+                const int toff = ((tap / TWD) * HW2 + (tap % TWD)) * RS;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const bool reads = ks == 0 || tap < 8;
+                    const bool reads = ks == 0 || tap < NTAP - 1;
                     const int ph = tap * 2 + ks;
                     if (ks == 0) {
 #pragma unroll
                         for (int i = 0; i < NI; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
-                    } else if (tap < 8) {
-                        const int toff1 = (((tap + 1) / 3) * HW2 + ((tap + 1) % 3)) * RS;
+                    } else if (tap < NTAP - 1) {
+                        const int toff1 = (((tap + 1) / TWD) * HW2 + ((tap + 1) % TWD)) * RS;
 #pragma unroll
                         for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff1);
                     }
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                     }
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        const int soff = (ph + RD >= 18) ? wnxt[j] + (ph + RD - 18) * 1024 : wcur[j] + (ph + RD) * 1024;
+                        const int soff = (ph + RD >= NPH) ? wnxt[j] + (ph + RD - NPH) * 1024 : wcur[j] + (ph + RD) * 1024;
                         bw[ph % RD][j] = wload(soff);
                     }
                     if (VQK_MX_PIN) {
@@ -225,10 +228,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     const int xt = tid - 256, xw = wave - 4;
     const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_raw*>(x), 0, (int)((int64_t)g.n * g.h_in * g.w_in * g.cin * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_raw*>(res), 0, res ? (int)((int64_t)g.m * g.cout * 2) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
-        y, 0, (int)(((int64_t)g.m * g.cout * 2) >> (POOL ? 2 : 0)), 0x00020000);
+    const int out_bytes = (int)((int64_t)g.m * g.cout * 2) * g.dst_s * g.dst_s;     // (dst_s h) x (dst_s w) output pixels
+    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(res), 0, res ? out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(y, 0, out_bytes >> (POOL ? 2 : 0), 0x00020000);
 
     // halo pieces of this wave: piece xw + 4*sl, lane -> 16-byte slot s = piece*64 + lane = halo pixel s/5, chunk s%5
     // (chunk 4 = pad).  rel = byte offset against the tile origin (input resolution), flg = border classes of the pixel
@@ -239,12 +241,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         const int s = (xw + 4 * sl) * 64 + lane;
         const int hp = s / 5, cp = s - hp * 5;
         const int hy = hp / HW2, hx = hp - hy * HW2;
-        rel[sl] = ((((hy - 1) >> g.ups) * g.w_in + ((hx - 1) >> g.ups)) * g.cin + cp * 8) * 2;
+        rel[sl] = (((((hy - 1) * g.src_s) >> g.ups) * g.w_in + (((hx - 1) * g.src_s) >> g.ups)) * g.cin + cp * 8) * 2;
         flg[sl] = (hy == 0 ? 1 : 0) | (hy == TH + 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == TW + 1 ? 8 : 0) |
                   ((cp == 4 || hp >= HROWS) ? 16 : 0);
     }
     auto issue_halo = [&](const TilePos& tp, int c, int bufi) {
-        const int base = (((tp.img * g.h_in + (tp.py0 >> g.ups)) * g.w_in + (tp.px0 >> g.ups)) * g.cin + c * 32) * 2;
+        const int base = (((tp.img * g.h_in + ((tp.py0 * g.src_s + g.src_a) >> g.ups)) * g.w_in + ((tp.px0 * g.src_s + g.src_b) >> g.ups)) * g.cin + c * 32) * 2;
         const int tb = (tp.py0 == 0 ? 1 : 0) | (tp.py0 + TH == g.h ? 2 : 0) | (tp.px0 == 0 ? 4 : 0) | (tp.px0 + TW == g.w ? 8 : 0) | 16;
 #pragma unroll
         for (int sl = 0; sl < XS; ++sl) {
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     struct OutPos { int pix0, ppix0, co, img; };
     auto out_pos = [&](const TilePos& tp) -> OutPos {
         OutPos o;
-        o.pix0 = (tp.img * g.h + tp.py0) * g.w + tp.px0;
+        o.pix0 = ((tp.img * g.h + tp.py0) * g.dst_s + g.dst_a) * (g.w * g.dst_s) + tp.px0 * g.dst_s + g.dst_b;
         o.ppix0 = (tp.img * (g.h >> 1) + (tp.py0 >> 1)) * (g.w >> 1) + (tp.px0 >> 1);
         o.co = tp.nt * 128 + slot * 8;
         o.img = tp.img;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         int ty, tx;
         if constexpr (!POOL) { const int pp = k * 16 + (xt >> 4); ty = pp >> TWLOG; tx = pp & (TW - 1); }
         else { const int opp = (k >> 2) * 16 + (xt >> 4); ty = 2 * (opp >> (TWLOG - 1)) + ((k >> 1) & 1); tx = 2 * (opp & (TW / 2 - 1)) + (k & 1); }
-        return ((o.pix0 + ty * g.w + tx) * g.cout + o.co) * 2;
+        return ((o.pix0 + (ty * g.w * g.dst_s + tx) * g.dst_s) * g.cout + o.co) * 2;
     };
     auto load_res = [&](const OutPos& o, u32x4 (&rv)[NR]) {
 #pragma unroll
@@ -466,8 +468,14 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     };
     constexpr int lds5 = 3 * (((256 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
     constexpr int lds4 = 3 * (((256 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
-    if (twlog == 5) { if (g.pool) launch(conv3x3_mx_kernel<5, true>, lds5); else launch(conv3x3_mx_kernel<5, false>, lds5); }
-    else { if (g.pool) launch(conv3x3_mx_kernel<4, true>, lds4); else launch(conv3x3_mx_kernel<4, false>, lds4); }
+    if (g.ntap == 4) {
+        if (g.pool) return VQK_ERR_ARG;
+        if (twlog == 5) launch(conv3x3_mx_kernel<5, false, 4>, lds5); else launch(conv3x3_mx_kernel<4, false, 4>, lds4);
+    } else if (twlog == 5) {
+        if (g.pool) launch(conv3x3_mx_kernel<5, true, 9>, lds5); else launch(conv3x3_mx_kernel<5, false, 9>, lds5);
+    } else {
+        if (g.pool) launch(conv3x3_mx_kernel<4, true, 9>, lds4); else launch(conv3x3_mx_kernel<4, false, 9>, lds4);
+    }
     if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
     return VQK_OK;
 }

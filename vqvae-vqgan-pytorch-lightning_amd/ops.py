@@ -278,6 +278,41 @@ def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: 
     return y
 
 
+UPS_PHASE = int(os.environ.get('VQK_UPS_PHASE', '1'))      # 0 off, 1 forward + data gradient, 2 forward only
+
+
+def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int = 0):
+    """The nearest-x2 upsample + 3x3 conv in phase form (vqk_conv2d_ups_phase: four 2x2-tap launches, 4/9 of the
+    multiply-adds).  forward: x [N,Cin,h,w] -> [N,cout,2h,2w] (+ bias; gn_groups: also the GroupNorm sums of the result);
+    backward: x = dy [N,C,2h,2w] -> dx [N,cout,h,w].  wq4: ``packed_weight(..., layout=2)`` (transpose for backward).
+    Returns None when the kernel does not serve the problem (nothing launched)."""
+    _require_gpu(x)
+    if not UPS_PHASE or x.dtype != torch.bfloat16:
+        return None
+    n, cin, hx, wx = x.shape
+    h, w = (hx // 2, wx // 2) if backward else (hx, wx)
+    if cout % 128 or cin % 64 or (backward and (hx % 2 or wx % 2)):
+        return None
+    y = empty_nhwc(n, cout, h if backward else 2 * h, w if backward else 2 * w, x.dtype, x.device)
+    ws = None
+    if gn_groups and not backward and FUSE_GN_STATS and 4 * h * w > 1024:
+        if _PENDING_GN is not None:
+            _claim_presummed(x, -1)
+        ws = _gn_ws(x.device, n * gn_groups * 2 + n)
+    flops = 2.0 * n * 4 * h * w * cout * cin * 9                 # ALGORITHMIC: the 3x3 conv over the upsampled image
+    nbytes = x.numel() * x.element_size() + y.numel() * y.element_size() + cout * cin * 9 * x.element_size()
+    st = _timed('conv3x3_mx_kernel<bf16>', flops,
+                lambda: _native.lib().vqk_conv2d_ups_phase(dcode(x.dtype), x.data_ptr(), wq4.data_ptr(), _p(bias), y.data_ptr(),
+                                                           n, h, w, cin, cout, int(backward), _p(ws), gn_groups,
+                                                           zero_page(x.device).data_ptr(), _stream()), nbytes)
+    if st == _native.ERR_SHAPE:
+        return None
+    _native.check(st, 'conv2d_ups_phase')
+    if ws is not None:
+        _note_presummed(y, gn_groups)
+    return y
+
+
 _DIRECT_GRAD = True
 
 
@@ -543,7 +578,14 @@ class Conv2dFn(torch.autograd.Function):
                 b32[:o] = bias.detach()
         res = nhwc(residual) if residual is not None else None
         y = None
-        if next_gn and k == 3 and act == 0 and layout == 1 and out_dtype == dt and cout_pad % 128 == 0 and cout_pad == o:
+        phase = False
+        if (ups and k == 3 and act == 0 and res is None and out_dtype == dt and cout_pad == o and cin == i and UPS_PHASE
+                and dt == torch.bfloat16 and o % 128 == 0 and i % 128 == 0
+                and weight_layout(dt, n_img, h_in, w_in, cin, cout_pad, 3, False) == 1):
+            # nearest x2 + 3x3 as four 2x2-tap convs on the low-resolution input (pre-summed weights)
+            y = raw_conv_ups_phase(x, packed_weight(weight, cin, cout_pad, dt, 3, False, 2), b32, cout_pad, False, next_gn)
+            phase = y is not None
+        if y is None and next_gn and k == 3 and act == 0 and layout == 1 and out_dtype == dt and cout_pad % 128 == 0 and cout_pad == o:
             y = raw_conv_fprop_gnstats(x, wq, b32, res, ups, cout_pad, next_gn)
             if y is not None:
                 _note_presummed(y, next_gn)
@@ -552,6 +594,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, y if act == 1 else None)
         ctx.bias_ref, ctx.weight_ref = bias, weight
         ctx.cfg = (k, ups, act, o, i, cin, cout_pad, bias is not None, residual is not None, dt)
+        ctx.phase = phase
         return y
 
     @staticmethod
@@ -570,10 +613,15 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             n_img, _, h_out, w_out = dyc.shape
             layout = weight_layout(dt, n_img, h_out, w_out, cout_pad, cin, k, False)
-            wt = packed_weight(weight, cin, cout_pad, dt, k, True, layout)
-            if ups and can_pool_epilogue(dt, cin, layout):
+            if ups and ctx.phase and UPS_PHASE == 1:             # data gradient in phase form: four 2x2-tap launches
+                dx = raw_conv_ups_phase(dyc, packed_weight(weight, cin, cout_pad, dt, k, True, 2), None, cin, True)
+            if dx is not None:
+                pass
+            elif ups and can_pool_epilogue(dt, cin, layout):
+                wt = packed_weight(weight, cin, cout_pad, dt, k, True, layout)
                 dx = raw_conv_fprop_pooled(dyc, wt, None, None, k, False, cin, 1.0)      # sum-pool in the epilogue
             else:
+                wt = packed_weight(weight, cin, cout_pad, dt, k, True, layout)
                 dx = raw_conv_fprop(dyc, wt, None, None, k, False, 0, dt, cin, layout)
                 if ups:
                     dx = raw_pool(dx, 1.0)
