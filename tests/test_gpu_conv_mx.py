@@ -53,3 +53,31 @@ def test_mx_matches_stream_kernel(n, cin, cout, h, w, ups, hb, hr, pool):
         scale = a.abs() + (res.float().abs().mean() if hr else 0.0) + 1.0
         assert float((err / scale).max()) < 1.2e-2
         assert float((a - b).norm() / a.norm()) < 4e-3
+
+
+@pytest.mark.parametrize('act,acc_scale,out_gain,hb,hr', [(2, 1.0, 1.0, 1, 0), (3, 0.03, 1.41421356, 1, 0), (3, 0.05, 0.70710678, 1, 1),
+                                                           (0, 0.02, 1.0, 0, 0)])
+def test_mx_epilogue_activation_and_gains(act, acc_scale, out_gain, hb, hr):
+    """y = out_gain * act(acc * acc_scale + bias) + residual in the drain (the VGG relu convs, the StyleGAN2 discriminator's
+    leaky-relu convs with their runtime weight gain, discriminator.py:165 / bias_act.py:55) against the stream kernel"""
+    n, cin, cout, h, w = 4, 128, 256, 32, 32
+    g = torch.Generator(device=DEV).manual_seed(17 + act + hr)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).to(BF).contiguous(memory_format=CL)
+    wt = torch.randn(cout, 3, 3, cin, device=DEV, generator=g).reshape(-1) * (1.0 if acc_scale != 1.0 else 0.03)
+    bias = torch.randn(cout, device=DEV, generator=g) if hb else None
+    res = torch.randn(n, cout, h, w, device=DEV, generator=g).to(BF).contiguous(memory_format=CL) if hr else None
+    wq = ops.pack_weights(wt, BF, cout, cin, 3, False, 1)
+    lib = native.lib()
+    outs = {}
+    for variant in (5, 6):
+        lib.vqk_conv_set_variant(variant)
+        try:
+            outs[variant] = ops._conv_general_raw(x, wq, bias, res, cout, 3, 1, 1, 0, h, w, act, acc_scale, out_gain, BF, 1)
+        finally:
+            lib.vqk_conv_set_variant(-1)
+    torch.cuda.synchronize()
+    a, b = outs[5].float(), outs[6].float()
+    scale = a.abs() + (res.float().abs().mean() if hr else 0.0) + 1.0
+    assert float(((a - b).abs() / scale).max()) < 1.2e-2
+    assert float((a - b).norm() / a.norm()) < 4e-3
+    assert float(a.abs().max()) > 0.5                      # not a trivially zero comparison

@@ -1805,10 +1805,13 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
             // on its halves to bf16 noise -- the two kernels round differently), hence no tile-count threshold by default
             static const int mx_on = getenv("VQK_MX") ? atoi(getenv("VQK_MX")) : 1;
             static const int mx_min = getenv("VQK_MX_MIN_TILES") ? atoi(getenv("VQK_MX_MIN_TILES")) : 1;
-            const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
+            // (bias / residual / pooling; relu or leaky relu with the StyleGAN2 gains: the VGG and discriminator convs)
+            const bool plain = (act == 0 || ((act == 2 || act == 3) && !g.pool && !g.gn_ws)) && (g.cout & 127) == 0;
             const bool fits32 = (int64_t)g.n * g.h_in * g.w_in * g.cin * 2 < 0x7fffffffLL && (int64_t)g.m * g.cout * 2 < 0x7fffffffLL;
             if (mx_on && g_force_variant != 5 && plain && fits32 && (g.cpt >> 2) >= 2 && (total >= mx_min || g_force_variant == 6)) {
-                return vqkd::launch_conv3x3_mx(x, w, bias, res, y, zeros, g, tw, st);
+                ConvGeom ga = g;
+                ga.act = act;
+                return vqkd::launch_conv3x3_mx(x, w, bias, res, y, zeros, ga, tw, st);
             }
         }
         if (g.gn_ws) return VQK_ERR_SHAPE;                       // fused statistics exist on the matrix/auxiliary-wave kernel only
@@ -1911,6 +1914,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.stride = 1; g.pad = ksize >> 1; g.zs = 0; g.vh = g.h; g.vw = g.w;
     g.acc_scale = 1.0f; g.out_gain = 1.0f; g.pool = 0; g.pool_scale = 1.0f;
     g.gn_ws = nullptr; g.gn_cpg = 0;
+    g.act = 0;
     g.ntap = 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;

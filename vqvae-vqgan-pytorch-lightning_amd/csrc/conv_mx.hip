@@ -340,20 +340,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!POOL) {
-            if (!bias && !res) {                                 // plain copy (wave-uniform)
+            if (!bias && !res && g.act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f) {     // plain copy (wave-uniform)
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     __builtin_amdgcn_raw_buffer_store_b128(t[k], ysrd, res_off(o, k), 0, VQK_MX_NT);
                     if (want_stats) tally(t[k]);
                 }
             } else {
+                const bool general = g.act != 0 || g.acc_scale != 1.0f || g.out_gain != 1.0f;     // wave-uniform
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     float f[8], r[8];
                     unpack8(t[k], f);
                     unpack8(rv[k], r);
+                    if (general) {                               // y = out_gain * act(acc * acc_scale + bias) + residual
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = f[e] + bv[e] + r[e];
+                        for (int e = 0; e < 8; ++e) {
+                            float v = __fmaf_rn(f[e], g.acc_scale, bv[e]);
+                            v = g.act == 2 ? fmaxf(v, 0.0f) : g.act == 3 ? fmaxf(v, 0.2f * v) : v;
+                            f[e] = __fmaf_rn(v, g.out_gain, r[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = f[e] + bv[e] + r[e];
+                    }
                     const u32x4 ov = pack8(f);
                     __builtin_amdgcn_raw_buffer_store_b128(ov, ysrd, res_off(o, k), 0, VQK_MX_NT);
                     if (want_stats) tally(ov);

@@ -92,7 +92,7 @@ def _fprop_kernel_name(dtype, wlayout: int, shape=None) -> str:
             return 'conv3x3_halo_breg_kernel<f32>'
         if shape is not None and _MX_ON:
             n, ho, wo, cin, cout, act, odt = shape
-            if (act == 0 and odt == torch.bfloat16 and cout % 128 == 0 and cin >= 64
+            if (act in (0, 2, 3) and odt == torch.bfloat16 and cout % 128 == 0 and cin >= 64
                     and n * ho * wo // 256 * (cout // 128) >= _MX_MIN_TILES):
                 return 'conv3x3_mx_kernel<bf16>'
         return 'conv3x3_stream_kernel<bf16>'
@@ -1247,7 +1247,7 @@ def _conv_general_raw(x, wq, bias, residual, cout, k, stride, pad, mode, h_out, 
     n, cin, h, w = x.shape
     y = empty_nhwc(n, cout, h_out, w_out, out_dtype, x.device)
     flops = 2.0 * n * h_out * w_out * cout * cin * k * k
-    st = _timed(_fprop_kernel_name(x.dtype, wlayout), flops,
+    st = _timed(_fprop_kernel_name(x.dtype, wlayout, (n, h_out, w_out, cin, cout, act, out_dtype) if stride == 1 and mode != 2 else None), flops,
                 lambda: _native.lib().vqk_conv2d_general(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias), _p(residual),
                                                          y.data_ptr(), dcode(out_dtype), n, h, w, cin, cout, k, stride, pad,
                                                          mode, h_out, w_out, act, float(acc_scale), float(out_gain), wlayout,
