@@ -1717,6 +1717,13 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restri
     else pack_any<bf16_raw>(src, reinterpret_cast<bf16_raw*>(d[1]), cout, cin, ks * ks, tr, lay);
 }
 
+// the same packing for ONE operand, descriptor by value (no device table: usable under stream capture)
+__global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__ src, void* __restrict__ dst, int dtype, int cout,
+                                                       int cin, int ks, int tr, int lay) {
+    if (dtype == VQK_F32) pack_any<float>(src, reinterpret_cast<float*>(dst), cout, cin, ks * ks, tr, lay);
+    else pack_any<bf16_raw>(src, reinterpret_cast<bf16_raw*>(dst), cout, cin, ks * ks, tr, lay);
+}
+
 // out[c] += sum_rows x[row][c].  c*sizeof(T) a multiple of 16 (VEC): a thread owns one 16-byte channel slot and strides
 // over rows (the GroupNorm kernels' mapping); otherwise one column per thread.
 template <typename T, bool VEC>
@@ -2136,14 +2143,7 @@ int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int ci
     } else if (layout == 2) {
         const int dcin = transpose ? cout : cin;
         VQK_REQUIRE(ksize == 3 && dtype == VQK_BF16 && dcin % 64 == 0, VQK_ERR_SHAPE);
-        // one descriptor through the multi-tensor kernel (it holds the only copy of the phase packing)
-        int64_t h[8] = {(int64_t)(uintptr_t)w, (int64_t)(uintptr_t)out, dtype, cout, cin, ksize, transpose, layout};
-        int64_t* d = nullptr;
-        if (hipMallocAsync((void**)&d, sizeof(h), st) != hipSuccess) return VQK_ERR_WORKSPACE;
-        hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, st);
-        hipStreamSynchronize(st);                              // h lives on this stack frame
-        hipLaunchKernelGGL(pack_multi_kernel, dim3(32, 1), dim3(256), 0, st, d);
-        hipFreeAsync(d, st);
+        hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, out, dtype, cout, cin, ksize, transpose, layout);
     } else return VQK_ERR_ARG;
     VQK_CHECK_LAUNCH();
     return VQK_OK;
