@@ -152,6 +152,12 @@ int vqk_conv2d_general(int dtype, const void* x, const void* w, const float* bia
                        int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int stride, int pad,
                        int mode, int h_out, int w_out, int act, float acc_scale, float out_gain, int wlayout,
                        const void* zeros, void* stream);
+/* The 3x3 weight gradient when dy is the gradient of a FUSED 2x2 average pool (vqk_conv2d_fprop_pooled): dy_pooled is
+ * [N][h/2][w/2][Cout], every pooled pixel stands for its 2x2 block, dW += scale * sum over the h x w pixels (scale = the
+ * pool's 0.25): the full-resolution copy of the gradient is never written.  bf16, h % 8 == 0, w % 16 == 0, Cin % 64 == 0,
+ * Cout % 64 == 0; VQK_ERR_SHAPE when not served (nothing launched: callers unpool and call vqk_conv2d_wgrad). */
+int vqk_conv2d_wgrad_pooled_dy(int dtype, const void* x, const void* dy_pooled, float* dw, int n, int h, int w, int cin,
+                               int cout, float scale, const void* zeros, void* stream);
 int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
                              int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out,
                              const void* zeros, void* stream);
@@ -217,6 +223,11 @@ int vqk_gn_forward_presummed(int dtype, const void* x, const float* w, const flo
 int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
                     void* dx, float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu,
                     int accumulate, const void* add, void* stream);
+/* vqk_gn_backward with dx += add_scale * (add_pooled read at pixel (row/2, col/2)): the skip-branch gradient of a ResBlock
+ * whose output went through a fused 2x2 average pool, still at half resolution ([N][h/2][wd/2][C]).  h * wd > 1024. */
+int vqk_gn_backward_pooled_add(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
+                               void* dx, float* dw, float* db, double* red, int n, int h, int wd, int c, int groups, int silu,
+                               const void* add_pooled, float add_scale, void* stream);
 
 /* ---------------------------------------------------------------- pooling / pointwise -------
  * 2x2 stride-2 pooling with a scale: scale = 0.25 is avg_pool2d (autoencoder.py:89-91), scale = 1 is the

@@ -52,6 +52,7 @@ _PROTOS = {
     'vqk_conv_set_block_caps': [I, I],
     'vqk_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
+    'vqk_conv2d_wgrad_pooled_dy': [I, P, P, P, I, I, I, I, I, F, P, P],
     'vqk_colsum': [I, P, L, I, P, P],
     'vqk_cast': [P, P, I, L, P],
     'vqk_gn_stats': [I, P, I, L, I, I, F, P, P, P],
@@ -59,6 +60,7 @@ _PROTOS = {
     'vqk_gn_forward': [I, P, P, P, P, P, P, I, L, I, I, F, I, P],
     'vqk_gn_forward_presummed': [I, P, P, P, P, P, P, I, L, I, I, F, I, P],
     'vqk_gn_backward': [I, P, P, P, P, P, P, P, P, P, I, L, I, I, I, I, P, P],
+    'vqk_gn_backward_pooled_add': [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, F, P],
     'vqk_pool2x2': [I, P, P, I, I, I, I, F, P],
     'vqk_unpool2x2': [I, P, P, I, I, I, I, F, P],
     'vqk_preprocess': [P, P, I, P, I, I, I, I, P],

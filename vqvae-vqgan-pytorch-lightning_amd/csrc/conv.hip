@@ -1921,7 +1921,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.stride = 1; g.pad = ksize >> 1; g.zs = 0; g.vh = g.h; g.vw = g.w;
     g.acc_scale = 1.0f; g.out_gain = 1.0f; g.pool = 0; g.pool_scale = 1.0f;
     g.gn_ws = nullptr; g.gn_cpg = 0;
-    g.act = 0;
+    g.act = 0; g.dy_pool = 0;
     g.ntap = 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
@@ -2171,7 +2171,8 @@ int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, 
 }
 
 static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin, int cout,
-                         int ksize, int stride, int pad, int mode, int h_out, int w_out, const void* zeros, void* stream) {
+                         int ksize, int stride, int pad, int mode, int h_out, int w_out, const void* zeros, void* stream,
+                         int dy_pool = 0, float dy_scale = 1.0f) {
     VQK_REQUIRE(x && dy && dw && zeros, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
     VQK_REQUIRE(mode >= 0 && mode <= 1 && (stride == 1 || stride == 2) && pad >= 0, VQK_ERR_ARG);
@@ -2224,8 +2225,11 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
             if (sm < 1) sm = 1;
             const int ppm = (total_patches + sm - 1) / sm;
             sm = (total_patches + ppm - 1) / ppm;
-            return vqkd::launch_conv3x3_wgrad_mx(x, dy, dw, zeros, g, tiles, sm, ppm, vqk_stream(stream));
+            ConvGeom gm = g;
+            gm.dy_pool = dy_pool; gm.acc_scale = dy_scale;
+            return vqkd::launch_conv3x3_wgrad_mx(x, dy, dw, zeros, gm, tiles, sm, ppm, vqk_stream(stream));
         }
+        if (dy_pool) return VQK_ERR_SHAPE;                      // half-resolution dy exists on the matrix/auxiliary-wave kernel only
         if (pw16 && (cin % 64) == 0 && (cout % 64) == 0 && !no_p16k) {
             static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_wgrad_p16_kernel,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 40960);
@@ -2269,6 +2273,14 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
     VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
     return wgrad_general(dtype, x, dy, dw, n, h_in, w_in, cin, cout, ksize, 1, ksize >> 1, ups, h_in << ups, w_in << ups,
                          zeros, stream);
+}
+
+int vqk_conv2d_wgrad_pooled_dy(int dtype, const void* x, const void* dy_pooled, float* dw, int n, int h, int w, int cin,
+                               int cout, float scale, const void* zeros, void* stream) {
+    VQK_REQUIRE(dtype == VQK_BF16 && (h % 8) == 0 && (w % 16) == 0 && (cin % 64) == 0 && (cout % 64) == 0, VQK_ERR_SHAPE);
+    static const int wgmx = getenv("VQK_WGMX") ? atoi(getenv("VQK_WGMX")) : 1;
+    VQK_REQUIRE(wgmx && g_force_variant != 0 && !getenv("VQK_WGRAD_BLOCKS") && !getenv("VQK_WGRAD_NO_PW16"), VQK_ERR_SHAPE);
+    return wgrad_general(dtype, x, dy_pooled, dw, n, h, w, cin, cout, 3, 1, 1, 0, h, w, zeros, stream, 1, scale);
 }
 
 int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
-                atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r]);
+                atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r] * g.acc_scale);
             }
         return;
     }
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
 #pragma unroll
     for (int sl = 0; sl < NDY; ++sl) {
         const int q = xw + 4 * sl, half = q >> 3, prow = q & 7;
-        dyoff[sl] = (unsigned)((((prow * g.w + lrow) * g.cout) + co0 + half * 32 + lch) * 2);
+        dyoff[sl] = g.dy_pool ? (unsigned)(((((prow >> 1) * (g.w >> 1) + (lrow >> 1)) * g.cout) + co0 + half * 32 + lch) * 2)
+                              : (unsigned)((((prow * g.w + lrow) * g.cout) + co0 + half * 32 + lch) * 2);
     }
 #pragma unroll
     for (int sl = 0; sl < NX; ++sl) {
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
         pp.py0 = pyi * 8; pp.px0 = pxi * PWD;
         pp.interior = !g.ups && pp.py0 >= 1 && pp.py0 + 8 < g.h && pp.px0 >= 1 && pp.px0 + PWD < g.w;
         const int64_t pix = ((int64_t)pp.img * g.h + pp.py0) * g.w + pp.px0;
-        pp.bdy = reinterpret_cast<const char*>(dy + pix * g.cout);
+        const int64_t dpix = g.dy_pool ? ((int64_t)pp.img * (g.h >> 1) + (pp.py0 >> 1)) * (g.w >> 1) + (pp.px0 >> 1) : pix;
+        pp.bdy = reinterpret_cast<const char*>(dy + dpix * g.cout);
         pp.bx = reinterpret_cast<const char*>(x + (pix - g.w - 1) * g.cin);         // halo origin (py0 - 1, px0 - 1)
         return pp;
     };

@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ dy, T* __restrict__ dx,
                                                            const T* __restrict__ add,
                                                            double* __restrict__ red, int64_t hw, int c,
-                                                           int groups, int silu, int accumulate, int pix_per_block) {
+                                                           int groups, int silu, int accumulate, int pix_per_block,
+                                                           int add_w, float add_scale) {
     constexpr int V = Vec16<T>::N;
     const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
     const int n = blockIdx.y, cpg = c / groups;
@@ -278,7 +279,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         float xv[V], gv[V], ov[V];
         if (NT) { Vec16<T>::load_nt(x + off + p * c, xv); Vec16<T>::load_nt(dy + off + p * c, gv); }
         else { Vec16<T>::load(x + off + p * c, xv); Vec16<T>::load(dy + off + p * c, gv); }
-        if (accumulate) Vec16<T>::load((add ? add : dx) + off + p * c, ov);
+        if (accumulate) {
+            if (add_w) {                                    // `add` at HALF resolution: pixel (r, q) reads pooled pixel (r/2, q/2)
+                const int64_t row = p / add_w, col = p - row * add_w;
+                Vec16<T>::load(add + ((int64_t)n * (hw >> 2) + (row >> 1) * (add_w >> 1) + (col >> 1)) * c + slot * V, ov);
+#pragma unroll
+                for (int i = 0; i < V; ++i) ov[i] *= add_scale;
+            } else {
+                Vec16<T>::load((add ? add : dx) + off + p * c, ov);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const float xh = (xv[i] - mean[i]) * rstd[i];
@@ -544,6 +554,47 @@ inline int pick_ppb(int n, int64_t hw, bool reducing = false) {
 
 }  // namespace
 
+static int gn_backward_impl(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy, void* dx,
+                            float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu, int accumulate,
+                            const void* add, int add_w, float add_scale, void* stream) {
+    VQK_REQUIRE(x && stats && w && b && dy && dx && dw && db && red, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
+    const int rc = check_gn(dtype, c, groups);
+    if (rc) return rc;
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(dx), VQK_ERR_ALIGN);
+    hipStream_t st = vqk_stream(stream);
+    // 16 pixels per thread (the 32^2 maps, re-read form) measured 106 us per call inside the step against 93 for the
+    // two-kernel form next to the weight-gradient kernels: the single-kernel backward is used up to 8 pixels per thread
+    if (const int ppt = add_w ? 0 : gn_small_ppt(dtype, hw, c, groups, 8)) {
+        const dim3 sgrid((unsigned)(c / 32), (unsigned)n);
+        const int acc = (accumulate || add) ? 1 : 0;
+#define VQK_GN_SMALL_BWD(T, P) hipLaunchKernelGGL((gn_small_bwd_kernel<T, P, (P < 16)>), sgrid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, dw, db, c, groups, silu, acc)
+#define VQK_GN_SMALL_BWD_T(T) do { switch (ppt) { case 1: VQK_GN_SMALL_BWD(T, 1); break; case 2: VQK_GN_SMALL_BWD(T, 2); break; \
+        case 4: VQK_GN_SMALL_BWD(T, 4); break; case 8: VQK_GN_SMALL_BWD(T, 8); break; default: VQK_GN_SMALL_BWD(T, 16); } } while (0)
+        if (dtype == VQK_F32) VQK_GN_SMALL_BWD_T(float); else VQK_GN_SMALL_BWD_T(bf16_raw);
+#undef VQK_GN_SMALL_BWD_T
+#undef VQK_GN_SMALL_BWD
+        VQK_CHECK_LAUNCH();
+        return VQK_OK;
+    }
+    const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
+    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
+    const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
+    const bool nt = (int64_t)n * hw * c * (dtype == VQK_F32 ? 4 : 2) >= ((int64_t)192 << 20);
+    if (dtype == VQK_F32) {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, rppb);
+        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb, add_w, add_scale);
+        else hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb, add_w, add_scale);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, dw, db, red, hw, c, groups, silu, rppb);
+        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_raw, true>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb, add_w, add_scale);
+        else hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_raw, false>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb, add_w, add_scale);
+    }
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+
 extern "C" {
 
 int vqk_gn_stats(int dtype, const void* x, int n, int64_t hw, int c, int groups, float eps, double* acc, float* stats,
@@ -633,44 +684,23 @@ int vqk_gn_forward_presummed(int dtype, const void* x, const float* w, const flo
     return VQK_OK;
 }
 
+}  // extern "C"
+
+extern "C" {
+
 int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy, void* dx,
                     float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu, int accumulate,
                     const void* add, void* stream) {
-    VQK_REQUIRE(x && stats && w && b && dy && dx && dw && db && red, VQK_ERR_ARG);
-    VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
-    const int rc = check_gn(dtype, c, groups);
-    if (rc) return rc;
-    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(dx), VQK_ERR_ALIGN);
-    hipStream_t st = vqk_stream(stream);
-    // 16 pixels per thread (the 32^2 maps, re-read form) measured 106 us per call inside the step against 93 for the
-    // two-kernel form next to the weight-gradient kernels: the single-kernel backward is used up to 8 pixels per thread
-    if (const int ppt = gn_small_ppt(dtype, hw, c, groups, 8)) {
-        const dim3 sgrid((unsigned)(c / 32), (unsigned)n);
-        const int acc = (accumulate || add) ? 1 : 0;
-#define VQK_GN_SMALL_BWD(T, P) hipLaunchKernelGGL((gn_small_bwd_kernel<T, P, (P < 16)>), sgrid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, dw, db, c, groups, silu, acc)
-#define VQK_GN_SMALL_BWD_T(T) do { switch (ppt) { case 1: VQK_GN_SMALL_BWD(T, 1); break; case 2: VQK_GN_SMALL_BWD(T, 2); break; \
-        case 4: VQK_GN_SMALL_BWD(T, 4); break; case 8: VQK_GN_SMALL_BWD(T, 8); break; default: VQK_GN_SMALL_BWD(T, 16); } } while (0)
-        if (dtype == VQK_F32) VQK_GN_SMALL_BWD_T(float); else VQK_GN_SMALL_BWD_T(bf16_raw);
-#undef VQK_GN_SMALL_BWD_T
-#undef VQK_GN_SMALL_BWD
-        VQK_CHECK_LAUNCH();
-        return VQK_OK;
-    }
-    const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
-    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
-    const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
-    const bool nt = (int64_t)n * hw * c * (dtype == VQK_F32 ? 4 : 2) >= ((int64_t)192 << 20);
-    if (dtype == VQK_F32) {
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, rppb);
-        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
-        else hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
-    } else {
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, dw, db, red, hw, c, groups, silu, rppb);
-        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_raw, true>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
-        else hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_raw, false>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb);
-    }
-    VQK_CHECK_LAUNCH();
-    return VQK_OK;
+    return gn_backward_impl(dtype, x, stats, w, b, dy, dx, dw, db, red, n, hw, c, groups, silu, accumulate, add, 0, 1.0f, stream);
+}
+
+int vqk_gn_backward_pooled_add(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
+                               void* dx, float* dw, float* db, double* red, int n, int h, int wd, int c, int groups, int silu,
+                               const void* add_pooled, float add_scale, void* stream) {
+    VQK_REQUIRE(add_pooled && h > 0 && wd > 0 && (h % 2) == 0 && (wd % 2) == 0, VQK_ERR_ARG);
+    VQK_REQUIRE((int64_t)h * wd > 1024, VQK_ERR_SHAPE);       // the two-kernel path (the single-kernel small-map form has no pooled add)
+    return gn_backward_impl(dtype, x, stats, w, b, dy, dx, dw, db, red, n, (int64_t)h * wd, c, groups, silu, 1, add_pooled, wd,
+                            add_scale, stream);
 }
 
 }  // extern "C"

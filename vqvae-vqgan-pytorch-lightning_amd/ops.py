@@ -355,6 +355,24 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None) -> torch.Tensor:
     return dw
 
 
+def raw_conv_wgrad_pooled_dy(x, dy_pooled, scale: float, out) -> bool:
+    """dW += scale * wgrad(x, unpool(dy_pooled)) without the unpooled tensor (vqk_conv2d_wgrad_pooled_dy); False when the
+    kernel does not serve the problem (nothing launched)."""
+    n, cin, h, w = x.shape
+    cout = dy_pooled.shape[1]
+    if not (_WGMX_ON and x.dtype == torch.bfloat16 and cin % 64 == 0 and cout % 64 == 0 and w % 16 == 0 and h % 8 == 0):
+        return False
+    flops = 2.0 * n * h * w * cout * cin * 9
+    st = _timed('conv3x3_wgrad_mx_kernel<bf16>', flops,
+                lambda: _native.lib().vqk_conv2d_wgrad_pooled_dy(dcode(x.dtype), x.data_ptr(), dy_pooled.data_ptr(), out.data_ptr(),
+                                                                 n, h, w, cin, cout, float(scale),
+                                                                 zero_page(x.device).data_ptr(), _stream()))
+    if st == _native.ERR_SHAPE:
+        return False
+    _native.check(st, 'conv2d_wgrad_pooled_dy')
+    return True
+
+
 def raw_colsum(x2d_rows: int, c: int, x, out=None) -> torch.Tensor:
     out = out if out is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     _native.check(_native.lib().vqk_colsum(dcode(x.dtype), x.data_ptr(), x2d_rows, c, out.data_ptr(), _stream()), 'colsum')
@@ -469,6 +487,22 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
                                                       _p(add), _stream()), passes * nb)
     _native.check(st, 'gn_backward')
     return dx, dw, db
+
+
+def raw_gn_backward_pooled_add(x, stats, w, b, dy, groups: int, silu: bool, dw, db, add_pooled, add_scale: float):
+    """raw_gn_backward whose skip-branch addend is still at half resolution (vqk_gn_backward_pooled_add)"""
+    n, c, h, wd = x.shape
+    dx = torch.empty_like(x, memory_format=_CL)
+    _claim_presummed(x, -1)
+    red = _gn_ws(x.device, n * groups * 2 + n)
+    nb = x.numel() * x.element_size()
+    st = _timed('group_norm_bwd (HBM)', 0.0,
+                lambda: _native.lib().vqk_gn_backward_pooled_add(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
+                                                                 b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                                 db.data_ptr(), red.data_ptr(), n, h, wd, c, groups, int(silu),
+                                                                 add_pooled.data_ptr(), float(add_scale), _stream()), 5.25 * nb)
+    _native.check(st, 'gn_backward_pooled_add')
+    return dx
 
 
 def raw_pool(x, scale: float) -> torch.Tensor:
@@ -673,6 +707,7 @@ class GroupNormSiLUFn(torch.autograd.Function):
         return dx, dw.view(wshape), db.view(bshape), None, None, None
 
 
+POOLED_BWD = os.environ.get('VQK_POOLED_BWD', '1') != '0'      # ResBlock + fused avg-pool: the backward keeps the gradient pooled
 OVERLAP_WGRAD = os.environ.get('VQK_OVERLAP_WGRAD', '1') == '1'
 OVERLAP_MODE = int(os.environ.get('VQK_OVERLAP_MODE', '3'))
 OVERLAP_STREAM_BLOCKS = int(os.environ.get('VQK_OVERLAP_STREAM_BLOCKS', '512'))
@@ -744,9 +779,41 @@ class ResBlockFn(torch.autograd.Function):
         groups, cin, cout, pool = ctx.cfg
         dt = x.dtype
         dout = nhwc(dout)
+        n, _, h, w = x.shape
+        t1, t2 = direct_grad(c1w), direct_grad(c2w)
+        tw1, tb1, tw2, tb2 = direct_grad(n1w), direct_grad(n1b), direct_grad(n2w), direct_grad(n2b)
+        if (pool and POOLED_BWD and scw is None and dt == torch.bfloat16 and t1 is not None and t2 is not None
+                and None not in (tw1, tb1, tw2, tb2) and OVERLAP_WGRAD and h * w > 1024 and cout % 128 == 0 and w % 16 == 0 and h % 8 == 0
+                and weight_layout(dt, n, h // 2, w // 2, cout, cout, 3, True) == 1 and _MX_ON and _WGMX_ON):
+            # The gradient of the fused avg-pool stays at HALF resolution: conv2's data gradient reads it through the nearest-x2
+            # addressing of the halo DMA (the pool's 0.25 in the drain), conv2's weight gradient and norm1's skip addend read
+            # the pooled pixel of each 2x2 block -- no unpool pass, a quarter of the gradient bytes for three consumers.
+            main, side = torch.cuda.current_stream(), _side_stream(x.device)
+            lib = _native.lib()
+            lib.vqk_conv_set_block_caps(OVERLAP_STREAM_BLOCKS, OVERLAP_WGRAD_BLOCKS)
+            try:
+                lay = weight_layout(dt, n, h // 2, w // 2, cout, cout, 3, True)
+                wt2 = packed_weight(c2w, cout, cout, dt, 3, True, lay)
+                d_a2 = _conv_general_raw(dout, wt2, None, None, cout, 3, 1, 1, 1, h, w, 0, 0.25, 1.0, dt, lay)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    if not raw_conv_wgrad_pooled_dy(a2, dout, 0.25, t2):
+                        raise RuntimeError('vqk: pooled weight gradient not served for an eligible shape')
+                d_r1, _, _ = raw_gn_backward(r1, st2, w2, b2, d_a2, groups, True, tw2, tb2)
+                if OVERLAP_MODE == 3:
+                    main.wait_stream(side)
+                lay1 = weight_layout(dt, n, h, w, cout, cin, 3, False)
+                d_a1 = raw_conv_fprop(d_r1, packed_weight(c1w, cin, cout, dt, 3, True, lay1), None, None, 3, False, 0, dt, cin, lay1)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                dx = raw_gn_backward_pooled_add(x, st1, w1, b1, d_a1, groups, True, tw1, tb1, dout, 0.25)
+                main.wait_stream(side)
+            finally:
+                lib.vqk_conv_set_block_caps(0, 0)
+            return dx, None, None, None, None, None, None, None, None, None, None, None
         if pool:
             dout = raw_unpool(dout, 0.25)                   # backward of the fused avg-pool
-        n, _, h, w = x.shape
 
         def conv_bwd(inp, dy, wparam, k, ci, co, need_dx=True, need_dw=True):
             dx = None
@@ -769,7 +836,6 @@ class ResBlockFn(torch.autograd.Function):
                 return dx, None, None
             return dx, dw.view(wparam.shape), db.view(bparam.shape)
 
-        t1, t2 = direct_grad(c1w), direct_grad(c2w)
         if OVERLAP_WGRAD and t1 is not None and t2 is not None:
             # the two weight-gradient convs (MFMA-bound, results only needed by the optimizer) run on a side stream,
             # one block per CU, next to the data-gradient convs and the memory-bound GroupNorm backward passes
