@@ -187,7 +187,9 @@ int vqk_conv_pack_multi(const int64_t* descs_dev, int ndesc, int blocks_per_desc
 int vqk_conv_set_variant(int variant);
 /* caps on the persistent grids of the 3x3 fprop/dgrad kernel and of the all-taps wgrad kernel (0 = default: two
  * blocks per CU).  256 = one block per CU, leaving room for a kernel that runs concurrently on another stream
- * (the host overlaps a layer's wgrad with its dgrad and GroupNorm backward). */
+ * (the host overlaps a layer's wgrad with its dgrad and GroupNorm backward).  The caps are THREAD-LOCAL: they apply to the
+ * launches the calling thread issues afterwards (set, launch, reset in one place), never to another thread or device
+ * context.  vqk_conv_set_variant above is a process-wide TEST hook and not meant for product code. */
 int vqk_conv_set_block_caps(int stream_blocks, int wgrad_blocks);
 /* w [Cout][ks][ks][Cin] -> wt [Cin][ks][ks][Cout] with both taps flipped; src fp32, dst `dtype`. */
 int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, int ksize, void* stream);

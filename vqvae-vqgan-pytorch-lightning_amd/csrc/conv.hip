@@ -1782,8 +1782,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 
 static int g_force_variant = -1;   // test hook: -1 auto, 0 im2col kernel only, 1 halo kernels when eligible,
                                    // 5 never the matrix/auxiliary-wave kernel, 6 that kernel whenever it is eligible
-static int g_stream_blocks = 0;    // persistent-grid caps (0 = default 2 blocks per CU): 256 leaves half of every CU to a
-static int g_wgrad_blocks = 0;     // kernel running concurrently on another stream (dgrad || wgrad || GroupNorm)
+static thread_local int g_stream_blocks = 0;    // persistent-grid caps (0 = default 2 blocks per CU): 256 leaves half of every CU to a
+static thread_local int g_wgrad_blocks = 0;     // kernel running concurrently on another stream (dgrad || wgrad || GroupNorm)
 
 // 0: not eligible for the halo kernels; 5 / 4: patch width log2 (8x32 / 16x16 pixel patches)
 inline int halo_twlog(const ConvGeom& g) {
