@@ -1788,6 +1788,8 @@ static thread_local int g_wgrad_blocks = 0;     // kernel running concurrently o
 // 0: not eligible for the halo kernels; 5 / 4: patch width log2 (8x32 / 16x16 pixel patches)
 inline int halo_twlog(const ConvGeom& g) {
     if (g.ks != 3 || (g.cpt % 8) != 0 || g_force_variant == 0) return 0;
+    static const int prefer16 = getenv("VQK_TW16") ? atoi(getenv("VQK_TW16")) : 0;      // A/B: 16x16 patches where both fit
+    if (prefer16 && (g.w % 16) == 0 && (g.h % 16) == 0) return 4;
     if ((g.w % 32) == 0 && (g.h % 8) == 0) return 5;
     if ((g.w % 16) == 0 && (g.h % 16) == 0) return 4;
     return 0;

@@ -41,6 +41,9 @@ using vqkd::xcd_remap;
 #ifndef VQK_MX_NT
 #define VQK_MX_NT 2          // output stores: 0 default policy, 2 nontemporal
 #endif
+#ifndef VQK_MX_HALO_AUX
+#define VQK_MX_HALO_AUX 0    // cache policy of the halo LDS-DMA: 0 default, 2 nontemporal
+#endif
 #ifndef VQK_MX_PRIO
 #define VQK_MX_PRIO 0        // s_setprio of the matrix waves
 #endif
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                 const int off = (flg[sl] & tb) ? OOB : base + rel[sl];
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     xsrd, (VQK_LDS void*)(smem + bufi * BUF + (xw + 4 * sl) * 1024), 16,
-                    (VQK_MXABL & 8) ? (off & 0x8003fff0) : off, 0, 0, 0);
+                    (VQK_MXABL & 8) ? (off & 0x8003fff0) : off, 0, 0, VQK_MX_HALO_AUX);
             }
         }
     };

@@ -68,9 +68,15 @@ def empty_nhwc(n, c, h, w, dtype, device) -> torch.Tensor:
 KERNEL_EVENTS = None      # bench.py sets this to a list: (kernel, algorithmic FLOPs, algorithmic bytes, start, stop)
 
 
+_EVENT_SHAPES = os.environ.get('VQK_EVENT_SHAPES') == '1'     # tooling: one statistics line per (kernel, FLOP count)
+
+
 def _timed(name: str, flops: float, launch, nbytes: float = 0.0):
     if KERNEL_EVENTS is None:
         return launch()
+    if _EVENT_SHAPES:
+        name = f'{name} {flops / 1e9:.2f}GF'
+
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     st = launch()
