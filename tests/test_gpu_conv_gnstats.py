@@ -91,3 +91,31 @@ def test_unclaimed_sums_do_not_leak_into_the_next_groupnorm():
     assert float((got.float() - ref.float()).norm() / ref.float().norm()) < 1e-3
     assert float((got2.float() - ref2.float()).norm() / ref2.float().norm()) < 1e-3
     assert float(ops._gn_ws(x.device, 4 * 64 + 4).abs().max()) == 0.0 and ops._PENDING_GN is None
+
+
+@pytest.mark.parametrize('cin,cout,h,ups,hr,pool', [(128, 128, 128, 0, 1, 0), (128, 256, 128, 0, 1, 1), (256, 256, 64, 0, 0, 0),
+                                                    (256, 512, 128, 0, 1, 1), (128, 128, 64, 1, 0, 0)])
+def test_conv_and_fused_sums_are_deterministic_and_batch_split_exact(cin, cout, h, ups, hr, pool):
+    """The same conv on a batch of 4 and on its two halves, and twice on the batch: outputs AND fused GroupNorm statistics
+    bit-identical (per-sample results must not depend on which block, or which launch, computes a tile -- this is what
+    caught an inline-asm DOT hazard that dropped the last products of a tile in the pooled / 8-channel-group launches)."""
+    hin = h >> ups
+    g = torch.Generator(device=DEV).manual_seed(cin + cout + h + ups + hr + pool)
+    x = (torch.randn(4, cin, hin, hin, device=DEV, generator=g) + 0.2).to(BF).contiguous(memory_format=CL)
+    wt = (torch.randn(cout, 3, 3, cin, device=DEV, generator=g) / (3 * cin ** 0.5)).reshape(-1)
+    res = torch.randn(4, cout, h, h, device=DEV, generator=g).to(BF).contiguous(memory_format=CL) if hr else None
+    gw, gb = torch.randn(cout, device=DEV, generator=g), torch.randn(cout, device=DEV, generator=g)
+    wq = ops.pack_weights(wt, BF, cout, cin, 3, False, 1)
+    outs = []
+    for n0, n1 in ((0, 4), (0, 2), (2, 4), (0, 4)):
+        xs = x[n0:n1].contiguous(memory_format=CL)
+        rs = res[n0:n1].contiguous(memory_format=CL) if hr else None
+        y = ops.raw_conv_fprop_gnstats(xs, wq, None, rs, bool(ups), cout, 32, pool=bool(pool), pool_scale=0.25)
+        assert y is not None
+        _, st = ops.raw_gn_forward(y, gw, gb, 32, 1e-6, True, presummed=True)
+        outs.append((y.clone(), st.clone()))
+    torch.cuda.synchronize()
+    (yf, sf), (ya, sa), (yb, sb), (yf2, sf2) = outs
+    assert torch.equal(yf, yf2) and torch.equal(sf, sf2)
+    assert torch.equal(yf, torch.cat([ya, yb], 0))
+    assert torch.equal(sf, torch.cat([sa, sb], 0))
