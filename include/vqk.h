@@ -292,6 +292,11 @@ int vqk_upfirdn2d(const float* x, const float* f, float* y, int n, int c, int in
  * dx = dy * scale * act'(y), act' recovered from the saved OUTPUT y (bias_act.cu grad=1 semantics): 1 tanh, 2 relu,
  * 3 leaky-relu(0.2), 0 plain scaling.  `scale` carries the activation gain and the runtime weight gain. */
 int vqk_act_backward(int dtype, const void* dy, const void* y, void* dx, int64_t n, int act, float scale, void* stream);
+/* the same on [rows][c] tensors, plus colsum[c] += the column sums of dx (as stored): the bias gradient of the conv whose
+ * output y is, without a second pass over dx (bias_act.py:196: db = dx summed over every dim but the channel).  c a whole
+ * number of 16-byte vectors, at most 256 of them. */
+int vqk_act_backward_colsum(int dtype, const void* dy, const void* y, void* dx, int64_t rows, int c, int act, float scale,
+                            float* colsum, void* stream);
 /* upfirdn2d (upfirdn2d.cpp:16 argument meaning) on NHWC tensors of `dtype`, C a whole 16-byte chunk. */
 int vqk_upfirdn2d_nhwc(int dtype, const void* x, const float* f, void* y, int n, int h, int w, int c, int fh, int fw,
                        int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip,

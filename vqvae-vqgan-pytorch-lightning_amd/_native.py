@@ -73,6 +73,7 @@ _PROTOS = {
     'vqk_axpby': [I, P, P, P, F, F, L, P],
     'vqk_adamw': [P, P, P, P, L, P, P, I, F, F, F, F, I, F, P, P],
     'vqk_act_backward': [I, P, P, P, L, I, F, P],
+    'vqk_act_backward_colsum': [I, P, P, P, L, I, I, F, P, P],
     'vqk_upfirdn2d_nhwc': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, I, P],
     'vqk_maxpool2x2': [I, P, P, P, I, I, I, I, I, P],
     'vqk_channel_affine': [I, P, P, P, P, L, I, P],

@@ -43,6 +43,50 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const T* __restrict__ 
     }
 }
 
+// act_bwd on [rows][c] plus the column sums of its RESULT (the bias gradient, rounded as stored): a thread owns one 16-byte
+// channel slot and strides over rows (the colsum kernel's mapping), so the bias gradient costs no second pass over dx
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                             int64_t rows, int c, int64_t rows_per_block, int act, float scale,
+                                                             float* __restrict__ colsum) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sh = reinterpret_cast<float*>(smem);            // [c]
+    for (int i = threadIdx.x; i < c; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    const int vpp = c / V;                                  // <= 256 (checked by the launcher)
+    const int slot = threadIdx.x % vpp, rlane = threadIdx.x / vpp, rstep = 256 / vpp;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (rlane < rstep) {
+        float a[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) a[k] = 0.f;
+        for (int64_t r = r0 + rlane; r < r1; r += rstep) {
+            float yv[V], g[V];
+            Vec16<T>::load(y + r * c + slot * V, yv);
+            Vec16<T>::load(dy + r * c + slot * V, g);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float t = g[k] * scale;
+                if (act == 1) t *= 1.0f - yv[k] * yv[k];
+                else if (act == 2) t = yv[k] > 0.0f ? t : 0.0f;
+                else if (act == 3) t = yv[k] > 0.0f ? t : 0.2f * t;
+                g[k] = t;
+            }
+            Vec16<T>::store(dx + r * c + slot * V, g);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {                   // the sum of the values AS STORED (what a separate colsum pass reads)
+                if constexpr (sizeof(T) == 2) a[k] += bf16_to_f32(f32_to_bf16(g[k]));
+                else a[k] += g[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) atomicAdd(sh + slot * V + k, a[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += 256) atomicAdd(colsum + i, sh[i]);
+}
+
 // y[n,oy,ox,:] = gain * sum_{fy,fx} F[fy][fx] * U[oy*down + fy - pad0][...]; U = zero-stuffed x
 template <typename T>
 __global__ __launch_bounds__(256) void upfirdn_nhwc_kernel(const T* __restrict__ x, const float* __restrict__ f,
@@ -553,6 +597,26 @@ int vqk_act_backward(int dtype, const void* dy, const void* y, void* dx, int64_t
     if (dtype == VQK_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)dy, (const float*)y, (float*)dx, n, act, scale);
     else if (dtype == VQK_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)dy, (const bf16_raw*)y, (bf16_raw*)dx, n, act, scale);
     else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_act_backward_colsum(int dtype, const void* dy, const void* y, void* dx, int64_t rows, int c, int act, float scale,
+                            float* colsum, void* stream) {
+    VQK_REQUIRE(dy && y && dx && colsum, VQK_ERR_ARG);
+    VQK_REQUIRE(act >= 0 && act <= 3 && rows >= 0 && c > 0, VQK_ERR_ARG);
+    VQK_REQUIRE(dtype == VQK_F32 || dtype == VQK_BF16, VQK_ERR_DTYPE);
+    const int v = dtype == VQK_F32 ? 4 : 8;
+    VQK_REQUIRE(c % v == 0 && c / v <= 256 && c <= 8192, VQK_ERR_SHAPE);
+    VQK_REQUIRE(vqk_aligned16(dy) && vqk_aligned16(y) && vqk_aligned16(dx), VQK_ERR_ALIGN);
+    if (rows == 0) return VQK_OK;
+    int64_t blocks = (rows + 63) / 64; if (blocks > 2048) blocks = 2048;
+    const int64_t rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    const size_t lds = (size_t)c * 4;
+    hipStream_t st = vqk_stream(stream);
+    if (dtype == VQK_F32) hipLaunchKernelGGL(act_bwd_colsum_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, (const float*)dy, (const float*)y, (float*)dx, rows, c, rpb, act, scale, colsum);
+    else hipLaunchKernelGGL(act_bwd_colsum_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_raw*)dy, (const bf16_raw*)y, (bf16_raw*)dx, rows, c, rpb, act, scale, colsum);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

@@ -1383,7 +1383,12 @@ class ConvActFn(torch.autograd.Function):
         lib, st = _native.lib(), _stream()
         # t and dx are built from differentiable Functions so that R1 (autograd.grad(..., create_graph=True) through
         # this backward, loss.py:98-112) can differentiate them again; in an ordinary backward they record nothing.
-        t = ActBwdFn.apply(nhwc(dy), y, act, float(out_gain))
+        want_db = bias is not None and ctx.needs_input_grad[2]
+        dyn = nhwc(dy)
+        dbsum = None
+        if want_db and dyn.dtype == dt:                      # the bias gradient rides in the act-backward pass
+            dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
+        t = ActBwdFn.apply(dyn, y, act, float(out_gain), dbsum)
         tc = t if t.dtype == dt else nhwc(t.to(dt))
         n, _, h, w = x.shape
         _, _, h_out, w_out = tc.shape
@@ -1399,8 +1404,9 @@ class ConvActFn(torch.autograd.Function):
             if wgain != 1.0:
                 _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain), 0.0, dwp.numel(), st), 'axpby')
             dw = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
-        if bias is not None and ctx.needs_input_grad[2]:
-            db = raw_colsum(n * h_out * w_out, cout_pad, tc.detach())[:o]
+        if want_db:
+            fused = dbsum is not None and cout_pad % (4 if dt == torch.float32 else 8) == 0 and cout_pad // (4 if dt == torch.float32 else 8) <= 256
+            db = (dbsum if fused else raw_colsum(n * h_out * w_out, cout_pad, tc.detach()))[:o]
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -1409,10 +1415,20 @@ class ActBwdFn(torch.autograd.Function):
     its own backward is the same op (bias_act.py:197-198: lrelu / relu have no second-order term)"""
 
     @staticmethod
-    def forward(ctx, dy, y, act: int, scale: float):
+    def forward(ctx, dy, y, act: int, scale: float, colsum=None):
+        """colsum: fp32 [C] buffer that ALSO receives the column sums of the result (the conv's bias gradient) -- one pass"""
         t = torch.empty_like(dy, memory_format=_CL)
-        _native.check(_native.lib().vqk_act_backward(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(), dy.numel(),
-                                                     act, scale, _stream()), 'act_backward')
+        n, c, h, w = dy.shape
+        v = 4 if dy.dtype == torch.float32 else 8
+        if colsum is not None and c % v == 0 and c // v <= 256:
+            _native.check(_native.lib().vqk_act_backward_colsum(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(),
+                                                                n * h * w, c, act, scale, colsum.data_ptr(), _stream()),
+                          'act_backward_colsum')
+            ctx.fused_colsum = True
+        else:
+            _native.check(_native.lib().vqk_act_backward(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(), dy.numel(),
+                                                         act, scale, _stream()), 'act_backward')
+            ctx.fused_colsum = False
         ctx.save_for_backward(y)
         ctx.cfg = (act, scale)
         if act == 1:
@@ -1425,7 +1441,7 @@ class ActBwdFn(torch.autograd.Function):
         act, scale = ctx.cfg
         if act == 1:
             raise NotImplementedError('second-order tanh epilogue is not on any path')
-        return ActBwdFn.apply(nhwc(v), y, act, scale), None, None, None
+        return ActBwdFn.apply(nhwc(v), y, act, scale), None, None, None, None
 
 
 class ConvDgradFn(torch.autograd.Function):
