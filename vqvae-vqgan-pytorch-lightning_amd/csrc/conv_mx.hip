@@ -26,6 +26,7 @@
 // follows (the epilogue arithmetic runs on the parked bf16 values, in fp32).
 // ------------------------------------------------------------------------------------------------
 #include "conv_geom.h"
+#include <stdlib.h>
 
 namespace {
 using vqkd::ConvGeom;
@@ -56,16 +57,19 @@ using vqkd::xcd_remap;
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
-template <int TWLOG, bool POOL, int NTAP>
+template <int TWLOG, bool POOL, int NTAP, int PIXELS = 256>
 __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ wp,
                                                             const float* __restrict__ bias,
                                                             const bf16_raw* __restrict__ res, bf16_raw* __restrict__ y,
                                                             ConvGeom g) {
-    constexpr int PIX = 256, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr int PIX = PIXELS, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
     constexpr int RS = 80;                                       // bytes per halo pixel: 64 data + 16 pad
     constexpr int PIECES = (HROWS * 5 + 63) / 64;                // 1-KiB LDS-DMA pieces per halo
     constexpr int BUF = PIECES * 1024, STG = 3 * BUF, SPITCH = 272, SCR = STG + PIX * SPITCH;   // SCR: 1 KiB of statistics partials
-    constexpr int NI = 4, NJ = 2;
+    constexpr int NI = PIX / 64, NJ = 2;                         // a matrix wave: NI x 32 pixels x 64 couts (PIX = 128: the half tile of the
+                                                                 // 16x16 maps, twice as many blocks for a chip that their 256-pixel tiles leave half empty)
+    constexpr int NQ = PIX / 16;                                 // 16-byte staging pieces per auxiliary thread and tile
+    static_assert(PIX == 256 || (PIX == 128 && !POOL && NTAP == 9), "256-pixel tiles, or plain 128-pixel half tiles");
     constexpr int NPH = NTAP * 2;                                // phases ((tap, k-substep) pairs) and weight fragments per unit
     static_assert(NTAP == 9 || (NTAP == 4 && !POOL), "3x3 taps, or the 2x2 taps of an upsample phase");
     constexpr int XS = (PIECES + 3) / 4;                         // pieces per X wave
@@ -270,8 +274,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         return o;
     };
     const int slot = xt & 15;                                    // 8 couts = one 16-byte piece of the 256-byte pixel row
-    constexpr int NP = POOL ? 4 : 16;                            // output pieces per thread and tile
-    constexpr int NR = 16;                                       // residual pieces per thread and tile
+    constexpr int NP = POOL ? 4 : NQ;                            // output pieces per thread and tile
+    constexpr int NR = NQ;                                       // residual pieces per thread and tile
     struct OutPos { int pix0, ppix0, co, img; };
     auto out_pos = [&](const TilePos& tp) -> OutPos {
         OutPos o;
@@ -328,14 +332,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                 : "+v"(ga), "+v"(qa), "+v"(gb), "+v"(qb) : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(ones2));
         };
         auto settle = [&]() { asm volatile("s_nop 3" : "+v"(ga), "+v"(qa), "+v"(gb), "+v"(qb)); };
-        u32x4 t[16];                                             // the thread's 16 staging pieces, all requested up front
+        u32x4 t[NQ];                                             // the thread's staging pieces, all requested up front
         if constexpr (!POOL) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
+            for (int k = 0; k < NQ; ++k)
                 t[k] = *reinterpret_cast<const u32x4*>(smem + STG + (k * 16 + (xt >> 4)) * SPITCH + slot * 16);
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < NQ; ++k) {
                 const int opp = (k >> 2) * 16 + (xt >> 4);
                 const int ty = 2 * (opp >> (TWLOG - 1)) + ((k >> 1) & 1), tx = 2 * (opp & (TW / 2 - 1)) + (k & 1);
                 t[k] = *reinterpret_cast<const u32x4*>(smem + STG + (ty * TW + tx) * SPITCH + slot * 16);
@@ -470,7 +474,12 @@ namespace vqkd {
 int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                       const ConvGeom& g, int twlog, hipStream_t st) {
     (void)zeros;
-    const int th = 256 >> twlog;
+    // 128-pixel half tiles for the 16x16 maps: a function of the image size only (never of the batch size: per-tile
+    // statistics partials group differently), they double the blocks of launches whose 256-pixel tiles fill half the chip
+    static const int half_on = getenv("VQK_MX_HALF") ? atoi(getenv("VQK_MX_HALF")) : 1;
+    static const int half_hw = getenv("VQK_MX_HALF_HW") ? atoi(getenv("VQK_MX_HALF_HW")) : 256;
+    const bool half = half_on && g.h * g.w <= half_hw && !g.pool && g.ntap == 9 && (twlog == 4 ? (g.h % 8) == 0 : (g.h % 4) == 0);
+    const int th = (half ? 128 : 256) >> twlog;
     const int total = g.n * (g.h / th) * (g.w >> twlog) * g.tiles_n;
     const dim3 grid((unsigned)(total < 256 ? total : 256));
     auto launch = [&](auto kern, int lds) {
@@ -481,7 +490,11 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     };
     constexpr int lds5 = 3 * (((256 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
     constexpr int lds4 = 3 * (((256 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
-    if (g.ntap == 4) {
+    constexpr int lds4h = 3 * (((128 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
+    constexpr int lds5h = 3 * (((128 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
+    if (half) {
+        if (twlog == 5) launch(conv3x3_mx_kernel<5, false, 9, 128>, lds5h); else launch(conv3x3_mx_kernel<4, false, 9, 128>, lds4h);
+    } else if (g.ntap == 4) {
         if (g.pool) return VQK_ERR_ARG;
         if (twlog == 5) launch(conv3x3_mx_kernel<5, false, 4>, lds5); else launch(conv3x3_mx_kernel<4, false, 4>, lds4);
     } else if (twlog == 5) {
