@@ -22,7 +22,7 @@ using vqkd::ConvGeom;
 using vqkd::xcd_remap;
 
 #ifndef VQK_WGMX_ABL
-#define VQK_WGMX_ABL 0       // timing-only ablation bits: 1 no pieces
+#define VQK_WGMX_ABL 0       // timing-only ablation bits: 1 no pieces, 2 no atomic pass over dW
 #endif
 #ifndef VQK_WGMX_NST
 #define VQK_WGMX_NST 3       // LDS stages (3: 120 KiB, 4: all 160 KiB)
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
             si = si == NST - 1 ? 0 : si + 1;
         }
         const int ci = ci0 + wj * 32 + (lane & 31);
+        if ((VQK_WGMX_ABL & 2) && g.n > 0 && acc[0][0] != 12345.678f) return;      // timing-only: no atomic pass
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
