@@ -186,13 +186,14 @@ def main():
     roofline = None
     if events:
         by_kernel = {}
-        for name, flops, nbytes, e0, e1 in events:
-            rec = by_kernel.setdefault(name, [0, 0.0, 0.0, 0.0])
+        for name, flops, nbytes, e0, e1, nlaunch in events:
+            rec = by_kernel.setdefault(name, [0, 0.0, 0.0, 0.0, 0])
             rec[0] += 1
             rec[1] += flops
             rec[2] += e0.elapsed_time(e1) * 1e-3
             rec[3] += nbytes
-        name, (count, flops, secs, nbytes) = max(((k, v) for k, v in by_kernel.items() if v[1] > 0), key=lambda kv: kv[1][2])
+            rec[4] += nlaunch
+        name, (count, flops, secs, nbytes, klaunches) = max(((k, v) for k, v in by_kernel.items() if v[1] > 0), key=lambda kv: kv[1][2])
         traffic = None
         try:                                   # HBM bytes per launch from the committed rocprofv3 --pmc passes
             for tag in ('round2', 'round1'):
@@ -210,6 +211,10 @@ def main():
                         frac=round(achieved / peak, 4), traffic=traffic, kernel=name,
                         algorithmic_bytes_per_launch=int(nbytes / count),
                         launches_per_step=count // event_steps, avg_launch_us=round(secs / count * 1e6, 2),
+                        # an upsample conv in phase form is ONE event (one algorithmic 3x3 conv) but FOUR kernel launches:
+                        # this is the figure that compares with rocprofv3's per-kernel average (profiles/*_kernel_stats.csv)
+                        kernel_launches_per_step=klaunches // event_steps,
+                        avg_kernel_launch_us=round(secs / klaunches * 1e6, 2),
                         avg_gflop_per_launch=round(flops / count / 1e9, 3),
                         kernel_time_frac_of_step=round((secs / event_steps) / (elapsed / args.steps), 3),
                         event_pass=('eager steps after the timed region, kernels serialised (no wgrad side stream)' if use_graph

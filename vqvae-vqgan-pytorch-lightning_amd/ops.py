@@ -71,7 +71,8 @@ KERNEL_EVENTS = None      # bench.py sets this to a list: (kernel, algorithmic F
 _EVENT_SHAPES = os.environ.get('VQK_EVENT_SHAPES') == '1'     # tooling: one statistics line per (kernel, FLOP count)
 
 
-def _timed(name: str, flops: float, launch, nbytes: float = 0.0):
+def _timed(name: str, flops: float, launch, nbytes: float = 0.0, launches: int = 1):
+    """``launches``: kernel launches behind this one event (an upsample conv in phase form is four)"""
     if KERNEL_EVENTS is None:
         return launch()
     if _EVENT_SHAPES:
@@ -81,7 +82,7 @@ def _timed(name: str, flops: float, launch, nbytes: float = 0.0):
     e0.record()
     st = launch()
     e1.record()
-    KERNEL_EVENTS.append((name, flops, nbytes, e0, e1))
+    KERNEL_EVENTS.append((name, flops, nbytes, e0, e1, launches))
     return st
 
 
@@ -310,7 +311,7 @@ def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int =
     st = _timed('conv3x3_mx_kernel<bf16>', flops,
                 lambda: _native.lib().vqk_conv2d_ups_phase(dcode(x.dtype), x.data_ptr(), wq4.data_ptr(), _p(bias), y.data_ptr(),
                                                            n, h, w, cin, cout, int(backward), _p(ws), gn_groups,
-                                                           zero_page(x.device).data_ptr(), _stream()), nbytes)
+                                                           zero_page(x.device).data_ptr(), _stream()), nbytes, launches=4)
     if st == _native.ERR_SHAPE:
         return None
     _native.check(st, 'conv2d_ups_phase')
