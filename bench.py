@@ -87,6 +87,122 @@ def cpu_baseline(run: dict, image_size: int, batch: int, steps: int):
                        f'torch-CPU oracle on {cores} threads; {t:.2f} s/step')
 
 
+OTHER_CONFIGS = {      # BASELINE.json configs[2..4], single-GPU part, at their per-GPU batch
+    'ema_vqvae cb=1024 bs=32': ['--quantizer', 'ema', '--codebook', '1024', '--batch', '32'],
+    'entropy_vqvae cb=8192 bs=64': ['--quantizer', 'entropy', '--codebook', '8192', '--batch', '64'],
+    'gumbel_vqgan bs=16 (LPIPS + discriminator + R1)': ['--gan', '--batch', '16'],
+}
+
+
+def _child(argv, timeout=600, wrap=None):
+    """this script again as a child process (its own HIP context), bench line parsed from stdout"""
+    import subprocess
+    env = dict(os.environ, VQK_BENCH_CHILD='1')
+    cmd = (wrap or []) + [sys.executable, os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd='/tmp' if wrap else None)
+    for line in reversed(r.stdout.splitlines()):
+        if line.startswith('{'):
+            return json.loads(line), r
+    return None, r
+
+
+def other_configs(steps: int = 20, warmup: int = 5) -> dict:
+    """ms/step and images/s of the other BASELINE.json configs on this GPU: >= 20 timed steps each, same timing rules"""
+    res = {}
+    for label, argv in OTHER_CONFIGS.items():
+        try:
+            j, r = _child(argv + ['--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline', '--no-kernel-events'])
+            if j is None:
+                res[label] = dict(error=(r.stderr or r.stdout)[-300:])
+            else:
+                res[label] = dict(ms_per_step=j['ms_per_step'], images_per_sec=j['value'], steps=j['steps'],
+                                  launch=j['config']['launch'], workload=j['config']['workload'])
+        except Exception as exc:
+            res[label] = dict(error=f'{type(exc).__name__}: {exc}')
+    return res
+
+
+def measure_traffic(kernel_sub: str, events_per_step: int, argv):
+    """HBM bytes per bench event of the dominant kernel, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE --
+    separate passes, counters only, as MI355X_MICROARCH.md prescribes) over a 2-step eager run of this same command;
+    bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB units; gfx950 tallies wide coalesced reads at half).  (None, None) when
+    rocprofv3 is absent or a pass fails."""
+    import shutil
+    import sqlite3
+    import tempfile
+    prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if prof is None:
+        return None, None
+    keep = []
+    skip = {'--steps', '--warmup', '--sustain-s', '--traffic', '--cpu-batch', '--cpu-steps'}
+    it = iter(argv)
+    for a in it:
+        if a in skip:
+            next(it, None)
+        elif a not in ('--no-graph', '--no-cpu-baseline', '--no-kernel-events', '--no-other-configs'):
+            keep.append(a)
+    steps = 2
+    total = {}
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = tempfile.mkdtemp(prefix=f'vqk_pmc_{ctr}_', dir='/tmp')
+            env_tmp = os.environ.get('TMPDIR')
+            os.environ['TMPDIR'] = '/tmp'
+            try:
+                _, r = _child(keep + ['--steps', str(steps), '--warmup', '1', '--no-graph', '--no-cpu-baseline', '--no-kernel-events'],
+                              timeout=420, wrap=[prof, '--pmc', ctr, '-d', d, '-o', 'p', '--'])
+            finally:
+                if env_tmp is None:
+                    os.environ.pop('TMPDIR', None)
+                else:
+                    os.environ['TMPDIR'] = env_tmp
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith('.db')]
+            if not dbs:
+                return None, None
+            db = sqlite3.connect(dbs[0])
+            tables = [r_[0] for r_ in db.execute("select name from sqlite_master where type='table'")]
+            t = lambda pfx: next(x for x in tables if x.startswith(pfx))
+            kd, ks, pe, pi = t('rocpd_kernel_dispatch'), t('rocpd_info_kernel_symbol'), t('rocpd_pmc_event'), t('rocpd_info_pmc')
+            cols = [r_[1] for r_ in db.execute(f'pragma table_info({ks})')]
+            name_col = 'display_name' if 'display_name' in cols else 'kernel_name'
+            q = (f'select sum(e.value), count(*) from {pe} e join {pi} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id '
+                 f"join {ks} s on d.kernel_id = s.id where p.name = '{ctr}' and s.{name_col} like '%{kernel_sub}%'")
+            tot, n = db.execute(q).fetchone()
+            db.close()
+            shutil.rmtree(d, ignore_errors=True)
+            if not n:
+                return None, None
+            total[ctr] = (float(tot), int(n))
+        # (warmup 1 + 2 timed) eager steps were traced: every step launches the same kernels
+        traced_steps = steps + 1
+        kib = (2.0 * total['FETCH_SIZE'][0] + total['WRITE_SIZE'][0]) / traced_steps / events_per_step
+        return int(kib * 1024), (f'measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over {traced_steps} '
+                                 f'eager steps, {total["FETCH_SIZE"][1]} kernel launches; 2*FETCH_SIZE + WRITE_SIZE per bench event')
+    except Exception as exc:
+        print(f'[bench] traffic pass failed ({type(exc).__name__}: {exc})', file=sys.stderr)
+        return None, None
+
+
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU of this node) under
+    torch.distributed.run (vqvae/train.py:128-131 lets Lightning spawn the DDP ranks; here the bench does).  Returns the
+    launcher's exit code; rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        print(f'bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs, this box has {have}', file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '4'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -104,16 +220,29 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel eagerly instead of replaying a hipGraph')
+    ap.add_argument('--sustain-s', type=float, default=10.0,
+                    help='after the K timed steps keep stepping for this many seconds and report the sustained ms/step '
+                         '(clock / power settle below the short run; 0 = off; N=1 only)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short runs of the other BASELINE.json configs (ema, entropy K=8192 bs=64, gumbel VQ-GAN bs=16)')
+    ap.add_argument('--traffic', choices=['auto', 'off'], default='auto',
+                    help='auto: measure HBM bytes per launch of the dominant kernel with rocprofv3 --pmc passes of a 2-step '
+                         'eager run (falls back to the committed profiles/ figure, labelled as such)')
     args = ap.parse_args()
+    if os.environ.get('VQK_BENCH_CHILD') == '1':
+        args.no_other_configs, args.traffic, args.sustain_s = True, 'off', 0.0
 
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the train step is HIP kernels only (no CPU fallback)')
+    if (args.gpus > 1 or os.environ.get('VQK_BENCH_SELF_LAUNCH') == '1') and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args.gpus))          # plain `python bench.py --gpus N`: one rank per GPU, this node
     trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
     model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
     ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
     rank, local, world = trainer_mod.init_distributed('nccl')
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the train step is HIP kernels only (no CPU fallback)')
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (the launcher started {world} ranks); '
+                         f'pass --gpus {world} or launch --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
@@ -166,6 +295,19 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    sustained = None
+    if world == 1 and args.sustain_s > 0:
+        # the K timed steps above are the metric; this is the same loop held for seconds, not fractions of one
+        n_sus, t1 = 0, time.perf_counter()
+        chunk = max(10, int(0.5 / max(elapsed / args.steps, 1e-4)))
+        while time.perf_counter() - t1 < args.sustain_s:
+            for i in range(chunk):
+                step_fn(model, images, args.warmup + args.steps + n_sus + i)
+            torch.cuda.synchronize()
+            n_sus += chunk
+        t_sus = time.perf_counter() - t1
+        sustained = dict(seconds=round(t_sus, 2), steps=n_sus, ms_per_step=round(t_sus / n_sus * 1e3, 3),
+                         images_per_sec=round(args.batch * n_sus / t_sus, 2))
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -194,21 +336,25 @@ def main():
             rec[3] += nbytes
             rec[4] += nlaunch
         name, (count, flops, secs, nbytes, klaunches) = max(((k, v) for k, v in by_kernel.items() if v[1] > 0), key=lambda kv: kv[1][2])
-        traffic = None
-        try:                                   # HBM bytes per launch from the committed rocprofv3 --pmc passes
-            for tag in ('round2', 'round1'):
-                tp = os.path.join(ROOT, 'profiles', f'{tag}_traffic.json')
-                if os.path.exists(tp):
-                    tj = json.load(open(tp))
-                    if tj['kernel'].startswith(name.split('<')[0]):
-                        traffic = tj['hbm_bytes_per_launch']
-                        break
-        except Exception:
-            pass
+        traffic, traffic_source = None, None
+        if rank == 0 and world == 1 and args.traffic == 'auto':
+            traffic, traffic_source = measure_traffic(name.split('<')[0], count // event_steps, sys.argv[1:])
+        if traffic is None:
+            try:                               # HBM bytes per launch from the committed rocprofv3 --pmc passes
+                for tag in ('round3', 'round2', 'round1'):
+                    tp = os.path.join(ROOT, 'profiles', f'{tag}_traffic.json')
+                    if os.path.exists(tp):
+                        tj = json.load(open(tp))
+                        if tj['kernel'].startswith(name.split('<')[0]):
+                            traffic = tj['hbm_bytes_per_launch']
+                            traffic_source = f'from profiles/{tag}_traffic.json (not measured in this run)'
+                            break
+            except Exception:
+                pass
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = flops / secs / 1e12
         roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                        frac=round(achieved / peak, 4), traffic=traffic, kernel=name,
+                        frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, kernel=name,
                         algorithmic_bytes_per_launch=int(nbytes / count),
                         launches_per_step=count // event_steps, avg_launch_us=round(secs / count * 1e6, 2),
                         # an upsample conv in phase form is ONE event (one algorithmic 3x3 conv) but FOUR kernel launches:
@@ -254,7 +400,9 @@ def main():
                                global_batch=world * args.batch, parallelism=f'dp{world}',
                                launch=('hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
                                final_loss=round(float(loss.item()), 6)),
-                   roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel)
+                   roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel, sustained=sustained)
+        if world == 1 and not args.no_other_configs:
+            out['other_configs'] = other_configs()
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

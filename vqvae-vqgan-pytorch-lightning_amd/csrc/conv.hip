@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     for (int i = threadIdx.x; i < c; i += 256) atomicAdd(out + i, sh[i]);
 }
 
-static int g_force_variant = -1;   // test hook: -1 auto, 0 im2col kernel only, 1 halo kernels when eligible,
+static thread_local int g_force_variant = -1;   // test hook (per host thread: the library keeps no process-global mutable state): -1 auto, 0 im2col kernel only, 1 halo kernels when eligible,
                                    // 5 never the matrix/auxiliary-wave kernel, 6 that kernel whenever it is eligible
 static thread_local int g_stream_blocks = 0;    // persistent-grid caps (0 = default 2 blocks per CU): 256 leaves half of every CU to a
 static thread_local int g_wgrad_blocks = 0;     // kernel running concurrently on another stream (dgrad || wgrad || GroupNorm)

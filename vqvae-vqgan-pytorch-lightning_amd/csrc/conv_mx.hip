@@ -471,6 +471,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
 
 namespace vqkd {
 
+namespace {
+// one instantiation per kernel symbol: the dynamic-LDS opt-in is set (and checked) for EVERY variant, once
+template <auto Kern>
+int mx_launch(dim3 grid, int lds, hipStream_t st, const void* x, const void* w, const float* bias, const void* res, void* y,
+              const ConvGeom& g) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return VQK_ERR_LAUNCH;
+    hipLaunchKernelGGL(Kern, grid, dim3(512), lds, st, (const bf16_raw*)x, (const bf16_raw*)w, bias, (const bf16_raw*)res,
+                       (bf16_raw*)y, g);
+    return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
+}
+
+int device_cus() {                                               // persistent grid: one 512-thread block per CU
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+}  // namespace
+
 int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                       const ConvGeom& g, int twlog, hipStream_t st) {
     (void)zeros;
@@ -481,29 +504,24 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     const bool half = half_on && g.h * g.w <= half_hw && !g.pool && g.ntap == 9 && (twlog == 4 ? (g.h % 8) == 0 : (g.h % 4) == 0);
     const int th = (half ? 128 : 256) >> twlog;
     const int total = g.n * (g.h / th) * (g.w >> twlog) * g.tiles_n;
-    const dim3 grid((unsigned)(total < 256 ? total : 256));
-    auto launch = [&](auto kern, int lds) {
-        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)attr;
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_raw*)x, (const bf16_raw*)w, bias,
-                           (const bf16_raw*)res, (bf16_raw*)y, g);
-    };
+    const int cus = device_cus();
+    const dim3 grid((unsigned)(total < cus ? total : cus));
     constexpr int lds5 = 3 * (((256 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
     constexpr int lds4 = 3 * (((256 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
     constexpr int lds4h = 3 * (((128 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
     constexpr int lds5h = 3 * (((128 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
+#define MXL(K, L) return mx_launch<K>(grid, L, st, x, w, bias, res, y, g)
     if (half) {
-        if (twlog == 5) launch(conv3x3_mx_kernel<5, false, 9, 128>, lds5h); else launch(conv3x3_mx_kernel<4, false, 9, 128>, lds4h);
+        if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 9, 128>), lds5h); else MXL((conv3x3_mx_kernel<4, false, 9, 128>), lds4h);
     } else if (g.ntap == 4) {
         if (g.pool) return VQK_ERR_ARG;
-        if (twlog == 5) launch(conv3x3_mx_kernel<5, false, 4>, lds5); else launch(conv3x3_mx_kernel<4, false, 4>, lds4);
+        if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 4>), lds5); else MXL((conv3x3_mx_kernel<4, false, 4>), lds4);
     } else if (twlog == 5) {
-        if (g.pool) launch(conv3x3_mx_kernel<5, true, 9>, lds5); else launch(conv3x3_mx_kernel<5, false, 9>, lds5);
+        if (g.pool) MXL((conv3x3_mx_kernel<5, true, 9>), lds5); else MXL((conv3x3_mx_kernel<5, false, 9>), lds5);
     } else {
-        if (g.pool) launch(conv3x3_mx_kernel<4, true, 9>, lds4); else launch(conv3x3_mx_kernel<4, false, 9>, lds4);
+        if (g.pool) MXL((conv3x3_mx_kernel<4, true, 9>), lds4); else MXL((conv3x3_mx_kernel<4, false, 9>), lds4);
     }
-    if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
-    return VQK_OK;
+#undef MXL
 }
 
 }  // namespace vqkd

@@ -75,9 +75,6 @@ def _timed(name: str, flops: float, launch, nbytes: float = 0.0, launches: int =
     """``launches``: kernel launches behind this one event (an upsample conv in phase form is four)"""
     if KERNEL_EVENTS is None:
         return launch()
-    if _EVENT_SHAPES:
-        name = f'{name} {flops / 1e9:.2f}GF'
-
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     st = launch()
@@ -94,6 +91,13 @@ _WGMX_ON = os.environ.get('VQK_WGMX', '1') != '0'
 def _fprop_kernel_name(dtype, wlayout: int, shape=None) -> str:
     """the kernel symbol the launcher picks (csrc/conv.hip::launch_fprop), for the per-kernel event statistics;
     shape = (n, h_out, w_out, cin, cout, act, out_dtype) lets it tell the matrix/auxiliary-wave kernel from the stream kernel"""
+    name = _fprop_kernel_name0(dtype, wlayout, shape)
+    if _EVENT_SHAPES and shape is not None:                      # tooling (tools/per_shape.py): one line per layer shape
+        name += f' {shape[3]}->{shape[4]}@{shape[1]}x{shape[2]}'
+    return name
+
+
+def _fprop_kernel_name0(dtype, wlayout: int, shape=None) -> str:
     if wlayout == 1:
         if dtype != torch.bfloat16:
             return 'conv3x3_halo_breg_kernel<f32>'
@@ -308,7 +312,7 @@ def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int =
         ws = _gn_ws(x.device, n * gn_groups * 2 + n)
     flops = 2.0 * n * 4 * h * w * cout * cin * 9                 # ALGORITHMIC: the 3x3 conv over the upsampled image
     nbytes = x.numel() * x.element_size() + y.numel() * y.element_size() + cout * cin * 9 * x.element_size()
-    st = _timed('conv3x3_mx_kernel<bf16>', flops,
+    st = _timed('conv3x3_mx_kernel<bf16>' + (f' {cin}->{cout}@{y.shape[2]}x{y.shape[3]} phase-{"dgrad" if backward else "fwd"}' if _EVENT_SHAPES else ''), flops,
                 lambda: _native.lib().vqk_conv2d_ups_phase(dcode(x.dtype), x.data_ptr(), wq4.data_ptr(), _p(bias), y.data_ptr(),
                                                            n, h, w, cin, cout, int(backward), _p(ws), gn_groups,
                                                            zero_page(x.device).data_ptr(), _stream()), nbytes, launches=4)
@@ -354,7 +358,10 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None) -> torch.Tensor:
     flops = 2.0 * n * dy.shape[2] * dy.shape[3] * cout * cin * ksize * ksize
     mxw = (_WGMX_ON and x.dtype == torch.bfloat16 and ksize == 3 and cin % 64 == 0 and cout % 64 == 0
            and dy.shape[3] % 16 == 0 and dy.shape[2] % 8 == 0)
-    st = _timed('conv3x3_wgrad_mx_kernel<bf16>' if mxw else f'conv_wgrad_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>', flops,
+    kname = 'conv3x3_wgrad_mx_kernel<bf16>' if mxw else f'conv_wgrad_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>'
+    if _EVENT_SHAPES:
+        kname += f' {cin}->{cout}@{dy.shape[2]}x{dy.shape[3]} k{ksize}'
+    st = _timed(kname, flops,
                 lambda: _native.lib().vqk_conv2d_wgrad(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h,
                                                        w, cin, cout, ksize, int(ups),
                                                        zero_page(x.device).data_ptr(), _stream()))
@@ -370,7 +377,7 @@ def raw_conv_wgrad_pooled_dy(x, dy_pooled, scale: float, out) -> bool:
     if not (_WGMX_ON and x.dtype == torch.bfloat16 and cin % 64 == 0 and cout % 64 == 0 and w % 16 == 0 and h % 8 == 0):
         return False
     flops = 2.0 * n * h * w * cout * cin * 9
-    st = _timed('conv3x3_wgrad_mx_kernel<bf16>', flops,
+    st = _timed('conv3x3_wgrad_mx_kernel<bf16>' + (f' {cin}->{cout}@{h}x{w} pooled-dy' if _EVENT_SHAPES else ''), flops,
                 lambda: _native.lib().vqk_conv2d_wgrad_pooled_dy(dcode(x.dtype), x.data_ptr(), dy_pooled.data_ptr(), out.data_ptr(),
                                                                  n, h, w, cin, cout, float(scale),
                                                                  zero_page(x.device).data_ptr(), _stream()))
@@ -462,7 +469,7 @@ def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool
     nb = x.numel() * x.element_size()
     presummed = presummed or _claim_presummed(x, groups)
     if presummed:
-        st = _timed('group_norm_fwd (HBM)', 0.0,
+        st = _timed('group_norm_fwd (HBM)' + (f' {c}@{h}x{wd} presummed' if _EVENT_SHAPES else ''), 0.0,
                     lambda: _native.lib().vqk_gn_forward_presummed(dcode(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(),
                                                                    y.data_ptr(), stats.data_ptr(), ws.data_ptr(), n, h * wd, c,
                                                                    groups, eps, int(silu), _stream()), 2 * nb)
@@ -470,7 +477,7 @@ def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool
         return y, stats
     # algorithmic bytes: x read for the statistics, x read + y written by the apply pass (one read, one write on the
     # single-kernel path of the small maps)
-    st = _timed('group_norm_fwd (HBM)', 0.0,
+    st = _timed('group_norm_fwd (HBM)' + (f' {c}@{h}x{wd}' if _EVENT_SHAPES else ''), 0.0,
                 lambda: _native.lib().vqk_gn_forward(dcode(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
                                                      stats.data_ptr(), ws.data_ptr(), n, h * wd, c, groups, eps, int(silu),
                                                      _stream()), (2 if h * wd <= 1024 else 3) * nb)
@@ -487,7 +494,7 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
     red = _gn_ws(x.device, n * groups * 2 + n)
     nb = x.numel() * x.element_size()
     passes = (3 if h * wd <= 512 else 5) + (1 if add is not None else 0)     # x, dy (twice on the two-kernel path), dx, skip
-    st = _timed('group_norm_bwd (HBM)', 0.0,
+    st = _timed('group_norm_bwd (HBM)' + (f' {c}@{h}x{wd}' if _EVENT_SHAPES else ''), 0.0,
                 lambda: _native.lib().vqk_gn_backward(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
                                                       b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
                                                       db.data_ptr(), red.data_ptr(), n, h * wd, c, groups, int(silu), 0,
@@ -503,7 +510,7 @@ def raw_gn_backward_pooled_add(x, stats, w, b, dy, groups: int, silu: bool, dw, 
     _claim_presummed(x, -1)
     red = _gn_ws(x.device, n * groups * 2 + n)
     nb = x.numel() * x.element_size()
-    st = _timed('group_norm_bwd (HBM)', 0.0,
+    st = _timed('group_norm_bwd (HBM)' + (f' {c}@{h}x{wd} pooled-add' if _EVENT_SHAPES else ''), 0.0,
                 lambda: _native.lib().vqk_gn_backward_pooled_add(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
                                                                  b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
                                                                  db.data_ptr(), red.data_ptr(), n, h, wd, c, groups, int(silu),

@@ -107,8 +107,15 @@ class FlatAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def load_state_dict(self, sd):
         params = self._params_in_order()
-        if len(sd['state']) not in (0, len(params)):
-            raise ValueError('FlatAdamW.load_state_dict: optimizer state does not match the parameter list')
+        # torch.optim.AdamW keeps state only for parameters that received a gradient (the reference's frozen EMA codebook
+        # never does): the state may be SPARSE; its keys index the parameter list, which 'param_groups' pins
+        saved = sum(len(g['params']) for g in sd['param_groups'])
+        if saved != len(params) or any(int(i) >= len(params) for i in sd['state']):
+            raise ValueError(f'FlatAdamW.load_state_dict: the saved optimizer holds {saved} parameters, this one {len(params)} '
+                             f'(reference checkpoints need optimizer_param_set="reference")')
+        for g, gs in zip(self.param_groups, sd['param_groups']):
+            if len(g['params']) != len(gs['params']):
+                raise ValueError('FlatAdamW.load_state_dict: parameter groups differ in size')
         for g, gs in zip(self.param_groups, sd['param_groups']):
             for k, v in gs.items():
                 if k != 'params':

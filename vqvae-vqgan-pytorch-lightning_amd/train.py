@@ -91,9 +91,30 @@ def parse_args(argv=None):
     p.add_argument('--batches_per_epoch', type=int, default=None, help='synthetic data: steps per epoch')
     p.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    p.add_argument('--optimizer_param_set', choices=['auto', 'all', 'reference'], default='auto',
+                   help="'reference': the tensors (and order) the reference hands AdamW (vqvae/model.py:384-410) -- what a "
+                        "reference checkpoint's optimizer state is indexed by; 'auto': every tensor, unless --loading_path "
+                        "holds an optimizer state of the reference's size")
     p.add_argument('--set', action='append', default=[], metavar='KEY=VALUE',
                    help='override a config entry, e.g. --set quantizer.num_embeddings=8192')
     return p.parse_args(argv)
+
+
+def detect_param_set(model_mod, ckpt_path: str, ctor_kw: dict) -> str:
+    """'reference' when the checkpoint's first optimizer state lists as many parameters as the reference's AdamW would
+    hold for this architecture (vqvae/model.py:384-410 drops encoder tensors shadowed by decoder names), else 'all'"""
+    ckpt = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+    states = ckpt.get('optimizer_states') or []
+    if not states:
+        return 'all'
+    saved = sum(len(g['params']) for g in states[0]['param_groups'])
+    probe = model_mod.VQVAE(init_cb=False, load_loss=False, **dict(ctor_kw, optimizer_param_set='reference'))
+    n_ref = sum(len(g) for g in probe.optimizer_groups())
+    probe.optimizer_param_set = 'all'
+    n_all = sum(len(g) for g in probe.optimizer_groups())
+    if saved == n_ref and saved != n_all:
+        return 'reference'
+    return 'all'
 
 
 def parse_overrides(pairs) -> dict:
@@ -129,6 +150,12 @@ def main(argv=None):
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     kw = dict(image_size=run['image_size'], ae_conf=run['ae_conf'], q_conf=run['q_conf'], l_conf=run['l_conf'],
               t_conf=run['t_conf'], compute_dtype=dtype)
+    param_set = args.optimizer_param_set
+    if param_set == 'auto':
+        param_set = 'all'
+        if args.loading_path is not None:
+            param_set = detect_param_set(model_mod, args.loading_path, kw)
+    kw['optimizer_param_set'] = param_set
     if args.loading_path is not None:                                # train.py:106-111
         model = model_mod.VQVAE.load_from_checkpoint(args.loading_path, strict=False, init_cb=False, load_loss=True, **kw)
     else:
@@ -138,6 +165,9 @@ def main(argv=None):
         model.criterion.discriminator.compute_dtype = dtype
         model.criterion.perceptual_loss.net.compute_dtype = dtype
     batches = _batches(args, run, device, rank, world)
+    if not batches:
+        raise SystemExit(f'train.py: the dataset holds fewer than one batch per rank '
+                         f'({run["batch_size_per_device"]} images x {world} ranks)')
     max_epochs = args.max_epochs or run['max_epochs']
     trainer = trainer_mod.MiniTrainer(max_epochs=max_epochs, num_training_batches=len(batches))
     trainer.attach(model)
@@ -153,7 +183,7 @@ def main(argv=None):
     graphed = False
     if not args.no_graph and not run['use_adversarial']:
         try:
-            trainer.capture(model, batches[0], warmup=1)
+            trainer.capture(model, batches[0], warmup=1, preserve_state=True)   # the settling step must not train
             graphed = True
         except RuntimeError as exc:
             if rank == 0:

@@ -71,13 +71,16 @@ class MiniTrainer:
             q.finish_update(force_collective=opt.force_collective)
 
     # ------------------------------------------------------------------ hipGraph replay of forward + backward
-    def capture(self, model, example_batch, warmup: int = 3):
+    def capture(self, model, example_batch, warmup: int = 3, preserve_state: bool = False):
         """Capture zero_grad + training_step + backward of ONE step into a hipGraph (shapes are static in
         training) and replay it afterwards: the step is ~600 short kernel launches, which is host-bound when
         issued one by one.  The gradient all-reduce and the AdamW launch stay outside the graph (one call
         each), so schedules (lr) remain ordinary host scalars.  ``warmup`` eager steps run first (they DO
-        update the model) so that every lazy allocation / kernel attribute is settled before capture."""
+        update the model) so that every lazy allocation / kernel attribute is settled before capture;
+        ``preserve_state``: weights, buffers, optimizer moments and step counts are put back afterwards, so a graphed run
+        takes exactly the optimizer steps an eager run takes (train.py)."""
         opt = self.optimizers[0]
+        snap = self._snapshot(model) if preserve_state else None
         q = getattr(model, 'quantizer', None)
         if getattr(q, 'kl_warmup', None) is not None or getattr(q, 'temp_decay', None) is not None:
             # the Gumbel temperature / KL weight are kernel ARGUMENTS: a replay would keep their capture-time values
@@ -91,6 +94,8 @@ class MiniTrainer:
                 self._eager_step(model, self._static_in, i)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if snap is not None:
+            self._restore(model, snap)
         # EMA quantizer: its statistics all-reduce must not sit inside the captured graph -- the update is deferred and
         # finished (collective + update kernel) after each replay
         self._deferred_q = getattr(model, 'quantizer', None) if hasattr(getattr(model, 'quantizer', None), 'defer_update') else None
@@ -109,6 +114,30 @@ class MiniTrainer:
             model.defer_usage_accumulation = False
         self._static_hist = model.quantizer.last_hist          # rewritten by every replay
         return self._graph
+
+    def _snapshot(self, model):
+        return dict(state={k: v.detach().clone() for k, v in model.state_dict().items()},
+                    opts=[(o.flat_v.clone(), None if o.flat_m is None else o.flat_m.clone(), o.step_count) for o in self.optimizers],
+                    usage=(None if getattr(model, 'train_epoch_usage_count', None) is None else model.train_epoch_usage_count.clone()),
+                    step=self.global_step)
+
+    @torch.no_grad()
+    def _restore(self, model, snap):
+        own = model.state_dict()
+        for k, v in snap['state'].items():
+            own[k].copy_(v)                                          # in place: parameters stay views of the flat arena
+        for o, (v, m, n) in zip(self.optimizers, snap['opts']):
+            o.flat_v.copy_(v)
+            if m is not None:
+                o.flat_m.copy_(m)
+            o.step_count = n
+            o.generation += 1
+            ops.repack_owned(o)
+            if o.shadow is not None:
+                o.shadow.copy_(o.flat_p)
+        if hasattr(model, 'train_epoch_usage_count'):
+            model.train_epoch_usage_count = snap['usage']
+        self.global_step = snap['step']
 
     def _eager_step(self, model, batch, batch_index):
         opt = self.optimizers[0]
