@@ -57,6 +57,13 @@ const char* vqk_arch(void);
 int vqk_row_sqnorm_f32(const float* x, int64_t rows, int d, float* out, void* stream);
 int vqk_vq_assign_f32(const float* z, const float* e, const float* z2, const float* e2,
                       int64_t n, int k, int d, int assoc, int64_t* idx, void* stream);
+/* vqk_vq_assign_f32 with the same result (bit-identical indices) computed as a bf16-MFMA candidate filter + an exact fp32
+ * re-rank of the candidates (csrc/vq_filter.hip states the error bound that keeps the exact winner inside the candidate
+ * set); d == 256, k % 32 == 0.  ws: >= vqk_vq_filter_ws_bytes(k, d) bytes of device scratch (the bf16 codebook and the
+ * per-code filter margins, rebuilt by every call).  VQK_ERR_SHAPE when not served (nothing launched). */
+int64_t vqk_vq_filter_ws_bytes(int k, int d);
+int vqk_vq_assign_filtered_f32(const float* z, const float* e, const float* z2, const float* e2, int64_t n, int k, int d,
+                               int assoc, int64_t* idx, void* ws, int64_t ws_bytes, void* stream);
 /* Same search, additionally writing the full fp32 distance matrix dmat[N][K] (Entropy quantizer). */
 int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const float* e2,
                          int64_t n, int k, int d, int assoc, int64_t* idx, float* dmat, void* stream);
@@ -197,6 +204,14 @@ int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, 
  * (split-K partials are combined with fp32 atomics). */
 int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
                      int cout, int ksize, int ups, const void* zeros, void* stream);
+/* The 3x3 weight gradient of the two EDGE convs (one 16-byte chunk of channels on one side: the padded 3-channel image /
+ * reconstruction; vqvae/modules/autoencoder.py:114 and :170), bf16: (cin, cout) = (8, 128) or (128, 8), N*h*w % 128 == 0.
+ * dw[Cout][3][3][Cin] += the gradient; split-K partials go through the caller's workspace `ws` (>=
+ * vqk_conv2d_wgrad_edge_ws_bytes() bytes) and are summed in a fixed order: no atomics, run-to-run deterministic.
+ * VQK_ERR_SHAPE when not served (nothing launched: callers use vqk_conv2d_wgrad). */
+int64_t vqk_conv2d_wgrad_edge_ws_bytes(void);
+int vqk_conv2d_wgrad_edge(int dtype, const void* x, const void* dy, float* dw, void* ws, int64_t ws_bytes, int n, int h,
+                          int w, int cin, int cout, const void* zeros, void* stream);
 /* out[c] (+)= sum over rows of x[rows][c]  (bias gradients); out pre-zeroed. */
 int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream);
 /* elementwise fp32 -> dtype cast (weight shadow copies) */

@@ -136,3 +136,56 @@ def test_wgrad_pooled_dy_vs_torch():
     assert _kernels() == ['conv3x3_wgrad_mx_kernel<bf16>']
     got = out.float().cpu()
     assert float((got - wt.grad).norm() / wt.grad.norm()) < 2e-5
+
+
+@pytest.mark.parametrize('cin,cout', [(8, 128), (128, 8)])
+@pytest.mark.parametrize('n,h,w', [(2, 64, 64), (2, 48, 80), (1, 256, 256)])
+def test_edge_wgrad_thin_kernel_vs_torch(cin, cout, n, h, w):
+    """the K = 72 weight-gradient kernel of the two edge convs (conv_edge.hip; autoencoder.py:114 conv_in, :170 conv_out with
+    the 3 image channels padded to 8) against torch autograd of F.conv2d in fp32; its workspace split-K is deterministic"""
+    g = torch.Generator().manual_seed(cin + h)
+    x = _bf(torch.randn(n, cin, h, w, generator=g))
+    dy = _bf(torch.randn(n, cout, h, w, generator=g))
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(x, wt, None, padding=1).backward(dy)
+    outs = []
+    for _ in range(2):
+        _events()
+        dw = ops.raw_conv_wgrad(_dev(x), _dev(dy), 3, False)
+        torch.cuda.synchronize()
+        assert _kernels() == ['conv3x3_wgrad_thin_kernel<bf16>']
+        outs.append(dw.float().cpu())
+    assert torch.equal(outs[0], outs[1])                             # ordered reduce: bit-identical run to run
+    want = wt.grad
+    assert outs[0].shape == want.shape
+    assert float((outs[0] - want).norm() / want.norm()) < 2e-5
+    assert float((outs[0] - want).abs().max() / want.abs().max()) < 1e-4
+    # accumulates into a pre-existing buffer
+    base = torch.ones((cout, 3, 3, cin), dtype=torch.float32, device=DEV).permute(0, 3, 1, 2)
+    ops.raw_conv_wgrad(_dev(x), _dev(dy), 3, False, out=base)
+    torch.cuda.synchronize()
+    assert float((base.float().cpu() - 1.0 - want).norm() / want.norm()) < 2e-5
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 128, 256, 64, 64), (3, 256, 128, 32, 64), (2, 256, 512, 16, 16), (1, 512, 256, 16, 32)])
+def test_conv1x1_on_mx_kernel_vs_torch(n, cin, cout, h, w):
+    """the ResBlock shortcut convs (autoencoder.py:52-55: 1x1, no bias) on the NTAP = 1 form of the matrix/auxiliary-wave
+    kernel: forward and data gradient against F.conv2d / its autograd in fp32"""
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = _bf(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
+    wt = _bf(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).requires_grad_(True)
+    dy = _bf(torch.randn(n, cout, h, w, generator=g))
+    want = F.conv2d(x, wt)
+    want.backward(dy)
+    xd = _dev(x.detach()).requires_grad_(True)
+    wd = wt.detach().to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+    _events()
+    y = ops.conv2d(xd, wd)
+    y.backward(_dev(dy))
+    torch.cuda.synchronize()
+    names = _kernels()
+    assert names.count('conv3x3_mx_kernel<bf16>') == 2, names      # forward + data gradient
+    _check(y.detach(), want.detach(), 1, '1x1 fprop')
+    _check(xd.grad, x.grad, 1, '1x1 dgrad')
+    gw = wd.grad.float().cpu()
+    assert float((gw - wt.grad).norm() / wt.grad.norm()) < 2e-5

@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../vqvae-vqgan-pytorch-lightning_amd/csrc"
 mkdir -p ../../scratch
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -c $src -o ../../scratch/${obj%.o}_$tag.o
 objs=""
-for o in vq.o entropy.o conv.o conv_mx.o conv_wgmx.o norm.o pointwise.o optim.o stylegan_ops.o gan_ops.o api.o; do
+for o in vq.o vq_filter.o entropy.o conv.o conv_mx.o conv_wgmx.o conv_edge.o norm.o pointwise.o optim.o stylegan_ops.o gan_ops.o api.o; do
   if [ "$o" = "$obj" ]; then objs="$objs ../../scratch/${obj%.o}_$tag.o"; else objs="$objs $o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libvqk_$tag.so $objs

@@ -27,6 +27,7 @@ I, L, F = c_int, c_int64, c_float
 _PROTOS = {
     'vqk_row_sqnorm_f32': [P, L, I, P, P],
     'vqk_vq_assign_f32': [P, P, P, P, L, I, I, I, P, P],
+    'vqk_vq_assign_filtered_f32': [P, P, P, P, L, I, I, I, P, P, L, P],
     'vqk_vq_distances_f32': [P, P, P, P, L, I, I, I, P, P, P],
     'vqk_entropy_forward_f32': [P, L, I, F, P, P, P, P, P, P, P],
     'vqk_entropy_backward_f32': [P, P, P, P, L, I, F, F, P, P],
@@ -53,6 +54,7 @@ _PROTOS = {
     'vqk_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
     'vqk_conv2d_wgrad_pooled_dy': [I, P, P, P, I, I, I, I, I, F, P, P],
+    'vqk_conv2d_wgrad_edge': [I, P, P, P, P, L, I, I, I, I, I, P, P],
     'vqk_colsum': [I, P, L, I, P, P],
     'vqk_cast': [P, P, I, L, P],
     'vqk_gn_stats': [I, P, I, L, I, I, F, P, P, P],
@@ -86,7 +88,7 @@ _PROTOS = {
     'vqk_bias_act': [P, P, P, P, P, P, L, L, I, I, I, F, F, F, P],
     'vqk_upfirdn2d': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, I, P],
 }
-_SPECIAL = {'vqk_conv_packed_elems': (c_int64, [I, I, I, I]), 'vqk_status_str': (c_char_p, [I]), 'vqk_version': (I, []), 'vqk_arch': (c_char_p, [])}
+_SPECIAL = {'vqk_conv_packed_elems': (c_int64, [I, I, I, I]), 'vqk_conv2d_wgrad_edge_ws_bytes': (c_int64, []), 'vqk_vq_filter_ws_bytes': (c_int64, [I, I]), 'vqk_status_str': (c_char_p, [I]), 'vqk_version': (I, []), 'vqk_arch': (c_char_p, [])}
 EXPORTS = sorted(list(_PROTOS) + list(_SPECIAL))
 
 

@@ -1097,14 +1097,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
                                                                       int pix_per_split) {
     typedef WgradFrag<bf16_raw> F;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_a = smem;                       // dy tile  [64 pix][128 co]
-    char* lds_b = smem + F::KP * F::ROWB;     // x tile   [64 pix][128 ci]
+    // TWO stages of (dy tile [64 pix][128 co], x tile [64 pix][128 ci]): the K-step p0 + KP is in flight (LDS-DMA) while step p0
+    // runs on the matrix pipe -- the loop used to load, wait, compute, which left the 1x1 / strided weight gradients
+    // latency-bound (167 us for 128->256 @128^2, bs = 32: 2.4 TB/s)
+    constexpr int TILE = F::KP * F::ROWB, STAGE = 2 * TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_ci = (g.cin + 127) >> 7;
     const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
     const int co0 = tco * 128, ci0 = tci * 128;
-    const int tap = blockIdx.y, kh = tap / g.ks, kw = tap - kh * g.ks, pad = g.ks >> 1;
+    const int tap = blockIdx.y, kh = tap / g.ks, kw = tap - kh * g.ks;
     const int p_begin = blockIdx.z * pix_per_split;
     const int p_end = min(g.m, p_begin + pix_per_split);
 
@@ -1120,7 +1122,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int hw = g.h * g.w;
-    for (int p0 = p_begin; p0 < p_end; p0 += F::KP) {
+    auto issue = [&](int p0, char* st) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = 4 * (4 * wave + t) + rsub;          // (row & 3) == rsub
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
             // A: dy[p][co0 + lc*8 ..]
             const bool oka = pv && (co0 + lc * 8) < g.cout;
             const void* sa = oka ? (const void*)(dy + (int64_t)p * g.cout + co0 + lc * 8) : (const void*)zeros;
-            glds16(sa, lds_a + (4 * wave + t) * 1024);
+            glds16(sa, st + (4 * wave + t) * 1024);
             // B: x[p (+) tap][ci0 + lc*8 ..]
             bool okb = pv && (ci0 + lc * 8) < g.cin;
             const void* sb = zeros;
@@ -1141,10 +1143,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
                 if (ih >= 0 && ih < g.vh && iw >= 0 && iw < g.vw && !(g.zs && ((ih | iw) & 1)))
                     sb = x + (((int64_t)img * g.h_in + (ih >> g.ups)) * g.w_in + (iw >> g.ups)) * g.cin + ci0 + lc * 8;
             }
-            glds16(sb, lds_b + (4 * wave + t) * 1024);
+            glds16(sb, st + TILE + (4 * wave + t) * 1024);
         }
+    };
+    if (p_begin < p_end) issue(p_begin, smem);
+    int buf = 0;
+    for (int p0 = p_begin; p0 < p_end; p0 += F::KP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();                                        // step p0 has landed; the other stage's readers are done
+        const char* lds_a = smem + buf * STAGE;
+        const char* lds_b = lds_a + TILE;
+        if (p0 + F::KP < p_end) issue(p0 + F::KP, smem + (buf ^ 1) * STAGE);
 #pragma unroll
         for (int k0 = 0; k0 < F::KP; k0 += 16) {
             bf16x8_t a[2], b[2];
@@ -1159,7 +1168,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        buf ^= 1;
     }
     const int taps = g.ks * g.ks;
 #pragma unroll
@@ -1785,9 +1794,19 @@ static thread_local int g_force_variant = -1;   // test hook (per host thread: t
 static thread_local int g_stream_blocks = 0;    // persistent-grid caps (0 = default 2 blocks per CU): 256 leaves half of every CU to a
 static thread_local int g_wgrad_blocks = 0;     // kernel running concurrently on another stream (dgrad || wgrad || GroupNorm)
 
+// 1x1 convs (the ResBlock shortcuts, autoencoder.py:52-55): the NTAP = 1 form of the matrix/auxiliary-wave kernel -- bf16, whole
+// 128-cout tiles, at least two 32-channel chunks, 32-bit buffer offsets
+inline bool mx_serves_1x1(const ConvGeom& g) {
+    static const int mx_on = getenv("VQK_MX") ? atoi(getenv("VQK_MX")) : 1;
+    static const int on = getenv("VQK_MX_1X1") ? atoi(getenv("VQK_MX_1X1")) : 1;
+    return mx_on && on && g_force_variant != 5 && (g.cout & 127) == 0 && (g.cpt >> 2) >= 2 && !g.ups &&
+           (int64_t)g.n * g.h_in * g.w_in * g.cin * 2 < 0x7fffffffLL && (int64_t)g.m * g.cout * 2 < 0x7fffffffLL;
+}
+
 // 0: not eligible for the halo kernels; 5 / 4: patch width log2 (8x32 / 16x16 pixel patches)
 inline int halo_twlog(const ConvGeom& g) {
-    if (g.ks != 3 || (g.cpt % 8) != 0 || g_force_variant == 0) return 0;
+    if ((g.ks != 3 && g.ks != 1) || (g.cpt % 8) != 0 || g_force_variant == 0) return 0;
+    if (g.ks == 1 && !mx_serves_1x1(g)) return 0;                // 1x1: only the matrix/auxiliary-wave kernel has a pixel-tile form
     static const int prefer16 = getenv("VQK_TW16") ? atoi(getenv("VQK_TW16")) : 0;      // A/B: 16x16 patches where both fit
     if (prefer16 && (g.w % 16) == 0 && (g.h % 16) == 0) return 4;
     if ((g.w % 32) == 0 && (g.h % 8) == 0) return 5;
@@ -1817,13 +1836,13 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
             // (bias / residual / pooling; relu or leaky relu with the StyleGAN2 gains: the VGG and discriminator convs)
             const bool plain = (act == 0 || ((act == 2 || act == 3) && !g.pool && !g.gn_ws)) && (g.cout & 127) == 0;
             const bool fits32 = (int64_t)g.n * g.h_in * g.w_in * g.cin * 2 < 0x7fffffffLL && (int64_t)g.m * g.cout * 2 < 0x7fffffffLL;
-            if (mx_on && g_force_variant != 5 && plain && fits32 && (g.cpt >> 2) >= 2 && (total >= mx_min || g_force_variant == 6)) {
+            if (mx_on && g_force_variant != 5 && plain && fits32 && (g.cpt >> 2) >= 2 && (total >= mx_min || g_force_variant == 6 || g.ks == 1)) {
                 ConvGeom ga = g;
                 ga.act = act;
                 return vqkd::launch_conv3x3_mx(x, w, bias, res, y, zeros, ga, tw, st);
             }
         }
-        if (g.gn_ws) return VQK_ERR_SHAPE;                       // fused statistics exist on the matrix/auxiliary-wave kernel only
+        if (g.gn_ws || g.ks == 1) return VQK_ERR_SHAPE;          // fused statistics / 1x1 tiles exist on the matrix/auxiliary-wave kernel only
         if (g.cout <= 32) {                                      // thin head: 32-wide cout tiles, waves split the pixels
             ConvGeom gt = g;
             gt.tiles_n = 1;
@@ -1852,7 +1871,7 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         return VQK_OK;
     }
     if (wlayout == 1) {
-        if (!tw) return VQK_ERR_SHAPE;                       // fragment-major weights need a halo-eligible shape
+        if (!tw || g.ks == 1) return VQK_ERR_SHAPE;          // fragment-major weights need a halo-eligible shape
         constexpr int lds = 11 * 4096;
         const int th = 256 >> tw;
         const dim3 grid((unsigned)(g.n * (g.h / th) * (g.w >> tw) * g.tiles_n));
@@ -1865,7 +1884,7 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
         return VQK_OK;
     }
-    if (tw) {
+    if (tw && g.ks == 3) {
         constexpr int lds = 11 * 4096 + 32768;
         const int th = 256 >> tw;
         const dim3 grid((unsigned)(g.n * (g.h / th) * (g.w >> tw) * g.tiles_n));
@@ -1924,7 +1943,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.acc_scale = 1.0f; g.out_gain = 1.0f; g.pool = 0; g.pool_scale = 1.0f;
     g.gn_ws = nullptr; g.gn_cpg = 0;
     g.act = 0; g.dy_pool = 0;
-    g.ntap = 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
+    g.ntap = ksize == 1 ? 1 : 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
     g.m = (int)m;
@@ -2107,6 +2126,7 @@ int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int co
     ConvGeom g;
     const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
     if (rc) return rc;
+    if (ksize == 1 && dtype != VQK_BF16) return 0;
     return (halo_twlog(g) && g_force_variant != 2) ? 1 : 0;
 }
 
@@ -2136,7 +2156,7 @@ int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int ci
     } else if (layout == 1) {
         const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
         const int e = dtype == VQK_F32 ? 4 : 8;
-        VQK_REQUIRE(ksize == 3 && dcin % (8 * e) == 0, VQK_ERR_SHAPE);
+        VQK_REQUIRE(dcin % (8 * e) == 0, VQK_ERR_SHAPE);
         const int cot_tiles = ((dcout + 127) / 128) * 4;
         const int64_t total = (int64_t)cot_tiles * 32 * taps * dcin;
         const dim3 grid(vqk_grid_1d(total, 256));
@@ -2253,8 +2273,12 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     }
     const int kp = dtype == VQK_F32 ? 32 : 64;
     const int tiles = ((cout + 127) / 128) * ((cin + 127) / 128) * ksize * ksize;
-    // split the pixel range so that ~2048 blocks are in flight, each with >= 4 K-steps
-    int splits = (2048 + tiles - 1) / tiles;
+    // split the pixel range so that ~2048 blocks are in flight, each with >= 4 K-steps (fp32); the double-buffered bf16
+    // kernel keeps two 64-KiB blocks per CU busy with ~512 blocks and a quarter of the atomic passes over dW (each block
+    // ends with one: at 2048 blocks the 1x1 shortcut's 128 x 256 gradient cost 134 MB of atomics per launch)
+    static const int wg_target = getenv("VQK_WGRAD_GEN_BLOCKS") ? atoi(getenv("VQK_WGRAD_GEN_BLOCKS")) : 512;
+    const int target_blocks = dtype == VQK_F32 ? 2048 : wg_target;
+    int splits = (target_blocks + tiles - 1) / tiles;
     const int max_splits = (g.m + 4 * kp - 1) / (4 * kp);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -2265,7 +2289,11 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     if (dtype == VQK_F32)
         hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 32768, vqk_stream(stream), (const float*)x, (const float*)dy, dw, (const char*)zeros, g, pps);
     else
-        hipLaunchKernelGGL(conv_wgrad_kernel<bf16_raw>, grid, dim3(256), 32768, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+    {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (attr != hipSuccess) return VQK_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv_wgrad_kernel<bf16_raw>, grid, dim3(256), 65536, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+    }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

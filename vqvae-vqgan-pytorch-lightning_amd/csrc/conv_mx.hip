@@ -62,7 +62,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                                                             const float* __restrict__ bias,
                                                             const bf16_raw* __restrict__ res, bf16_raw* __restrict__ y,
                                                             ConvGeom g) {
-    constexpr int PIX = PIXELS, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr int HM = NTAP == 1 ? 0 : 1;                        // halo margin: a 1x1 conv (NTAP = 1) reads the tile's own pixels only
+    constexpr int PIX = PIXELS, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2 * HM, HROWS = (TH + 2 * HM) * HW2;
     constexpr int RS = 80;                                       // bytes per halo pixel: 64 data + 16 pad
     constexpr int PIECES = (HROWS * 5 + 63) / 64;                // 1-KiB LDS-DMA pieces per halo
     constexpr int BUF = PIECES * 1024, STG = 3 * BUF, SPITCH = 272, SCR = STG + PIX * SPITCH;   // SCR: 1 KiB of statistics partials
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     constexpr int NQ = PIX / 16;                                 // 16-byte staging pieces per auxiliary thread and tile
     static_assert(PIX == 256 || (PIX == 128 && !POOL && NTAP == 9), "256-pixel tiles, or plain 128-pixel half tiles");
     constexpr int NPH = NTAP * 2;                                // phases ((tap, k-substep) pairs) and weight fragments per unit
-    static_assert(NTAP == 9 || (NTAP == 4 && !POOL), "3x3 taps, or the 2x2 taps of an upsample phase");
+    static_assert(NTAP == 9 || ((NTAP == 4 || NTAP == 1) && !POOL), "3x3 taps, the 2x2 taps of an upsample phase, or a 1x1 conv");
     constexpr int XS = (PIECES + 3) / 4;                         // pieces per X wave
     constexpr int OOB = (int)0x80000000;
     typedef bf16x8_t frag_t;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, soff, 0));
         };
 
-        constexpr int RD = NTAP == 9 ? VQK_MX_RD : 4;
+        constexpr int RD = NTAP == 9 ? VQK_MX_RD : NTAP == 4 ? 4 : 2;
         static_assert(NPH % RD == 0, "weight ring depth must divide the phases of a unit");
         f32x16 acc[NI][NJ];
         frag_t bw[RD][NJ];
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tap = 0; tap < NTAP; ++tap) {
-                constexpr int TWD = NTAP == 9 ? 3 : 2;           // taps per window row
+                constexpr int TWD = NTAP == 9 ? 3 : NTAP == 4 ? 2 : 1;      // taps per window row
                 const int toff = ((tap / TWD) * HW2 + (tap % TWD)) * RS;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         const int s = (xw + 4 * sl) * 64 + lane;
         const int hp = s / 5, cp = s - hp * 5;
         const int hy = hp / HW2, hx = hp - hy * HW2;
-        rel[sl] = (((((hy - 1) * g.src_s) >> g.ups) * g.w_in + (((hx - 1) * g.src_s) >> g.ups)) * g.cin + cp * 8) * 2;
-        flg[sl] = (hy == 0 ? 1 : 0) | (hy == TH + 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == TW + 1 ? 8 : 0) |
+        rel[sl] = (((((hy - HM) * g.src_s) >> g.ups) * g.w_in + (((hx - HM) * g.src_s) >> g.ups)) * g.cin + cp * 8) * 2;
+        flg[sl] = (HM && hy == 0 ? 1 : 0) | (HM && hy == TH + 1 ? 2 : 0) | (HM && hx == 0 ? 4 : 0) | (HM && hx == TW + 1 ? 8 : 0) |
                   ((cp == 4 || hp >= HROWS) ? 16 : 0);
     }
     auto issue_halo = [&](const TilePos& tp, int c, int bufi) {
@@ -516,6 +517,10 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     } else if (g.ntap == 4) {
         if (g.pool) return VQK_ERR_ARG;
         if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 4>), lds5); else MXL((conv3x3_mx_kernel<4, false, 4>), lds4);
+    } else if (g.ntap == 1) {                                    // 1x1 conv: no halo, 2 phases per unit
+        if (g.pool) return VQK_ERR_ARG;
+        constexpr int lds1 = 3 * ((256 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
+        if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 1>), lds1); else MXL((conv3x3_mx_kernel<4, false, 1>), lds1);
     } else if (twlog == 5) {
         if (g.pool) MXL((conv3x3_mx_kernel<5, true, 9>), lds5); else MXL((conv3x3_mx_kernel<5, false, 9>), lds5);
     } else {

@@ -111,8 +111,11 @@ def _fprop_kernel_name0(dtype, wlayout: int, shape=None) -> str:
 
 
 
-def weight_layout(dtype, n, h_in, w_in, cin, cout, ksize, ups) -> int:
-    """operand layout the fprop launcher wants for this problem (include/vqk.h: 0 = [O][kh][kw][I], 1 = fragment-major)"""
+def weight_layout(dtype, n, h_in, w_in, cin, cout, ksize, ups, out_dtype=None) -> int:
+    """operand layout the fprop launcher wants for this problem (include/vqk.h: 0 = [O][kh][kw][I], 1 = fragment-major);
+    a 1x1 conv has a fragment-major form only on the bf16 -> bf16 matrix/auxiliary-wave kernel"""
+    if ksize == 1 and (dtype != torch.bfloat16 or (out_dtype is not None and out_dtype != torch.bfloat16)):
+        return 0
     r = _native.lib().vqk_conv_weight_layout(dcode(dtype), n, h_in, w_in, cin, cout, ksize, int(ups))
     if r < 0:
         _native.check(r, 'conv_weight_layout')
@@ -348,6 +351,19 @@ def direct_grad(param):
     return None
 
 
+_EDGE_WGRAD = os.environ.get('VQK_EDGE_WGRAD', '1') != '0'
+_EDGE_WS: dict = {}
+
+
+def _edge_ws(device) -> torch.Tensor:
+    """split-K workspace of vqk_conv2d_wgrad_edge, one per (device, stream): plain stores + ordered reduce, no atomics"""
+    key = (device, _stream())
+    ws = _EDGE_WS.get(key)
+    if ws is None:
+        ws = _EDGE_WS[key] = torch.empty(_native.lib().vqk_conv2d_wgrad_edge_ws_bytes() // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None) -> torch.Tensor:
     """dw as fp32 with memory [Cout][k][k][Cin] (logical [Cout,Cin,k,k] channels_last); ``out``: accumulate
     into this (pre-existing) buffer instead of a fresh zeroed one."""
@@ -356,6 +372,17 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None) -> torch.Tensor:
     dw = out if out is not None else \
         torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
     flops = 2.0 * n * dy.shape[2] * dy.shape[3] * cout * cin * ksize * ksize
+    if (_EDGE_WGRAD and x.dtype == torch.bfloat16 and ksize == 3 and not ups and (cin, cout) in ((8, 128), (128, 8))
+            and (n * h * w) % 128 == 0):
+        # the two edge convs (padded 3-channel image / reconstruction): K = 72 GEMM, HBM-bound, workspace split-K
+        ws = _edge_ws(x.device)
+        nbytes = (x.numel() + dy.numel()) * 2
+        st = _timed('conv3x3_wgrad_thin_kernel<bf16>' + (f' {cin}->{cout}@{h}x{w}' if _EVENT_SHAPES else ''), 0.0,
+                    lambda: _native.lib().vqk_conv2d_wgrad_edge(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
+                                                                ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout,
+                                                                zero_page(x.device).data_ptr(), _stream()), nbytes)
+        _native.check(st, 'conv2d_wgrad_edge')
+        return dw
     mxw = (_WGMX_ON and x.dtype == torch.bfloat16 and ksize == 3 and cin % 64 == 0 and cout % 64 == 0
            and dy.shape[3] % 16 == 0 and dy.shape[2] % 8 == 0)
     kname = 'conv3x3_wgrad_mx_kernel<bf16>' if mxw else f'conv_wgrad_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>'
@@ -616,7 +643,7 @@ class Conv2dFn(torch.autograd.Function):
         if cin < i or cin % epc(dt):
             raise RuntimeError(f'vqk: conv input has {cin} channels, weight expects {i}')
         n_img, _, h_in, w_in = x.shape
-        layout = weight_layout(dt, n_img, h_in, w_in, cin, cout_pad, k, ups)
+        layout = weight_layout(dt, n_img, h_in, w_in, cin, cout_pad, k, ups, out_dtype)
         wq = packed_weight(weight, cin, cout_pad, dt, k, False, layout)
         b32 = None
         if bias is not None:
@@ -764,8 +791,9 @@ class ResBlockFn(torch.autograd.Function):
         a2, st2 = raw_gn_forward(r1, w2, b2, groups, eps, True, presummed=fused)
         skip = x
         if scw is not None:
-            skip = raw_conv_fprop(x, packed_weight(scw, cin, cout, dt, 1, False, 0), None, None, 1,
-                                  False, 0, dt, cout, 0)
+            lsc = weight_layout(dt, n, h, w, cin, cout, 1, False)
+            skip = raw_conv_fprop(x, packed_weight(scw, cin, cout, dt, 1, False, lsc), None, None, 1,
+                                  False, 0, dt, cout, lsc)
         l2 = weight_layout(dt, n, h, w, cout, cout, 3, False)
         wq2 = packed_weight(c2w, cout, cout, dt, 3, False, l2)
         out = None
@@ -963,6 +991,18 @@ class _MSE(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 # vector quantizer
 # ------------------------------------------------------------------------------------------------------
+VQ_FILTER = os.environ.get('VQK_VQ_FILTER', '1') != '0'
+_VQ_WS: dict = {}
+
+
+def _vq_filter_ws(device, k: int, d: int) -> torch.Tensor:
+    key = (device, _stream(), k, d)
+    ws = _VQ_WS.get(key)
+    if ws is None:
+        ws = _VQ_WS[key] = torch.empty(_native.lib().vqk_vq_filter_ws_bytes(k, d), dtype=torch.uint8, device=device)
+    return ws
+
+
 def vq_assign(flat_z: torch.Tensor, codebook: torch.Tensor, assoc: int) -> torch.Tensor:
     """flat_z [N,D] fp32, codebook [K,D] fp32 -> idx [N] int64 (bit-exact vs oracle/vq_oracle.c)."""
     _require_gpu(flat_z)
@@ -975,6 +1015,14 @@ def vq_assign(flat_z: torch.Tensor, codebook: torch.Tensor, assoc: int) -> torch
     s = _stream()
     _native.check(lib.vqk_row_sqnorm_f32(flat_z.data_ptr(), n, d, z2.data_ptr(), s), 'row_sqnorm(z)')
     _native.check(lib.vqk_row_sqnorm_f32(codebook.data_ptr(), k, d, e2.data_ptr(), s), 'row_sqnorm(e)')
+    if VQ_FILTER and d == 256 and k % 32 == 0:
+        # bf16 candidate filter + exact fp32 re-rank: the same indices, bit for bit (csrc/vq_filter.hip)
+        ws = _vq_filter_ws(flat_z.device, k, d)
+        st = lib.vqk_vq_assign_filtered_f32(flat_z.data_ptr(), codebook.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d,
+                                            assoc, idx.data_ptr(), ws.data_ptr(), ws.numel(), s)
+        if st != _native.ERR_SHAPE:
+            _native.check(st, 'vq_assign_filtered')
+            return idx
     _native.check(lib.vqk_vq_assign_f32(flat_z.data_ptr(), codebook.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d,
                                         assoc, idx.data_ptr(), s), 'vq_assign')
     return idx
@@ -1367,7 +1415,7 @@ class ConvActFn(torch.autograd.Function):
         h_out = (h + 2 * pad - k) // stride + 1
         w_out = (w + 2 * pad - k) // stride + 1
         plain = stride == 1 and pad == k // 2
-        layout = weight_layout(dt, n, h, w, cin, cout_pad, k, False) if plain else 0
+        layout = weight_layout(dt, n, h, w, cin, cout_pad, k, False, out_dtype) if plain else 0
         w4 = weight.reshape(o, i, k, k)
         wq = _packed_w4(weight, w4, cin, cout_pad, dt, k, False, layout)
         b32 = None
