@@ -205,7 +205,8 @@ int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, 
 int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
                      int cout, int ksize, int ups, const void* zeros, void* stream);
 /* The 3x3 weight gradient of the two EDGE convs (one 16-byte chunk of channels on one side: the padded 3-channel image /
- * reconstruction; vqvae/modules/autoencoder.py:114 and :170), bf16: (cin, cout) = (8, 128) or (128, 8), N*h*w % 128 == 0.
+ * reconstruction; vqvae/modules/autoencoder.py:114 and :170), bf16: (cin, cout) = (8, 128) or (128, 8), h*w % 128 == 0 and
+ * (w % 128 == 0 or 128 % w == 0).
  * dw[Cout][3][3][Cin] += the gradient; split-K partials go through the caller's workspace `ws` (>=
  * vqk_conv2d_wgrad_edge_ws_bytes() bytes) and are summed in a fixed order: no atomics, run-to-run deterministic.
  * VQK_ERR_SHAPE when not served (nothing launched: callers use vqk_conv2d_wgrad). */

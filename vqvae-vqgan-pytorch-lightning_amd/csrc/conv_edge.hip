@@ -45,6 +45,9 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int k0, int cbase,
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+#ifndef VQK_EDGE_ABL
+#define VQK_EDGE_ABL 0       // timing-only ablation bits (tools/ab_build.sh): 1 im2col pieces from the zero page, 2 no wide pieces, 4 no MFMA loop
+#endif
 constexpr int EDGE_CW = 128;                                     // wide channels
 constexpr int EDGE_PIX = 128;                                    // pixels per patch
 constexpr int EDGE_WIDE_B = EDGE_PIX * EDGE_CW * 2;              // 32768
@@ -68,30 +71,43 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_thin_kernel(const bf16_r
     const int hw = h * w;
     constexpr int SGN = MODE == 0 ? 1 : -1;
 
+    // slot = (pixel of the patch, tap) is a property of the lane: decoded ONCE (the per-patch address arithmetic used to
+    // redo three integer divisions per slot -- 2400 of the 3400 cycles a patch took with all loads stubbed out).  A patch is
+    // 128 consecutive pixels that never straddle an image (h*w % 128 == 0) and lie in ONE row (w % 128 == 0) or cover whole
+    // rows (128 % w == 0): pixel = (y0 + ry, x0 + rx) with (ry, rx) fixed per slot.
+    int s_ry[5], s_rx[5], s_ty[5], s_tx[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int q = wave + 4 * t;
+        const int slot = q * 64 + lane;
+        const int pl = slot / 9, tap = slot - pl * 9;
+        s_ry[t] = w >= EDGE_PIX ? 0 : pl / w;
+        s_rx[t] = w >= EDGE_PIX ? pl : pl - (pl / w) * w;
+        s_ty[t] = SGN * (tap / 3 - 1);
+        s_tx[t] = SGN * (tap - (tap / 3) * 3 - 1);
+    }
     auto issue = [&](int patch, int stage) {
         char* st = smem + stage * EDGE_STAGE;
         const int64_t p0 = (int64_t)patch * EDGE_PIX;
+        const int img = (int)(p0 / hw), rem = (int)(p0 - (int64_t)img * hw);          // wave-uniform
+        const int y0 = rem / w, x0 = rem - y0 * w;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {                            // wide: piece q covers rows 4q .. 4q+3
             const int q = wave * 8 + t;
             const int row = 4 * q + (lane >> 4), pc = lane & 15;
             const int lc = pc ^ ((row & 3) << 2);
-            glds16(wide + (p0 + row) * EDGE_CW + lc * 8, st + q * 1024);
+            if (!((VQK_EDGE_ABL & 2) && n > 0)) glds16(wide + (p0 + row) * EDGE_CW + lc * 8, st + q * 1024);
+            else glds16(zeros, st + q * 1024);
         }
+        const bf16_raw* timg = thin + (int64_t)img * hw * 8;
 #pragma unroll
         for (int t = 0; t < 5; ++t) {                            // im2col: slot = pixel * 9 + tap, 64 slots per piece
             const int q = wave + 4 * t;
             if (q < 18) {
-                const int slot = q * 64 + lane;
-                const int pl = slot / 9, tap = slot - pl * 9;
-                const int64_t p = p0 + pl;
-                const int img = (int)(p / hw), rem = (int)(p - (int64_t)img * hw);
-                const int y = rem / w, x = rem - y * w;
-                const int ty = tap / 3 - 1, tx = tap - (tap / 3) * 3 - 1;
-                const int yy = y + SGN * ty, xx = x + SGN * tx;
+                const int yy = y0 + s_ry[t] + s_ty[t], xx = x0 + s_rx[t] + s_tx[t];
                 const void* src = zeros;
-                if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w)
-                    src = thin + (((int64_t)img * h + yy) * w + xx) * 8;
+                if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && !((VQK_EDGE_ABL & 1) && n > 0))
+                    src = timg + ((int64_t)yy * w + xx) * 8;
                 glds16(src, st + EDGE_WIDE_B + q * 1024);
             } else {
                 glds16(zeros, smem + 3 * EDGE_STAGE + wave * 1024);      // keeps every wave at 13 operations per patch
@@ -115,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_thin_kernel(const bf16_r
         if (i + 2 < cnt) issue(b + (i + 2) * G, (i + 2) % 3);
         const char* st = smem + (i % 3) * EDGE_STAGE;
 #pragma unroll
-        for (int k0 = 0; k0 < EDGE_PIX; k0 += 16) {
+        for (int k0 = 0; k0 < (((VQK_EDGE_ABL & 4) && n > 0) ? 0 : EDGE_PIX); k0 += 16) {
             const bf16x8_t a = tr_frag<EDGE_CW * 2, true>(st, k0, 32 * wave, lane);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -180,7 +196,9 @@ int vqk_conv2d_wgrad_edge(int dtype, const void* x, const void* dy, float* dw, v
     VQK_REQUIRE(n > 0 && h > 0 && w > 0, VQK_ERR_SHAPE);
     const bool first = cin == 8 && cout == EDGE_CW, last = cout == 8 && cin == EDGE_CW;
     const int64_t m = (int64_t)n * h * w;
-    VQK_REQUIRE((first || last) && m % EDGE_PIX == 0 && m < 0x7fffffffLL, VQK_ERR_SHAPE);
+    // a 128-pixel patch lies inside one image, and inside one row or on whole rows (the kernel decodes a slot's pixel once)
+    VQK_REQUIRE((first || last) && ((int64_t)h * w) % EDGE_PIX == 0 && (w % EDGE_PIX == 0 || EDGE_PIX % w == 0) && m < 0x7fffffffLL,
+                VQK_ERR_SHAPE);
     const int total = (int)(m / EDGE_PIX);
     int blocks = total < 256 ? total : 256;
     VQK_REQUIRE(ws_bytes >= (int64_t)blocks * EDGE_OUT * 4, VQK_ERR_ARG);

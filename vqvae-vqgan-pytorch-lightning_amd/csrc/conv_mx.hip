@@ -356,11 +356,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                 }
             } else {
                 const bool general = g.act != 0 || g.acc_scale != 1.0f || g.out_gain != 1.0f;     // wave-uniform
+                float abl_b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, abl_g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     float f[8], r[8];
                     unpack8(t[k], f);
                     unpack8(rv[k], r);
+                    if ((VQK_MXABL & 16) && g.n > 0) {
+                        // TIMING-ONLY experiment (profiles/round3_gn_bwd_fusion_ab.txt): the arithmetic a fused GroupNorm+SiLU
+                        // BACKWARD reduction would add to a data-gradient drain -- the residual operand stands in for the
+                        // GroupNorm input x (same bytes), per element: x_hat, u = gamma x_hat + beta, sigmoid, SiLU', t = dy SiLU',
+                        // two per-channel sums (d beta, d gamma).  Constants instead of per-group statistics; sums folded into
+                        // the statistics accumulators so that nothing is dead code.
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xh = __fmaf_rn(r[e], 1.3f, -0.13f);
+                            const float u = __fmaf_rn(xh, 1.1f, 0.05f);
+                            const float sg = __frcp_rn(1.0f + __expf(-u));
+                            const float t = f[e] * (sg * (1.0f + u * (1.0f - sg)));
+                            abl_b[e] += t;
+                            abl_g[e] = __fmaf_rn(t, xh, abl_g[e]);
+                        }
+                    }
                     if (general) {                               // y = out_gain * act(acc * acc_scale + bias) + residual
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -375,6 +392,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                     const u32x4 ov = pack8(f);
                     __builtin_amdgcn_raw_buffer_store_b128(ov, ysrd, res_off(o, k), 0, VQK_MX_NT);
                     if (want_stats) tally(ov);
+                }
+                if ((VQK_MXABL & 16) && g.n > 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ga += abl_b[e]; qa += abl_g[e]; }
                 }
             }
         } else {

@@ -373,7 +373,7 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None) -> torch.Tensor:
         torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
     flops = 2.0 * n * dy.shape[2] * dy.shape[3] * cout * cin * ksize * ksize
     if (_EDGE_WGRAD and x.dtype == torch.bfloat16 and ksize == 3 and not ups and (cin, cout) in ((8, 128), (128, 8))
-            and (n * h * w) % 128 == 0):
+            and (h * w) % 128 == 0 and (w % 128 == 0 or 128 % w == 0)):
         # the two edge convs (padded 3-channel image / reconstruction): K = 72 GEMM, HBM-bound, workspace split-K
         ws = _edge_ws(x.device)
         nbytes = (x.numel() + dy.numel()) * 2
