@@ -183,6 +183,14 @@ def measure_traffic(kernel_sub: str, events_per_step: int, argv):
         return None, None
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU of this node) under
     torch.distributed.run (vqvae/train.py:128-131 lets Lightning spawn the DDP ranks; here the bench does).  Returns the
@@ -372,6 +380,7 @@ def main():
                                               hbm_frac=round(v[3] / v[2] / HBM_PEAK_BPS, 3)))
                                      for k, v in by_kernel.items()})
 
+    result_line = None
     vq_kernel = None
     if rank == 0 and not args.no_kernel_events:
         # the other kernel BASELINE.json's north_star names: the VQ distance / argmin kernel at this config's (N, K, D)
@@ -399,14 +408,19 @@ def main():
                                yaml=os.path.relpath(conf_path, ROOT), yaml_overrides=conf_over,
                                learning_rate=run['learning_rate'],
                                global_batch=world * args.batch, parallelism=f'dp{world}',
-                               launch=('hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
+                               launch=(('two hipGraphs (fwd + decoder bwd | quantizer + encoder bwd), decoder-range all-reduce under the second, '
+                                        'tail all-reduce, AdamW') if (use_graph and getattr(trainer, '_graph2', None) is not None) else
+                                       'hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
                                final_loss=round(float(loss.item()), 6)),
                    roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel, sustained=sustained)
         if world == 1 and not args.no_other_configs:
             out['other_configs'] = other_configs()
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
     if dist.is_initialized():
         dist.destroy_process_group()
+    _flush_c_stdio()                   # RCCL's version banner sits in the C stdio buffer: push it out BEFORE the JSON line
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == '__main__':

@@ -129,3 +129,46 @@ def test_ema_statistics_allreduce_equals_single_process():
 
 def test_dead_code_reinit_is_identical_on_every_rank():
     _run(_reinit_worker, 29613)
+
+
+def _ranged_worker(rank, world, port, out):
+    _init(rank, world, port)
+    optim = importlib.import_module(PKG + '.optim')
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in ((5, 3), (70,), (4, 4, 3, 3), (9,))]
+    front = {id(ps[2]), id(ps[3])}
+    opt = optim.FlatAdamW([{'params': ps[:2], 'weight_decay': 0.1}, {'params': ps[2:], 'weight_decay': 0.0}], lr=1e-3,
+                          betas=(0.0, 0.99), arena_front=front)
+    # the front tensors sit first in the arena, param_groups (= state_dict order) is untouched
+    assert opt.offsets[id(ps[2])] == 0 and opt.offsets[id(ps[3])] == 192 and opt.front_numel == 256
+    assert opt.offsets[id(ps[0])] == 256 and [len(g['params']) for g in opt.param_groups] == [2, 2]
+    assert opt.seg_end.tolist() == sorted(opt.seg_end.tolist())
+    g = torch.Generator().manual_seed(10 + rank)
+    opt.flat_g.copy_(torch.randn(opt.flat_g.numel(), generator=g))
+    mine = opt.flat_g.clone()
+    w1 = opt.all_reduce_range(0, opt.front_numel)
+    w2 = opt.all_reduce_range(opt.front_numel, opt.flat_g.numel())
+    for w in (w1, w2):
+        w.wait()
+    two = opt.flat_g.clone()
+    opt.flat_g.copy_(mine)
+    opt.all_reduce_grads()
+    assert torch.equal(two, opt.flat_g) and opt.grad_scale == 1.0 / world
+    if rank == 0:
+        out.put('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranged_all_reduce_equals_flat_all_reduce_gloo():
+    """the overlapped gradient reduction = two ranged all-reduces (decoder range first) over an arena whose
+    front holds the decoder's tensors; same numbers as the single flat all-reduce, world size 2 over gloo"""
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_ranged_worker, args=(r, 2, 29733, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get() == 'ok'

@@ -71,9 +71,19 @@ def _world1_worker(rank, port, out):
         before = calls['n']
         l1, s1 = _trajectory(qtype, force=True)
         issued = calls['n'] - before
-        # 2 eager warm-up steps + 4 replays: one gradient all-reduce each; the 4 replays also finish the deferred EMA update
-        # with its statistics all-reduce (the eager warm-up steps update inline: world size 1 needs no collective there)
-        assert issued == (10 if qtype == 'ema' else 6), (qtype, issued)
+        # 2 eager warm-up steps + 4 replays, TWO gradient all-reduces each (the decoder's arena range under the encoder's
+        # backward -- two captured graphs --, then the rest); the 4 replays also finish the deferred EMA update with its
+        # statistics all-reduce (the eager warm-up steps update inline: world size 1 needs no collective there)
+        assert issued == (16 if qtype == 'ema' else 12), (qtype, issued)
+        # the single-collective form (VQK_OVERLAP_ALLREDUCE=0): one all-reduce per step, same trajectory
+        trainer_mod.MiniTrainer.OVERLAP_ALLREDUCE = False
+        try:
+            before = calls['n']
+            l2, s2 = _trajectory(qtype, force=True)
+            assert calls['n'] - before == (10 if qtype == 'ema' else 6), (qtype, calls['n'] - before)
+        finally:
+            trainer_mod.MiniTrainer.OVERLAP_ALLREDUCE = True
+        np.testing.assert_allclose(l1, l2, rtol=2e-3)
         before = calls['n']
         l0, s0 = _trajectory(qtype, force=False)
         assert calls['n'] == before
@@ -139,6 +149,24 @@ def _world2_worker(rank, port, out):
         np.testing.assert_allclose(q.ema_weight.cpu().numpy(), ref['extra']['ema_weight'].numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(q.codebook.weight.detach().cpu().numpy(), ref['extra']['codebook'].numpy(), rtol=1e-4,
                                    atol=1e-6)
+    # the overlapped form (backward cut at the decoder's input, two ranged all-reduces) gives the same reduced gradients
+    torch.manual_seed(1)
+    m2 = model_mod.VQVAE(32, AE, _qc('standard'), None, TC).to(dev).train()
+    tr2 = trainer_mod.MiniTrainer(num_training_batches=1)
+    opt2 = tr2.attach(m2)[0]
+    mine = all_images[rank * b:(rank + 1) * b].to(dev)
+    assert tr2._use_split(m2, opt2) and 0 < opt2.front_numel < opt2.flat_g.numel()
+    opt2.zero_grad()
+    tr2._split_step(m2, opt2, mine, 0)
+    torch.cuda.synchronize()
+    g_split = opt2.flat_g.clone()
+    opt2.zero_grad()
+    m2.training_step(mine, 0).backward()
+    opt2.all_reduce_grads()
+    torch.cuda.synchronize()
+    rel = float((g_split - opt2.flat_g).norm() / opt2.flat_g.norm())
+    assert rel < 1e-5, rel
+    if rank == 0:
         out.put('ok')
     dist.barrier()
     dist.destroy_process_group()

@@ -79,6 +79,8 @@ class VQVAE(BaseVQVAE, _LightningBase):
         self.reinit_every_n_epochs = q_conf['reinit_every_n_epochs']
         self.optimizer_param_set = optimizer_param_set
         self.defer_usage_accumulation = False
+        self.split_backward = False            # MiniTrainer (data parallel): backward in two halves around the decoder's input
+        self._backward_cut = self._backward_terms = None
         self.kl_warmup_epochs = self.temp_decay_epochs = self.temp_final = None
 
         qt, qp = q_conf['type'], q_conf['params']
@@ -177,7 +179,13 @@ class VQVAE(BaseVQVAE, _LightningBase):
         x_pad, target = self._preprocess_train(images, training)                          # clamp, normalise, NHWC
         z = self.encoder(x_pad)
         quantized, used_indices, q_loss = self.quantizer(z)
-        recon_pad = self.decoder.forward_padded(quantized)
+        dec_in = quantized
+        if training and self.split_backward:
+            # cut the autograd graph at the decoder's input: the trainer runs the decoder's backward first, starts the
+            # all-reduce of the decoder's gradients and runs the quantizer + encoder backward underneath it
+            dec_in = quantized.detach().requires_grad_(True)
+            self._backward_cut = (quantized, dec_in)
+        recon_pad = self.decoder.forward_padded(dec_in)
         l2_loss = ops.mse_loss(recon_pad, target, true_channels=3)
         return recon_pad, used_indices, q_loss, l2_loss
 
@@ -217,6 +225,8 @@ class VQVAE(BaseVQVAE, _LightningBase):
             return self._gan_training_step(batch, batch_index)
         _, used_indices, q_loss, l2_loss = self._step_losses(batch, training=True)
         ae_loss = q_loss + l2_loss
+        if self.split_backward:
+            self._backward_terms = (l2_loss, q_loss)       # d(ae_loss)/d(l2_loss) = d(ae_loss)/d(q_loss) = 1
         for name, value in (('train/loss', ae_loss), ('train/l2_loss', l2_loss), ('train/quant_loss', q_loss)):
             self.log(name, value.detach(), sync_dist=True, on_step=False, on_epoch=True)      # device scalars: no sync
         self.accumulate_usage(self.quantizer.last_hist)
@@ -320,7 +330,9 @@ class VQVAE(BaseVQVAE, _LightningBase):
         decay, no_decay = self.optimizer_groups()
         groups = [{'params': [p for _, p in decay], 'weight_decay': wd},
                   {'params': [p for _, p in no_decay], 'weight_decay': 0.0}]
-        ae_optimizer = FlatAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+        # the decoder's tensors come first in the gradient arena: their all-reduce starts while the encoder's backward runs
+        front = {id(p) for p in self.decoder.parameters()}
+        ae_optimizer = FlatAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd, arena_front=front)
         if isinstance(self.criterion, VQLPIPSWithDiscriminator):                      # model.py:431-438
             disc_optimizer = FlatAdamW(list(self.criterion.discriminator.parameters()), lr=lr, betas=betas, eps=eps,
                                        weight_decay=wd)

@@ -18,19 +18,27 @@ def _is_channels_last_param(p: torch.Tensor) -> bool:
 
 
 class FlatAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, arena_front=None):
+        """``arena_front``: ids of the parameters laid out FIRST in the arenas (any order of ``param_groups`` -- which is what
+        ``state_dict`` is indexed by -- is kept): ``front_numel`` elements that can be all-reduced on their own."""
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         plist = [(p, g['weight_decay']) for g in self.param_groups for p in g['params']]
         if not plist:
             raise ValueError('FlatAdamW got no parameters')
         dev = plist[0][0].device
-        offs, total = [], 0
-        for p, _ in plist:
+        front = arena_front or set()
+        order = sorted(range(len(plist)), key=lambda i: (0 if id(plist[i][0]) in front else 1, i))
+        offs, total = [0] * len(plist), 0
+        self.front_numel = 0
+        for i in order:
+            p = plist[i][0]
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError('FlatAdamW needs fp32 parameters on one device')
-            offs.append(total)
+            offs[i] = total
             total += -(-p.numel() // _ALIGN) * _ALIGN
+            if id(p) in front:
+                self.front_numel = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -38,7 +46,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev) if b1 != 0.0 else None
         seg_end, seg_wd = [], []
         with torch.no_grad():
-            for (p, wd), off in zip(plist, offs):
+            for (p, wd), off in ((plist[i], offs[i]) for i in order):      # segments in ARENA order (binary-searched by the kernel)
                 n = p.numel()
                 for buf, is_grad in ((self.flat_p, False), (self.flat_g, True)):
                     seg = buf[off:off + n]
@@ -141,13 +149,26 @@ class FlatAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
 
+    def collective_on(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective)
+
     def all_reduce_grads(self, world_size: int | None = None):
         """ONE collective per optimizer step (replaces DDP's bucketed reducer, vqvae/train.py:128)."""
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective):
+        if self.collective_on():
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
             self.grad_scale = 1.0 / dist.get_world_size()
         else:
             self.grad_scale = 1.0
+
+    def all_reduce_range(self, lo: int, hi: int, async_op: bool = True):
+        """all-reduce of arena elements [lo, hi) (the overlapped form: the front range -- the decoder's gradients -- while the
+        rest of the backward still runs; RCCL orders it after the work already queued on the current stream).  Returns the
+        work handle (None when no collective is needed)."""
+        if not self.collective_on() or hi <= lo:
+            self.grad_scale = 1.0 / dist.get_world_size() if self.collective_on() else 1.0
+            return None
+        self.grad_scale = 1.0 / dist.get_world_size()
+        return dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -56,12 +56,60 @@ class MiniTrainer:
             self.global_step += 1
             return loss
         opt.zero_grad()
-        loss = model.training_step(batch, batch_index)
-        loss.backward()
-        self._finish_deferred(model, opt)
-        opt.all_reduce_grads()
+        if self._use_split(model, opt):
+            loss = self._split_step(model, opt, batch, batch_index)
+        else:
+            loss = model.training_step(batch, batch_index)
+            loss.backward()
+            self._finish_deferred(model, opt)
+            opt.all_reduce_grads()
         opt.step()
         self.global_step += 1
+        return loss
+
+    # ------------------------------------------------------------------ gradient all-reduce under the backward
+    # Lightning's DDP overlaps its bucketed all-reduce with the backward (vqvae/train.py:128).  Here the backward is cut at
+    # the decoder's input (VQVAE.split_backward): the decoder's gradients -- laid out first in the arena -- are all-reduced
+    # while the quantizer + encoder backward runs; the second all-reduce covers the rest.  Two collectives instead of one.
+    OVERLAP_ALLREDUCE = os.environ.get('VQK_OVERLAP_ALLREDUCE', '1') != '0'
+
+    def _use_split(self, model, opt) -> bool:
+        return (self.OVERLAP_ALLREDUCE and opt.collective_on() and getattr(opt, 'front_numel', 0) > 0
+                and hasattr(model, 'split_backward') and getattr(model, 'automatic_optimization', True))
+
+    @staticmethod
+    def _backward_halves(model):
+        """(first, second): callables running the decoder half and the quantizer + encoder half of the backward"""
+        l2_loss, q_loss = model._backward_terms
+        zq, dec_in = model._backward_cut
+
+        def first():
+            l2_loss.backward()
+
+        def second():
+            tensors, grads = [zq], [dec_in.grad]
+            if q_loss.requires_grad:
+                tensors.append(q_loss)
+                grads.append(torch.ones_like(q_loss))
+            torch.autograd.backward(tensors, grads)
+            dec_in.grad = None
+        return first, second
+
+    def _split_step(self, model, opt, batch, batch_index):
+        model.split_backward = True
+        try:
+            loss = model.training_step(batch, batch_index)
+        finally:
+            model.split_backward = False
+        first, second = self._backward_halves(model)
+        first()
+        w1 = opt.all_reduce_range(0, opt.front_numel)
+        second()
+        self._finish_deferred(model, opt)
+        w2 = opt.all_reduce_range(opt.front_numel, opt.flat_g.numel())
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()
         return loss
 
     @staticmethod
@@ -102,16 +150,32 @@ class MiniTrainer:
         if self._deferred_q is not None:
             self._deferred_q.defer_update = True
         self._graph = torch.cuda.CUDAGraph()
+        self._graph2 = None
         # thread_local: the autograd worker thread and (multi-GPU) the RCCL watchdog thread issue runtime calls
         # of their own while this thread captures
         model.defer_usage_accumulation = True      # host-side bookkeeping stays out of the captured region
+        split = self._use_split(model, opt)
         try:
-            with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
-                opt.zero_grad()
-                self._static_loss = model.training_step(self._static_in, 0)
-                self._static_loss.backward()
+            if split:
+                # two graphs sharing one memory pool: [zero_grad, forward, decoder backward] and [quantizer + encoder backward];
+                # the all-reduce of the decoder's arena range is issued between the two replays
+                model.split_backward = True
+                with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
+                    opt.zero_grad()
+                    self._static_loss = model.training_step(self._static_in, 0)
+                    first, second = self._backward_halves(model)
+                    first()
+                self._graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph2, pool=self._graph.pool(), capture_error_mode='thread_local'):
+                    second()
+            else:
+                with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
+                    opt.zero_grad()
+                    self._static_loss = model.training_step(self._static_in, 0)
+                    self._static_loss.backward()
         finally:
             model.defer_usage_accumulation = False
+            model.split_backward = False
         self._static_hist = model.quantizer.last_hist          # rewritten by every replay
         return self._graph
 
@@ -142,10 +206,13 @@ class MiniTrainer:
     def _eager_step(self, model, batch, batch_index):
         opt = self.optimizers[0]
         opt.zero_grad()
-        loss = model.training_step(batch, batch_index)
-        loss.backward()
-        self._finish_deferred(model, opt)
-        opt.all_reduce_grads()
+        if self._use_split(model, opt):
+            loss = self._split_step(model, opt, batch, batch_index)
+        else:
+            loss = model.training_step(batch, batch_index)
+            loss.backward()
+            self._finish_deferred(model, opt)
+            opt.all_reduce_grads()
         opt.step()
         return loss
 
@@ -156,9 +223,19 @@ class MiniTrainer:
             self._static_in.copy_(batch, non_blocking=True)
         ops.repack_owned(None)               # operands of weights changed outside the optimizer (normally none)
         self._graph.replay()
-        model.accumulate_usage(self._static_hist)          # epoch code histogram: eager add of the replay's histogram
-        self._finish_deferred(model, opt)
-        opt.all_reduce_grads()
+        if self._graph2 is not None:
+            w1 = opt.all_reduce_range(0, opt.front_numel)  # the decoder's gradients, under the encoder's backward
+            self._graph2.replay()
+            model.accumulate_usage(self._static_hist)
+            self._finish_deferred(model, opt)
+            w2 = opt.all_reduce_range(opt.front_numel, opt.flat_g.numel())
+            for w in (w1, w2):
+                if w is not None:
+                    w.wait()
+        else:
+            model.accumulate_usage(self._static_hist)      # epoch code histogram: eager add of the replay's histogram
+            self._finish_deferred(model, opt)
+            opt.all_reduce_grads()
         opt.step()
         self.global_step += 1
         return self._static_loss
