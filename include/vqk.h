@@ -213,6 +213,11 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
 int64_t vqk_conv2d_wgrad_edge_ws_bytes(void);
 int vqk_conv2d_wgrad_edge(int dtype, const void* x, const void* dy, float* dw, void* ws, int64_t ws_bytes, int n, int h,
                           int w, int cin, int cout, const void* zeros, void* stream);
+/* The decoder's last conv (autoencoder.py:170): 3x3, stride 1, 'same', cin = 128 -> cout = 8 (the 3 image channels padded to
+ * one 16-byte chunk), y = act(conv(x, w) + bias) with act 0 none / 1 tanh; bf16 in and out, h % 8 == 0, w % 32 == 0;
+ * w: bf16 [8][3][3][128] (weight layout 0).  VQK_ERR_SHAPE when not served (nothing launched: callers use vqk_conv2d_fprop). */
+int vqk_conv2d_thin_out(int dtype, const void* x, const void* w, const float* bias, void* y, int n, int h, int wd, int cin,
+                        int cout, int act, const void* zeros, void* stream);
 /* out[c] (+)= sum over rows of x[rows][c]  (bias gradients); out pre-zeroed. */
 int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream);
 /* elementwise fp32 -> dtype cast (weight shadow copies) */

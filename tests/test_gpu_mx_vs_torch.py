@@ -184,8 +184,28 @@ def test_conv1x1_on_mx_kernel_vs_torch(n, cin, cout, h, w):
     y.backward(_dev(dy))
     torch.cuda.synchronize()
     names = _kernels()
-    assert names.count('conv3x3_mx_kernel<bf16>') == 2, names      # forward + data gradient
+    assert names.count('conv1x1_mx_kernel<bf16> (HBM)') == 2, names  # forward + data gradient
     _check(y.detach(), want.detach(), 1, '1x1 fprop')
     _check(xd.grad, x.grad, 1, '1x1 dgrad')
     gw = wd.grad.float().cpu()
     assert float((gw - wt.grad).norm() / wt.grad.norm()) < 2e-5
+
+
+@pytest.mark.parametrize('n,h,w,act', [(2, 64, 64, 1), (1, 256, 256, 1), (3, 8, 32, 0), (2, 24, 96, 1)])
+def test_thin_out_head_conv_vs_torch(n, h, w, act):
+    """the decoder's last conv (autoencoder.py:170: 128 -> 3 channels padded to 8, + bias + tanh) on the 16x16x32-MFMA kernel of
+    csrc/conv_edge.hip against F.conv2d in fp32, through the product's Conv2dFn (forward; its backward kernels are pinned above)"""
+    g = torch.Generator().manual_seed(h + w)
+    x = _bf(torch.randn(n, 128, h, w, generator=g))
+    wt = _bf(torch.randn(3, 128, 3, 3, generator=g) / 34.0)
+    bias = torch.randn(3, generator=g) * 0.1
+    want = F.conv2d(x, wt, bias, padding=1)
+    if act == 1:
+        want = torch.tanh(want)
+    wd = wt.to(DEV).contiguous(memory_format=CL)
+    _events()
+    y = ops.conv2d(_dev(x), wd, bias.to(DEV), act=act)
+    torch.cuda.synchronize()
+    assert _kernels() == ['conv3x3_thin_out_kernel<bf16> (HBM)']
+    assert y.shape[1] == 8 and float(y[:, 3:].float().abs().max()) == 0.0          # pad channels stay zero
+    _check(y[:, :3], want, 1, 'thin-out head')

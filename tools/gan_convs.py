@@ -32,10 +32,11 @@ wrap('vqk_upfirdn2d_nhwc', lambda a: 'upfirdn')
 
 dev = torch.device('cuda:0')
 torch.manual_seed(1234)
-l_conf = dict(l1_weight=0.8, l2_weight=0.2, perc_weight=1.0,
-              adversarial_params=dict(start_epoch=0, loss_type='non-saturating', g_weight=0.1, use_adaptive=False,
-                                      r1_reg_weight=None, r1_reg_every=16))
-m = model_mod.VQVAE(256, bench.AE_CONF, bench.q_conf('gumbel', 1024), l_conf, bench.T_CONF, compute_dtype=torch.bfloat16).to(dev)
+train_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.train')
+conf = train_mod.get_model_conf(os.path.join(ROOT, 'example_confs', 'gumbel_vqgan.yaml'))
+run = train_mod.derive_run_config(conf, 1, {'training.cumulative_bs': 16, 'loss.adversarial_params.start_epoch': 0,
+                                            'loss.adversarial_params.r1_reg_weight': None})
+m = model_mod.VQVAE(run['image_size'], run['ae_conf'], run['q_conf'], run['l_conf'], run['t_conf'], compute_dtype=torch.bfloat16).to(dev)
 m.criterion.discriminator.compute_dtype = torch.bfloat16
 m.criterion.perceptual_loss.net.compute_dtype = torch.bfloat16
 m.train()

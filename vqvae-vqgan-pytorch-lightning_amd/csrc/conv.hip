@@ -1097,6 +1097,93 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
                                                                       int pix_per_split) {
     typedef WgradFrag<bf16_raw> F;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_a = smem;                       // dy tile  [64 pix][128 co]
+    char* lds_b = smem + F::KP * F::ROWB;     // x tile   [64 pix][128 ci]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_ci = (g.cin + 127) >> 7;
+    const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
+    const int co0 = tco * 128, ci0 = tci * 128;
+    const int tap = blockIdx.y, kh = tap / g.ks, kw = tap - kh * g.ks, pad = g.ks >> 1;
+    const int p_begin = blockIdx.z * pix_per_split;
+    const int p_end = min(g.m, p_begin + pix_per_split);
+
+    // load slots: one wave instruction = 4 rows x 16 chunks; 16 instructions per tile, 4 per wave
+    const int pc = lane & 15, rsub = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int hw = g.h * g.w;
+    for (int p0 = p_begin; p0 < p_end; p0 += F::KP) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 4 * (4 * wave + t) + rsub;          // (row & 3) == rsub
+            const int lc = pc ^ (rsub << 2);
+            const int p = p0 + row;
+            const bool pv = p < p_end;
+            // A: dy[p][co0 + lc*8 ..]
+            const bool oka = pv && (co0 + lc * 8) < g.cout;
+            const void* sa = oka ? (const void*)(dy + (int64_t)p * g.cout + co0 + lc * 8) : (const void*)zeros;
+            glds16(sa, lds_a + (4 * wave + t) * 1024);
+            // B: x[p (+) tap][ci0 + lc*8 ..]
+            bool okb = pv && (ci0 + lc * 8) < g.cin;
+            const void* sb = zeros;
+            if (okb) {
+                const int img = p / hw, rem = p - img * hw;
+                const int oh = rem / g.w, ow = rem - oh * g.w;
+                const int ih = oh * g.stride + kh - g.pad, iw = ow * g.stride + kw - g.pad;
+                if (ih >= 0 && ih < g.vh && iw >= 0 && iw < g.vw && !(g.zs && ((ih | iw) & 1)))
+                    sb = x + (((int64_t)img * g.h_in + (ih >> g.ups)) * g.w_in + (iw >> g.ups)) * g.cin + ci0 + lc * 8;
+            }
+            glds16(sb, lds_b + (4 * wave + t) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < F::KP; k0 += 16) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = F::frag(lds_a, k0, wm * 64 + i * 32, lane);
+                b[i] = F::frag(lds_b, k0, wn * 64 + i * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int taps = g.ks * g.ks;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+        if (ci >= g.cin) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < g.cout) atomicAdd(dw + ((int64_t)co * taps + tap) * g.cin + ci, acc[i][j][r]);
+            }
+    }
+}
+
+// double-buffered form of conv_wgrad_kernel<bf16_raw> for the 1x1 convs (one tap: few tiles, long pixel ranges per block)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_db_kernel(const bf16_raw* __restrict__ x,
+                                                                      const bf16_raw* __restrict__ dy,
+                                                                      float* __restrict__ dw,
+                                                                      const char* __restrict__ zeros, ConvGeom g,
+                                                                      int pix_per_split) {
+    typedef WgradFrag<bf16_raw> F;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     // TWO stages of (dy tile [64 pix][128 co], x tile [64 pix][128 ci]): the K-step p0 + KP is in flight (LDS-DMA) while step p0
     // runs on the matrix pipe -- the loop used to load, wait, compute, which left the 1x1 / strided weight gradients
     // latency-bound (167 us for 128->256 @128^2, bs = 32: 2.4 TB/s)
@@ -2276,8 +2363,11 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     // split the pixel range so that ~2048 blocks are in flight, each with >= 4 K-steps (fp32); the double-buffered bf16
     // kernel keeps two 64-KiB blocks per CU busy with ~512 blocks and a quarter of the atomic passes over dW (each block
     // ends with one: at 2048 blocks the 1x1 shortcut's 128 x 256 gradient cost 134 MB of atomics per launch)
+    // (measured, tools/wgrad_gen_bench.py: 1x1 128->256 @128^2 167 -> 67 us; the strided 3x3 gathers are faster on the
+    // single-stage kernel with ~2048 blocks -- 421 vs 302 us at 128->256 @257^2 stride 2 -- and keep it)
     static const int wg_target = getenv("VQK_WGRAD_GEN_BLOCKS") ? atoi(getenv("VQK_WGRAD_GEN_BLOCKS")) : 512;
-    const int target_blocks = dtype == VQK_F32 ? 2048 : wg_target;
+    const bool db = dtype == VQK_BF16 && ksize == 1;
+    const int target_blocks = db ? wg_target : 2048;
     int splits = (target_blocks + tiles - 1) / tiles;
     const int max_splits = (g.m + 4 * kp - 1) / (4 * kp);
     if (splits > max_splits) splits = max_splits;
@@ -2288,11 +2378,12 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     const dim3 grid((unsigned)(((cout + 127) / 128) * ((cin + 127) / 128)), (unsigned)(ksize * ksize), (unsigned)splits);
     if (dtype == VQK_F32)
         hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 32768, vqk_stream(stream), (const float*)x, (const float*)dy, dw, (const char*)zeros, g, pps);
-    else
-    {
-        static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_raw>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    else if (db) {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         if (attr != hipSuccess) return VQK_ERR_LAUNCH;
-        hipLaunchKernelGGL(conv_wgrad_kernel<bf16_raw>, grid, dim3(256), 65536, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+        hipLaunchKernelGGL(conv_wgrad_db_kernel, grid, dim3(256), 65536, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+    } else {
+        hipLaunchKernelGGL(conv_wgrad_kernel<bf16_raw>, grid, dim3(256), 32768, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
     }
     VQK_CHECK_LAUNCH();
     return VQK_OK;

@@ -182,6 +182,134 @@ __global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// conv3x3_thin_out_kernel: the decoder's last conv (autoencoder.py:170: 128 -> 3 channels, padded to 8, + bias + tanh).
+// A GEMM with N = 8 output columns: on the 32-wide tiles of the stream kernel three quarters of the MFMA work multiplied
+// padding (262 us at 256^2, bs = 32, against ~95 us of memory time for the 128-channel input).  Here the 16x16x32 MFMA carries
+// the weights as the A operand (rows = output channels, 8 of 16 used) and SIXTEEN pixels as the B operand:
+//   block = 256 threads, persistent over 8x32-pixel tiles x two 64-channel halves ("units"); the 10x34 halo of a unit is
+//   staged in LDS by global_load_lds (144-byte pixel pitch = 8 data slots + 1 pad slot fetched from the zero page:
+//   conflict-free ds_read_b128 of 16 pixels x 4 k-slices), double-buffered; all nine taps read it at shifted addresses;
+//   the 36 weight fragments of both halves stay in registers; wave w owns rows 2w, 2w+1 of the tile (4 groups of 16 pixels).
+// ------------------------------------------------------------------------------------------------
+constexpr int TO_TH = 8, TO_TW = 32, TO_HW2 = TO_TW + 2, TO_HPIX = (TO_TH + 2) * TO_HW2;      // 340 halo pixels
+constexpr int TO_PITCH = 144, TO_PIECES = 48, TO_STAGE = TO_PIECES * 1024, TO_LDS = 2 * TO_STAGE;
+typedef __attribute__((ext_vector_type(4))) unsigned int eu32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int eu32x2;
+
+__global__ __launch_bounds__(256, 1) void conv3x3_thin_out_kernel(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ wgt,
+                                                                  const float* __restrict__ bias, bf16_raw* __restrict__ y,
+                                                                  const char* __restrict__ zeros, int n, int h, int w, int act) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, kq = lane >> 4;
+    const int tiles_x = w / TO_TW, tiles_y = h / TO_TH;
+    const int total = n * tiles_y * tiles_x;
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int cnt = (total - b + G - 1) / G;
+    if (cnt <= 0) return;
+
+    // weights: A fragment (half, tap, ks): row co = lane & 15 (rows 8..15 are zero), columns half*64 + ks*32 + kq*8 .. + 7
+    bf16x8_t wf[2][9][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                eu32x4 v = {0u, 0u, 0u, 0u};
+                if (px < 8) v = *reinterpret_cast<const eu32x4*>(wgt + ((int64_t)px * 9 + tap) * 128 + hf * 64 + ks * 32 + kq * 8);
+                wf[hf][tap][ks] = __builtin_bit_cast(bf16x8_t, v);
+            }
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias && kq < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = bias[4 * kq + i];
+    }
+
+    // this lane's twelve halo slots per unit: slot -> (halo pixel, 16-byte chunk; chunk 8 = pad)
+    int rel[12], flg[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        const int slot = (wave * 12 + t) * 64 + lane;
+        const int hp = slot / 9, pc = slot - hp * 9;
+        const int hy = hp / TO_HW2, hx = hp - hy * TO_HW2;
+        rel[t] = (((hy - 1) * w + (hx - 1)) * 128 + pc * 8) * 2;
+        flg[t] = (hy == 0 ? 1 : 0) | (hy == TO_TH + 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == TO_TW + 1 ? 8 : 0) |
+                 ((pc == 8 || hp >= TO_HPIX) ? 16 : 0);
+    }
+    struct Tile { int img, y0, x0; };
+    auto tile_of = [&](int i) -> Tile {
+        int t = b + i * G;
+        Tile tl;
+        const int txi = t % tiles_x; t /= tiles_x;
+        const int tyi = t % tiles_y;
+        tl.img = t / tiles_y; tl.y0 = tyi * TO_TH; tl.x0 = txi * TO_TW;
+        return tl;
+    };
+    auto issue = [&](const Tile& tl, int hf, int stage) {
+        const char* base = reinterpret_cast<const char*>(x) + ((((int64_t)tl.img * h + tl.y0) * w + tl.x0) * 128 + hf * 64) * 2;
+        const int tb = (tl.y0 == 0 ? 1 : 0) | (tl.y0 + TO_TH == h ? 2 : 0) | (tl.x0 == 0 ? 4 : 0) | (tl.x0 + TO_TW == w ? 8 : 0) | 16;
+        char* st = smem + stage * TO_STAGE + wave * 12 * 1024;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            const void* src = (flg[t] & tb) ? (const void*)zeros : (const void*)(base + rel[t]);
+            glds16(src, st + t * 1024);
+        }
+    };
+
+    f32x4 acc[4];
+    Tile cur = tile_of(0);
+    issue(cur, 0, 0);
+    int stage = 0;
+    for (int i = 0; i < cnt; ++i) {
+        const Tile nxt = tile_of(i + 1 < cnt ? i + 1 : i);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                     // this unit has landed; the other stage's readers are done
+            if (hf == 0) issue(cur, 1, stage ^ 1);
+            else if (i + 1 < cnt) issue(nxt, 0, stage ^ 1);
+            const char* st = smem + stage * TO_STAGE;
+            if (hf == 0) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) acc[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ty = tap / 3, tx = tap - ty * 3;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {             // group gq: tile row 2*wave + (gq >> 1), columns 16*(gq & 1) ..
+                        const int hp = (2 * wave + (gq >> 1) + ty) * TO_HW2 + 16 * (gq & 1) + px + tx;
+                        const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(st + hp * TO_PITCH + (ks * 4 + kq) * 16);
+                        acc[gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hf][tap][ks], bf, acc[gq], 0, 0, 0);
+                    }
+            }
+            stage ^= 1;
+        }
+        // epilogue: lane (pixel px of its groups, output channels 4 kq .. + 3); only kq < 2 holds real rows
+        if (kq < 2) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[gq][e] + bv[e];
+                    if (act == 1) v[e] = tanhf(v[e]);
+                }
+                const int yy = cur.y0 + 2 * wave + (gq >> 1), xx = cur.x0 + 16 * (gq & 1) + px;
+                const eu32x2 o = {vqkd::pack_bf16x2(v[0], v[1]), vqkd::pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<eu32x2*>(y + (((int64_t)cur.img * h + yy) * w + xx) * 8 + 4 * kq) = o;
+            }
+        }
+        cur = nxt;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -219,6 +347,25 @@ int vqk_conv2d_wgrad_edge(int dtype, const void* x, const void* dy, float* dw, v
     VQK_CHECK_LAUNCH();
     static_assert(EDGE_OUT % 16 == 0, "reduce blocks own 16 outputs");
     hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3(EDGE_OUT / 16), dim3(256), 0, st, (const float*)ws, dw, blocks);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_conv2d_thin_out(int dtype, const void* x, const void* w, const float* bias, void* y, int n, int h, int wd, int cin,
+                        int cout, int act, const void* zeros, void* stream) {
+    VQK_REQUIRE(x && w && y && zeros, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w) && vqk_aligned16(y) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
+    VQK_REQUIRE(dtype == VQK_BF16, VQK_ERR_DTYPE);
+    VQK_REQUIRE(act == 0 || act == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && cin == 128 && cout == 8 && h > 0 && wd > 0 && (h % TO_TH) == 0 && (wd % TO_TW) == 0 &&
+                (int64_t)n * h * wd * 128 * 2 < 0x7fffffff0LL, VQK_ERR_SHAPE);
+    const int total = n * (h / TO_TH) * (wd / TO_TW);
+    const int blocks = total < 256 ? total : 256;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_thin_out_kernel,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, TO_LDS);
+    if (attr != hipSuccess) return VQK_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv3x3_thin_out_kernel, dim3((unsigned)blocks), dim3(256), TO_LDS, vqk_stream(stream), (const bf16_raw*)x,
+                       (const bf16_raw*)w, bias, (bf16_raw*)y, (const char*)zeros, n, h, wd, act);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

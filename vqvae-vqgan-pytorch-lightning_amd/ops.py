@@ -84,6 +84,7 @@ def _timed(name: str, flops: float, launch, nbytes: float = 0.0, launches: int =
 
 
 _MX_ON = os.environ.get('VQK_MX', '1') != '0'
+_THIN_OUT = os.environ.get('VQK_THIN_OUT', '1') != '0'
 _MX_MIN_TILES = int(os.environ.get('VQK_MX_MIN_TILES', '1'))
 _WGMX_ON = os.environ.get('VQK_WGMX', '1') != '0'
 
@@ -116,6 +117,9 @@ def weight_layout(dtype, n, h_in, w_in, cin, cout, ksize, ups, out_dtype=None) -
     a 1x1 conv has a fragment-major form only on the bf16 -> bf16 matrix/auxiliary-wave kernel"""
     if ksize == 1 and (dtype != torch.bfloat16 or (out_dtype is not None and out_dtype != torch.bfloat16)):
         return 0
+    if (_THIN_OUT and ksize == 3 and not ups and dtype == torch.bfloat16 and out_dtype in (None, torch.bfloat16)
+            and cin == 128 and cout == 8 and h_in % 8 == 0 and w_in % 32 == 0):
+        return 0                                   # the decoder's last conv: plain weights for vqk_conv2d_thin_out
     r = _native.lib().vqk_conv_weight_layout(dcode(dtype), n, h_in, w_in, cin, cout, ksize, int(ups))
     if r < 0:
         _native.check(r, 'conv_weight_layout')
@@ -227,7 +231,20 @@ def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_d
     flops = 2.0 * n * h * s * w * s * cout * cin * ksize * ksize
     nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size() * (2 if residual is not None else 1)
               + cout * cin * ksize * ksize * x.element_size())
-    st = _timed(_fprop_kernel_name(x.dtype, wlayout, (n, h * s, w * s, cin, cout, act, out_dtype)), flops,
+    if (_THIN_OUT and x.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and ksize == 3 and not ups and wlayout == 0
+            and residual is None and act in (0, 1) and cin == 128 and cout == 8 and h % 8 == 0 and w % 32 == 0):
+        # the decoder's last conv: 8 output channels on 16x16x32 MFMAs (csrc/conv_edge.hip)
+        st = _timed('conv3x3_thin_out_kernel<bf16> (HBM)' + (f' {cin}->{cout}@{h}x{w}' if _EVENT_SHAPES else ''), 0.0,
+                    lambda: _native.lib().vqk_conv2d_thin_out(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias), y.data_ptr(),
+                                                              n, h, w, cin, cout, act, zero_page(x.device).data_ptr(), _stream()),
+                    x.numel() * 2 + y.numel() * 2)
+        _native.check(st, 'conv2d_thin_out')
+        return y
+    kname = _fprop_kernel_name(x.dtype, wlayout, (n, h * s, w * s, cin, cout, act, out_dtype))
+    if ksize == 1 and kname.startswith('conv3x3_mx_kernel'):
+        # the NTAP = 1 instantiation (ResBlock shortcuts): memory-bound, reported with its bytes like the GroupNorm passes
+        kname, flops = kname.replace('conv3x3_mx_kernel<bf16>', 'conv1x1_mx_kernel<bf16> (HBM)'), 0.0
+    st = _timed(kname, flops,
                 lambda: _native.lib().vqk_conv2d_fprop(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias),
                                                        _p(residual), y.data_ptr(), dcode(out_dtype), n, h, w, cin,
                                                        cout, ksize, int(ups), act, wlayout,
