@@ -280,9 +280,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = not args.no_graph
-    if args.gan:
-        use_graph = False      # manual optimisation with two optimizers: eager (the step is kernel-bound)
+    use_graph = not args.no_graph      # (VQ-GAN: three graphs -- AE half, discriminator half, discriminator half with R1)
     step_fn = trainer.train_batch
     if use_graph:
         try:
@@ -410,6 +408,7 @@ def main():
                                global_batch=world * args.batch, parallelism=f'dp{world}',
                                launch=(('two hipGraphs (fwd + decoder bwd | quantizer + encoder bwd), decoder-range all-reduce under the second, '
                                         'tail all-reduce, AdamW') if (use_graph and getattr(trainer, '_graph2', None) is not None) else
+                                       'three hipGraphs (AE half | discriminator half | discriminator half + R1), optimizer steps between' if (use_graph and args.gan) else
                                        'hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
                                final_loss=round(float(loss.item()), 6)),
                    roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel, sustained=sustained)

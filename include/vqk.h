@@ -91,10 +91,14 @@ int vqk_row_scale_add_f32(float* out, const float* m, const float* scale, int64_
  * argmax] written as `dtype`, idx = argmax y, klsum[0] += sum_i sum_n qy log(qy*K + 1e-10), qy = softmax(logits).
  * noise ~ Exp(1) is drawn by the caller (the reference's F.gumbel_softmax draws the same tensor first). */
 int vqk_gumbel_forward(int dtype, const float* logits, const float* noise, int64_t n, int k, float tau, int hard,
-                       void* y, int64_t* idx, float* klsum, int32_t* hist /* optional */, void* stream);
-/* dlogits = y (dy - <y,dy>)/tau + s*(kl_cost/n) qy (r - <qy,r>), s = *gscale_dev (soft sample path). */
+                       void* y, int64_t* idx, float* klsum, int32_t* hist /* optional */,
+                       const float* sched_dev /* optional */, void* stream);
+/* dlogits = y (dy - <y,dy>)/tau + s*(kl_cost/n) qy (r - <qy,r>), s = *gscale_dev (soft sample path).
+ * sched_dev (both calls, optional): device floats {tau, kl_cost} that REPLACE the scalar arguments -- the reference schedules
+ * both per step (vqvae/model.py:218-225); reading them on the device lets a captured hipGraph follow the schedule. */
 int vqk_gumbel_backward(int dtype, const float* logits, const float* noise, const void* dy, int64_t n, int k,
-                        float tau, float kl_cost, const float* gscale_dev, float* dlogits, void* stream);
+                        float tau, float kl_cost, const float* gscale_dev, float* dlogits,
+                        const float* sched_dev /* optional */, void* stream);
 /* q = e[idx] (written as fp32 and, if q_lo != NULL, also as bf16), sse[0] += sum (q - z)^2,
  * hist[idx] += 1 (int32, optional).  sse must be zeroed by the caller. */
 int vqk_vq_gather_f32(const float* z, const float* e, const int64_t* idx, int64_t n, int k, int d,

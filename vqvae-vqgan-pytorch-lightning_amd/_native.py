@@ -34,8 +34,8 @@ _PROTOS = {
     'vqk_entropy_argmax_forward_f32': [P, P, P, L, I, F, P, P, P, P, P, P, P, P],
     'vqk_entropy_argmax_backward_f32': [P, P, P, P, P, L, I, F, F, P, P],
     'vqk_row_scale_add_f32': [P, P, P, L, I, F, P],
-    'vqk_gumbel_forward': [I, P, P, L, I, F, I, P, P, P, P, P],
-    'vqk_gumbel_backward': [I, P, P, P, L, I, F, F, P, P, P],
+    'vqk_gumbel_forward': [I, P, P, L, I, F, I, P, P, P, P, P, P],
+    'vqk_gumbel_backward': [I, P, P, P, L, I, F, F, P, P, P, P],
     'vqk_vq_gather_f32': [P, P, P, L, I, I, P, P, P, P, P],
     'vqk_vq_backward_f32': [P, P, P, P, I, L, I, I, F, F, P, P, P, P],
     'vqk_ema_stats_f32': [P, P, L, I, I, P, P, P],

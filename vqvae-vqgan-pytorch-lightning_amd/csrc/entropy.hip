@@ -231,10 +231,11 @@ __global__ __launch_bounds__(256) void gumbel_rows_fwd_kernel(const float* __res
                                                               const float* __restrict__ noise, int64_t n, int k,
                                                               float inv_tau, int hard, T* __restrict__ y,
                                                               int64_t* __restrict__ idx, float* __restrict__ klsum,
-                                                              int32_t* __restrict__ hist) {
+                                                              int32_t* __restrict__ hist, const float* __restrict__ sched) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
+    if (sched) inv_tau = 1.0f / sched[0];                      // scheduled temperature read on the device (graph replay)
     const float* lr = logits + row * k;
     const float* nr = noise + row * k;
     float m1 = -INFINITY, m2 = -INFINITY;
@@ -273,10 +274,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void gumbel_rows_bwd_kernel(const float* __restrict__ logits,
                                                               const float* __restrict__ noise, const T* __restrict__ dy,
                                                               int64_t n, int k, float inv_tau, float klc_over_m,
-                                                              const float* __restrict__ gs, float* __restrict__ dlogits) {
+                                                              const float* __restrict__ gs, float* __restrict__ dlogits,
+                                                              const float* __restrict__ sched) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
+    if (sched) { inv_tau = 1.0f / sched[0]; klc_over_m = sched[1] / (float)n; }
     if (gs) klc_over_m *= *gs;
     const float* lr = logits + row * k;
     const float* nr = noise + row * k;
@@ -317,25 +320,25 @@ __global__ __launch_bounds__(256) void gumbel_rows_bwd_kernel(const float* __res
 extern "C" {
 
 int vqk_gumbel_forward(int dtype, const float* logits, const float* noise, int64_t n, int k, float tau, int hard, void* y,
-                       int64_t* idx, float* klsum, int32_t* hist, void* stream) {
+                       int64_t* idx, float* klsum, int32_t* hist, const float* sched_dev, void* stream) {
     VQK_REQUIRE(logits && noise && y && idx && klsum, VQK_ERR_ARG);
     VQK_REQUIRE(n > 0 && k > 0 && tau > 0.f, VQK_ERR_SHAPE);
     const dim3 grid((unsigned)((n + 3) / 4));
-    if (dtype == VQK_F32) hipLaunchKernelGGL(gumbel_rows_fwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, n, k, 1.0f / tau, hard, (float*)y, idx, klsum, hist);
-    else if (dtype == VQK_BF16) hipLaunchKernelGGL(gumbel_rows_fwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, n, k, 1.0f / tau, hard, (bf16_raw*)y, idx, klsum, hist);
+    if (dtype == VQK_F32) hipLaunchKernelGGL(gumbel_rows_fwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, n, k, 1.0f / tau, hard, (float*)y, idx, klsum, hist, sched_dev);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(gumbel_rows_fwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, n, k, 1.0f / tau, hard, (bf16_raw*)y, idx, klsum, hist, sched_dev);
     else return VQK_ERR_DTYPE;
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }
 
 int vqk_gumbel_backward(int dtype, const float* logits, const float* noise, const void* dy, int64_t n, int k, float tau,
-                        float kl_cost, const float* gscale_dev, float* dlogits, void* stream) {
+                        float kl_cost, const float* gscale_dev, float* dlogits, const float* sched_dev, void* stream) {
     VQK_REQUIRE(logits && noise && dy && dlogits, VQK_ERR_ARG);
     VQK_REQUIRE(n > 0 && k > 0 && tau > 0.f, VQK_ERR_SHAPE);
     const dim3 grid((unsigned)((n + 3) / 4));
     const float c = kl_cost / (float)n;
-    if (dtype == VQK_F32) hipLaunchKernelGGL(gumbel_rows_bwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, (const float*)dy, n, k, 1.0f / tau, c, gscale_dev, dlogits);
-    else if (dtype == VQK_BF16) hipLaunchKernelGGL(gumbel_rows_bwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, (const bf16_raw*)dy, n, k, 1.0f / tau, c, gscale_dev, dlogits);
+    if (dtype == VQK_F32) hipLaunchKernelGGL(gumbel_rows_bwd_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, (const float*)dy, n, k, 1.0f / tau, c, gscale_dev, dlogits, sched_dev);
+    else if (dtype == VQK_BF16) hipLaunchKernelGGL(gumbel_rows_bwd_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), logits, noise, (const bf16_raw*)dy, n, k, 1.0f / tau, c, gscale_dev, dlogits, sched_dev);
     else return VQK_ERR_DTYPE;
     VQK_CHECK_LAUNCH();
     return VQK_OK;

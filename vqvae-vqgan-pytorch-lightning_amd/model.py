@@ -189,36 +189,54 @@ class VQVAE(BaseVQVAE, _LightningBase):
         l2_loss = ops.mse_loss(recon_pad, target, true_channels=3)
         return recon_pad, used_indices, q_loss, l2_loss
 
-    def _gan_training_step(self, batch: Any, batch_index: int):
-        """manual optimisation, model.py:244-264: AE step (nll + g_weight * g_loss + q_loss), then discriminator step"""
+    def _gan_ae_half(self, batch: Any):
+        """first half of model.py:244-264: zero the AE gradients, forward, nll + g_weight * g_loss + q_loss, backward"""
         images = batch[0] if isinstance(batch, (tuple, list)) else batch
         x_pad, target = self._preprocess_train(images, True)
         z = self.encoder(x_pad)
         quantized, _, q_loss = self.quantizer(z)
         recon_pad = self.decoder.forward_padded(quantized)
-        ae_opt, disc_opt = self.optimizers()
+        ae_opt, _ = self.optimizers()
         ae_opt.zero_grad()
         res = self.criterion.forward_autoencoder(q_loss, target, recon_pad, self.current_epoch,
                                                  last_layer=self.decoder.conv_out.weight)
-        ae_loss, l1_loss, l2_loss, p_loss, g_loss, g_weight = res
-        self.manual_backward(ae_loss)
-        ae_opt.all_reduce_grads()
-        ae_opt.step()
-        step = self.current_epoch * self.trainer.num_training_batches + batch_index
+        self.manual_backward(res[0])
+        self._gan_state = (target, recon_pad, q_loss, res)
+        return res
+
+    def _gan_disc_half(self, step: int):
+        """second half: discriminator loss (+ R1 every r1_reg_every steps) and its backward; (loss, d_loss, r1_penalty)"""
+        target, recon_pad, _, _ = self._gan_state
+        _, disc_opt = self.optimizers()
         loss, d_loss, r1_penalty = self.criterion.forward_discriminator(target, recon_pad, self.current_epoch, step)
         if loss is not None:
             disc_opt.zero_grad()
             self.manual_backward(loss)
-            disc_opt.all_reduce_grads()
-            disc_opt.step()
+        return loss, d_loss, r1_penalty
+
+    def _gan_log(self, res, q_loss, d_loss, r1_penalty):
+        ae_loss, l1_loss, l2_loss, p_loss, g_loss, g_weight = res
         for name, value in (('g_weight', g_weight), ('r1_penalty', r1_penalty)):          # model.py:277-278
             self.log(name, value.detach() if torch.is_tensor(value) else value, sync_dist=True, on_step=False, on_epoch=True)
         for name, value in (('train/loss', ae_loss), ('train/l1_loss', l1_loss), ('train/l2_loss', l2_loss),
                             ('train/quant_loss', q_loss), ('train/perc_loss', p_loss), ('train/gen_loss', g_loss),
                             ('train/disc_loss', d_loss)):
             self.log(name, value.detach(), sync_dist=True, on_step=False, on_epoch=True)
+
+    def _gan_training_step(self, batch: Any, batch_index: int):
+        """manual optimisation, model.py:244-264: AE step (nll + g_weight * g_loss + q_loss), then discriminator step"""
+        res = self._gan_ae_half(batch)
+        ae_opt, disc_opt = self.optimizers()
+        ae_opt.all_reduce_grads()
+        ae_opt.step()
+        step = self.current_epoch * self.trainer.num_training_batches + batch_index
+        loss, d_loss, r1_penalty = self._gan_disc_half(step)
+        if loss is not None:
+            disc_opt.all_reduce_grads()
+            disc_opt.step()
+        self._gan_log(res, self._gan_state[2], d_loss, r1_penalty)
         self.accumulate_usage(self.quantizer.last_hist)
-        return ae_loss
+        return res[0]
 
     def training_step(self, batch: Any, batch_index: int):
         if isinstance(self.criterion, VQLPIPSWithDiscriminator):

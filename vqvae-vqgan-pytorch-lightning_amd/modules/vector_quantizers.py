@@ -131,6 +131,12 @@ class GumbelVectorQuantizer(BaseVectorQuantizer):
         self.straight_through = straight_through
         self.temp = temp
         self.kl_cost = kl_cost
+        self.sched_dev = None          # device [temp, kl_cost]: set by MiniTrainer before a hipGraph capture (replays follow the schedule)
+
+    def enable_device_schedule(self, device) -> torch.Tensor:
+        if self.sched_dev is None:
+            self.sched_dev = torch.tensor([float(self.temp), float(self.kl_cost)], dtype=torch.float32, device=device)
+        return self.sched_dev
 
     def forward(self, x: torch.Tensor, exp_noise: torch.Tensor = None):
         """``exp_noise`` ~ Exp(1) with the shape of x: injected for parity tests; drawn with torch's RNG otherwise."""
@@ -139,7 +145,8 @@ class GumbelVectorQuantizer(BaseVectorQuantizer):
         if exp_noise is None:
             exp_noise = torch.empty_like(logits).exponential_()
         q, idx, kl, hist = ops.GumbelVQFn.apply(logits, self.codebook.weight, exp_noise, float(self.temp),
-                                                float(self.kl_cost), bool(hard), self.compute_dtype)
+                                                float(self.kl_cost), bool(hard), self.compute_dtype,
+                                                self.sched_dev if self.training else None)
         self.last_hist = hist
         return q, idx, kl
 
@@ -151,6 +158,9 @@ class GumbelVectorQuantizer(BaseVectorQuantizer):
             self.temp = temp
         if kl_cost is not None:
             self.kl_cost = kl_cost
+        if self.sched_dev is not None:                     # two scalar fills on the stream: no host synchronisation
+            self.sched_dev[0:1].fill_(float(self.temp))
+            self.sched_dev[1:2].fill_(float(self.kl_cost))
 
     @torch.no_grad()
     def vec_to_codes(self, x: torch.Tensor) -> torch.Tensor:

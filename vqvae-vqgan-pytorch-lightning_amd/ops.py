@@ -1197,7 +1197,8 @@ class GumbelVQFn(torch.autograd.Function):
     kernels.  Returns (q [B,D,H,W], idx [B,H,W], kl, hist)."""
 
     @staticmethod
-    def forward(ctx, logits, codebook, noise, tau: float, kl_cost: float, hard: bool, out_dtype):
+    def forward(ctx, logits, codebook, noise, tau: float, kl_cost: float, hard: bool, out_dtype, sched=None):
+        """``sched``: optional device tensor [tau, kl_cost] that overrides the two scalars inside the kernels (graph replay)"""
         _require_gpu(logits)
         logits = nhwc(logits.to(torch.float32))
         noise = nhwc(noise.to(torch.float32))
@@ -1212,15 +1213,17 @@ class GumbelVQFn(torch.autograd.Function):
         klsum = torch.zeros((), dtype=torch.float32, device=dev)
         hist = torch.zeros(k, dtype=torch.int32, device=dev)
         _native.check(lib.vqk_gumbel_forward(dcode(dt), logits.data_ptr(), noise.data_ptr(), n, k, tau, int(hard),
-                                             y.data_ptr(), idx.data_ptr(), klsum.data_ptr(), hist.data_ptr(), st),
+                                             y.data_ptr(), idx.data_ptr(), klsum.data_ptr(), hist.data_ptr(), _p(sched), st),
                       'gumbel_forward')
         et = pack_weights(cb.t().contiguous().reshape(-1), dt, d, k, 1, False, 0)                # [D][K]
         q = raw_conv_fprop(y, et, None, None, 1, False, 0, dt, d, 0)                              # [1,D,N,1] == [N][D]
         q = q.permute(0, 2, 3, 1).reshape(b, h, w, d).permute(0, 3, 1, 2)                         # [B,D,H,W] nhwc view
         ctx.save_for_backward(logits, noise, cb, y)
         ctx.cfg = (tau, kl_cost, n, k, d, dt, (b, h, w))
+        ctx.sched = sched
         ctx.mark_non_differentiable(idx, hist)
-        return q, idx.view(b, h, w), klsum * (kl_cost / float(n)), hist
+        kl = klsum * (kl_cost / float(n)) if sched is None else klsum * sched[1] / float(n)
+        return q, idx.view(b, h, w), kl, hist
 
     @staticmethod
     def backward(ctx, dq, _didx, dkl, _dhist):
@@ -1234,12 +1237,13 @@ class GumbelVQFn(torch.autograd.Function):
         gs = dkl.to(torch.float32).contiguous() if dkl is not None else None
         dlogits = torch.empty_like(logits, memory_format=_CL)
         _native.check(lib.vqk_gumbel_backward(dcode(dt), logits.data_ptr(), noise.data_ptr(), dyv.data_ptr(), n, k, tau,
-                                              kl_cost if gs is not None else 0.0, _p(gs), dlogits.data_ptr(), st),
+                                              kl_cost if gs is not None else 0.0, _p(gs), dlogits.data_ptr(),
+                                              _p(ctx.sched) if gs is not None else 0, st),
                       'gumbel_backward')
         de = None
         if ctx.needs_input_grad[1]:
             de = raw_conv_wgrad(dq_img, y, 1, False).permute(0, 2, 3, 1).reshape(k, d)            # y^T @ dq
-        return dlogits, de, None, None, None, None, None
+        return dlogits, de, None, None, None, None, None, None
 
 
 def ema_stats(flat_z, idx, k: int, out=None) -> torch.Tensor:

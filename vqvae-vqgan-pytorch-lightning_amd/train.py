@@ -181,7 +181,7 @@ def main(argv=None):
         print(f'[INFO] final learning rate: {run["learning_rate"]}')
     model.on_train_start()
     graphed = False
-    if not args.no_graph and not run['use_adversarial']:
+    if not args.no_graph:
         try:
             trainer.capture(model, batches[0], warmup=1, preserve_state=True)   # the settling step must not train
             graphed = True

@@ -130,10 +130,12 @@ class MiniTrainer:
         opt = self.optimizers[0]
         snap = self._snapshot(model) if preserve_state else None
         q = getattr(model, 'quantizer', None)
-        if getattr(q, 'kl_warmup', None) is not None or getattr(q, 'temp_decay', None) is not None:
-            # the Gumbel temperature / KL weight are kernel ARGUMENTS: a replay would keep their capture-time values
-            raise RuntimeError('MiniTrainer.capture: Gumbel quantizer with a temperature / KL schedule cannot be replayed '
-                               'from a hipGraph (scheduled scalars are baked at capture); run it eagerly')
+        if hasattr(q, 'enable_device_schedule'):
+            # the Gumbel temperature / KL weight are scheduled per step (model.py:218-225): the kernels read them from a device
+            # buffer that set_consts() refreshes, so a replay follows the schedule
+            q.enable_device_schedule(example_batch.device)
+        if not getattr(model, 'automatic_optimization', True):
+            return self._capture_gan(model, example_batch, warmup)
         self._static_in = example_batch.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -179,6 +181,67 @@ class MiniTrainer:
         self._static_hist = model.quantizer.last_hist          # rewritten by every replay
         return self._graph
 
+    # ------------------------------------------------------------------ VQ-GAN step (manual optimisation) as three graphs
+    def _capture_gan(self, model, example_batch, warmup: int):
+        """model.py:244-264 under hipGraph replay: [AE half: zero_grad, forward, LPIPS + generator loss, backward] /
+        [discriminator half] / [discriminator half with the R1 term] -- the two optimizer steps, the gradient all-reduces and
+        the choice of the R1 variant (every ``r1_reg_every`` steps) stay on the host between the replays."""
+        ae_opt, disc_opt = self.optimizers
+        self._static_in = example_batch.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(max(warmup, 2)):               # both discriminator variants (with / without R1) run once
+                model.on_train_batch_start(self._static_in, i)
+                model.training_step(self._static_in, i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        crit = model.criterion
+        every = crit.r1_regularization_every if crit.r1_regularization_cost is not None else 0
+        model.defer_usage_accumulation = True
+        self._gan = {}
+        try:
+            g_ae = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_ae, capture_error_mode='thread_local'):
+                res = model._gan_ae_half(self._static_in)
+            self._gan['ae'] = (g_ae, res, model._gan_state[2])
+            for key, step in (('d', 1), ('d_r1', 0)):
+                if key == 'd_r1' and not every:
+                    continue
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=g_ae.pool(), capture_error_mode='thread_local'):
+                    out = model._gan_disc_half(step if every else 1)
+                self._gan[key] = (g, out)
+        finally:
+            model.defer_usage_accumulation = False
+        self._gan_every = every
+        self._static_hist = model.quantizer.last_hist
+        self._graph = g_ae
+        self._graph2 = None
+        return g_ae
+
+    def _train_batch_gan_graphed(self, model, batch, batch_index: int):
+        ae_opt, disc_opt = self.optimizers
+        model.on_train_batch_start(batch, batch_index)
+        if batch is not self._static_in:
+            self._static_in.copy_(batch, non_blocking=True)
+        ops.repack_owned(None)
+        g_ae, res, q_loss = self._gan['ae']
+        g_ae.replay()
+        ae_opt.all_reduce_grads()
+        ae_opt.step()
+        step = model.current_epoch * self.num_training_batches + batch_index
+        key = 'd_r1' if (self._gan_every and step % self._gan_every == 0) else 'd'
+        g, (loss, d_loss, r1_penalty) = self._gan[key]
+        g.replay()
+        if loss is not None:
+            disc_opt.all_reduce_grads()
+            disc_opt.step()
+        model._gan_log(res, q_loss, d_loss, r1_penalty)
+        model.accumulate_usage(self._static_hist)
+        self.global_step += 1
+        return res[0]
+
     def _snapshot(self, model):
         return dict(state={k: v.detach().clone() for k, v in model.state_dict().items()},
                     opts=[(o.flat_v.clone(), None if o.flat_m is None else o.flat_m.clone(), o.step_count) for o in self.optimizers],
@@ -217,6 +280,8 @@ class MiniTrainer:
         return loss
 
     def train_batch_graphed(self, model, batch, batch_index: int):
+        if not getattr(model, 'automatic_optimization', True):
+            return self._train_batch_gan_graphed(model, batch, batch_index)
         opt = self.optimizers[0]
         model.on_train_batch_start(batch, batch_index)
         if batch is not self._static_in:
