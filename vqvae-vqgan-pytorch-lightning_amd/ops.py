@@ -71,15 +71,16 @@ KERNEL_EVENTS = None      # bench.py sets this to a list: (kernel, algorithmic F
 _EVENT_SHAPES = os.environ.get('VQK_EVENT_SHAPES') == '1'     # tooling: one statistics line per (kernel, FLOP count)
 
 
-def _timed(name: str, flops: float, launch, nbytes: float = 0.0, launches: int = 1):
-    """``launches``: kernel launches behind this one event (an upsample conv in phase form is four)"""
+def _timed(name: str, flops: float, launch, nbytes: float = 0.0, launches: int = 1, exec_flops: float | None = None):
+    """``launches``: kernel launches behind this one event (an upsample conv in phase form is four); ``exec_flops``: the
+    multiply-adds the launches actually execute when that differs from the algorithmic count (phase form: 4/9)"""
     if KERNEL_EVENTS is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     st = launch()
     e1.record()
-    KERNEL_EVENTS.append((name, flops, nbytes, e0, e1, launches))
+    KERNEL_EVENTS.append((name, flops, nbytes, e0, e1, launches, flops if exec_flops is None else exec_flops))
     return st
 
 
@@ -335,7 +336,8 @@ def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int =
     st = _timed('conv3x3_mx_kernel<bf16>' + (f' {cin}->{cout}@{y.shape[2]}x{y.shape[3]} phase-{"dgrad" if backward else "fwd"}' if _EVENT_SHAPES else ''), flops,
                 lambda: _native.lib().vqk_conv2d_ups_phase(dcode(x.dtype), x.data_ptr(), wq4.data_ptr(), _p(bias), y.data_ptr(),
                                                            n, h, w, cin, cout, int(backward), _p(ws), gn_groups,
-                                                           zero_page(x.device).data_ptr(), _stream()), nbytes, launches=4)
+                                                           zero_page(x.device).data_ptr(), _stream()), nbytes, launches=4,
+                exec_flops=flops * 4.0 / 9.0)
     if st == _native.ERR_SHAPE:
         return None
     _native.check(st, 'conv2d_ups_phase')
@@ -467,8 +469,10 @@ _PENDING_GN = None
 
 
 def _note_presummed(y, groups: int) -> None:
+    """the note is keyed by the tensor OBJECT (weak reference), not by its address: a freed tensor whose memory the caching
+    allocator hands to another tensor of the same shape can never claim stale sums"""
     global _PENDING_GN
-    _PENDING_GN = (y.data_ptr(), tuple(y.shape), groups, _stream())
+    _PENDING_GN = (weakref.ref(y), groups, _stream(), y.device)
 
 
 def _claim_presummed(x, groups: int) -> bool:
@@ -477,10 +481,16 @@ def _claim_presummed(x, groups: int) -> bool:
     if p is None:
         return False
     _PENDING_GN = None
-    if p == (x.data_ptr(), tuple(x.shape), groups, _stream()):
+    ref, g, stream, device = p
+    if ref() is x and g == groups and stream == _stream():
         return True
-    for ws in _GN_WS.values():
-        ws.zero_()
+    ws = _GN_WS.get((device, stream))          # only the workspace the unclaimed sums were left in -- never another stream's,
+    if ws is not None:                         # which a GroupNorm kernel of that stream may be using right now
+        if stream == _stream():
+            ws.zero_()
+        else:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=device)):
+                ws.zero_()
     return False
 
 
