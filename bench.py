@@ -91,6 +91,8 @@ OTHER_CONFIGS = {      # BASELINE.json configs[2..4], single-GPU part, at their 
     'ema_vqvae cb=1024 bs=32': ['--quantizer', 'ema', '--codebook', '1024', '--batch', '32'],
     'entropy_vqvae cb=8192 bs=64': ['--quantizer', 'entropy', '--codebook', '8192', '--batch', '64'],
     'gumbel_vqgan bs=16 (LPIPS + discriminator + R1)': ['--gan', '--batch', '16'],
+    # the headline config again with ordered partial sums instead of atomics (vqvae/train.py:130: Trainer(deterministic=True))
+    'standard_vqvae cb=1024 bs=32, deterministic mode': ['--deterministic'],
 }
 
 
@@ -166,7 +168,8 @@ def measure_traffic(kernel_sub: str, events_per_step: int, argv):
             cols = [r_[1] for r_ in db.execute(f'pragma table_info({ks})')]
             name_col = 'display_name' if 'display_name' in cols else 'kernel_name'
             q = (f'select sum(e.value), count(*) from {pe} e join {pi} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id '
-                 f"join {ks} s on d.kernel_id = s.id where p.name = '{ctr}' and s.{name_col} like '%{kernel_sub}%'")
+                 f"join {ks} s on d.kernel_id = s.id where p.name = '{ctr}' and s.{name_col} like '%{kernel_sub}%' "
+                 f"and s.{name_col} not like '%, 1, 256>%'")          # (the NTAP = 1 instantiations are the 1x1 convs: their own line)
             tot, n = db.execute(q).fetchone()
             db.close()
             shutil.rmtree(d, ignore_errors=True)
@@ -228,6 +231,7 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel eagerly instead of replaying a hipGraph')
+    ap.add_argument('--deterministic', action='store_true', help='deterministic mode (vqvae/train.py:130): ordered partial sums instead of atomics; reports its cost')
     ap.add_argument('--sustain-s', type=float, default=10.0,
                     help='after the K timed steps keep stepping for this many seconds and report the sustained ms/step '
                          '(clock / power settle below the short run; 0 = off; N=1 only)')
@@ -267,7 +271,7 @@ def main():
         model.criterion.discriminator.compute_dtype = dtype
         model.criterion.perceptual_loss.net.compute_dtype = dtype
     model.train()
-    trainer = trainer_mod.MiniTrainer(num_training_batches=args.steps + args.warmup)
+    trainer = trainer_mod.MiniTrainer(num_training_batches=args.steps + args.warmup, deterministic=True if args.deterministic else None)
     trainer.attach(model)
     if os.environ.get('VQK_FORCE_DIST') == '1':
         trainer.optimizers[0].force_collective = True
@@ -414,7 +418,7 @@ def main():
                                         'tail all-reduce, AdamW') if (use_graph and getattr(trainer, '_graph2', None) is not None) else
                                        'three hipGraphs (AE half | discriminator half | discriminator half + R1), optimizer steps between' if (use_graph and args.gan) else
                                        'hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
-                               final_loss=round(float(loss.item()), 6)),
+                               deterministic=bool(ops.DETERMINISTIC), final_loss=round(float(loss.item()), 6)),
                    roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel, sustained=sustained)
         if world == 1 and not args.no_other_configs:
             out['other_configs'] = other_configs()

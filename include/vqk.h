@@ -196,6 +196,14 @@ int vqk_conv_pack_multi(const int64_t* descs_dev, int ndesc, int blocks_per_desc
  * register-weight halo kernel instead of the persistent stream kernel (bf16), 4 stream kernel without its half-tile
  * (128-pixel) form for maps with fewer 256-pixel tiles than CUs */
 int vqk_conv_set_variant(int variant);
+/* Deterministic mode (the reference trains with `deterministic=True`, vqvae/train.py:130).  on = 1: the float accumulations of
+ * the train step that are otherwise combined with atomics in arrival order -- split-K partials of the weight gradients, column
+ * sums (bias gradients), the cross-block sums of the GroupNorm statistics / backward reductions and of d gamma / d beta, the
+ * per-code sums of the codebook gradient -- go through `ws` (>= 64 MiB recommended; VQK_ERR_WORKSPACE when a call needs more)
+ * as per-block partials that are added in index order, or run unsplit.  THREAD-LOCAL like the block caps; the workspace must
+ * belong to the stream the following launches go to (two streams = two workspaces, re-armed on every switch).  The scalar
+ * loss sums and the EMA statistics keep their atomics (values, not gradients). */
+int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes);
 /* caps on the persistent grids of the 3x3 fprop/dgrad kernel and of the all-taps wgrad kernel (0 = default: two
  * blocks per CU).  256 = one block per CU, leaving room for a kernel that runs concurrently on another stream
  * (the host overlaps a layer's wgrad with its dgrad and GroupNorm backward).  The caps are THREAD-LOCAL: they apply to the

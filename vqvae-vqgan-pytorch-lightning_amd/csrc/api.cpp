@@ -1,5 +1,5 @@
 // Status strings / version of the vqk C-ABI (include/vqk.h).
-#include "../../include/vqk.h"
+#include "common.h"
 
 extern "C" {
 
@@ -20,3 +20,19 @@ int vqk_version(void) { return 1; }
 const char* vqk_arch(void) { return "gfx950"; }
 
 }  // extern "C"
+
+// deterministic mode: see include/vqk.h
+namespace vqkd {
+DetState& det_state() {
+    static thread_local DetState st = {0, nullptr, 0};
+    return st;
+}
+}  // namespace vqkd
+
+extern "C" int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes) {
+    vqkd::DetState& d = vqkd::det_state();
+    d.on = on ? 1 : 0;
+    d.ws = (on && ws) ? reinterpret_cast<float*>(ws) : nullptr;
+    d.bytes = (on && ws) ? ws_bytes : 0;
+    return VQK_OK;
+}

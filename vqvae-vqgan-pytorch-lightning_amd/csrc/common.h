@@ -90,6 +90,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// deterministic mode (vqk_set_deterministic, api.cpp): per host thread, like the block caps -- set, launch, reset in one place
+namespace vqkd {
+struct DetState { int on; float* ws; int64_t bytes; };
+DetState& det_state();
+}
 #define VQK_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH; } while (0)
 #define VQK_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
 static inline bool vqk_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1087,14 +1087,14 @@ template <> struct WgradFrag<bf16_raw> {
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                             float* __restrict__ dw, const char* __restrict__ zeros,
-                                                            ConvGeom g, int pix_per_split);
+                                                            ConvGeom g, int pix_per_split, int64_t split_stride);
 
 template <>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16_raw* __restrict__ x,
                                                                       const bf16_raw* __restrict__ dy,
                                                                       float* __restrict__ dw,
                                                                       const char* __restrict__ zeros, ConvGeom g,
-                                                                      int pix_per_split) {
+                                                                      int pix_per_split, int64_t split_stride) {
     typedef WgradFrag<bf16_raw> F;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_a = smem;                       // dy tile  [64 pix][128 co]
@@ -1162,6 +1162,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
         __syncthreads();
     }
     const int taps = g.ks * g.ks;
+    dw += (int64_t)blockIdx.z * split_stride;                    // deterministic mode: every split has its own copy of dW in the workspace
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
@@ -1181,7 +1182,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_db_kernel(const bf16_raw* _
                                                                       const bf16_raw* __restrict__ dy,
                                                                       float* __restrict__ dw,
                                                                       const char* __restrict__ zeros, ConvGeom g,
-                                                                      int pix_per_split) {
+                                                                      int pix_per_split, int64_t split_stride) {
     typedef WgradFrag<bf16_raw> F;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // TWO stages of (dy tile [64 pix][128 co], x tile [64 pix][128 ci]): the K-step p0 + KP is in flight (LDS-DMA) while step p0
@@ -1258,6 +1259,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_db_kernel(const bf16_raw* _
         buf ^= 1;
     }
     const int taps = g.ks * g.ks;
+    dw += (int64_t)blockIdx.z * split_stride;                    // deterministic mode: every split has its own copy of dW in the workspace
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
@@ -1278,7 +1280,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<float>(const float* 
                                                                    const float* __restrict__ dy,
                                                                    float* __restrict__ dw,
                                                                    const char* __restrict__ zeros, ConvGeom g,
-                                                                   int pix_per_split) {
+                                                                   int pix_per_split, int64_t split_stride) {
     constexpr int KP = 32, ROWB = 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_a = smem;
@@ -1343,6 +1345,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<float>(const float* 
         __syncthreads();
     }
     const int taps = g.ks * g.ks;
+    dw += (int64_t)blockIdx.z * split_stride;                    // deterministic mode: every split has its own copy of dW in the workspace
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
@@ -1876,8 +1879,48 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     for (int i = threadIdx.x; i < c; i += 256) atomicAdd(out + i, sh[i]);
 }
 
+// deterministic column sums: one thread per column walks its block's rows in order (coalesced across the threads of a row),
+// block partials to the workspace, then one thread per column adds the blocks in index order
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_det_kernel(const T* __restrict__ x, int64_t rows, int c, int64_t rows_per_block,
+                                                         float* __restrict__ part) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int col = threadIdx.x; col < c; col += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            a0 += Elem<T>::ld(x + r * c + col); a1 += Elem<T>::ld(x + (r + 1) * c + col);
+            a2 += Elem<T>::ld(x + (r + 2) * c + col); a3 += Elem<T>::ld(x + (r + 3) * c + col);
+        }
+        for (; r < r1; ++r) a0 += Elem<T>::ld(x + r * c + col);
+        part[(int64_t)blockIdx.x * c + col] = (a0 + a1) + (a2 + a3);
+    }
+}
+__global__ __launch_bounds__(256) void colsum_det_reduce_kernel(const float* __restrict__ part, int blocks, int c, float* __restrict__ out) {
+    const int col = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (col >= c) return;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b) s += part[(int64_t)b * c + col];
+    out[col] += s;
+}
+
+// deterministic split-K of the general weight-gradient kernels: dw[i] += sum over the splits' private copies, in split order
+__global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(const float* __restrict__ part, int64_t elems, int splits,
+                                                                 float* __restrict__ dw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * elems + i];
+    dw[i] += s;
+}
+
 static thread_local int g_force_variant = -1;   // test hook (per host thread: the library keeps no process-global mutable state): -1 auto, 0 im2col kernel only, 1 halo kernels when eligible,
                                    // 5 never the matrix/auxiliary-wave kernel, 6 that kernel whenever it is eligible
+// deterministic mode (vqk_set_deterministic; the reference trains with deterministic=True, vqvae/train.py:130): split-K partials
+// go through this workspace and are summed in a fixed order, kernels without a workspace form run unsplit
+#define g_det (vqkd::det_state().on)
+#define g_det_ws (vqkd::det_state().ws)
+#define g_det_ws_bytes (vqkd::det_state().bytes)
 static thread_local int g_stream_blocks = 0;    // persistent-grid caps (0 = default 2 blocks per CU): 256 leaves half of every CU to a
 static thread_local int g_wgrad_blocks = 0;     // kernel running concurrently on another stream (dgrad || wgrad || GroupNorm)
 
@@ -2317,7 +2360,7 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
         }
         const int minp = pw16 ? 2 : 4;                                              // >= 256 pixels per block
         if (splits > (total_patches + minp - 1) / minp) splits = (total_patches + minp - 1) / minp;
-        if (splits < 1) splits = 1;
+        if (splits < 1 || g_det) splits = 1;                     // deterministic: one block per dW tile, no cross-block sums
         const int pps = (total_patches + splits - 1) / splits;
         splits = (total_patches + pps - 1) / pps;
         const dim3 grid((unsigned)tiles, (unsigned)splits);
@@ -2331,12 +2374,20 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
             int sm = (int)(sqrt(coef * (double)g.m / tiles) + 0.5);
             if (sm > (capm + tiles - 1) / tiles) sm = (capm + tiles - 1) / tiles;
             if (sm > (total_patches + 3) / 4) sm = (total_patches + 3) / 4;          // >= 4 patches per block
+            float* part = nullptr;
+            if (g_det) {                                         // partial tiles in the workspace, summed in split order
+                const int64_t per_split = (int64_t)tiles * 64 * 9 * 64 * 4;
+                const int fit = (int)(g_det_ws_bytes / per_split);
+                if (sm > fit) sm = fit;
+                part = sm >= 2 ? g_det_ws : nullptr;             // a single split owns every element: its atomics are plain adds
+            }
             if (sm < 1) sm = 1;
             const int ppm = (total_patches + sm - 1) / sm;
             sm = (total_patches + ppm - 1) / ppm;
+            if (sm < 2) part = nullptr;
             ConvGeom gm = g;
             gm.dy_pool = dy_pool; gm.acc_scale = dy_scale;
-            return vqkd::launch_conv3x3_wgrad_mx(x, dy, dw, zeros, gm, tiles, sm, ppm, vqk_stream(stream));
+            return vqkd::launch_conv3x3_wgrad_mx(x, dy, dw, zeros, gm, tiles, sm, ppm, vqk_stream(stream), part);
         }
         if (dy_pool) return VQK_ERR_SHAPE;                      // half-resolution dy exists on the matrix/auxiliary-wave kernel only
         if (pw16 && (cin % 64) == 0 && (cout % 64) == 0 && !no_p16k) {
@@ -2371,20 +2422,35 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     int splits = (target_blocks + tiles - 1) / tiles;
     const int max_splits = (g.m + 4 * kp - 1) / (4 * kp);
     if (splits > max_splits) splits = max_splits;
+    const int64_t dw_elems = (int64_t)cout * ksize * ksize * cin;
+    if (g_det) {                                                 // deterministic: private copies of dW per split + ordered reduce
+        const int64_t fit = g_det_ws ? g_det_ws_bytes / (dw_elems * 4) : 0;
+        if (splits > fit) splits = (int)fit;
+    }
     if (splits < 1) splits = 1;
     int pps = (g.m + splits - 1) / splits;
     pps = ((pps + kp - 1) / kp) * kp;
     splits = (g.m + pps - 1) / pps;
     const dim3 grid((unsigned)(((cout + 127) / 128) * ((cin + 127) / 128)), (unsigned)(ksize * ksize), (unsigned)splits);
+    float* dst = dw;
+    int64_t sstride = 0;
+    const bool det_split = g_det && splits > 1;
+    if (det_split) {
+        dst = g_det_ws; sstride = dw_elems;
+        if (hipMemsetAsync(g_det_ws, 0, (size_t)splits * dw_elems * 4, vqk_stream(stream)) != hipSuccess) return VQK_ERR_LAUNCH;
+    }
     if (dtype == VQK_F32)
-        hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 32768, vqk_stream(stream), (const float*)x, (const float*)dy, dw, (const char*)zeros, g, pps);
+        hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 32768, vqk_stream(stream), (const float*)x, (const float*)dy, dst, (const char*)zeros, g, pps, sstride);
     else if (db) {
         static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         if (attr != hipSuccess) return VQK_ERR_LAUNCH;
-        hipLaunchKernelGGL(conv_wgrad_db_kernel, grid, dim3(256), 65536, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+        hipLaunchKernelGGL(conv_wgrad_db_kernel, grid, dim3(256), 65536, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dst, (const char*)zeros, g, pps, sstride);
     } else {
-        hipLaunchKernelGGL(conv_wgrad_kernel<bf16_raw>, grid, dim3(256), 32768, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+        hipLaunchKernelGGL(conv_wgrad_kernel<bf16_raw>, grid, dim3(256), 32768, vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)dy, dst, (const char*)zeros, g, pps, sstride);
     }
+    if (det_split)
+        hipLaunchKernelGGL(wgrad_split_reduce_kernel, dim3((unsigned)((dw_elems + 255) / 256)), dim3(256), 0, vqk_stream(stream),
+                           (const float*)g_det_ws, dw_elems, splits, dw);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }
@@ -2415,6 +2481,19 @@ int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* 
     VQK_REQUIRE(rows >= 0 && c > 0 && c <= 8192, VQK_ERR_SHAPE);
     VQK_REQUIRE(dtype == VQK_F32 || dtype == VQK_BF16, VQK_ERR_DTYPE);
     if (rows == 0) return VQK_OK;
+    if (g_det) {
+        int64_t nb = (rows + 63) / 64; if (nb > 512) nb = 512;
+        while (nb > 1 && nb * c * 4 > g_det_ws_bytes) nb >>= 1;
+        VQK_REQUIRE(g_det_ws && nb * c * 4 <= g_det_ws_bytes, VQK_ERR_ARG);
+        const int64_t rb = (rows + nb - 1) / nb;
+        nb = (rows + rb - 1) / rb;
+        hipStream_t sd = vqk_stream(stream);
+        if (dtype == VQK_F32) hipLaunchKernelGGL(colsum_det_kernel<float>, dim3((unsigned)nb), dim3(256), 0, sd, (const float*)x, rows, c, rb, g_det_ws);
+        else hipLaunchKernelGGL(colsum_det_kernel<bf16_raw>, dim3((unsigned)nb), dim3(256), 0, sd, (const bf16_raw*)x, rows, c, rb, g_det_ws);
+        hipLaunchKernelGGL(colsum_det_reduce_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, sd, (const float*)g_det_ws, (int)nb, c, out);
+        VQK_CHECK_LAUNCH();
+        return VQK_OK;
+    }
     const int v = dtype == VQK_F32 ? 4 : 8;
     const bool vec = (c % v) == 0 && vqk_aligned16(x);
     int64_t blocks = (rows + 63) / 64; if (blocks > 1024) blocks = 1024;

@@ -58,7 +58,9 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
 
 // matrix-wave / auxiliary-wave 3x3 weight-gradient kernel (conv_wgmx.hip): bf16, Cin % 64 == 0, Cout % 64 == 0, W % 16 == 0;
 // grid = tiles x splits blocks of 512 threads, `pps` 8x16-pixel patches per split
+// `part` (deterministic mode): workspace of splits * tiles * 64*9*64 floats -- the splits' partial tiles are stored there and
+// summed in split order by a second launch instead of being accumulated with fp32 atomics
 int launch_conv3x3_wgrad_mx(const void* x, const void* dy, float* dw, const void* zeros, const ConvGeom& g, int tiles,
-                            int splits, int pps, hipStream_t st);
+                            int splits, int pps, hipStream_t st, float* part = nullptr);
 
 }  // namespace vqkd

@@ -46,7 +46,7 @@ __device__ __forceinline__ bf16x8_t tr_frag2(const char* p) {
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw* __restrict__ x,
                                                                   const bf16_raw* __restrict__ dy, float* __restrict__ dw,
                                                                   const char* __restrict__ zeros, ConvGeom g,
-                                                                  int patches_per_split) {
+                                                                  int patches_per_split, float* __restrict__ part) {
     constexpr int PWD = 16, PIX = 128, HWD = 18, HROWS = 180, X_ROWS = 192;
     constexpr int DY_HALF = PIX * 64, X_HALF = X_ROWS * 64, STAGE = 2 * DY_HALF + 2 * X_HALF;     // 40960
     constexpr int NDY = 4, NX = 6;                               // pieces per X wave and stage: 16 dy + 24 x over 4 waves
@@ -122,6 +122,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
         }
         const int ci = ci0 + wj * 32 + (lane & 31);
         if ((VQK_WGMX_ABL & 2) && g.n > 0 && acc[0][0] != 12345.678f) return;      // timing-only: no atomic pass
+        if (part) {
+            // deterministic mode: this block's partial tile goes to the workspace slot (split by, tile bx) with plain stores;
+            // wgrad_mx_reduce_kernel adds the splits in index order
+            float* mine = part + ((int64_t)by * gridDim.x + bx) * (64 * 9 * 64);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+                    mine[(col * 9 + t) * 64 + wj * 32 + (lane & 31)] = acc[t][r] * g.acc_scale;
+                }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -224,18 +237,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
     }
 }
 
+// dw[(co0 + col) * 9 + t][ci0 + cil] += sum over the splits, in split order, of part[split][tile][(col * 9 + t) * 64 + cil]
+__global__ __launch_bounds__(256) void wgrad_mx_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int tiles,
+                                                              int splits, int cin) {
+    const int tile = blockIdx.y, tiles_ci = cin >> 6;
+    const int e = (int)(blockIdx.x * 256 + threadIdx.x);          // element of the 64 x 9 x 64 tile
+    if (e >= 64 * 9 * 64) return;
+    const int cil = e & 63, ct = e >> 6, col = ct / 9, t = ct - col * 9;
+    const int tco = tile / tiles_ci, tci = tile - tco * tiles_ci;
+    float s = 0.0f;
+    for (int k = 0; k < splits; ++k) s += part[((int64_t)k * tiles + tile) * (64 * 9 * 64) + e];
+    dw[((int64_t)(tco * 64 + col) * 9 + t) * cin + tci * 64 + cil] += s;
+}
+
 }  // namespace
 
 namespace vqkd {
 
 int launch_conv3x3_wgrad_mx(const void* x, const void* dy, float* dw, const void* zeros, const ConvGeom& g, int tiles,
-                            int splits, int pps, hipStream_t st) {
+                            int splits, int pps, hipStream_t st, float* part) {
     static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_wgrad_mx_kernel,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, VQK_WGMX_NST * 40960);
     (void)attr;
     hipLaunchKernelGGL(conv3x3_wgrad_mx_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(512), VQK_WGMX_NST * 40960, st,
-                       (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps);
+                       (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps, part);
     if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+    if (part) {
+        hipLaunchKernelGGL(wgrad_mx_reduce_kernel, dim3((64 * 9 * 64) / 256, (unsigned)tiles), dim3(256), 0, st, (const float*)part, dw,
+                           tiles, splits, g.cin);
+        if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+    }
     return VQK_OK;
 }
 

@@ -40,9 +40,12 @@ __device__ __forceinline__ void block_colsum(const float (&p0)[V], const float (
     __syncthreads();
 }
 
+// `dpart` (deterministic mode): the block's group sums are STORED at dpart[((n*groups + g) * gridDim.x + block) * 2 + j] and the
+// consumer adds the blocks in index order; otherwise they are accumulated with fp64 atomics (order-dependent in the last bits)
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int64_t hw, int c, int groups,
-                                                       int pix_per_block, double* __restrict__ acc) {
+                                                       int pix_per_block, double* __restrict__ acc,
+                                                       double* __restrict__ dpart = nullptr) {
     constexpr int V = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = reinterpret_cast<double*>(smem);          // [2][c] column sums
@@ -67,8 +70,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     for (int g = threadIdx.x; g < groups; g += 256) {
         double a = 0.0, b = 0.0;
         for (int i = 0; i < cpg; ++i) { a += sh[g * cpg + i]; b += sh[c + g * cpg + i]; }
-        atomicAdd(&acc[((int64_t)n * groups + g) * 2 + 0], a);
-        atomicAdd(&acc[((int64_t)n * groups + g) * 2 + 1], b);
+        if (dpart) {
+            double* q = dpart + (((int64_t)n * groups + g) * gridDim.x + blockIdx.x) * 2;
+            q[0] = a; q[1] = b;
+        } else {
+            atomicAdd(&acc[((int64_t)n * groups + g) * 2 + 0], a);
+            atomicAdd(&acc[((int64_t)n * groups + g) * 2 + 1], b);
+        }
     }
 }
 
@@ -142,7 +150,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_fin_kernel(const T* __restrict__ x, double* __restrict__ ws,
                                                            float* __restrict__ stats, const float* __restrict__ w,
                                                            const float* __restrict__ b, T* __restrict__ y, int64_t hw,
-                                                           int c, int groups, int silu, int pix_per_block, float eps) {
+                                                           int c, int groups, int silu, int pix_per_block, float eps,
+                                                           const double* __restrict__ part = nullptr, int nblk = 0) {
     constexpr int V = Vec16<T>::N;
     const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
     const int n = blockIdx.y, cpg = c / groups;
@@ -151,7 +160,14 @@ __global__ __launch_bounds__(256) void gn_apply_fin_kernel(const T* __restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sh = reinterpret_cast<float*>(smem);            // [groups][2]
     for (int g = threadIdx.x; g < groups; g += 256) {
-        const double s_ = ws[((int64_t)n * groups + g) * 2], ss = ws[((int64_t)n * groups + g) * 2 + 1];
+        double s_, ss;
+        if (part) {                                         // deterministic mode: the statistics blocks' partials, in block order
+            s_ = 0.0; ss = 0.0;
+            const double* q = part + ((int64_t)n * groups + g) * nblk * 2;
+            for (int k = 0; k < nblk; ++k) { s_ += q[2 * k]; ss += q[2 * k + 1]; }
+        } else {
+            s_ = ws[((int64_t)n * groups + g) * 2]; ss = ws[((int64_t)n * groups + g) * 2 + 1];
+        }
         const double mean = s_ / m;
         double var = (ss - s_ * mean) / (m - 1.0);          // unbiased (torch.var default)
         if (var < 0.0) var = 0.0;
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(256) void gn_apply_fin_kernel(const T* __restrict__
         }
         GN_STORE_FWD(y + off + p * c, v);
     }
-    ws_release(ws, gridDim.y, groups);
+    if (!part) ws_release(ws, gridDim.y, groups);
 }
 
 // pass 1 of the backward: per-channel sums of dy_pre and dy_pre*xhat (-> dw, db) and the per-group
@@ -195,7 +211,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ dy, float* __restrict__ dw,
                                                             float* __restrict__ db, double* __restrict__ red,
                                                             int64_t hw, int c, int groups, int silu,
-                                                            int pix_per_block) {
+                                                            int pix_per_block, double* __restrict__ gpart = nullptr,
+                                                            float* __restrict__ cpart = nullptr) {
     constexpr int V = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = reinterpret_cast<double*>(smem);          // [2][c] column sums
@@ -231,9 +248,16 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         }
     }
     block_colsum<V>(a, bb, part, sh, c);
+    // deterministic mode: per-block channel sums to cpart[(n * gridDim.x + block)][2c] (added up in (sample, block) order by
+    // gn_bwd_finish_kernel) and group sums to gpart[((n*groups + g) * gridDim.x + block) * 2] (added up by the apply pass)
     for (int ch = threadIdx.x; ch < c; ch += 256) {
-        atomicAdd(db + ch, (float)sh[ch]);
-        atomicAdd(dw + ch, (float)sh[c + ch]);
+        if (cpart) {
+            float* q = cpart + ((int64_t)n * gridDim.x + blockIdx.x) * 2 * c;
+            q[ch] = (float)sh[ch]; q[c + ch] = (float)sh[c + ch];
+        } else {
+            atomicAdd(db + ch, (float)sh[ch]);
+            atomicAdd(dw + ch, (float)sh[c + ch]);
+        }
     }
     for (int g = threadIdx.x; g < groups; g += 256) {
         double s1 = 0.0, s2 = 0.0;
@@ -242,8 +266,32 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
             s1 += sh[ch] * (double)w[ch];
             s2 += sh[c + ch] * (double)w[ch];
         }
-        atomicAdd(&red[((int64_t)n * groups + g) * 2 + 0], s1);
-        atomicAdd(&red[((int64_t)n * groups + g) * 2 + 1], s2);
+        if (gpart) {
+            double* q = gpart + (((int64_t)n * groups + g) * gridDim.x + blockIdx.x) * 2;
+            q[0] = s1; q[1] = s2;
+        } else {
+            atomicAdd(&red[((int64_t)n * groups + g) * 2 + 0], s1);
+            atomicAdd(&red[((int64_t)n * groups + g) * 2 + 1], s2);
+        }
+    }
+}
+
+// deterministic mode: db[ch] += sum over (sample, block) rows of cpart[row][ch], dw[ch] likewise, in a FIXED order: a block owns
+// 8 columns; 32 row lanes add rows lane, lane + 32, ... each, then thread `col` adds the 32 lane sums in lane order
+__global__ __launch_bounds__(256) void gn_bwd_finish_kernel(const float* __restrict__ cpart, int rows, int c, float* __restrict__ dw,
+                                                            float* __restrict__ db) {
+    __shared__ float part[32][8];
+    const int col = (int)blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
+    float s = 0.f;
+    if (col < 2 * c)
+        for (int r = rl; r < rows; r += 32) s += cpart[(int64_t)r * 2 * c + col];
+    part[rl][threadIdx.x & 7] = s;
+    __syncthreads();
+    if (threadIdx.x < 8 && col < 2 * c) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += part[k][threadIdx.x];
+        if (col < c) db[col] += t; else dw[col - c] += t;
     }
 }
 
@@ -257,19 +305,34 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ add,
                                                            double* __restrict__ red, int64_t hw, int c,
                                                            int groups, int silu, int accumulate, int pix_per_block,
-                                                           int add_w, float add_scale) {
+                                                           int add_w, float add_scale,
+                                                           const double* __restrict__ gpart = nullptr, int nblk = 0) {
     constexpr int V = Vec16<T>::N;
     const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
     const int n = blockIdx.y, cpg = c / groups;
     const double m = (double)hw * cpg;
     float mean[V], rstd[V], wv[V], bv[V], k1[V], k2[V];
+    __shared__ float gk[256][2];                            // deterministic mode: (k1, k2) per group, summed once per block
+    if (gpart) {                                            // the reduce blocks' partials, in block order
+        for (int g = threadIdx.x; g < groups; g += 256) {
+            double r1 = 0.0, r2 = 0.0;
+            const double* q = gpart + ((int64_t)n * groups + g) * nblk * 2;
+            for (int k = 0; k < nblk; ++k) { r1 += q[2 * k]; r2 += q[2 * k + 1]; }
+            gk[g][0] = (float)(r1 / m); gk[g][1] = (float)(r2 / (m - 1.0));
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int ch = slot * V + i, g = ch / cpg;
         mean[i] = stats[((int64_t)n * groups + g) * 2]; rstd[i] = stats[((int64_t)n * groups + g) * 2 + 1];
         wv[i] = w[ch]; bv[i] = b[ch];
-        k1[i] = (float)(red[((int64_t)n * groups + g) * 2] / m);
-        k2[i] = (float)(red[((int64_t)n * groups + g) * 2 + 1] / (m - 1.0));
+        if (gpart) {
+            k1[i] = gk[g][0]; k2[i] = gk[g][1];
+        } else {
+            k1[i] = (float)(red[((int64_t)n * groups + g) * 2] / m);
+            k2[i] = (float)(red[((int64_t)n * groups + g) * 2 + 1] / (m - 1.0));
+        }
     }
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
@@ -303,7 +366,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         }
         GN_STORE_BWD(dx + off + p * c, ov);
     }
-    ws_release(red, gridDim.y, groups);
+    if (!gpart) ws_release(red, gridDim.y, groups);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -332,11 +395,10 @@ __global__ __launch_bounds__(256) void gn_small_fwd_kernel(const T* __restrict__
     constexpr int V = Vec16<T>::N, SLOTS = 32 / V, ROWS = 256 / SLOTS, HW = PPT * ROWS;
     typedef typename Raw16<T>::type raw_t;
     __shared__ double sh[2][32];                                 // per-channel sums of the slice
+    __shared__ double shw[4][2][32];                             // ... per wave: added in wave order (no atomics: deterministic)
     __shared__ float gstat[32][2];                               // (mean, rstd) per channel of the slice
     const int slot = threadIdx.x % SLOTS, prow = threadIdx.x / SLOTS;
     const int n = blockIdx.y, ch0 = blockIdx.x * 32, cpg = c / groups;
-    if (threadIdx.x < 64) sh[threadIdx.x >> 5][threadIdx.x & 31] = 0.0;
-    __syncthreads();
     const int64_t off = (int64_t)n * HW * c + ch0 + slot * V;
     raw_t r[PPT];
 #pragma unroll
@@ -363,9 +425,14 @@ __global__ __launch_bounds__(256) void gn_small_fwd_kernel(const T* __restrict__
     if ((threadIdx.x & 63) < SLOTS) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            atomicAdd(&sh[0][slot * V + i], (double)s[i]);
-            atomicAdd(&sh[1][slot * V + i], (double)ss[i]);
+            shw[threadIdx.x >> 6][0][slot * V + i] = (double)s[i];
+            shw[threadIdx.x >> 6][1][slot * V + i] = (double)ss[i];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int j = threadIdx.x >> 5, cl = threadIdx.x & 31;
+        sh[j][cl] = ((shw[0][j][cl] + shw[1][j][cl]) + shw[2][j][cl]) + shw[3][j][cl];
     }
     __syncthreads();
     if (threadIdx.x < 32) {                                      // thread = channel of the slice: its group's moments
@@ -412,15 +479,14 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const T* __restrict__
                                                            const T* __restrict__ dy, T* __restrict__ dx,
                                                            const T* __restrict__ add, float* __restrict__ dw,
                                                            float* __restrict__ db, int c, int groups, int silu,
-                                                           int accumulate) {
+                                                           int accumulate, float* __restrict__ cpart = nullptr) {
     constexpr int V = Vec16<T>::N, SLOTS = 32 / V, ROWS = 256 / SLOTS, HW = PPT * ROWS;
     typedef typename Raw16<T>::type raw_t;
     __shared__ float sh[2][32];                                  // per-channel sums of g and g * xhat
+    __shared__ float shw[4][2][32];                              // ... per wave: added in wave order (no atomics: deterministic)
     __shared__ float kk[32][2];                                  // (k1, k2) of the channel's group
     const int slot = threadIdx.x % SLOTS, prow = threadIdx.x / SLOTS;
     const int n = blockIdx.y, ch0 = blockIdx.x * 32, cpg = c / groups;
-    if (threadIdx.x < 64) sh[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
-    __syncthreads();
     const int64_t off = (int64_t)n * HW * c + ch0 + slot * V;
     raw_t rx[KEEP ? PPT : 1], rg[KEEP ? PPT : 1];
     if (KEEP) {
@@ -476,15 +542,25 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const T* __restrict__
     if ((threadIdx.x & 63) < SLOTS) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            atomicAdd(&sh[0][slot * V + i], a[i]);
-            atomicAdd(&sh[1][slot * V + i], bb[i]);
+            shw[threadIdx.x >> 6][0][slot * V + i] = a[i];
+            shw[threadIdx.x >> 6][1][slot * V + i] = bb[i];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int j = threadIdx.x >> 5, cl = threadIdx.x & 31;
+        sh[j][cl] = ((shw[0][j][cl] + shw[1][j][cl]) + shw[2][j][cl]) + shw[3][j][cl];
     }
     __syncthreads();
     if (threadIdx.x < 32) {
         const int cl = threadIdx.x, ch = ch0 + cl;
-        atomicAdd(db + ch, sh[0][cl]);
-        atomicAdd(dw + ch, sh[1][cl]);
+        if (cpart) {                                             // deterministic mode: per-sample sums, added up in sample order afterwards
+            cpart[(int64_t)n * 2 * c + ch] = sh[0][cl];
+            cpart[(int64_t)n * 2 * c + c + ch] = sh[1][cl];
+        } else {
+            atomicAdd(db + ch, sh[0][cl]);
+            atomicAdd(dw + ch, sh[1][cl]);
+        }
         const int g0 = (cl / cpg) * cpg;
         double s1 = 0.0, s2 = 0.0;
         for (int i = 0; i < cpg; ++i) {
@@ -568,12 +644,19 @@ static int gn_backward_impl(int dtype, const void* x, const float* stats, const 
     if (const int ppt = add_w ? 0 : gn_small_ppt(dtype, hw, c, groups, 8)) {
         const dim3 sgrid((unsigned)(c / 32), (unsigned)n);
         const int acc = (accumulate || add) ? 1 : 0;
-#define VQK_GN_SMALL_BWD(T, P) hipLaunchKernelGGL((gn_small_bwd_kernel<T, P, (P < 16)>), sgrid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, dw, db, c, groups, silu, acc)
+        vqkd::DetState& det = vqkd::det_state();
+        float* cpart = nullptr;
+        if (det.on) {
+            VQK_REQUIRE(det.ws && (int64_t)n * 2 * c * 4 <= det.bytes, VQK_ERR_WORKSPACE);
+            cpart = det.ws;
+        }
+#define VQK_GN_SMALL_BWD(T, P) hipLaunchKernelGGL((gn_small_bwd_kernel<T, P, (P < 16)>), sgrid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, dw, db, c, groups, silu, acc, cpart)
 #define VQK_GN_SMALL_BWD_T(T) do { switch (ppt) { case 1: VQK_GN_SMALL_BWD(T, 1); break; case 2: VQK_GN_SMALL_BWD(T, 2); break; \
         case 4: VQK_GN_SMALL_BWD(T, 4); break; case 8: VQK_GN_SMALL_BWD(T, 8); break; default: VQK_GN_SMALL_BWD(T, 16); } } while (0)
         if (dtype == VQK_F32) VQK_GN_SMALL_BWD_T(float); else VQK_GN_SMALL_BWD_T(bf16_raw);
 #undef VQK_GN_SMALL_BWD_T
 #undef VQK_GN_SMALL_BWD
+        if (cpart) hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((unsigned)((2 * c + 7) / 8)), dim3(256), 0, st, (const float*)cpart, n, c, dw, db);
         VQK_CHECK_LAUNCH();
         return VQK_OK;
     }
@@ -581,15 +664,26 @@ static int gn_backward_impl(int dtype, const void* x, const float* stats, const 
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
     const bool nt = (int64_t)n * hw * c * (dtype == VQK_F32 ? 4 : 2) >= ((int64_t)192 << 20);
-    if (dtype == VQK_F32) {
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, stats, w, b, (const float*)dy, dw, db, red, hw, c, groups, silu, rppb);
-        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb, add_w, add_scale);
-        else hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (const float*)dy, (float*)dx, (const float*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb, add_w, add_scale);
-    } else {
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, dw, db, red, hw, c, groups, silu, rppb);
-        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_raw, true>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb, add_w, add_scale);
-        else hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_raw, false>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (const bf16_raw*)dy, (bf16_raw*)dx, (const bf16_raw*)add, red, hw, c, groups, silu, (accumulate || add) ? 1 : 0, ppb, add_w, add_scale);
+    // deterministic mode: group partials [n][groups][nblk][2] doubles, then channel partials [n][nblk][2c] floats, in the workspace
+    vqkd::DetState& det = vqkd::det_state();
+    double* gpart = nullptr;
+    float* cpart = nullptr;
+    const int nblk = (int)rgrid.x;
+    if (det.on) {
+        const int64_t gbytes = (int64_t)n * groups * nblk * 2 * 8, cbytes = (int64_t)n * nblk * 2 * c * 4;
+        VQK_REQUIRE(det.ws && gbytes + cbytes <= det.bytes, VQK_ERR_WORKSPACE);
+        gpart = reinterpret_cast<double*>(det.ws);
+        cpart = reinterpret_cast<float*>(reinterpret_cast<char*>(det.ws) + gbytes);
     }
+    const int acc = (accumulate || add) ? 1 : 0;
+#define VQK_GN_BWD(T) do { \
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, rgrid, dim3(256), lds, st, (const T*)x, stats, w, b, (const T*)dy, dw, db, red, hw, c, groups, silu, rppb, gpart, cpart); \
+        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, red, hw, c, groups, silu, acc, ppb, add_w, add_scale, (const double*)gpart, nblk); \
+        else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, red, hw, c, groups, silu, acc, ppb, add_w, add_scale, (const double*)gpart, nblk); \
+    } while (0)
+    if (dtype == VQK_F32) VQK_GN_BWD(float); else VQK_GN_BWD(bf16_raw);
+#undef VQK_GN_BWD
+    if (cpart) hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((unsigned)((2 * c + 7) / 8)), dim3(256), 0, st, (const float*)cpart, n * nblk, c, dw, db);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }
@@ -655,12 +749,19 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
     const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
+    vqkd::DetState& det = vqkd::det_state();
+    double* part = nullptr;
+    const int nblk = (int)rgrid.x;
+    if (det.on) {                                            // deterministic mode: block partials + ordered sums, no atomics
+        VQK_REQUIRE(det.ws && (int64_t)n * groups * nblk * 2 * 8 <= det.bytes, VQK_ERR_WORKSPACE);
+        part = reinterpret_cast<double*>(det.ws);
+    }
     if (dtype == VQK_F32) {
-        hipLaunchKernelGGL(gn_stats_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, hw, c, groups, rppb, ws);
-        hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps);
+        hipLaunchKernelGGL(gn_stats_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, hw, c, groups, rppb, ws, part);
+        hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk);
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, rppb, ws);
-        hipLaunchKernelGGL(gn_apply_fin_kernel<bf16_raw>, grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps);
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, rppb, ws, part);
+        hipLaunchKernelGGL(gn_apply_fin_kernel<bf16_raw>, grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk);
     }
     VQK_CHECK_LAUNCH();
     return VQK_OK;

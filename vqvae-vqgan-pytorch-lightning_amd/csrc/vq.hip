@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restric
 __global__ __launch_bounds__(256) void vq_code_grad_kernel(const float* __restrict__ z, const float* __restrict__ e,
                                                            const int64_t* __restrict__ idx, int64_t n, int d,
                                                            int64_t span, float ce, const float* __restrict__ gs,
-                                                           float* __restrict__ de) {
+                                                           float* __restrict__ de, int ordered) {
     constexpr int CAP = 2048;
     __shared__ int rows[CAP];
     __shared__ int nrows;
@@ -289,8 +289,28 @@ __global__ __launch_bounds__(256) void vq_code_grad_kernel(const float* __restri
         if (threadIdx.x == 0) nrows = 0;
         __syncthreads();
         const int64_t lim = min(r1, base + CAP);
-        for (int64_t r = base + threadIdx.x; r < lim; r += 256)
-            if (idx[r] == k) rows[atomicAdd(&nrows, 1)] = (int)(r - r0);
+        if (ordered) {
+            // deterministic mode: the matching rows are listed in ROW ORDER (ballot + prefix counts, wave by wave), so every
+            // channel adds them in the same order in every run
+            __shared__ int wcount[4];
+            for (int64_t rb = base; rb < lim; rb += 256) {
+                const int64_t r = rb + threadIdx.x;
+                const bool hit = r < lim && idx[r] == k;
+                const unsigned long long m = __ballot(hit);
+                const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+                if (lane == 0) wcount[wv] = __popcll(m);
+                __syncthreads();
+                int pos = nrows + __popcll(m & ((1ull << lane) - 1ull));
+                for (int q = 0; q < wv; ++q) pos += wcount[q];
+                if (hit) rows[pos] = (int)(r - r0);
+                __syncthreads();
+                if (threadIdx.x == 0) nrows += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+                __syncthreads();
+            }
+        } else {
+            for (int64_t r = base + threadIdx.x; r < lim; r += 256)
+                if (idx[r] == k) rows[atomicAdd(&nrows, 1)] = (int)(r - r0);
+        }
         __syncthreads();
         const int cnt = nrows;
         if (cnt) {
@@ -441,9 +461,11 @@ int vqk_vq_backward_f32(const float* z, const float* e, const int64_t* idx, cons
     if (de) {
         int splits = (int)((n + 255) / 256);              // <= 256 rows per block even when every row hits one code
         if (splits > 64) splits = 64;
+        const int det = vqkd::det_state().on;
+        if (det) splits = 1;                              // deterministic mode: one block per code, rows added in row order
         const int64_t span = (n + splits - 1) / splits;
         hipLaunchKernelGGL(vq_code_grad_kernel, dim3((unsigned)k, (unsigned)splits), dim3(256), 0, vqk_stream(stream), z, e,
-                           idx, n, d, span, ce, gscale_dev, de);
+                           idx, n, d, span, ce, gscale_dev, de, det);
     }
     VQK_CHECK_LAUNCH();
     return VQK_OK;

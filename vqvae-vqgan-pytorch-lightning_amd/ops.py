@@ -8,6 +8,7 @@ Tensor convention: activations keep the reference's logical NCHW shape but are p
 from __future__ import annotations
 
 import os
+import threading
 import weakref
 
 import torch
@@ -31,8 +32,41 @@ def epc(dtype: torch.dtype) -> int:
     return 4 if dtype == torch.float32 else 8
 
 
+DETERMINISTIC = False
+_DET_WS: dict = {}
+_DET_TLS = threading.local()           # the library's flag is per HOST THREAD (autograd runs the backward on its own thread):
+_DET_GEN = 0                           # every thread tracks what IT armed, against the generation of the last mode switch
+_DET_WS_BYTES = 64 << 20
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """handle of the current stream (every launcher passes it to the C-ABI).  In deterministic mode this is also where the
+    library's per-thread workspace follows the stream (partial sums of two concurrent streams must not share a buffer), and
+    where a thread that was armed before the mode was switched off disarms itself."""
+    s = torch.cuda.current_stream().cuda_stream
+    key = getattr(_DET_TLS, 'key', None)
+    if DETERMINISTIC:
+        if key != (_DET_GEN, s):
+            dev = torch.cuda.current_device()
+            ws = _DET_WS.get((dev, s))
+            if ws is None:
+                ws = _DET_WS[(dev, s)] = torch.empty(_DET_WS_BYTES, dtype=torch.uint8, device=f'cuda:{dev}')
+            _native.check(_native.lib().vqk_set_deterministic(1, ws.data_ptr(), ws.numel()), 'set_deterministic')
+            _DET_TLS.key = (_DET_GEN, s)
+    elif key is not None:
+        _native.check(_native.lib().vqk_set_deterministic(0, 0, 0), 'set_deterministic')
+        _DET_TLS.key = None
+    return s
+
+
+def set_deterministic(on: bool) -> None:
+    """``pl.Trainer(deterministic=True)`` (vqvae/train.py:130) for the vqk kernels: ordered partial sums instead of atomics in
+    arrival order (include/vqk.h: vqk_set_deterministic); the GroupNorm sums are no longer fused into the conv drains (those
+    use atomics).  Two identical steps then produce bit-identical gradients."""
+    global DETERMINISTIC, _DET_GEN, FUSE_GN_STATS
+    DETERMINISTIC = bool(on)
+    _DET_GEN += 1
+    FUSE_GN_STATS = False if on else os.environ.get('VQK_FUSE_GN_STATS', '1') != '0'
 
 
 def _p(t):
@@ -279,6 +313,8 @@ def raw_conv_fprop_pooled(x, wq, bias, residual, ksize: int, ups: bool, cout: in
 
 
 FUSE_GN_STATS = os.environ.get('VQK_FUSE_GN_STATS', '1') != '0'
+if os.environ.get('VQK_DETERMINISTIC') == '1':          # same as set_deterministic(True), from the environment
+    DETERMINISTIC, FUSE_GN_STATS = True, False
 
 
 def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: int, pool: bool = False,

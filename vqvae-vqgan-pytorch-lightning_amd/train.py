@@ -91,6 +91,7 @@ def parse_args(argv=None):
     p.add_argument('--batches_per_epoch', type=int, default=None, help='synthetic data: steps per epoch')
     p.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    p.add_argument('--deterministic', action='store_true', help='Trainer(deterministic=True) of the reference (train.py:130): bit-reproducible gradients')
     p.add_argument('--optimizer_param_set', choices=['auto', 'all', 'reference'], default='auto',
                    help="'reference': the tensors (and order) the reference hands AdamW (vqvae/model.py:384-410) -- what a "
                         "reference checkpoint's optimizer state is indexed by; 'auto': every tensor, unless --loading_path "
@@ -169,7 +170,8 @@ def main(argv=None):
         raise SystemExit(f'train.py: the dataset holds fewer than one batch per rank '
                          f'({run["batch_size_per_device"]} images x {world} ranks)')
     max_epochs = args.max_epochs or run['max_epochs']
-    trainer = trainer_mod.MiniTrainer(max_epochs=max_epochs, num_training_batches=len(batches))
+    trainer = trainer_mod.MiniTrainer(max_epochs=max_epochs, num_training_batches=len(batches),
+                                      deterministic=True if args.deterministic else None)
     trainer.attach(model)
     start_epoch = 0
     if args.loading_path is not None:

@@ -33,7 +33,11 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
 
 
 class MiniTrainer:
-    def __init__(self, max_epochs: int = 1, num_training_batches: int | None = None):
+    def __init__(self, max_epochs: int = 1, num_training_batches: int | None = None, deterministic: bool | None = None):
+        """``deterministic``: ``pl.Trainer(deterministic=True)`` of vqvae/train.py:130 -- ordered partial sums instead of atomics
+        in every gradient accumulation of the step (ops.set_deterministic); None leaves the process-wide setting alone."""
+        if deterministic is not None:
+            ops.set_deterministic(deterministic)
         self.max_epochs = max_epochs
         self.num_training_batches = num_training_batches
         self.optimizers = []
@@ -135,7 +139,7 @@ class MiniTrainer:
             # buffer that set_consts() refreshes, so a replay follows the schedule
             q.enable_device_schedule(example_batch.device)
         if not getattr(model, 'automatic_optimization', True):
-            return self._capture_gan(model, example_batch, warmup)
+            return self._capture_gan(model, example_batch, warmup, snap)
         self._static_in = example_batch.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -182,7 +186,7 @@ class MiniTrainer:
         return self._graph
 
     # ------------------------------------------------------------------ VQ-GAN step (manual optimisation) as three graphs
-    def _capture_gan(self, model, example_batch, warmup: int):
+    def _capture_gan(self, model, example_batch, warmup: int, snap=None):
         """model.py:244-264 under hipGraph replay: [AE half: zero_grad, forward, LPIPS + generator loss, backward] /
         [discriminator half] / [discriminator half with the R1 term] -- the two optimizer steps, the gradient all-reduces and
         the choice of the R1 variant (every ``r1_reg_every`` steps) stay on the host between the replays."""
@@ -196,6 +200,8 @@ class MiniTrainer:
                 model.training_step(self._static_in, i)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if snap is not None:
+            self._restore(model, snap)
         crit = model.criterion
         every = crit.r1_regularization_every if crit.r1_regularization_cost is not None else 0
         model.defer_usage_accumulation = True
