@@ -198,8 +198,18 @@ class VQVAE(BaseVQVAE, _LightningBase):
         recon_pad = self.decoder.forward_padded(quantized)
         ae_opt, _ = self.optimizers()
         ae_opt.zero_grad()
-        res = self.criterion.forward_autoencoder(q_loss, target, recon_pad, self.current_epoch,
-                                                 last_layer=self.decoder.conv_out.weight)
+        # the generator loss needs the discriminator's INPUT gradient only: its weight / bias gradients from this half are thrown
+        # away by the reference too (model.py:258 zeroes them before the discriminator step) -- not computing them saves every
+        # weight-gradient kernel of one of the step's three discriminator passes
+        disc_params = [p for p in self.criterion.discriminator.parameters() if p.requires_grad]
+        for p in disc_params:
+            p.requires_grad_(False)
+        try:
+            res = self.criterion.forward_autoencoder(q_loss, target, recon_pad, self.current_epoch,
+                                                     last_layer=self.decoder.conv_out.weight)
+        finally:
+            for p in disc_params:
+                p.requires_grad_(True)
         self.manual_backward(res[0])
         self._gan_state = (target, recon_pad, q_loss, res)
         return res
