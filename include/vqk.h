@@ -204,6 +204,10 @@ int vqk_conv_set_variant(int variant);
  * belong to the stream the following launches go to (two streams = two workspaces, re-armed on every switch).  The scalar
  * loss sums and the EMA statistics keep their atomics (values, not gradients). */
 int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes);
+/* Optional fp32 scratch of the CURRENT stream (thread-local like the block caps; NULL = none): ZERO on entry, left zero by every
+ * user.  With it the general conv kernel splits K for problems whose pixel x cout tile grid would leave most of the chip idle
+ * (the discriminator's 4x4 / 8x8 convs and fully connected layers: 8-32 tiles with K up to 8192). */
+int vqk_set_scratch(void* ws, int64_t ws_bytes);
 /* caps on the persistent grids of the 3x3 fprop/dgrad kernel and of the all-taps wgrad kernel (0 = default: two
  * blocks per CU).  256 = one block per CU, leaving room for a kernel that runs concurrently on another stream
  * (the host overlaps a layer's wgrad with its dgrad and GroupNorm backward).  The caps are THREAD-LOCAL: they apply to the

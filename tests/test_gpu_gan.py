@@ -218,3 +218,28 @@ def test_vqgan_step_graph_replay_matches_eager():
         bad += (~torch.isclose(s_g[k], s_e[k], rtol=5e-3, atol=2e-4)).sum().item()
         total += s_e[k].numel()
     assert bad <= 0.02 * total, (bad, total)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,c,h,w', [(2, 64, 32, 32), (1, 128, 37, 50), (2, 64, 8, 8), (1, 64, 64, 64)])
+def test_upfirdn_tiled_kernel_vs_oracle(dtype, n, c, h, w):
+    """the LDS-tiled resampling filters of the discriminator (csrc/gan_ops.hip: upfirdn_tile_kernel) -- blur with padding
+    (conv2d_resample.py:119-122), blur + decimate (:107-110) and their adjoints (zero-stuff + blur, upfirdn2d.py:246-262) --
+    forward and backward against the oracle's restatement of upfirdn2d.py:169-208, odd sizes and tile borders included"""
+    from oracle import vqvae_oracle as O
+    f = torch.outer(torch.tensor([1., 3., 3., 1.]), torch.tensor([1., 3., 3., 1.])); f = f / f.sum()
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(n, c, h, w, generator=g).to(dtype).float()
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1e-2)
+    for kw in (dict(up=1, down=1, padding=(2, 2, 2, 2)), dict(up=1, down=2, padding=(1, 1, 1, 1)),
+               dict(up=2, down=1, padding=(2, 1, 2, 1), gain=4.0), dict(up=1, down=1, padding=(1, 2, 1, 2), flip_filter=True)):
+        xr = x.clone().requires_grad_(True)
+        want = O.upfirdn2d(xr, f, (kw['up'],) * 2, (kw['down'],) * 2, kw['padding'], kw.get('flip_filter', False), kw.get('gain', 1.0))
+        dy = torch.randn(want.shape, generator=g).to(dtype).float()
+        want.backward(dy)
+        xd = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = ops.upfirdn2d_nhwc(xd, f.to(DEV), **kw)
+        assert y.shape == want.shape
+        np.testing.assert_allclose(y.detach().float().cpu().numpy(), want.detach().numpy(), **tol)
+        dx, = torch.autograd.grad(y, xd, dy.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last))
+        np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.numpy(), **tol)

@@ -28,7 +28,7 @@ wrap('vqk_conv2d_general', lambda a: ('n%d %dx%d cin%d cout%d k%d s%d pad%d mode
 wrap('vqk_conv2d_fprop', lambda a: ('n%d %dx%d cin%d cout%d k%d ups%d lay%d' % (a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[15])))
 wrap('vqk_conv2d_wgrad_general', lambda a: ('n%d %dx%d cin%d cout%d k%d s%d pad%d -> %dx%d' % (a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[13], a[14])))
 wrap('vqk_conv2d_wgrad', lambda a: ('n%d %dx%d cin%d cout%d k%d ups%d' % (a[4], a[5], a[6], a[7], a[8], a[9], a[10])))
-wrap('vqk_upfirdn2d_nhwc', lambda a: 'upfirdn')
+wrap('vqk_upfirdn2d_nhwc', lambda a: 'upfirdn n%d %dx%d c%d up%d down%d' % (a[4], a[5], a[6], a[7], a[10], a[12]))
 
 dev = torch.device('cuda:0')
 torch.manual_seed(1234)

@@ -27,7 +27,19 @@ DetState& det_state() {
     static thread_local DetState st = {0, nullptr, 0};
     return st;
 }
+DetState& scratch_state() {
+    static thread_local DetState st = {0, nullptr, 0};
+    return st;
+}
 }  // namespace vqkd
+
+extern "C" int vqk_set_scratch(void* ws, int64_t ws_bytes) {
+    vqkd::DetState& d = vqkd::scratch_state();
+    d.on = ws ? 1 : 0;
+    d.ws = reinterpret_cast<float*>(ws);
+    d.bytes = ws ? ws_bytes : 0;
+    return VQK_OK;
+}
 
 extern "C" int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes) {
     vqkd::DetState& d = vqkd::det_state();

@@ -94,6 +94,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 namespace vqkd {
 struct DetState { int on; float* ws; int64_t bytes; };
 DetState& det_state();
+DetState& scratch_state();      // vqk_set_scratch: zero-initialised fp32 scratch of the current stream (split-K partial sums)
 }
 #define VQK_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH; } while (0)
 #define VQK_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)

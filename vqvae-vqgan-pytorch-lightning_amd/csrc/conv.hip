@@ -104,7 +104,8 @@ template <typename T, typename TO, bool FASTK>
 __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict__ x, const T* __restrict__ wgt,
                                                             const float* __restrict__ bias, const TO* __restrict__ res,
                                                             TO* __restrict__ y, const char* __restrict__ zeros,
-                                                            ConvGeom g, int act) {
+                                                            ConvGeom g, int act, float* __restrict__ skws = nullptr,
+                                                            int steps_per_split = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_a = smem;              // [128][128 B]
     char* lds_b = smem + 16384;      // [128][128 B]
@@ -176,8 +177,12 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
 
     const int ksteps = (g.kchunks + 7) >> 3;
     const int steps_per_tap = FASTK ? (g.cpt >> 3) : 1;
+    // split-K (tiny pixel counts with a long K: the 4x4 / 8x8 maps and the fully connected layer of the discriminator run as
+    // 8-32 blocks otherwise): blockIdx.y owns a range of k-steps, the fp32 partials meet in the (zeroed) scratch `skws`
+    const int s_begin = skws ? (int)blockIdx.y * steps_per_split : 0;
+    const int s_end = skws ? min(ksteps, s_begin + steps_per_split) : ksteps;
 
-    for (int s = 0; s < ksteps; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
         // ---------------- stage: 4 A + 4 B 16-byte pieces per lane
         int tap_u = 0, kh_u = 0, kw_u = 0, cbase_u = 0;
         if (FASTK) {
@@ -246,6 +251,12 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             for (int rq = 0; rq < 4; ++rq) {
                 const int co = n0 + wn * 64 + j * 32 + 8 * rq + 4 * okg;
                 if (co >= g.cout) continue;
+                if (skws) {                                      // split-K partial: the epilogue runs in conv_splitk_epilogue_kernel
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < g.cout) atomicAdd(skws + orow + co + e, acc[i][j][4 * rq + e]);
+                    continue;
+                }
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -263,6 +274,20 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                 }
             }
     }
+}
+
+// epilogue of the split-K form: y = out_gain * act(ws * acc_scale + bias) (+ residual); the scratch is left ZERO for its next user
+template <typename TO>
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(float* __restrict__ ws, const float* __restrict__ bias,
+                                                                   const TO* __restrict__ res, TO* __restrict__ y, int64_t total,
+                                                                   int cout, float acc_scale, float out_gain, int act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int co = (int)(i % cout);
+    float v = epi_act(ws[i] * acc_scale + (bias ? bias[co] : 0.0f), act) * out_gain;
+    ws[i] = 0.0f;
+    if (res) v += Elem<TO>::ld(res + i);
+    Elem<TO>::st(y + i, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2050,6 +2075,30 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
     }
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
     const bool fastk = (g.cpt % 8) == 0;
+    {
+        // split-K through the caller's scratch (vqk_set_scratch) when the tile grid leaves most of the chip idle
+        vqkd::DetState& sc = vqkd::scratch_state();
+        const int tiles = g.tiles_m * g.tiles_n, ksteps = (g.kchunks + 7) >> 3;
+        const int64_t out_elems = (int64_t)g.m * g.cout;
+        static const int sk_on = getenv("VQK_FPROP_SPLITK") ? atoi(getenv("VQK_FPROP_SPLITK")) : 1;
+        if (sk_on && sc.ws && !g.sub && !vqkd::det_state().on && tiles <= 32 && ksteps >= 16 && out_elems * 4 <= sc.bytes) {
+            int splits = 256 / tiles;
+            if (splits > ksteps / 2) splits = ksteps / 2;
+            const int sps = (ksteps + splits - 1) / splits;
+            splits = (ksteps + sps - 1) / sps;
+            const dim3 sgrid((unsigned)tiles, (unsigned)splits);
+            if (fastk)
+                hipLaunchKernelGGL((conv_fprop_kernel<T, TO, true>), sgrid, dim3(256), 32768, st, (const T*)x, (const T*)w, bias,
+                                   (const TO*)res, (TO*)y, (const char*)zeros, g, act, sc.ws, sps);
+            else
+                hipLaunchKernelGGL((conv_fprop_kernel<T, TO, false>), sgrid, dim3(256), 32768, st, (const T*)x, (const T*)w, bias,
+                                   (const TO*)res, (TO*)y, (const char*)zeros, g, act, sc.ws, sps);
+            hipLaunchKernelGGL(conv_splitk_epilogue_kernel<TO>, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, st, sc.ws, bias,
+                               (const TO*)res, (TO*)y, out_elems, g.cout, g.acc_scale, g.out_gain, act);
+            if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
+            return VQK_OK;
+        }
+    }
     if (fastk)
         hipLaunchKernelGGL((conv_fprop_kernel<T, TO, true>), grid, dim3(256), 32768, st, (const T*)x, (const T*)w, bias,
                            (const TO*)res, (TO*)y, (const char*)zeros, g, act);

@@ -37,6 +37,8 @@ _DET_WS: dict = {}
 _DET_TLS = threading.local()           # the library's flag is per HOST THREAD (autograd runs the backward on its own thread):
 _DET_GEN = 0                           # every thread tracks what IT armed, against the generation of the last mode switch
 _DET_WS_BYTES = 64 << 20
+_SCRATCH: dict = {}
+_SCRATCH_BYTES = 8 << 20
 
 
 def _stream() -> int:
@@ -44,6 +46,13 @@ def _stream() -> int:
     library's per-thread workspace follows the stream (partial sums of two concurrent streams must not share a buffer), and
     where a thread that was armed before the mode was switched off disarms itself."""
     s = torch.cuda.current_stream().cuda_stream
+    if getattr(_DET_TLS, 'scratch', None) != s:                  # split-K scratch of this stream (zero on entry, left zero)
+        dev = torch.cuda.current_device()
+        sc = _SCRATCH.get((dev, s))
+        if sc is None:
+            sc = _SCRATCH[(dev, s)] = torch.zeros(_SCRATCH_BYTES // 4, dtype=torch.float32, device=f'cuda:{dev}')
+        _native.check(_native.lib().vqk_set_scratch(sc.data_ptr(), sc.numel() * 4), 'set_scratch')
+        _DET_TLS.scratch = s
     key = getattr(_DET_TLS, 'key', None)
     if DETERMINISTIC:
         if key != (_DET_GEN, s):
