@@ -32,6 +32,11 @@ __device__ __forceinline__ float epi_act(float v, int act) {
     if (act == 3) return v > 0.0f ? v : 0.2f * v;
     return v;
 }
+// the non-tanh activations without control flow (act is a run-time value: a branch per element serialises an epilogue)
+__device__ __forceinline__ float epi_act_sel(float v, int act) {
+    const float lo = act == 2 ? 0.0f : act == 3 ? 0.2f * v : v;  // relu: max(v, 0); lrelu: max(v, 0.2 v); linear: max(v, v)
+    return fmaxf(v, lo);
+}
 
 
 template <typename T> struct Mma;
@@ -234,6 +239,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     // ---------------- epilogue: bias, residual, activation, store.  D[cout][pixel]: a lane owns one pixel (column)
     // and, per MFMA tile, four runs of 4 consecutive couts -> 8 / 16-byte stores
     const int opix = lane & 31, okg = lane >> 5;
+    const bool bias16 = (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+    auto epilogue = [&](auto TANH) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 64 + i * 32 + opix;
@@ -257,10 +264,21 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                         if (co + e < g.cout) atomicAdd(skws + orow + co + e, acc[i][j][4 * rq + e]);
                     continue;
                 }
-                float v[4];
+                float v[4], bq[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+                    if (co + 3 < g.cout && bias16) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + co);     // co % 4 == 0
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = epi_act(acc[i][j][4 * rq + e] * g.acc_scale + ((bias && co + e < g.cout) ? bias[co + e] : 0.0f), act) * g.out_gain;
+                        for (int e = 0; e < 4; ++e) bq[e] = b4[e];
+                    } else {
+                        for (int e = 0; e < 4 && co + e < g.cout; ++e) bq[e] = bias[co + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[i][j][4 * rq + e] * g.acc_scale + bq[e];
+                    v[e] = (decltype(TANH)::value ? tanhf(t) : epi_act_sel(t, act)) * g.out_gain;
+                }
                 const int64_t o = orow + co;
                 if (co + 3 < g.cout && (g.cout & 3) == 0) {
                     if (res) add4(res + o, v);
@@ -274,6 +292,9 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                 }
             }
     }
+    };
+    if (act == 1) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 // epilogue of the split-K form: y = out_gain * act(ws * acc_scale + bias) (+ residual); the scratch is left ZERO for its next user
@@ -991,6 +1012,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(const bf16_raw*
         }
     };
     int t = (int)blockIdx.x * 4 + wave;
+    float* bl = reinterpret_cast<float*>(smem + 4 * 32 * RS);     // the block's NJ*32 biases (read as float4 in the epilogue)
+    if (tid < NJ * 32) bl[tid] = (bias && cout_base + tid < g.cout) ? bias[cout_base + tid] : 0.0f;
+    __syncthreads();
     if (t >= total) return;
     bf16x8_t a[5], an[5];
     load_a(t, a);
@@ -1007,24 +1031,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(const bf16_raw*
 #pragma unroll
             for (int s5 = 1; s5 < 5; ++s5) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][s5], a[s5], acc[j], 0, 0, 0);
         }
-        // epilogue -> LDS (row = pixel, 4-cout pieces)
+        // epilogue -> LDS (row = pixel, 4-cout pieces); the activation is a compile-time constant of each body (a
+        // run-time switch per element serialised the epilogue: 183-238 us against 65 us for the plain one)
+        auto stage = [&](auto A) {
+            constexpr int AC = decltype(A)::value;               // -1: plain
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v[4];
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+                    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+                    if (AC >= 0) bq = *reinterpret_cast<const f32x4*>(bl + j * 32 + 8 * q + 4 * kg);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[j][4 * q + e];
-                    if (!plain) {
-                        const int co = cout_base + j * 32 + 8 * q + 4 * kg + e;
-                        const float bvv = (bias && co < g.cout) ? bias[co] : 0.0f;
-                        v[e] = epi_act(v[e] * g.acc_scale + bvv, act) * g.out_gain;
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[j][4 * q + e];
+                        if (AC >= 0) v[e] = epi_act(v[e] * g.acc_scale + bq[e], AC) * g.out_gain;
                     }
+                    const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(lds + p * RS + (j * 32 + 8 * q + 4 * kg) * 2) = o;
                 }
-                const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *reinterpret_cast<u32x2*>(lds + p * RS + (j * 32 + 8 * q + 4 * kg) * 2) = o;
-            }
+        };
+        if (plain) stage(std::integral_constant<int, -1>{});
+        else if (act == 3) stage(std::integral_constant<int, 3>{});
+        else if (act == 0) stage(std::integral_constant<int, 0>{});
+        else if (act == 1) stage(std::integral_constant<int, 1>{});
+        else stage(std::integral_constant<int, 2>{});
         // LDS -> global: the wave's 32 pixels x NJ*64 B are consecutive rows of y
         const int cout_blk = NJ * 32;
         char* ybase = reinterpret_cast<char*>(y + ((int64_t)row * g.w + xs * 32) * g.cout + cout_base);
@@ -2064,10 +2095,10 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         int blocks = (total + 3) / 4; if (blocks > 1024) blocks = 1024;
         for (int cb = 0; cb < g.cout; cb += 128) {
             if (g.cout - cb > 64)
-                hipLaunchKernelGGL((conv3x3_thin_in_kernel<4>), dim3((unsigned)blocks), dim3(256), 4 * 32 * (4 * 64 + 8), st,
+                hipLaunchKernelGGL((conv3x3_thin_in_kernel<4>), dim3((unsigned)blocks), dim3(256), 4 * 32 * (4 * 64 + 8) + 4 * 128, st,
                                    (const bf16_raw*)x, (const bf16_raw*)w, bias, (bf16_raw*)y, g, act, cb);
             else
-                hipLaunchKernelGGL((conv3x3_thin_in_kernel<2>), dim3((unsigned)blocks), dim3(256), 4 * 32 * (2 * 64 + 8), st,
+                hipLaunchKernelGGL((conv3x3_thin_in_kernel<2>), dim3((unsigned)blocks), dim3(256), 4 * 32 * (2 * 64 + 8) + 4 * 64, st,
                                    (const bf16_raw*)x, (const bf16_raw*)w, bias, (bf16_raw*)y, g, act, cb);
         }
         if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
