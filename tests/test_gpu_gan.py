@@ -243,3 +243,34 @@ def test_upfirdn_tiled_kernel_vs_oracle(dtype, n, c, h, w):
         np.testing.assert_allclose(y.detach().float().cpu().numpy(), want.detach().numpy(), **tol)
         dx, = torch.autograd.grad(y, xd, dy.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last))
         np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.numpy(), **tol)
+
+
+def _lpips_tap_ref(fx, fy, lin):
+    """the reference's tap (lpips.py:28-33,52-56: unit-normalise over channels with eps 1e-10, squared difference, 1x1 `lin`
+    conv without bias, spatial mean) in fp64 autograd"""
+    fx, fy, lin = fx.double(), fy.double(), lin.double()
+    nx = fx / (fx.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+    ny = fy / (fy.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+    return ((nx - ny).pow(2) * lin.view(1, -1, 1, 1)).sum(1).mean((1, 2))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(3, 64, 24, 20), (2, 128, 16, 16), (5, 256, 8, 8), (4, 512, 4, 4), (16, 512, 16, 16),
+                                   (2, 48, 6, 10)])
+def test_lpips_tap_forward_backward(dtype, shape):
+    """both vectorised kernels (and the scalar pair: 48 channels is not a power-of-two number of 16-byte slots) against fp64
+    autograd of the reference formula, ragged pixel counts included"""
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w = shape
+    fx = torch.randn(n, c, h, w, generator=g).relu().to(dtype)
+    fy = torch.randn(n, c, h, w, generator=g).relu().to(dtype)
+    lin = torch.rand(c, generator=g)
+    up = torch.randn(n, generator=g)
+    fy_ref = fy.float().clone().requires_grad_(True)
+    ref = _lpips_tap_ref(fx.float(), fy_ref, lin)
+    (ref * up.double()).sum().backward()
+    fyd = fy.to(DEV).requires_grad_(True)
+    out = ops.LpipsTapFn.apply(fx.to(DEV), fyd, lin.to(DEV))
+    (out * up.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5 if dtype == torch.float32 else 1e-4)
+    assert rel(fyd.grad.float(), fy_ref.grad) < (1e-5 if dtype == torch.float32 else 6e-3)
