@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     const int ksteps = (g.kchunks + 7) >> 3;
     const int steps_per_tap = FASTK ? (g.cpt >> 3) : 1;
     // split-K (tiny pixel counts with a long K: the 4x4 / 8x8 maps and the fully connected layer of the discriminator run as
-    // 8-32 blocks otherwise): blockIdx.y owns a range of k-steps, the fp32 partials meet in the (zeroed) scratch `skws`
+    // 8-32 blocks otherwise): blockIdx.y owns a range of k-steps and a private slice of the scratch `skws`
     const int s_begin = skws ? (int)blockIdx.y * steps_per_split : 0;
     const int s_end = skws ? min(ksteps, s_begin + steps_per_split) : ksteps;
 
@@ -258,10 +258,16 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             for (int rq = 0; rq < 4; ++rq) {
                 const int co = n0 + wn * 64 + j * 32 + 8 * rq + 4 * okg;
                 if (co >= g.cout) continue;
-                if (skws) {                                      // split-K partial: the epilogue runs in conv_splitk_epilogue_kernel
+                if (skws) {                                      // split-K partial -> this split's private slice (plain stores;
+                    float* sl = skws + (int64_t)blockIdx.y * g.m * g.cout + orow + co;   // conv_splitk_epilogue_kernel sums them)
+                    if (co + 3 < g.cout && (g.cout & 3) == 0) {
+                        const f32x4 pv = {acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]};
+                        *reinterpret_cast<f32x4*>(sl) = pv;
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (co + e < g.cout) atomicAdd(skws + orow + co + e, acc[i][j][4 * rq + e]);
+                        for (int e = 0; e < 4; ++e)
+                            if (co + e < g.cout) sl[e] = acc[i][j][4 * rq + e];
+                    }
                     continue;
                 }
                 float v[4], bq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -297,16 +303,19 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     else epilogue(std::false_type{});
 }
 
-// epilogue of the split-K form: y = out_gain * act(ws * acc_scale + bias) (+ residual); the scratch is left ZERO for its next user
+// epilogue of the split-K form: y = out_gain * act(sum_s ws[s] * acc_scale + bias) (+ residual).  Every split wrote its own
+// slice of the scratch with plain stores and the slices are summed in split order here: no atomics (4.2 M device-scope
+// fp32 atomics per 8x8 conv were most of its 123 us), no zero-initialised scratch, the same bits every run.
 template <typename TO>
-__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(float* __restrict__ ws, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                                    const TO* __restrict__ res, TO* __restrict__ y, int64_t total,
-                                                                   int cout, float acc_scale, float out_gain, int act) {
+                                                                   int cout, float acc_scale, float out_gain, int act, int splits) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int co = (int)(i % cout);
-    float v = epi_act(ws[i] * acc_scale + (bias ? bias[co] : 0.0f), act) * out_gain;
-    ws[i] = 0.0f;
+    float a = 0.0f;
+    for (int sidx = 0; sidx < splits; ++sidx) a += ws[(int64_t)sidx * total + i];
+    float v = epi_act(a * acc_scale + (bias ? bias[co] : 0.0f), act) * out_gain;
     if (res) v += Elem<TO>::ld(res + i);
     Elem<TO>::st(y + i, v);
 }
@@ -2112,9 +2121,10 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         const int tiles = g.tiles_m * g.tiles_n, ksteps = (g.kchunks + 7) >> 3;
         const int64_t out_elems = (int64_t)g.m * g.cout;
         static const int sk_on = getenv("VQK_FPROP_SPLITK") ? atoi(getenv("VQK_FPROP_SPLITK")) : 1;
-        if (sk_on && sc.ws && !g.sub && !vqkd::det_state().on && tiles <= 32 && ksteps >= 16 && out_elems * 4 <= sc.bytes) {
+        if (sk_on && sc.ws && !g.sub && tiles <= 32 && ksteps >= 16 && 2 * out_elems * 4 <= sc.bytes) {
             int splits = 256 / tiles;
             if (splits > ksteps / 2) splits = ksteps / 2;
+            if ((int64_t)splits * out_elems * 4 > sc.bytes) splits = (int)(sc.bytes / (out_elems * 4));
             const int sps = (ksteps + splits - 1) / splits;
             splits = (ksteps + sps - 1) / sps;
             const dim3 sgrid((unsigned)tiles, (unsigned)splits);
@@ -2125,7 +2135,7 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
                 hipLaunchKernelGGL((conv_fprop_kernel<T, TO, false>), sgrid, dim3(256), 32768, st, (const T*)x, (const T*)w, bias,
                                    (const TO*)res, (TO*)y, (const char*)zeros, g, act, sc.ws, sps);
             hipLaunchKernelGGL(conv_splitk_epilogue_kernel<TO>, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, st, sc.ws, bias,
-                               (const TO*)res, (TO*)y, out_elems, g.cout, g.acc_scale, g.out_gain, act);
+                               (const TO*)res, (TO*)y, out_elems, g.cout, g.acc_scale, g.out_gain, act, splits);
             if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
             return VQK_OK;
         }

@@ -367,12 +367,12 @@ __global__ __launch_bounds__(256) void lpips_tap_bwd_vec_kernel(const T* __restr
 
 // minibatch-stddev: sample b = g*(n/G) + m.  stat[m] = mean_{c,h,w} sqrt(var_g + 1e-8).  one block per m.
 template <typename T>
-__global__ __launch_bounds__(256) void mbstd_stat_kernel(const T* __restrict__ x, int n, int64_t chw, int gsz,
+__global__ __launch_bounds__(1024) void mbstd_stat_kernel(const T* __restrict__ x, int n, int64_t chw, int gsz,
                                                          float* __restrict__ stat) {
-    __shared__ float part[4];
+    __shared__ float part[16];
     const int m = blockIdx.x, cols = n / gsz;
     float acc = 0.f;
-    for (int64_t e = threadIdx.x; e < chw; e += 256) {
+    for (int64_t e = threadIdx.x; e < chw; e += blockDim.x) {
         float mean = 0.f, v[8];
         for (int g = 0; g < gsz; ++g) { v[g] = Elem<T>::ld(x + ((int64_t)(g * cols + m)) * chw + e); mean += v[g]; }
         mean /= (float)gsz;
@@ -383,7 +383,11 @@ __global__ __launch_bounds__(256) void mbstd_stat_kernel(const T* __restrict__ x
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) stat[m] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)chw;
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];         // fixed order
+        stat[m] = t / (float)chw;
+    }
 }
 
 // y[b][pix][0..c) = x ; y[b][pix][c] = stat[b % cols] ; y[b][pix][c+1..cp) = 0
@@ -404,14 +408,14 @@ __global__ __launch_bounds__(256) void mbstd_concat_kernel(const T* __restrict__
 
 // dx[b][e] = dy[b][e (channels < c)] + dstat[m] * (x - mean_g) / (G * chw * std_e),  dstat[m] = sum dy[.., channel c]
 template <typename T>
-__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+__global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                         int n, int64_t hw, int c, int cp, int gsz) {
-    __shared__ float part[4];
+    __shared__ float part[16];
     __shared__ float dstat;
     const int m = blockIdx.x, cols = n / gsz;
     const int64_t chw = hw * c;
     float acc = 0.f;
-    for (int64_t q = threadIdx.x; q < (int64_t)gsz * hw; q += 256) {
+    for (int64_t q = threadIdx.x; q < (int64_t)gsz * hw; q += blockDim.x) {
         const int g = (int)(q / hw);
         const int64_t pix = (int64_t)(g * cols + m) * hw + (q - g * hw);
         acc += Elem<T>::ld(dy + pix * cp + c);
@@ -419,11 +423,15 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ x,
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) dstat = (part[0] + part[1]) + (part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+        dstat = t;
+    }
     __syncthreads();
     const float ds = dstat / ((float)gsz * (float)chw);
-    for (int64_t e = threadIdx.x; e < chw; e += 256) {
-        const int64_t pixe = e / c; const int ch = (int)(e - pixe * c);
+    for (int64_t e = threadIdx.x; e < chw; e += blockDim.x) {
+        const int64_t pixe = (int64_t)((unsigned)e / (unsigned)c); const int ch = (int)(e - pixe * c);   // chw < 2^31 (launcher)
         float mean = 0.f, v[8];
         for (int g = 0; g < gsz; ++g) { v[g] = Elem<T>::ld(x + ((int64_t)(g * cols + m)) * chw + e); mean += v[g]; }
         mean /= (float)gsz;
@@ -908,19 +916,21 @@ int vqk_mbstd(int dtype, const void* x, const void* dy, void* out, float* stat, 
               int backward, void* stream) {
     VQK_REQUIRE(x && out && (backward ? dy != nullptr : stat != nullptr), VQK_ERR_ARG);
     VQK_REQUIRE(n > 0 && hw > 0 && c > 0 && cpad > c && group >= 1 && group <= 8 && n % group == 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(hw * c < 0x7fffffff, VQK_ERR_SHAPE);
     const int cols = n / group;
+    const int mthreads = hw * c >= 4096 ? 1024 : 256;             // one block per group column
     hipStream_t st = vqk_stream(stream);
     if (!backward) {
         if (dtype == VQK_F32) {
-            hipLaunchKernelGGL(mbstd_stat_kernel<float>, dim3(cols), dim3(256), 0, st, (const float*)x, n, hw * c, group, stat);
+            hipLaunchKernelGGL(mbstd_stat_kernel<float>, dim3(cols), dim3(mthreads), 0, st, (const float*)x, n, hw * c, group, stat);
             hipLaunchKernelGGL(mbstd_concat_kernel<float>, dim3(vqk_grid_1d((int64_t)n * hw * cpad, 256)), dim3(256), 0, st, (const float*)x, stat, (float*)out, n, hw, c, cpad, cols);
         } else if (dtype == VQK_BF16) {
-            hipLaunchKernelGGL(mbstd_stat_kernel<bf16_raw>, dim3(cols), dim3(256), 0, st, (const bf16_raw*)x, n, hw * c, group, stat);
+            hipLaunchKernelGGL(mbstd_stat_kernel<bf16_raw>, dim3(cols), dim3(mthreads), 0, st, (const bf16_raw*)x, n, hw * c, group, stat);
             hipLaunchKernelGGL(mbstd_concat_kernel<bf16_raw>, dim3(vqk_grid_1d((int64_t)n * hw * cpad, 256)), dim3(256), 0, st, (const bf16_raw*)x, stat, (bf16_raw*)out, n, hw, c, cpad, cols);
         } else return VQK_ERR_DTYPE;
     } else {
-        if (dtype == VQK_F32) hipLaunchKernelGGL(mbstd_bwd_kernel<float>, dim3(cols), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)out, n, hw, c, cpad, group);
-        else if (dtype == VQK_BF16) hipLaunchKernelGGL(mbstd_bwd_kernel<bf16_raw>, dim3(cols), dim3(256), 0, st, (const bf16_raw*)x, (const bf16_raw*)dy, (bf16_raw*)out, n, hw, c, cpad, group);
+        if (dtype == VQK_F32) hipLaunchKernelGGL(mbstd_bwd_kernel<float>, dim3(cols), dim3(mthreads), 0, st, (const float*)x, (const float*)dy, (float*)out, n, hw, c, cpad, group);
+        else if (dtype == VQK_BF16) hipLaunchKernelGGL(mbstd_bwd_kernel<bf16_raw>, dim3(cols), dim3(mthreads), 0, st, (const bf16_raw*)x, (const bf16_raw*)dy, (bf16_raw*)out, n, hw, c, cpad, group);
         else return VQK_ERR_DTYPE;
     }
     VQK_CHECK_LAUNCH();

@@ -38,7 +38,7 @@ _DET_TLS = threading.local()           # the library's flag is per HOST THREAD (
 _DET_GEN = 0                           # every thread tracks what IT armed, against the generation of the last mode switch
 _DET_WS_BYTES = 64 << 20
 _SCRATCH: dict = {}
-_SCRATCH_BYTES = 8 << 20
+_SCRATCH_BYTES = 32 << 20
 
 
 def _stream() -> int:
@@ -46,7 +46,7 @@ def _stream() -> int:
     library's per-thread workspace follows the stream (partial sums of two concurrent streams must not share a buffer), and
     where a thread that was armed before the mode was switched off disarms itself."""
     s = torch.cuda.current_stream().cuda_stream
-    if getattr(_DET_TLS, 'scratch', None) != s:                  # split-K scratch of this stream (zero on entry, left zero)
+    if getattr(_DET_TLS, 'scratch', None) != s:                  # split-K scratch of this stream (private slices per split)
         dev = torch.cuda.current_device()
         sc = _SCRATCH.get((dev, s))
         if sc is None:
