@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     const int s_begin = skws ? (int)blockIdx.y * steps_per_split : 0;
     const int s_end = skws ? min(ksteps, s_begin + steps_per_split) : ksteps;
 
-    for (int s = s_begin; s < s_end; ++s) {
+    // (a second LDS stage -- loads of step s + 1 in flight under the MFMAs of step s -- was measured on the VQ-GAN layer list:
+    // no gain on small grids, -15 % on large ones, where it halves the resident blocks; tools/db_sweep.sh, round 3)
+    auto stage = [&](int s, int boff) {
         // ---------------- stage: 4 A + 4 B 16-byte pieces per lane
         int tap_u = 0, kh_u = 0, kw_u = 0, cbase_u = 0;
         if (FASTK) {
@@ -214,13 +216,16 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             ok = ok && ih >= 0 && ih < g.vh && iw >= 0 && iw < g.vw && !(g.zs && ((ih | iw) & 1));
             const T* src = a_img[t] + ((int64_t)(ih >> g.ups) * g.w_in + (iw >> g.ups)) * g.cin + coff * EPC;
             const void* sa = ok ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(zeros);
-            glds16(sa, lds_a + (4 * wave + t) * 1024);
+            glds16(sa, lds_a + boff + (4 * wave + t) * 1024);
             const bool okb = b_ok[t] && gch < g.kchunks;
             const int wch = g.sub ? (kh * g.ks + kw) * g.cpt + coff : gch;       // chunk inside the full weight row
             const void* sb = okb ? reinterpret_cast<const void*>(b_row[t] + (int64_t)wch * 16)
                                  : reinterpret_cast<const void*>(zeros);
-            glds16(sb, lds_b + (4 * wave + t) * 1024);
+            glds16(sb, lds_b + boff + (4 * wave + t) * 1024);
         }
+    };
+    for (int s = s_begin; s < s_end; ++s) {
+        stage(s, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // ---------------- compute: 4 k-substeps of two 16-byte chunks
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
                 const int co = n0 + wn * 64 + j * 32 + 8 * rq + 4 * okg;
                 if (co >= g.cout) continue;
                 if (skws) {                                      // split-K partial -> this split's private slice (plain stores;
-                    float* sl = skws + (int64_t)blockIdx.y * g.m * g.cout + orow + co;   // conv_splitk_epilogue_kernel sums them)
+                    float* sl = skws + ((int64_t)blockIdx.y * g.m + m) * g.cout + co;    // conv_splitk_epilogue_kernel sums them)
                     if (co + 3 < g.cout && (g.cout & 3) == 0) {
                         const f32x4 pv = {acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]};
                         *reinterpret_cast<f32x4*>(sl) = pv;
@@ -308,16 +313,26 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
 // fp32 atomics per 8x8 conv were most of its 123 us), no zero-initialised scratch, the same bits every run.
 template <typename TO>
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
-                                                                   const TO* __restrict__ res, TO* __restrict__ y, int64_t total,
-                                                                   int cout, float acc_scale, float out_gain, int act, int splits) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                                   const TO* __restrict__ res, TO* __restrict__ y, ConvGeom g,
+                                                                   int act, int splits) {
+    const int64_t total = (int64_t)g.m * g.cout;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;       // 4 consecutive couts (cout % 4 == 0: launcher)
     if (i >= total) return;
-    const int co = (int)(i % cout);
-    float a = 0.0f;
-    for (int sidx = 0; sidx < splits; ++sidx) a += ws[(int64_t)sidx * total + i];
-    float v = epi_act(a * acc_scale + (bias ? bias[co] : 0.0f), act) * out_gain;
-    if (res) v += Elem<TO>::ld(res + i);
-    Elem<TO>::st(y + i, v);
+    const int m = (int)(i / g.cout), co = (int)(i - (int64_t)m * g.cout);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int sidx = 0; sidx < splits; ++sidx) a += *reinterpret_cast<const f32x4*>(ws + (int64_t)sidx * total + i);
+    int64_t orow = (int64_t)m * g.cout;
+    if (g.sub) {                                                 // one output-parity class of a zero-stuffed conv
+        const int hw = g.sub_h * g.sub_w;
+        const int img = m / hw, rem = m - img * hw;
+        const int pa = rem / g.sub_w, pb = rem - pa * g.sub_w;
+        orow = (((int64_t)img * g.h + 2 * pa + g.sub_py) * g.w + 2 * pb + g.sub_px) * g.cout;
+    }
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = epi_act(a[e] * g.acc_scale + (bias ? bias[co + e] : 0.0f), act) * g.out_gain;
+    if (res) add4(res + orow + co, v);
+    store4(y + orow + co, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2121,10 +2136,15 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         const int tiles = g.tiles_m * g.tiles_n, ksteps = (g.kchunks + 7) >> 3;
         const int64_t out_elems = (int64_t)g.m * g.cout;
         static const int sk_on = getenv("VQK_FPROP_SPLITK") ? atoi(getenv("VQK_FPROP_SPLITK")) : 1;
-        if (sk_on && sc.ws && !g.sub && tiles <= 32 && ksteps >= 16 && 2 * out_elems * 4 <= sc.bytes) {
-            int splits = 256 / tiles;
-            if (splits > ksteps / 2) splits = ksteps / 2;
-            if ((int64_t)splits * out_elems * 4 > sc.bytes) splits = (int)(sc.bytes / (out_elems * 4));
+        // (this kernel runs one k-step at a time per block: below ~4 blocks per CU nothing hides its load -> LDS -> MFMA latency)
+        static const int sk_blocks = getenv("VQK_SK_BLOCKS") ? atoi(getenv("VQK_SK_BLOCKS")) : 2048;
+        static const int sk_minsteps = getenv("VQK_SK_MINSTEPS") ? atoi(getenv("VQK_SK_MINSTEPS")) : 4;
+        static const int sk_maxmb = getenv("VQK_SK_MAXMB") ? atoi(getenv("VQK_SK_MAXMB")) : 32;
+        int splits = tiles * 2 <= sk_blocks ? sk_blocks / tiles : 1;
+        if (splits > ksteps / sk_minsteps) splits = ksteps / sk_minsteps;
+        if ((int64_t)splits * out_elems * 4 > ((int64_t)sk_maxmb << 20)) splits = (int)(((int64_t)sk_maxmb << 20) / (out_elems * 4));
+        if (sc.ws && (int64_t)splits * out_elems * 4 > sc.bytes) splits = (int)(sc.bytes / (out_elems * 4));
+        if (sk_on && sc.ws && (g.cout & 3) == 0 && splits >= 2) {
             const int sps = (ksteps + splits - 1) / splits;
             splits = (ksteps + sps - 1) / sps;
             const dim3 sgrid((unsigned)tiles, (unsigned)splits);
@@ -2134,8 +2154,8 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
             else
                 hipLaunchKernelGGL((conv_fprop_kernel<T, TO, false>), sgrid, dim3(256), 32768, st, (const T*)x, (const T*)w, bias,
                                    (const TO*)res, (TO*)y, (const char*)zeros, g, act, sc.ws, sps);
-            hipLaunchKernelGGL(conv_splitk_epilogue_kernel<TO>, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, st, sc.ws, bias,
-                               (const TO*)res, (TO*)y, out_elems, g.cout, g.acc_scale, g.out_gain, act, splits);
+            hipLaunchKernelGGL(conv_splitk_epilogue_kernel<TO>, dim3((unsigned)((out_elems / 4 + 255) / 256)), dim3(256), 0, st, sc.ws, bias,
+                               (const TO*)res, (TO*)y, g, act, splits);
             if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
             return VQK_OK;
         }

@@ -38,7 +38,7 @@ _DET_TLS = threading.local()           # the library's flag is per HOST THREAD (
 _DET_GEN = 0                           # every thread tracks what IT armed, against the generation of the last mode switch
 _DET_WS_BYTES = 64 << 20
 _SCRATCH: dict = {}
-_SCRATCH_BYTES = 32 << 20
+_SCRATCH_BYTES = 64 << 20
 
 
 def _stream() -> int:
