@@ -1527,27 +1527,35 @@ class ConvActFn(torch.autograd.Function):
         want_db = bias is not None and ctx.needs_input_grad[2]
         dyn = nhwc(dy)
         dbsum = None
-        if want_db and dyn.dtype == dt:                      # the bias gradient rides in the act-backward pass
-            dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
-        t = ActBwdFn.apply(dyn, y, act, float(out_gain), dbsum)
+        gscale = 1.0
+        if act == 0 and dyn.dtype == dt:
+            # linear layer (the discriminator's skip convs, its last fully connected layer): t = out_gain * dy is no pass over
+            # the tensor -- the scalar rides in the data- / weight-gradient scale (and on the bias sum)
+            t, gscale = dyn, float(out_gain)
+        else:
+            if want_db and dyn.dtype == dt:                  # the bias gradient rides in the act-backward pass
+                dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
+            t = ActBwdFn.apply(dyn, y, act, float(out_gain), dbsum)
         tc = t if t.dtype == dt else nhwc(t.to(dt))
         n, _, h, w = x.shape
         _, _, h_out, w_out = tc.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ConvDgradFn.apply(tc, weight, k, stride, pad, float(wgain), cin, cout_pad, h, w)
+            dx = ConvDgradFn.apply(tc, weight, k, stride, pad, float(wgain) * gscale, cin, cout_pad, h, w)
         if ctx.needs_input_grad[1]:
             tcd = tc.detach()
             dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=x.device)
             _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tcd.data_ptr(), dwp.data_ptr(), n, h, w, cin,
                                                        cout_pad, k, stride, pad, 0, h_out, w_out,
                                                        zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
-            if wgain != 1.0:
-                _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain), 0.0, dwp.numel(), st), 'axpby')
+            if wgain * gscale != 1.0:
+                _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain) * gscale, 0.0, dwp.numel(), st), 'axpby')
             dw = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
         if want_db:
             fused = dbsum is not None and cout_pad % (4 if dt == torch.float32 else 8) == 0 and cout_pad // (4 if dt == torch.float32 else 8) <= 256
             db = (dbsum if fused else raw_colsum(n * h_out * w_out, cout_pad, tc.detach()))[:o]
+            if gscale != 1.0:
+                db = db * gscale
         return dx, dw, db, None, None, None, None, None, None, None
 
 
