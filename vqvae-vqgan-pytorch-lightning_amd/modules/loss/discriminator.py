@@ -114,7 +114,12 @@ class MinibatchStdLayer(nn.Module):
             raise NotImplementedError('one minibatch-stddev feature (the default) is built')
         self.group_size, self.num_channels = group_size, num_channels
 
-    def forward(self, x):
+    def forward(self, x, halves: int = 1):
+        """halves > 1: x is `halves` independent batches concatenated (real | fake in one discriminator pass): the statistic
+        groups samples inside each batch exactly as separate calls would (discriminator.py:277-293)"""
+        if halves > 1:
+            return torch.cat([ops.MbstdFn.apply(c, self.group_size if self.group_size is not None else c.shape[0])
+                              for c in x.chunk(halves, 0)], 0)
         return ops.MbstdFn.apply(x, self.group_size if self.group_size is not None else x.shape[0])
 
 
@@ -130,9 +135,9 @@ class DiscriminatorEpilogue(nn.Module):
         self.fc = FullyConnectedLayer(in_channels * (resolution ** 2), in_channels, activation=activation)
         self.out = FullyConnectedLayer(in_channels, 1)
 
-    def forward(self, x, img=None, cmap=None):
+    def forward(self, x, img=None, cmap=None, halves: int = 1):
         if self.mbstd is not None:
-            x = self.mbstd(x)
+            x = self.mbstd(x, halves)
         x = self.conv(x)[:, :self.in_channels]
         x = x.permute(0, 1, 2, 3).reshape(x.shape[0], -1)      # flatten(1) of the LOGICAL NCHW tensor (c, h, w order)
         x = self.fc(x)
@@ -161,9 +166,10 @@ class Discriminator(nn.Module):
         self.b4 = DiscriminatorEpilogue(ch[4], cmap_dim=0, resolution=4, img_channels=img_channels,
                                         architecture=architecture, **(epilogue_kwargs or {}))
 
-    def forward(self, img, **_):
+    def forward(self, img, halves: int = 1, **_):
+        """halves: number of independent batches concatenated along dim 0 (only the minibatch-stddev layer couples samples)"""
         img = _to_internal(img, self.compute_dtype)
         x = None
         for res in self.block_resolutions:
             x, _unused = getattr(self, f'b{res}')(x, img)
-        return self.b4(x)
+        return self.b4(x, halves=halves)

@@ -3,12 +3,17 @@
 
 R1 regularisation (loss.py:98-112) is built on double-differentiable backward pieces (``ops.ConvDgradFn``,
 ``ops.ActBwdFn``, ``ops.MbstdBwdFn``, ``ops.UpfirdnNhwcFn``).  ``VQLPIPS`` (AlexNet ablation) is out of scope."""
+import os
+
 import torch
 from torch import nn
 
 from ... import ops
 from .discriminator import Discriminator
 from .lpips import LPIPS
+from ..autoencoder import _to_internal
+
+BATCHED_DISC = os.environ.get('VQK_BATCHED_DISC', '1') == '1'    # discriminator step: real | fake in one pass (0: two passes)
 
 _MODE = {'hinge': 0, 'non-saturating': 1}
 
@@ -79,8 +84,15 @@ class VQLPIPSWithDiscriminator(nn.Module):
             compute_r1 = (self.training and current_step % self.r1_regularization_every == 0
                           and self.r1_regularization_cost is not None)
             images = images.detach().requires_grad_(compute_r1)
-            logits_real = self.discriminator(images)
-            logits_fake = self.discriminator(reconstructions.detach())
+            if BATCHED_DISC and not compute_r1 and images.shape[0] == reconstructions.shape[0] and images.shape[2:] == reconstructions.shape[2:]:
+                # real | fake through the discriminator as ONE batch (same logits: only the minibatch-stddev layer couples
+                # samples and it groups inside each half): half the launches, no per-parameter gradient accumulation
+                dt = self.discriminator.compute_dtype
+                both = torch.cat([_to_internal(images, dt), _to_internal(reconstructions.detach(), dt)], 0)
+                logits_real, logits_fake = self.discriminator(both, halves=2).chunk(2, 0)
+            else:
+                logits_real = self.discriminator(images)
+                logits_fake = self.discriminator(reconstructions.detach())
             d_loss = discriminator_loss(logits_real, logits_fake, loss_type=self.adversarial_loss_type)
             r1_term = self.calculate_r1_regularization_term(logits_real, images, compute_r1)
             return d_loss + r1_term, d_loss, r1_term
