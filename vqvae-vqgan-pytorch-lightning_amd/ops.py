@@ -1528,6 +1528,14 @@ class ConvActFn(torch.autograd.Function):
         dyn = nhwc(dy)
         dbsum = None
         gscale = 1.0
+        # weight gradient straight into the optimizer's flat gradient arena (unpadded layers of a FlatAdamW-owned module): the
+        # 1/sqrt(fan_in) weight gain then rides in t (t' = wgain * t: dx = dgrad(t', W), dW += wgrad(x, t'), db = colsum(t') / wgain)
+        # -- no zero-filled temporary, no scale pass, no accumulate pass per parameter
+        tgt = None
+        if (ctx.needs_input_grad[1] and act != 0 and dyn.dtype == dt and cout_pad == o and cin == i and wgain > 0.0
+                and not torch.is_grad_enabled()):            # (a create_graph pass -- R1's inner autograd.grad -- must not touch .grad)
+            tgt = direct_grad(weight)
+        fold = float(wgain) if tgt is not None else 1.0
         if act == 0 and dyn.dtype == dt:
             # linear layer (the discriminator's skip convs, its last fully connected layer): t = out_gain * dy is no pass over
             # the tensor -- the scalar rides in the data- / weight-gradient scale (and on the bias sum)
@@ -1535,14 +1543,18 @@ class ConvActFn(torch.autograd.Function):
         else:
             if want_db and dyn.dtype == dt:                  # the bias gradient rides in the act-backward pass
                 dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
-            t = ActBwdFn.apply(dyn, y, act, float(out_gain), dbsum)
+            t = ActBwdFn.apply(dyn, y, act, float(out_gain) * fold, dbsum)
         tc = t if t.dtype == dt else nhwc(t.to(dt))
         n, _, h, w = x.shape
         _, _, h_out, w_out = tc.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ConvDgradFn.apply(tc, weight, k, stride, pad, float(wgain) * gscale, cin, cout_pad, h, w)
-        if ctx.needs_input_grad[1]:
+            dx = ConvDgradFn.apply(tc, weight, k, stride, pad, 1.0 if tgt is not None else float(wgain) * gscale, cin, cout_pad, h, w)
+        if tgt is not None:
+            _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tc.detach().data_ptr(), tgt.data_ptr(), n, h, w, cin,
+                                                       cout_pad, k, stride, pad, 0, h_out, w_out,
+                                                       zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
+        elif ctx.needs_input_grad[1]:
             tcd = tc.detach()
             dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=x.device)
             _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tcd.data_ptr(), dwp.data_ptr(), n, h, w, cin,
@@ -1554,8 +1566,8 @@ class ConvActFn(torch.autograd.Function):
         if want_db:
             fused = dbsum is not None and cout_pad % (4 if dt == torch.float32 else 8) == 0 and cout_pad // (4 if dt == torch.float32 else 8) <= 256
             db = (dbsum if fused else raw_colsum(n * h_out * w_out, cout_pad, tc.detach()))[:o]
-            if gscale != 1.0:
-                db = db * gscale
+            if gscale != 1.0 or fold != 1.0:
+                db = db * (gscale / fold)
         return dx, dw, db, None, None, None, None, None, None, None
 
 
