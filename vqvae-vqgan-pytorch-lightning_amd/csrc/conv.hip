@@ -1030,9 +1030,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(const bf16_raw*
             const int tap = 2 * s5 + kg;
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
             const bool ok = tap < 9 && (unsigned)(yy + dy) < (unsigned)g.h && (unsigned)(px + dx) < (unsigned)g.w;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4*>(xrow + ((int64_t)dy * g.w + dx) * 8);
-            a[s5] = __builtin_bit_cast(bf16x8_t, v);
+            // unconditional load at a valid address + select (an `if (ok) load` is an exec-masked block with its own wait:
+            // the five loads of a tile would return one after the other)
+            const u32x4 ld = *reinterpret_cast<const u32x4*>(ok ? xrow + ((int64_t)dy * g.w + dx) * 8 : xrow);
+            const u32x4 zero4 = {0u, 0u, 0u, 0u};
+            a[s5] = __builtin_bit_cast(bf16x8_t, ok ? ld : zero4);
         }
     };
     int t = (int)blockIdx.x * 4 + wave;
