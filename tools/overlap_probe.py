@@ -7,9 +7,10 @@ import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
 
 
-def run(n, c, h, w, L=8, reps=6):
+def run(n, c, h, w, L=8, reps=6, cap=0):
     dev = 'cuda'
     g = torch.Generator().manual_seed(0)
     x = ops.nhwc((torch.randn(n, c, h, w, generator=g)).to(torch.bfloat16).to(dev))
@@ -46,6 +47,7 @@ def run(n, c, h, w, L=8, reps=6):
         full()
 
     def t_pipe():
+        native.lib().vqk_conv_set_block_caps(cap, cap)        # persistent conv grid capped: room for the GroupNorm blocks
         e = torch.cuda.Event()
         cur = torch.cuda.current_stream()
         s1.wait_stream(cur); s2.wait_stream(cur)
@@ -54,6 +56,7 @@ def run(n, c, h, w, L=8, reps=6):
         with torch.cuda.stream(s2):
             fb(wait_evt=e)
         cur.wait_stream(s1); cur.wait_stream(s2)
+        native.lib().vqk_conv_set_block_caps(0, 0)
 
     out = {}
     for name, fn in (('serial', t_serial), ('pipelined', t_pipe)):
@@ -67,12 +70,12 @@ def run(n, c, h, w, L=8, reps=6):
         e1.record()
         torch.cuda.synchronize()
         out[name] = e0.elapsed_time(e1) / reps
-    print(f'n{n} c{c} {h}x{w} L={L}: serial {out["serial"]:.3f} ms, pipelined halves {out["pipelined"]:.3f} ms '
+    print(f'n{n} c{c} {h}x{w} L={L} cap={cap}: serial {out["serial"]:.3f} ms, pipelined halves {out["pipelined"]:.3f} ms '
           f'({100 * (1 - out["pipelined"] / out["serial"]):+.1f} % saved)')
 
 
 if __name__ == '__main__':
-    run(32, 128, 256, 256)
-    run(32, 256, 128, 128)
-    run(32, 128, 128, 128)
-    run(32, 256, 64, 64)
+    for cap in (0, 448, 384, 320, 256):
+        run(32, 128, 256, 256, cap=cap)
+    for cap in (0, 384, 320):
+        run(32, 256, 128, 128, cap=cap)
