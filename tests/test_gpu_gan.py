@@ -274,3 +274,63 @@ def test_lpips_tap_forward_backward(dtype, shape):
     (out * up.to(DEV)).sum().backward()
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5 if dtype == torch.float32 else 1e-4)
     assert rel(fyd.grad.float(), fy_ref.grad) < (1e-5 if dtype == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [
+    # (n, cin, cout, h, k, stride, pad): the discriminator's small maps -- grids of 8-150 tiles with K up to 4608, where the
+    # general conv kernel splits K through private scratch slices (forward, and the zero-stuffed data gradient of the strided ones)
+    (16, 512, 512, 8, 3, 1, 1), (16, 512, 512, 4, 3, 1, 1), (16, 512, 512, 17, 3, 2, 0), (16, 512, 512, 9, 3, 2, 0),
+    (4, 256, 512, 33, 3, 2, 0), (16, 512, 512, 8, 1, 1, 0), (3, 520, 512, 4, 3, 1, 1)])
+def test_conv_act_small_maps_split_k(dtype, case):
+    """conv + bias + lrelu + gain, its data / weight / bias gradients against fp64 torch autograd on operands exact in the
+    compute dtype (the split-K epilogue kernel, the parity-class mapping of the zero-stuffed gradient, direct accumulation off)"""
+    n, cin, cout, h, k, stride, pad = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, h, generator=g).to(dtype).float()
+    w = torch.randn(cout, cin, k, k, generator=g).to(dtype).float()
+    b = torch.randn(cout, generator=g)
+    wgain, gain = 1.0 / (cin * k * k) ** 0.5, 2 ** 0.5
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xr, wr * wgain, br, stride=stride, padding=pad), 0.2) * gain
+    up = torch.randn(ref.shape, generator=g).to(dtype).float()
+    ref.backward(up.double())
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True)
+    y = ops.conv_act(xd, wd, bd, k=k, stride=stride, pad=pad, act='lrelu', wgain=wgain, out_gain=gain)
+    y.backward(up.to(DEV).to(y.dtype))
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    assert rel(y.float(), ref) < tol
+    assert rel(xd.grad.float(), xr.grad) < tol
+    assert rel(wd.grad.float(), wr.grad) < tol
+    assert rel(bd.grad.float(), br.grad) < tol
+
+
+def test_discriminator_step_batched_equals_two_passes():
+    """real | fake as ONE discriminator pass (loss.BATCHED_DISC) against the reference's two passes (loss.py:82-83): same
+    logits-derived loss, same parameter gradients (fp32; only the summation order of the weight gradients differs)"""
+    torch.manual_seed(3)
+    d = disc.Discriminator(32, channel_base=1024, channel_max=64).to(DEV)
+    crit = loss_mod.VQLPIPSWithDiscriminator.__new__(loss_mod.VQLPIPSWithDiscriminator)
+    torch.nn.Module.__init__(crit)
+    crit.discriminator = d
+    crit.adversarial_start_epoch, crit.adversarial_loss_type = 0, 'non-saturating'
+    crit.r1_regularization_every, crit.r1_regularization_cost = 16, 10.0
+    crit.train()
+    real = torch.randn(8, 3, 32, 32, device=DEV)
+    fake = torch.randn(8, 3, 32, 32, device=DEV)
+    out = []
+    for batched in (True, False):
+        loss_mod.BATCHED_DISC = batched
+        try:
+            d.zero_grad()
+            loss, d_loss, r1 = crit.forward_discriminator(real, fake, 0, 1)        # step 1: no R1
+            loss.backward()
+            out.append((loss.detach().clone(), [p.grad.detach().clone() for p in d.parameters()]))
+        finally:
+            loss_mod.BATCHED_DISC = True
+    (l1, g1), (l2, g2) = out
+    assert abs(l1.item() - l2.item()) < 1e-5 * max(1.0, abs(l2.item()))
+    for a, b in zip(g1, g2):
+        assert rel(a, b) < 1e-4
