@@ -823,6 +823,7 @@ class GroupNormSiLUFn(torch.autograd.Function):
 POOLED_BWD = os.environ.get('VQK_POOLED_BWD', '1') != '0'      # ResBlock + fused avg-pool: the backward keeps the gradient pooled
 OVERLAP_WGRAD = os.environ.get('VQK_OVERLAP_WGRAD', '1') == '1'
 OVERLAP_MODE = int(os.environ.get('VQK_OVERLAP_MODE', '3'))
+OVERLAP_WAIT_MIN_HW = int(os.environ.get('VQK_OVERLAP_WAIT_MIN_HW', '0'))   # maps below this many pixels: dgrad1 does not wait for wgrad2
 OVERLAP_STREAM_BLOCKS = int(os.environ.get('VQK_OVERLAP_STREAM_BLOCKS', '512'))
 OVERLAP_WGRAD_BLOCKS = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS', '320'))   # swept 192...512 with the 8x16-patch wgrad: flat 224...320
 _SIDE_STREAMS: dict = {}
@@ -974,7 +975,7 @@ class ResBlockFn(torch.autograd.Function):
                         raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
                     d_a1, _ = conv_bwd(a1, d_r1, c1w, 3, cin, cout, need_dw=False)
                 else:
-                    if OVERLAP_MODE == 3:
+                    if OVERLAP_MODE == 3 and h * w >= OVERLAP_WAIT_MIN_HW:
                         main.wait_stream(side)           # dgrad1 alone on the chip
                     d_a1, _ = conv_bwd(a1, d_r1, c1w, 3, cin, cout, need_dw=False)
                     side.wait_stream(main)
