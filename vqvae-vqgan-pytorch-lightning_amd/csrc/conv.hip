@@ -121,7 +121,6 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
     const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
     const int mt = tile / g.tiles_n, nt = tile - mt * g.tiles_n;
     const int m0 = mt * 128, n0 = nt * 128;
-    const int pad = g.ks >> 1;
 
     // ---- per-lane load slots: 4 A rows + 4 B rows (row = 8*(4*wave+t) + lane/8), fixed over K
     int a_oh[4], a_ow[4];
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
 
     // (a second LDS stage -- loads of step s + 1 in flight under the MFMAs of step s -- was measured on the VQ-GAN layer list:
     // no gain on small grids, -15 % on large ones, where it halves the resident blocks; tools/db_sweep.sh, round 3)
-    auto stage = [&](int s, int boff) {
+    auto stage = [&](int s) {
         // ---------------- stage: 4 A + 4 B 16-byte pieces per lane
         int tap_u = 0, kh_u = 0, kw_u = 0, cbase_u = 0;
         if (FASTK) {
@@ -216,16 +215,16 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(const T* __restrict_
             ok = ok && ih >= 0 && ih < g.vh && iw >= 0 && iw < g.vw && !(g.zs && ((ih | iw) & 1));
             const T* src = a_img[t] + ((int64_t)(ih >> g.ups) * g.w_in + (iw >> g.ups)) * g.cin + coff * EPC;
             const void* sa = ok ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(zeros);
-            glds16(sa, lds_a + boff + (4 * wave + t) * 1024);
+            glds16(sa, lds_a + (4 * wave + t) * 1024);
             const bool okb = b_ok[t] && gch < g.kchunks;
             const int wch = g.sub ? (kh * g.ks + kw) * g.cpt + coff : gch;       // chunk inside the full weight row
             const void* sb = okb ? reinterpret_cast<const void*>(b_row[t] + (int64_t)wch * 16)
                                  : reinterpret_cast<const void*>(zeros);
-            glds16(sb, lds_b + boff + (4 * wave + t) * 1024);
+            glds16(sb, lds_b + (4 * wave + t) * 1024);
         }
     };
     for (int s = s_begin; s < s_end; ++s) {
-        stage(s, 0);
+        stage(s);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // ---------------- compute: 4 k-substeps of two 16-byte chunks
@@ -1186,7 +1185,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
     const int tiles_ci = (g.cin + 127) >> 7;
     const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
     const int co0 = tco * 128, ci0 = tci * 128;
-    const int tap = blockIdx.y, kh = tap / g.ks, kw = tap - kh * g.ks, pad = g.ks >> 1;
+    const int tap = blockIdx.y, kh = tap / g.ks, kw = tap - kh * g.ks;
     const int p_begin = blockIdx.z * pix_per_split;
     const int p_end = min(g.m, p_begin + pix_per_split);
 
@@ -1372,7 +1371,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<float>(const float* 
     const int tiles_ci = (g.cin + 127) >> 7;
     const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
     const int co0 = tco * 128, ci0 = tci * 128;
-    const int tap = blockIdx.y, kh = tap / g.ks, kw = tap - kh * g.ks, pad = g.ks >> 1;
+    const int tap = blockIdx.y, kh = tap / g.ks, kw = tap - kh * g.ks;
     const int p_begin = blockIdx.z * pix_per_split;
     const int p_end = min(g.m, p_begin + pix_per_split);
 
