@@ -414,7 +414,10 @@ def main():
                                yaml=os.path.relpath(conf_path, ROOT), yaml_overrides=conf_over,
                                learning_rate=run['learning_rate'],
                                global_batch=world * args.batch, parallelism=f'dp{world}',
-                               launch=(('two hipGraphs (fwd + decoder bwd | quantizer + encoder bwd), decoder-range all-reduce under the second, '
+                               launch=(('three hipGraphs (fwd + decoder bwd | quantizer + deep encoder bwd | encoder head bwd), decoder-range '
+                                        'all-reduce under the second, deep-encoder range under the third, head all-reduce, AdamW')
+                                       if (use_graph and getattr(trainer, '_graph3', None) is not None) else
+                                       ('two hipGraphs (fwd + decoder bwd | quantizer + encoder bwd), decoder-range all-reduce under the second, '
                                         'tail all-reduce, AdamW') if (use_graph and getattr(trainer, '_graph2', None) is not None) else
                                        'three hipGraphs (AE half | discriminator half | discriminator half + R1), optimizer steps between' if (use_graph and args.gan) else
                                        'hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),

@@ -154,6 +154,23 @@ def _ranged_worker(rank, world, port, out):
     opt.flat_g.copy_(mine)
     opt.all_reduce_grads()
     assert torch.equal(two, opt.flat_g) and opt.grad_scale == 1.0 / world
+    # three-stage form (the encoder's high-resolution head laid out LAST): front | rest | back, the trainer's three ranges
+    trainer_mod = importlib.import_module(PKG + '.trainer')
+    qs = [torch.nn.Parameter(torch.randn(s)) for s in ((5, 3), (70,), (4, 4, 3, 3), (9,))]
+    opt3 = optim.FlatAdamW(qs, lr=1e-3, betas=(0.0, 0.99), arena_front={id(qs[2]), id(qs[3])}, arena_back={id(qs[0])})
+    assert opt3.front_numel == 256 and opt3.offsets[id(qs[1])] == 256 and opt3.offsets[id(qs[0])] == opt3.back_start == 384
+    assert opt3.seg_end.tolist() == sorted(opt3.seg_end.tolist())
+    opt3.flat_g.copy_(mine[:opt3.flat_g.numel()])
+    ranges = trainer_mod.MiniTrainer._ranges(opt3, 3)
+    assert ranges == [(0, 256), (256, 384), (384, opt3.flat_g.numel())]
+    for w in [opt3.all_reduce_range(lo, hi) for lo, hi in ranges]:
+        w.wait()
+    three = opt3.flat_g.clone()
+    opt3.flat_g.copy_(mine[:opt3.flat_g.numel()])
+    opt3.all_reduce_grads()
+    assert torch.equal(three, opt3.flat_g)
+    no_back = optim.FlatAdamW([torch.nn.Parameter(torch.randn(8))], lr=1e-3)
+    assert no_back.back_start == no_back.flat_g.numel()
     if rank == 0:
         out.put('ok')
     dist.barrier()

@@ -28,7 +28,8 @@ def _qc(qtype):
 
 def _env(rank, world, port):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
-                      WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY='0',
+                      VQK_SPLIT_ENCODER_FRACTION='0.5')      # the tiny test encoder gets a cut too (default 0.12: none)
 
 
 def _trajectory(qtype, force, steps=4):
@@ -71,10 +72,20 @@ def _world1_worker(rank, port, out):
         before = calls['n']
         l1, s1 = _trajectory(qtype, force=True)
         issued = calls['n'] - before
-        # 2 eager warm-up steps + 4 replays, TWO gradient all-reduces each (the decoder's arena range under the encoder's
-        # backward -- two captured graphs --, then the rest); the 4 replays also finish the deferred EMA update with its
-        # statistics all-reduce (the eager warm-up steps update inline: world size 1 needs no collective there)
-        assert issued == (16 if qtype == 'ema' else 12), (qtype, issued)
+        # 2 eager warm-up steps + 4 replays, THREE gradient all-reduces each (the decoder's arena range under the encoder's
+        # backward, the quantizer + deep encoder levels under the encoder head's backward -- three captured graphs --, then
+        # the head); the 4 replays also finish the deferred EMA update with its statistics all-reduce (the eager warm-up
+        # steps update inline: world size 1 needs no collective there)
+        assert issued == (22 if qtype == 'ema' else 18), (qtype, issued)
+        # backward cut at the decoder's input only (VQK_SPLIT_ENCODER=0): two all-reduces per step
+        os.environ['VQK_SPLIT_ENCODER'] = '0'
+        try:
+            before = calls['n']
+            l3, s3 = _trajectory(qtype, force=True)
+            assert calls['n'] - before == (16 if qtype == 'ema' else 12), (qtype, calls['n'] - before)
+        finally:
+            os.environ['VQK_SPLIT_ENCODER'] = '1'
+        np.testing.assert_allclose(l1, l3, rtol=2e-3)
         # the single-collective form (VQK_OVERLAP_ALLREDUCE=0): one all-reduce per step, same trajectory
         trainer_mod.MiniTrainer.OVERLAP_ALLREDUCE = False
         try:
@@ -98,6 +109,29 @@ def _world1_worker(rank, port, out):
             total += s0[k].numel()
         assert bad <= 0.02 * total, (qtype, bad, total)
         res[qtype] = l1
+    # the three-stage backward (cuts at the decoder's input and behind the encoder's high-resolution head, three ranged
+    # all-reduces) leaves the same gradients in the arena as one backward + one flat all-reduce
+    model_mod = importlib.import_module(PKG + '.model')
+    torch.manual_seed(1)
+    m2 = model_mod.VQVAE(32, AE, _qc('standard'), None, TC).to('cuda').train()
+    tr2 = trainer_mod.MiniTrainer(num_training_batches=1)
+    opt2 = tr2.attach(m2)[0]
+    opt2.force_collective = True
+    mine = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(5)).cuda()
+    assert tr2._use_split(m2, opt2) and 0 < opt2.front_numel < opt2.back_start < opt2.flat_g.numel()
+    opt2.zero_grad()
+    tr2._split_step(m2, opt2, mine, 0)
+    assert m2._encoder_cut is not None and len(tr2._backward_halves(m2)) == 3
+    torch.cuda.synchronize()
+    g_split = opt2.flat_g.clone()
+    opt2.zero_grad()
+    m2.training_step(mine, 0).backward()
+    opt2.all_reduce_grads()
+    torch.cuda.synchronize()
+    rel = float((g_split - opt2.flat_g).norm() / opt2.flat_g.norm())
+    assert rel < 1e-5, rel
+    for lo, hi in tr2._ranges(opt2, 3):                      # every range carries gradient
+        assert float(opt2.flat_g[lo:hi].abs().sum()) > 0.0
     dist.destroy_process_group()
     out.put(res)
 
@@ -155,7 +189,7 @@ def _world2_worker(rank, port, out):
     tr2 = trainer_mod.MiniTrainer(num_training_batches=1)
     opt2 = tr2.attach(m2)[0]
     mine = all_images[rank * b:(rank + 1) * b].to(dev)
-    assert tr2._use_split(m2, opt2) and 0 < opt2.front_numel < opt2.flat_g.numel()
+    assert tr2._use_split(m2, opt2) and 0 < opt2.front_numel < opt2.back_start < opt2.flat_g.numel()
     opt2.zero_grad()
     tr2._split_step(m2, opt2, mine, 0)
     torch.cuda.synchronize()

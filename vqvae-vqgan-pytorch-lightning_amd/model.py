@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Any
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -79,8 +81,9 @@ class VQVAE(BaseVQVAE, _LightningBase):
         self.reinit_every_n_epochs = q_conf['reinit_every_n_epochs']
         self.optimizer_param_set = optimizer_param_set
         self.defer_usage_accumulation = False
-        self.split_backward = False            # MiniTrainer (data parallel): backward in two halves around the decoder's input
-        self._backward_cut = self._backward_terms = None
+        self.split_backward = False            # MiniTrainer (data parallel): backward cut at the decoder's input ...
+        self.split_encoder = os.environ.get('VQK_SPLIT_ENCODER', '1') != '0'     # ... and behind the encoder's high-resolution head
+        self._backward_cut = self._backward_terms = self._encoder_cut = None
         self.kl_warmup_epochs = self.temp_decay_epochs = self.temp_final = None
 
         qt, qp = q_conf['type'], q_conf['params']
@@ -177,7 +180,9 @@ class VQVAE(BaseVQVAE, _LightningBase):
     def _step_losses(self, batch, training: bool):
         images = batch[0] if isinstance(batch, (tuple, list)) else batch
         x_pad, target = self._preprocess_train(images, training)                          # clamp, normalise, NHWC
-        z = self.encoder(x_pad)
+        enc_split = self._encoder_split() if (training and self.split_backward and self.split_encoder) else None
+        z = self.encoder(x_pad, cut_after=enc_split) if enc_split is not None else self.encoder(x_pad)
+        self._encoder_cut = self.encoder.last_cut if enc_split is not None else None
         quantized, used_indices, q_loss = self.quantizer(z)
         dec_in = quantized
         if training and self.split_backward:
@@ -351,6 +356,13 @@ class VQVAE(BaseVQVAE, _LightningBase):
         no_decay = [(full, p) for key, (full, p, d) in sorted(seen.items()) if not d]
         return decay, no_decay
 
+    def _encoder_split(self):
+        if not hasattr(self, '_enc_split_cache'):
+            fn = getattr(self.encoder, 'shallow_split', None)
+            frac = float(os.environ.get('VQK_SPLIT_ENCODER_FRACTION', '0.12'))
+            self._enc_split_cache = fn(frac) if (fn is not None and self.split_encoder) else None
+        return self._enc_split_cache
+
     def configure_optimizers(self):
         lr = float(self.t_conf['lr'])
         betas = [float(b) for b in self.t_conf['betas']]
@@ -359,8 +371,12 @@ class VQVAE(BaseVQVAE, _LightningBase):
         groups = [{'params': [p for _, p in decay], 'weight_decay': wd},
                   {'params': [p for _, p in no_decay], 'weight_decay': 0.0}]
         # the decoder's tensors come first in the gradient arena: their all-reduce starts while the encoder's backward runs
+        # ... and the encoder's high-resolution head (few parameters, ready last) at the very end: the only range whose
+        # all-reduce is exposed (trainer.MiniTrainer._split_step)
         front = {id(p) for p in self.decoder.parameters()}
-        ae_optimizer = FlatAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd, arena_front=front)
+        split = self._encoder_split()
+        back = {id(p) for p in self.encoder.shallow_parameters(split)} if split is not None else set()
+        ae_optimizer = FlatAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd, arena_front=front, arena_back=back)
         if isinstance(self.criterion, VQLPIPSWithDiscriminator):                      # model.py:431-438
             disc_optimizer = FlatAdamW(list(self.criterion.discriminator.parameters()), lr=lr, betas=betas, eps=eps,
                                        weight_decay=wd)

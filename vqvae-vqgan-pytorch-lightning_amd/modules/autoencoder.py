@@ -133,24 +133,50 @@ class Encoder(nn.Module):
         self.final_residual = nn.Sequential(*[ResBlock(ch_in) for _ in range(num_res_blocks)])
         self.norm = GroupNorm(32, ch_in, eps=1e-6)
         self.conv_out = Conv2d(ch_in, embedding_dim, 1, bias=True)
+        self.last_cut = None
 
-    def forward(self, x):
+    def shallow_split(self, max_fraction: float = 0.12):
+        """Index of the Downsample that ends the last resolution level whose cumulative parameter count (from the input) is
+        still <= ``max_fraction`` of the encoder's, or None.  The high-resolution levels hold few parameters but most of the
+        backward's time: cutting the backward there lets the deep levels' gradients be all-reduced under it, and leaves only
+        this small head exposed (trainer.MiniTrainer._split_step)."""
+        total = sum(p.numel() for p in self.parameters())
+        cum, best = sum(p.numel() for p in self.conv_in.parameters()), None
+        for i, m in enumerate(self.blocks):
+            cum += sum(p.numel() for p in m.parameters())
+            if isinstance(m, Downsample) and cum <= max_fraction * total and i + 1 < len(self.blocks):
+                best = i
+        return best
+
+    def shallow_parameters(self, split):
+        mods = list(self.blocks)
+        return list(self.conv_in.parameters()) + [p for m in mods[:split + 1] for p in m.parameters()]
+
+    def forward(self, x, cut_after=None):
+        """``cut_after``: index into ``self.blocks`` (``shallow_split()``): the autograd graph is cut behind that module and
+        the pair (tensor before the cut, detached leaf after it) is left in ``self.last_cut``"""
         x = _to_internal(x, self.compute_dtype)
         x = self.conv_in(x)
         mods = list(self.blocks)
         i = 0
         # every ResBlock / pooled output is read next by a 32-group GroupNorm (the next block's norm1, finally self.norm)
         gn = self.norm.num_groups
+        self.last_cut = None
         while i < len(mods):                                  # ResBlock + Downsample pairs run as one fused op
-            if isinstance(mods[i], ResBlock) and i + 1 < len(mods) and isinstance(mods[i + 1], Downsample):
-                x = mods[i](x, pool=True, next_gn=gn)
-                i += 2
+            step = 2 if (isinstance(mods[i], ResBlock) and i + 1 < len(mods) and isinstance(mods[i + 1], Downsample)) else 1
+            cut_here = cut_after is not None and i <= cut_after < i + step
+            ngn = 0 if cut_here else gn                       # (the fused GroupNorm sums are keyed to the producing tensor: not across a cut)
+            if step == 2:
+                x = mods[i](x, pool=True, next_gn=ngn)
             elif isinstance(mods[i], ResBlock):
-                x = mods[i](x, next_gn=gn)
-                i += 1
+                x = mods[i](x, next_gn=ngn)
             else:
                 x = mods[i](x)
-                i += 1
+            i += step
+            if cut_here and torch.is_grad_enabled() and x.requires_grad:
+                xc = x.detach().requires_grad_(True)
+                self.last_cut = (x, xc)
+                x = xc
         for blk in self.final_residual:
             x = blk(x, next_gn=gn)
         x = self.norm(x, silu=True)

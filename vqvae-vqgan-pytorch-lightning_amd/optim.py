@@ -18,27 +18,33 @@ def _is_channels_last_param(p: torch.Tensor) -> bool:
 
 
 class FlatAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, arena_front=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, arena_front=None, arena_back=None):
         """``arena_front``: ids of the parameters laid out FIRST in the arenas (any order of ``param_groups`` -- which is what
-        ``state_dict`` is indexed by -- is kept): ``front_numel`` elements that can be all-reduced on their own."""
+        ``state_dict`` is indexed by -- is kept): ``front_numel`` elements that can be all-reduced on their own;
+        ``arena_back``: ids laid out LAST, from ``back_start`` on (the tensors whose gradients are ready last)."""
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         plist = [(p, g['weight_decay']) for g in self.param_groups for p in g['params']]
         if not plist:
             raise ValueError('FlatAdamW got no parameters')
         dev = plist[0][0].device
-        front = arena_front or set()
-        order = sorted(range(len(plist)), key=lambda i: (0 if id(plist[i][0]) in front else 1, i))
+        front, back = arena_front or set(), arena_back or set()
+        order = sorted(range(len(plist)), key=lambda i: (0 if id(plist[i][0]) in front else 2 if id(plist[i][0]) in back else 1, i))
         offs, total = [0] * len(plist), 0
         self.front_numel = 0
+        self.back_start = None                # offset of the first ``arena_back`` tensor (== total when there is none)
         for i in order:
             p = plist[i][0]
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError('FlatAdamW needs fp32 parameters on one device')
+            if id(p) in back and id(p) not in front and self.back_start is None:
+                self.back_start = total
             offs[i] = total
             total += -(-p.numel() // _ALIGN) * _ALIGN
             if id(p) in front:
                 self.front_numel = total
+        if self.back_start is None:
+            self.back_start = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)

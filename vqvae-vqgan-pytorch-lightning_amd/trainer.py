@@ -83,9 +83,11 @@ class MiniTrainer:
 
     @staticmethod
     def _backward_halves(model):
-        """(first, second): callables running the decoder half and the quantizer + encoder half of the backward"""
+        """callables running the backward in stages: the decoder; the quantizer + the deep part of the encoder; and -- when the
+        encoder was cut (VQVAE.split_encoder) -- its high-resolution head"""
         l2_loss, q_loss = model._backward_terms
         zq, dec_in = model._backward_cut
+        enc_cut = getattr(model, '_encoder_cut', None)
 
         def first():
             l2_loss.backward()
@@ -97,7 +99,23 @@ class MiniTrainer:
                 grads.append(torch.ones_like(q_loss))
             torch.autograd.backward(tensors, grads)
             dec_in.grad = None
-        return first, second
+
+        if enc_cut is None:
+            return first, second
+        x_pre, x_leaf = enc_cut
+
+        def third():
+            torch.autograd.backward([x_pre], [x_leaf.grad])
+            x_leaf.grad = None
+        return first, second, third
+
+    @staticmethod
+    def _ranges(opt, n_stages: int):
+        """arena ranges whose gradients are complete after each stage of the backward"""
+        total = opt.flat_g.numel()
+        if n_stages == 3:
+            return [(0, opt.front_numel), (opt.front_numel, opt.back_start), (opt.back_start, total)]
+        return [(0, opt.front_numel), (opt.front_numel, total)]
 
     def _split_step(self, model, opt, batch, batch_index):
         model.split_backward = True
@@ -105,13 +123,15 @@ class MiniTrainer:
             loss = model.training_step(batch, batch_index)
         finally:
             model.split_backward = False
-        first, second = self._backward_halves(model)
-        first()
-        w1 = opt.all_reduce_range(0, opt.front_numel)
-        second()
-        self._finish_deferred(model, opt)
-        w2 = opt.all_reduce_range(opt.front_numel, opt.flat_g.numel())
-        for w in (w1, w2):
+        stages = self._backward_halves(model)
+        works = []
+        for k, (stage, (lo, hi)) in enumerate(zip(stages, self._ranges(opt, len(stages)))):
+            stage()
+            if k == len(stages) - 1:
+                self._finish_deferred(model, opt)
+            if hi > lo:
+                works.append(opt.all_reduce_range(lo, hi))         # async: runs under the next stage
+        for w in works:
             if w is not None:
                 w.wait()
         return loss
@@ -156,7 +176,7 @@ class MiniTrainer:
         if self._deferred_q is not None:
             self._deferred_q.defer_update = True
         self._graph = torch.cuda.CUDAGraph()
-        self._graph2 = None
+        self._graph2 = self._graph3 = None
         # thread_local: the autograd worker thread and (multi-GPU) the RCCL watchdog thread issue runtime calls
         # of their own while this thread captures
         model.defer_usage_accumulation = True      # host-side bookkeeping stays out of the captured region
@@ -169,11 +189,15 @@ class MiniTrainer:
                 with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
                     opt.zero_grad()
                     self._static_loss = model.training_step(self._static_in, 0)
-                    first, second = self._backward_halves(model)
-                    first()
+                    stages = self._backward_halves(model)
+                    stages[0]()
                 self._graph2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph2, pool=self._graph.pool(), capture_error_mode='thread_local'):
-                    second()
+                    stages[1]()
+                if len(stages) == 3:                      # the encoder's high-resolution head: the deep levels' range is reduced under it
+                    self._graph3 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph3, pool=self._graph.pool(), capture_error_mode='thread_local'):
+                        stages[2]()
             else:
                 with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
                     opt.zero_grad()
@@ -223,7 +247,7 @@ class MiniTrainer:
         self._gan_every = every
         self._static_hist = model.quantizer.last_hist
         self._graph = g_ae
-        self._graph2 = None
+        self._graph2 = self._graph3 = None
         return g_ae
 
     def _train_batch_gan_graphed(self, model, batch, batch_index: int):
@@ -295,12 +319,18 @@ class MiniTrainer:
         ops.repack_owned(None)               # operands of weights changed outside the optimizer (normally none)
         self._graph.replay()
         if self._graph2 is not None:
-            w1 = opt.all_reduce_range(0, opt.front_numel)  # the decoder's gradients, under the encoder's backward
+            g3 = getattr(self, '_graph3', None)
+            ranges = self._ranges(opt, 3 if g3 is not None else 2)
+            works = [opt.all_reduce_range(*ranges[0])]     # the decoder's gradients, under the encoder's backward
             self._graph2.replay()
+            if g3 is not None:
+                works.append(opt.all_reduce_range(*ranges[1]))     # quantizer + deep encoder levels, under the encoder head's backward
+                g3.replay()
             model.accumulate_usage(self._static_hist)
             self._finish_deferred(model, opt)
-            w2 = opt.all_reduce_range(opt.front_numel, opt.flat_g.numel())
-            for w in (w1, w2):
+            if ranges[-1][1] > ranges[-1][0]:
+                works.append(opt.all_reduce_range(*ranges[-1]))
+            for w in works:
                 if w is not None:
                     w.wait()
         else:
