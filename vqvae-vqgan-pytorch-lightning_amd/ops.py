@@ -825,7 +825,9 @@ OVERLAP_WGRAD = os.environ.get('VQK_OVERLAP_WGRAD', '1') == '1'
 OVERLAP_MODE = int(os.environ.get('VQK_OVERLAP_MODE', '3'))
 OVERLAP_WAIT_MIN_HW = int(os.environ.get('VQK_OVERLAP_WAIT_MIN_HW', '0'))   # maps below this many pixels: dgrad1 does not wait for wgrad2
 OVERLAP_STREAM_BLOCKS = int(os.environ.get('VQK_OVERLAP_STREAM_BLOCKS', '512'))
-OVERLAP_WGRAD_BLOCKS = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS', '320'))   # swept 192...512 with the 8x16-patch wgrad: flat 224...320
+OVERLAP_WGRAD_BLOCKS = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS', '320'))
+OVERLAP_WGRAD_BLOCKS_HI = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS_HI', '256'))   # the 256x256 levels: GroupNorm-bound in the backward -- the weight gradient on half the CUs (swept 192 / 224 / 256 / 288 / 320 / 448: -0.15 ms at 256)
+OVERLAP_WGRAD_BLOCKS_MID = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS_MID', str(OVERLAP_WGRAD_BLOCKS)))   # the 128x128 levels   # swept 192...512 with the 8x16-patch wgrad: flat 224...320
 _SIDE_STREAMS: dict = {}
 
 
@@ -834,6 +836,11 @@ def _side_stream(device) -> torch.cuda.Stream:
     if st is None:
         st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
     return st
+
+
+def _wgrad_cap(hw: int) -> int:
+    """grid cap of the weight-gradient kernel next to the GroupNorm backward, per resolution level"""
+    return OVERLAP_WGRAD_BLOCKS_HI if hw >= 65536 else OVERLAP_WGRAD_BLOCKS_MID if hw >= 16384 else OVERLAP_WGRAD_BLOCKS
 
 
 class ResBlockFn(torch.autograd.Function):
@@ -905,7 +912,7 @@ class ResBlockFn(torch.autograd.Function):
             # the pooled pixel of each 2x2 block -- no unpool pass, a quarter of the gradient bytes for three consumers.
             main, side = torch.cuda.current_stream(), _side_stream(x.device)
             lib = _native.lib()
-            lib.vqk_conv_set_block_caps(OVERLAP_STREAM_BLOCKS, OVERLAP_WGRAD_BLOCKS)
+            lib.vqk_conv_set_block_caps(OVERLAP_STREAM_BLOCKS, _wgrad_cap(h * w))
             try:
                 lay = weight_layout(dt, n, h // 2, w // 2, cout, cout, 3, True)
                 wt2 = packed_weight(c2w, cout, cout, dt, 3, True, lay)
@@ -956,7 +963,7 @@ class ResBlockFn(torch.autograd.Function):
             # one block per CU, next to the data-gradient convs and the memory-bound GroupNorm backward passes
             main, side = torch.cuda.current_stream(), _side_stream(x.device)
             lib = _native.lib()
-            lib.vqk_conv_set_block_caps(OVERLAP_STREAM_BLOCKS, OVERLAP_WGRAD_BLOCKS)
+            lib.vqk_conv_set_block_caps(OVERLAP_STREAM_BLOCKS, _wgrad_cap(h * w))
             try:
                 if OVERLAP_MODE == 1:
                     side.wait_stream(main)
