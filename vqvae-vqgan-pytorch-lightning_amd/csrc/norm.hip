@@ -621,7 +621,9 @@ int check_gn(int dtype, int c, int groups) {
 // sums) pay per-block LDS + global atomics for every channel / group, so they want fewer, fatter blocks (~768 total):
 // measured -8...27 % per reducing pass on the 64^2 / 128^2 maps, -2...5 % on 256^2 (sweep 256...4096 blocks).
 inline int pick_ppb(int n, int64_t hw, bool reducing = false) {
-    const int total = reducing ? 768 : 2048;
+    static const int tot_r = getenv("VQK_GN_BLOCKS_REDUCE") ? atoi(getenv("VQK_GN_BLOCKS_REDUCE")) : 768;
+    static const int tot_a = getenv("VQK_GN_BLOCKS_APPLY") ? atoi(getenv("VQK_GN_BLOCKS_APPLY")) : 2048;
+    const int total = reducing ? tot_r : tot_a;
     int64_t blocks_per_sample = (total + n - 1) / n;
     int64_t ppb = (hw + blocks_per_sample - 1) / blocks_per_sample;
     if (ppb < 64) ppb = 64;
