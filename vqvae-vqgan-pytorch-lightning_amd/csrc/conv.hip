@@ -1148,7 +1148,6 @@ template <typename T> struct WgradFrag;
 template <> struct WgradFrag<bf16_raw> {
     static constexpr int KP = 64;           // pixels per K-step
     static constexpr int ROWB = 256;        // bytes per LDS row
-    static constexpr int EPC = 8;
     // one 32x32x16 step: 16 pixels starting at row k0; operand columns [cbase, cbase+32)
     __device__ static __forceinline__ bf16x8_t frag(const char* tile, int k0, int cbase, int lane) {
         const int i = lane & 15, grp = (lane >> 4) & 1, kgrp = lane >> 5;
