@@ -665,7 +665,8 @@ static int gn_backward_impl(int dtype, const void* x, const float* stats, const 
     const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
-    const bool nt = (int64_t)n * hw * c * (dtype == VQK_F32 ? 4 : 2) >= ((int64_t)192 << 20);
+    static const int64_t nt_mb = getenv("VQK_GN_NT_MB") ? atoll(getenv("VQK_GN_NT_MB")) : 192;
+    const bool nt = (int64_t)n * hw * c * (dtype == VQK_F32 ? 4 : 2) >= (nt_mb << 20);
     // deterministic mode: group partials [n][groups][nblk][2] doubles, then channel partials [n][nblk][2c] floats, in the workspace
     vqkd::DetState& det = vqkd::det_state();
     double* gpart = nullptr;
