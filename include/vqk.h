@@ -208,7 +208,8 @@ int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes);
  * initialised).  With it the general conv kernel splits K for problems whose pixel x cout tile grid would leave most of the
  * chip idle (the discriminator's 4x4 / 8x8 convs and fully connected layers: 8-32 tiles with K up to 8192): every split
  * stores its partial tile into its own slice and an epilogue kernel adds the slices in split order (no atomics: the same
- * bits every run, so the split is also taken in deterministic mode).  Needs >= 2 * pixels * cout * 4 bytes to be used. */
+ * bits every run, so the split is also taken in deterministic mode).  Needs >= 2 * pixels * cout * 4 bytes to be used.
+ * ws must be 16-byte aligned (VQK_ERR_ALIGN), ws_bytes >= 0 (VQK_ERR_ARG); the same checks apply to vqk_set_deterministic. */
 int vqk_set_scratch(void* ws, int64_t ws_bytes);
 /* caps on the persistent grids of the 3x3 fprop/dgrad kernel and of the all-taps wgrad kernel (0 = default: two
  * blocks per CU).  256 = one block per CU, leaving room for a kernel that runs concurrently on another stream

@@ -1,4 +1,5 @@
 // Status strings / version of the vqk C-ABI (include/vqk.h).
+#include <stdint.h>
 #include "common.h"
 
 extern "C" {
@@ -34,6 +35,8 @@ DetState& scratch_state() {
 }  // namespace vqkd
 
 extern "C" int vqk_set_scratch(void* ws, int64_t ws_bytes) {
+    if (ws && ws_bytes < 0) return VQK_ERR_ARG;
+    if (ws && (reinterpret_cast<uintptr_t>(ws) & 15)) return VQK_ERR_ALIGN;       // the split slices are written with 16-byte stores
     vqkd::DetState& d = vqkd::scratch_state();
     d.on = ws ? 1 : 0;
     d.ws = reinterpret_cast<float*>(ws);
@@ -42,6 +45,8 @@ extern "C" int vqk_set_scratch(void* ws, int64_t ws_bytes) {
 }
 
 extern "C" int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes) {
+    if (on && ws && ws_bytes < 0) return VQK_ERR_ARG;
+    if (on && ws && (reinterpret_cast<uintptr_t>(ws) & 15)) return VQK_ERR_ALIGN;
     vqkd::DetState& d = vqkd::det_state();
     d.on = on ? 1 : 0;
     d.ws = (on && ws) ? reinterpret_cast<float*>(ws) : nullptr;
