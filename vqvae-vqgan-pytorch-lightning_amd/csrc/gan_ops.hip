@@ -740,7 +740,9 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(const T* __restrict__
     const int ux_first = (ox0 + 4 * oxq) * DOWN - px0;           // U column of output 0, tap 0
     auto body = [&](auto par_c) {
         constexpr int PAR = decltype(par_c)::value;               // UP = 2: ux_first & 1
-        const int rx_first = (UP == 1 ? ux_first : ((ux_first + PAR) >> 1)) - ix0;
+        // UP = 2: U column ux_first + o + kx = 2a + PAR + o + kx carries input column a + ((o + kx + PAR) >> 1), a = ux_first >> 1
+        // (arithmetic shift: floor, also left of the image); q below is the second term
+        const int rx_first = (UP == 1 ? ux_first : (ux_first >> 1)) - ix0;
 #pragma unroll 1
         for (int ky = 0; ky < 4; ++ky) {                        // (not unrolled: one row of columns in registers at a time)
             const int u = uy + ky;

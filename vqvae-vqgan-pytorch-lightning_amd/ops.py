@@ -46,22 +46,21 @@ def _stream() -> int:
     library's per-thread workspace follows the stream (partial sums of two concurrent streams must not share a buffer), and
     where a thread that was armed before the mode was switched off disarms itself."""
     s = torch.cuda.current_stream().cuda_stream
-    if getattr(_DET_TLS, 'scratch', None) != s:                  # split-K scratch of this stream (private slices per split)
-        dev = torch.cuda.current_device()
+    dev = torch.cuda.current_device()                            # (the default stream's handle is 0 on every device)
+    if getattr(_DET_TLS, 'scratch', None) != (dev, s):           # split-K scratch of this stream (private slices per split)
         sc = _SCRATCH.get((dev, s))
-        if sc is None:
-            sc = _SCRATCH[(dev, s)] = torch.zeros(_SCRATCH_BYTES // 4, dtype=torch.float32, device=f'cuda:{dev}')
+        if sc is None:                                           # no zero fill: every slice is written before it is summed
+            sc = _SCRATCH[(dev, s)] = torch.empty(_SCRATCH_BYTES // 4, dtype=torch.float32, device=f'cuda:{dev}')
         _native.check(_native.lib().vqk_set_scratch(sc.data_ptr(), sc.numel() * 4), 'set_scratch')
-        _DET_TLS.scratch = s
+        _DET_TLS.scratch = (dev, s)
     key = getattr(_DET_TLS, 'key', None)
     if DETERMINISTIC:
-        if key != (_DET_GEN, s):
-            dev = torch.cuda.current_device()
+        if key != (_DET_GEN, dev, s):
             ws = _DET_WS.get((dev, s))
             if ws is None:
                 ws = _DET_WS[(dev, s)] = torch.empty(_DET_WS_BYTES, dtype=torch.uint8, device=f'cuda:{dev}')
             _native.check(_native.lib().vqk_set_deterministic(1, ws.data_ptr(), ws.numel()), 'set_deterministic')
-            _DET_TLS.key = (_DET_GEN, s)
+            _DET_TLS.key = (_DET_GEN, dev, s)
     elif key is not None:
         _native.check(_native.lib().vqk_set_deterministic(0, 0, 0), 'set_deterministic')
         _DET_TLS.key = None
@@ -838,6 +837,26 @@ def _side_stream(device) -> torch.cuda.Stream:
     return st
 
 
+# hipGraph replay maps the captured nodes to hardware queues by a depth-first walk in which the FIRST successor of a node
+# (in capture order) inherits its queue and every further successor gets another one (clr: Graph::ScheduleOneNode).  The
+# weight-gradient launch used to be captured right behind the data-gradient conv it forks from, so the replay ran conv ->
+# wgrad -> conv on one queue and the whole GroupNorm-backward chain -- the critical path -- on the other: every conv ->
+# GroupNorm -> conv hop crossed queues (84 gaps of ~10 us, main queue idle 1.04 ms: profiles/round3_step_timeline.txt).
+# CHAIN_FIRST: the critical chain's next kernel is launched (captured) first; the side stream then waits on an event
+# recorded at the fork point, so the weight gradient still depends on the data gradient only.
+CHAIN_FIRST = os.environ.get('VQK_CHAIN_FIRST', '1') != '0'
+
+
+def _fork_point(main):
+    ev = torch.cuda.Event()
+    ev.record(main)
+    return ev
+
+
+def _side_after(side, fork) -> None:
+    side.wait_event(fork)
+
+
 def _wgrad_cap(hw: int) -> int:
     """grid cap of the weight-gradient kernel next to the GroupNorm backward, per resolution level"""
     return OVERLAP_WGRAD_BLOCKS_HI if hw >= 65536 else OVERLAP_WGRAD_BLOCKS_MID if hw >= 16384 else OVERLAP_WGRAD_BLOCKS
@@ -917,19 +936,32 @@ class ResBlockFn(torch.autograd.Function):
                 lay = weight_layout(dt, n, h // 2, w // 2, cout, cout, 3, True)
                 wt2 = packed_weight(c2w, cout, cout, dt, 3, True, lay)
                 d_a2 = _conv_general_raw(dout, wt2, None, None, cout, 3, 1, 1, 1, h, w, 0, 0.25, 1.0, dt, lay)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    if not raw_conv_wgrad_pooled_dy(a2, dout, 0.25, t2):
-                        raise RuntimeError('vqk: pooled weight gradient not served for an eligible shape')
+                fork = _fork_point(main)
+                if not CHAIN_FIRST:
+                    _side_after(side, fork)
+                    with torch.cuda.stream(side):
+                        if not raw_conv_wgrad_pooled_dy(a2, dout, 0.25, t2):
+                            raise RuntimeError('vqk: pooled weight gradient not served for an eligible shape')
                 d_r1, _, _ = raw_gn_backward(r1, st2, w2, b2, d_a2, groups, True, tw2, tb2)
+                if CHAIN_FIRST:
+                    _side_after(side, fork)
+                    with torch.cuda.stream(side):
+                        if not raw_conv_wgrad_pooled_dy(a2, dout, 0.25, t2):
+                            raise RuntimeError('vqk: pooled weight gradient not served for an eligible shape')
                 if OVERLAP_MODE == 3:
                     main.wait_stream(side)
                 lay1 = weight_layout(dt, n, h, w, cout, cin, 3, False)
                 d_a1 = raw_conv_fprop(d_r1, packed_weight(c1w, cin, cout, dt, 3, True, lay1), None, None, 3, False, 0, dt, cin, lay1)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                fork = _fork_point(main)
+                if not CHAIN_FIRST:
+                    _side_after(side, fork)
+                    with torch.cuda.stream(side):
+                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
                 dx = raw_gn_backward_pooled_add(x, st1, w1, b1, d_a1, groups, True, tw1, tb1, dout, 0.25)
+                if CHAIN_FIRST:
+                    _side_after(side, fork)
+                    with torch.cuda.stream(side):
+                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
                 main.wait_stream(side)
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)
@@ -972,10 +1004,16 @@ class ResBlockFn(torch.autograd.Function):
                     d_a2, _ = conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)
                 else:                                    # wgrad starts behind the dgrad: it overlaps GroupNorm only
                     d_a2, _ = conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)
-                    side.wait_stream(main)
+                    fork = _fork_point(main)
+                    if not CHAIN_FIRST:
+                        _side_after(side, fork)
+                        with torch.cuda.stream(side):
+                            raw_conv_wgrad(a2, dout, 3, False, out=t2)
+                d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
+                if OVERLAP_MODE != 1 and CHAIN_FIRST:
+                    _side_after(side, fork)
                     with torch.cuda.stream(side):
                         raw_conv_wgrad(a2, dout, 3, False, out=t2)
-                d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
                 if OVERLAP_MODE == 1:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
@@ -985,13 +1023,19 @@ class ResBlockFn(torch.autograd.Function):
                     if OVERLAP_MODE == 3 and h * w >= OVERLAP_WAIT_MIN_HW:
                         main.wait_stream(side)           # dgrad1 alone on the chip
                     d_a1, _ = conv_bwd(a1, d_r1, c1w, 3, cin, cout, need_dw=False)
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                    fork = _fork_point(main)
+                    if not CHAIN_FIRST:
+                        _side_after(side, fork)
+                        with torch.cuda.stream(side):
+                            raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
                 dskip, dwsc = dout, None
                 if scw is not None:
                     dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
                 dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip)
+                if OVERLAP_MODE != 1 and CHAIN_FIRST:
+                    _side_after(side, fork)
+                    with torch.cuda.stream(side):
+                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
                 main.wait_stream(side)
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)

@@ -161,9 +161,13 @@ class MiniTrainer:
         if not getattr(model, 'automatic_optimization', True):
             return self._capture_gan(model, example_batch, warmup, snap)
         self._static_in = example_batch.clone()
-        side = torch.cuda.Stream()
+        # the settling steps run on the stream the capture will use: every per-(device, stream) workspace of ops.py (split-K
+        # scratch, GroupNorm sums, deterministic-mode slices) exists before the capture starts -- a first use INSIDE the
+        # capture would put the allocation in the graph's pool and its zero fill into every replay
+        side = self._cap_stream = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            ops._stream()
             for i in range(warmup):
                 self._eager_step(model, self._static_in, i)
         torch.cuda.current_stream().wait_stream(side)
@@ -186,20 +190,20 @@ class MiniTrainer:
                 # two graphs sharing one memory pool: [zero_grad, forward, decoder backward] and [quantizer + encoder backward];
                 # the all-reduce of the decoder's arena range is issued between the two replays
                 model.split_backward = True
-                with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
+                with torch.cuda.graph(self._graph, stream=side, capture_error_mode='thread_local'):
                     opt.zero_grad()
                     self._static_loss = model.training_step(self._static_in, 0)
                     stages = self._backward_halves(model)
                     stages[0]()
                 self._graph2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph2, pool=self._graph.pool(), capture_error_mode='thread_local'):
+                with torch.cuda.graph(self._graph2, pool=self._graph.pool(), stream=side, capture_error_mode='thread_local'):
                     stages[1]()
                 if len(stages) == 3:                      # the encoder's high-resolution head: the deep levels' range is reduced under it
                     self._graph3 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self._graph3, pool=self._graph.pool(), capture_error_mode='thread_local'):
+                    with torch.cuda.graph(self._graph3, pool=self._graph.pool(), stream=side, capture_error_mode='thread_local'):
                         stages[2]()
             else:
-                with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
+                with torch.cuda.graph(self._graph, stream=side, capture_error_mode='thread_local'):
                     opt.zero_grad()
                     self._static_loss = model.training_step(self._static_in, 0)
                     self._static_loss.backward()
@@ -216,9 +220,14 @@ class MiniTrainer:
         the choice of the R1 variant (every ``r1_reg_every`` steps) stay on the host between the replays."""
         ae_opt, disc_opt = self.optimizers
         self._static_in = example_batch.clone()
-        side = torch.cuda.Stream()
+        # forward_autoencoder / forward_discriminator branch ON THE HOST on `current_epoch >= adversarial_start_epoch`
+        # (loss.py:121,143): the captured graphs hold ONE side of that branch.  The phase they were captured in is kept, and
+        # _train_batch_gan_graphed re-captures when the epoch crosses the threshold (gumbel_vqgan.yaml: start_epoch 100).
+        self._gan_phase = self._gan_adversarial(model)
+        side = self._cap_stream = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            ops._stream()
             for i in range(max(warmup, 2)):               # both discriminator variants (with / without R1) run once
                 model.on_train_batch_start(self._static_in, i)
                 model.training_step(self._static_in, i)
@@ -232,14 +241,14 @@ class MiniTrainer:
         self._gan = {}
         try:
             g_ae = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_ae, capture_error_mode='thread_local'):
+            with torch.cuda.graph(g_ae, stream=side, capture_error_mode='thread_local'):
                 res = model._gan_ae_half(self._static_in)
             self._gan['ae'] = (g_ae, res, model._gan_state[2])
             for key, step in (('d', 1), ('d_r1', 0)):
                 if key == 'd_r1' and not every:
                     continue
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=g_ae.pool(), capture_error_mode='thread_local'):
+                with torch.cuda.graph(g, pool=g_ae.pool(), stream=side, capture_error_mode='thread_local'):
                     out = model._gan_disc_half(step if every else 1)
                 self._gan[key] = (g, out)
         finally:
@@ -250,8 +259,18 @@ class MiniTrainer:
         self._graph2 = self._graph3 = None
         return g_ae
 
+    @staticmethod
+    def _gan_adversarial(model) -> bool:
+        return model.current_epoch >= model.criterion.adversarial_start_epoch
+
     def _train_batch_gan_graphed(self, model, batch, batch_index: int):
         ae_opt, disc_opt = self.optimizers
+        if self._gan_adversarial(model) != self._gan_phase:
+            # the adversarial phase starts (or, on a resumed / rewound run, ends): the graphs of the other phase would keep
+            # replaying a step without generator loss and never step the discriminator.  Capture this phase's graphs; the
+            # settling steps of the capture do not train (state snapshot put back).
+            self._gan = None
+            self._capture_gan(model, batch, warmup=2, snap=self._snapshot(model))
         model.on_train_batch_start(batch, batch_index)
         if batch is not self._static_in:
             self._static_in.copy_(batch, non_blocking=True)
@@ -276,7 +295,10 @@ class MiniTrainer:
         return dict(state={k: v.detach().clone() for k, v in model.state_dict().items()},
                     opts=[(o.flat_v.clone(), None if o.flat_m is None else o.flat_m.clone(), o.step_count) for o in self.optimizers],
                     usage=(None if getattr(model, 'train_epoch_usage_count', None) is None else model.train_epoch_usage_count.clone()),
-                    step=self.global_step)
+                    step=self.global_step,
+                    # the settling steps draw Gumbel noise / augmentation boxes and log: neither may leak into the run
+                    rng=(torch.cuda.get_rng_state() if torch.cuda.is_available() else None, torch.get_rng_state()),
+                    logged=(dict(model.logged) if isinstance(getattr(model, 'logged', None), dict) else None))
 
     @torch.no_grad()
     def _restore(self, model, snap):
@@ -295,6 +317,12 @@ class MiniTrainer:
         if hasattr(model, 'train_epoch_usage_count'):
             model.train_epoch_usage_count = snap['usage']
         self.global_step = snap['step']
+        if snap.get('rng') is not None:
+            if snap['rng'][0] is not None:
+                torch.cuda.set_rng_state(snap['rng'][0])
+            torch.set_rng_state(snap['rng'][1])
+        if snap.get('logged') is not None:
+            model.logged = snap['logged']
 
     def _eager_step(self, model, batch, batch_index):
         opt = self.optimizers[0]
