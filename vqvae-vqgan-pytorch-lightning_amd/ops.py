@@ -838,13 +838,16 @@ def _side_stream(device) -> torch.cuda.Stream:
 
 
 # hipGraph replay maps the captured nodes to hardware queues by a depth-first walk in which the FIRST successor of a node
-# (in capture order) inherits its queue and every further successor gets another one (clr: Graph::ScheduleOneNode).  The
-# weight-gradient launch used to be captured right behind the data-gradient conv it forks from, so the replay ran conv ->
-# wgrad -> conv on one queue and the whole GroupNorm-backward chain -- the critical path -- on the other: every conv ->
-# GroupNorm -> conv hop crossed queues (84 gaps of ~10 us, main queue idle 1.04 ms: profiles/round3_step_timeline.txt).
-# CHAIN_FIRST: the critical chain's next kernel is launched (captured) first; the side stream then waits on an event
-# recorded at the fork point, so the weight gradient still depends on the data gradient only.
-CHAIN_FIRST = os.environ.get('VQK_CHAIN_FIRST', '1') != '0'
+# (in capture order) inherits its queue and every further successor gets another one.  The weight-gradient launch is
+# captured right behind the data-gradient conv it forks from, so the replay runs conv -> wgrad -> conv on one queue and the
+# GroupNorm-backward chain on the other: every conv -> GroupNorm -> conv hop crosses queues (84 gaps of ~10 us,
+# profiles/round3_step_timeline.txt).  CHAIN_FIRST = 1 captures the chain's next kernel first (the side stream then waits on
+# an event recorded at the fork point): the replay does put the whole chain on one queue (profiles/round4_chain_first_ab.txt:
+# 311 + 40 kernels instead of 275 + 76) -- and the step is SLOWER, 29.8-30.2 against 29.1-29.3 ms same box, with every cap /
+# join variant tried: the kernel that reaches the chip first takes the CUs, the GroupNorm pass floods all 256 and the
+# weight gradient (one 512-thread, 120-KiB block per CU) only gets in as its blocks retire (wgrad 11.3 instead of 9.9 ms,
+# main queue waits 2.0 ms on it).  The weight gradient has to be launched first; the 10-us hops are the price.
+CHAIN_FIRST = os.environ.get('VQK_CHAIN_FIRST', '0') == '1'
 
 
 def _fork_point(main):
