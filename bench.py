@@ -69,6 +69,8 @@ def cpu_baseline(run: dict, image_size: int, batch: int, steps: int):
     decay, _ = O.decay_split(list(params))
     v = {k: torch.zeros_like(p) for k, p in params.items()}
     times = []
+    first = None
+    params0 = {k: v.clone() for k, v in params.items()}
     budget_t0 = time.perf_counter()
     for s in range(steps + 1):
         if s >= 2 and time.perf_counter() - budget_t0 > 60.0:      # keep the default run within minutes
@@ -77,6 +79,8 @@ def cpu_baseline(run: dict, image_size: int, batch: int, steps: int):
         t0 = time.perf_counter()
         r = O.train_step_mse(images, params, run['ae_conf']['num_res_blocks'], len(run['ae_conf']['channel_multipliers']),
                              'standard', dict(commitment_cost=0.25))
+        if first is None:
+            first = r
         for k_, gr in r['grads'].items():
             params[k_], _, v[k_] = O.adamw_step(params[k_], gr, v[k_], s + 1, run['t_conf']['lr'], 0.0, 0.99, 1e-8,
                                                 1e-4 if k_ in decay else 0.0)
@@ -84,7 +88,42 @@ def cpu_baseline(run: dict, image_size: int, batch: int, steps: int):
     t = sum(times[1:]) / steps
     return dict(value=round(batch / t, 4), unit='images/sec', cores=cores, kind='port',
                 sample=f'{steps} timed steps (+1 warm-up) of the same train step at batch {batch}, fp32, '
-                       f'torch-CPU oracle on {cores} threads; {t:.2f} s/step')
+                       f'torch-CPU oracle on {cores} threads; {t:.2f} s/step'), (params0, images, first)
+
+
+def parity_cost(run: dict, image_size: int, oracle_step, device) -> dict:
+    """what the benchmarked precision costs in parity: the throughput (bf16) mode of THIS build on the inputs and weights of
+    the CPU oracle's first step (fp32 restatement of the reference) -- index agreement, reconstruction error, loss, cosine
+    of the whole-model gradient.  The fp32 parity mode holds indices bit-exact / recon 1e-5 on the same comparison
+    (tests/test_gpu_fullsize.py); its speed is `other_configs['... fp32 parity mode']`."""
+    model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
+    trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
+    params0, images, r = oracle_step
+    out = {}
+    for label, dt in (('bf16', torch.bfloat16), ('f32', torch.float32)):
+        m = model_mod.VQVAE(image_size, run['ae_conf'], run['q_conf'], None, run['t_conf'], compute_dtype=dt)
+        m.load_state_dict(params0, strict=True)
+        m = m.to(device).train()
+        tr = trainer_mod.MiniTrainer(num_training_batches=1)
+        opt = tr.attach(m)[0]
+        opt.zero_grad()
+        loss = m.training_step(images.to(device), 0)
+        loss.backward()
+        named = dict(m.named_parameters())
+        num = da = db = 0.0
+        for k, gr in r['grads'].items():
+            a = named[k].grad.detach().double().cpu().reshape(-1)
+            b = gr.double().reshape(-1)
+            num += float((a * b).sum()); da += float((a * a).sum()); db += float((b * b).sum())
+        with torch.no_grad():
+            recon, _, idx = m(m.preprocess_batch(images.to(device)))
+        out[label] = dict(indices_equal_pct=round(100.0 * float((idx.cpu().reshape(-1) == r['idx'].reshape(-1)).float().mean()), 2),
+                          recon_rel_err=float(f"{float((recon.float().cpu() - r['recon']).norm() / r['recon'].norm()):.3e}"),
+                          loss=round(float(loss), 6), oracle_loss=round(float(r['loss']), 6),
+                          gradient_cosine=round(num / (da * db) ** 0.5, 6), gradient_norm_ratio=round((da / db) ** 0.5, 4))
+        del m, tr, opt
+    out['sample'] = f'batch {images.shape[0]} at {image_size}x{image_size}, random-init weights, the CPU oracle step of cpu_baseline'
+    return out
 
 
 OTHER_CONFIGS = {      # BASELINE.json configs[2..4], single-GPU part, at their per-GPU batch
@@ -93,6 +132,8 @@ OTHER_CONFIGS = {      # BASELINE.json configs[2..4], single-GPU part, at their 
     'gumbel_vqgan bs=16 (LPIPS + discriminator + R1)': ['--gan', '--batch', '16'],
     # the headline config again with ordered partial sums instead of atomics (vqvae/train.py:130: Trainer(deterministic=True))
     'standard_vqvae cb=1024 bs=32, deterministic mode': ['--deterministic'],
+    # the mode in which north_star's parity statement holds bit for bit (fp32 storage, exact-fp32 MFMA): what parity costs
+    'standard_vqvae cb=1024 bs=8, fp32 parity mode': ['--dtype', 'f32', '--batch', '8'],
 }
 
 
@@ -335,6 +376,43 @@ def main():
         ops.OVERLAP_WGRAD = overlap
         events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
 
+    comm = None
+    if dist.is_initialized():
+        # proof of what RCCL saw, and what the collectives cost on the critical path (same loop, collectives muted)
+        opt0 = trainer.optimizers[0]
+        vqm = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.vector_quantizers')
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        c0 = sum(o.collectives_issued for o in trainer.optimizers) + vqm.EMA_COLLECTIVES[0]
+        b0 = sum(o.collective_bytes for o in trainer.optimizers) + vqm.EMA_COLLECTIVES[1]
+        probe = max(5, min(args.steps, 20))
+        barrier()
+        ta = time.perf_counter()
+        for i in range(probe):
+            step_fn(model, images, args.warmup + args.steps + i)
+        barrier()
+        t_on = (time.perf_counter() - ta) / probe
+        c1 = sum(o.collectives_issued for o in trainer.optimizers) + vqm.EMA_COLLECTIVES[0]
+        b1 = sum(o.collective_bytes for o in trainer.optimizers) + vqm.EMA_COLLECTIVES[1]
+        for o in trainer.optimizers:
+            o.mute_collectives = True
+        barrier()
+        ta = time.perf_counter()
+        for i in range(probe):
+            step_fn(model, images, args.warmup + args.steps + probe + i)
+        barrier()
+        t_off = (time.perf_counter() - ta) / probe
+        for o in trainer.optimizers:
+            o.mute_collectives = False
+        tt = torch.tensor([t_on, t_off], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        comm = dict(rccl_ranks=int(ones.item()), backend=dist.get_backend(), collectives_per_step=round((c1 - c0) / probe, 2),
+                    collective_mb_per_step=round((b1 - b0) / probe / 1e6, 2),
+                    ms_per_step_with_collectives=round(float(tt[0]) * 1e3, 3), ms_per_step_collectives_muted=round(float(tt[1]) * 1e3, 3),
+                    exposed_comm_ms=round(float(tt[0] - tt[1]) * 1e3, 3), probe_steps=probe,
+                    overlap='gradient ranges all-reduced under the remaining backward (VQK_OVERLAP_ALLREDUCE=0: one flat all-reduce)'
+                            if trainer_mod.MiniTrainer.OVERLAP_ALLREDUCE else 'one flat all-reduce after the backward')
+
     roofline = None
     if events:
         by_kernel = {}
@@ -400,9 +478,14 @@ def main():
         except Exception as exc:
             vq_kernel = dict(error=f'{type(exc).__name__}: {exc}')
     if rank == 0:
-        cpu = None
+        cpu = parity = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(run, args.image_size, args.cpu_batch, args.cpu_steps)
+            cpu, oracle_step = cpu_baseline(run, args.image_size, args.cpu_batch, args.cpu_steps)
+            if qtype == 'standard' and not args.gan:
+                try:
+                    parity = parity_cost(run, args.image_size, oracle_step, device)
+                except Exception as exc:
+                    parity = dict(error=f'{type(exc).__name__}: {exc}')
         value = world * args.batch * args.steps / elapsed
         out = dict(metric='images/sec/node (256x256 bs=32/GPU) VQ-VAE train step', value=round(value, 2),
                    unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -421,8 +504,11 @@ def main():
                                         'tail all-reduce, AdamW') if (use_graph and getattr(trainer, '_graph2', None) is not None) else
                                        'three hipGraphs (AE half | discriminator half | discriminator half + R1), optimizer steps between' if (use_graph and args.gan) else
                                        'hipGraph replay (fwd+bwd) + eager all-reduce + AdamW' if use_graph else 'eager'),
-                               deterministic=bool(ops.DETERMINISTIC), final_loss=round(float(loss.item()), 6)),
-                   roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel, sustained=sustained)
+                               deterministic=bool(ops.DETERMINISTIC), final_loss=round(float(loss.item()), 6),
+                               rccl_ranks=None if comm is None else comm['rccl_ranks'],
+                               collectives_per_step=0 if comm is None else comm['collectives_per_step']),
+                   roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel, sustained=sustained, comm=comm,
+                   bf16_vs_fp32_oracle=parity)
         if world == 1 and not args.no_other_configs:
             out['other_configs'] = other_configs()
         result_line = json.dumps(out)

@@ -3,7 +3,15 @@
  * Boundary rules:
  *   - plain C: raw device pointers + sizes + scalars, no torch types;
  *   - the CALLER owns every buffer (outputs, workspaces); nothing is allocated, nothing is
- *     synchronised, no global mutable state is kept inside the library;
+ *     synchronised, and a call's RESULT depends on its arguments only.  The library reads no environment variable.
+ *     What state it does keep, all of it launch POLICY (which kernel / grid / accumulation order serves a call), and its scope:
+ *       THREAD-LOCAL (applies to the launches the calling host thread issues afterwards; another thread -- e.g. autograd's
+ *       backward worker -- arms its own): vqk_set_deterministic (+ its workspace), vqk_set_scratch, vqk_conv_set_block_caps,
+ *       vqk_conv_set_variant.  These act at LAUNCH (= graph capture) time: a hipGraph captured under them replays the
+ *       captured kernels and workspace pointers from any thread, whatever that thread's own settings are
+ *       (tests/test_gpu_deterministic.py::test_graph_captured_on_one_thread_replays_identically_from_another);
+ *       PROCESS-WIDE: the tuning slots of vqk_set_tuning (grid sizes, kernel-choice thresholds: never the arithmetic of a
+ *       kernel, except where a slot's description says it selects a differently rounding kernel);
  *   - every launch goes to the `stream` argument (a hipStream_t passed as void*; NULL = the
  *     null stream);
  *   - return value: 0 = ok, negative = vqk_status (see vqk_status_str).  There is NO fallback
@@ -64,6 +72,16 @@ int vqk_vq_assign_f32(const float* z, const float* e, const float* z2, const flo
 int64_t vqk_vq_filter_ws_bytes(int k, int d);
 int vqk_vq_assign_filtered_f32(const float* z, const float* e, const float* z2, const float* e2, int64_t n, int k, int d,
                                int assoc, int64_t* idx, void* ws, int64_t ws_bytes, void* stream);
+/* The quantizer FORWARD as one kernel (vector_quantizers.py:37-56): the filtered assignment above with |z|^2 computed in the
+ * kernel (same bits as vqk_row_sqnorm_f32) and the gather fused into its epilogue -- idx[N]; optionally q = e[idx] as fp32
+ * (q) and / or bf16 (q_lo), sse[0] += sum (q - z)^2, hist[idx] += 1 (sse / hist pre-zeroed by the caller).
+ * ws = what vqk_vq_prepare_f32 built from THIS codebook (bf16 fragment-major copy, |e|^2, filter margins, max |e|^2:
+ * vqk_vq_filter_ws_bytes(k, d) bytes): call it once per codebook CHANGE (optimizer step, EMA update), not per step.
+ * d == 256, k % 32 == 0 (VQK_ERR_SHAPE otherwise, nothing launched). */
+int vqk_vq_prepare_f32(const float* e, int k, int d, void* ws, int64_t ws_bytes, void* stream);
+int vqk_vq_forward_f32(const float* z, const float* e, const void* ws, int64_t ws_bytes, int64_t n, int k, int d, int assoc,
+                       int64_t* idx, float* q /* optional */, void* q_lo /* optional */, float* sse /* optional */,
+                       int32_t* hist /* optional */, void* stream);
 /* Same search, additionally writing the full fp32 distance matrix dmat[N][K] (Entropy quantizer). */
 int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const float* e2,
                          int64_t n, int k, int d, int assoc, int64_t* idx, float* dmat, void* stream);
@@ -109,6 +127,11 @@ int vqk_vq_gather_f32(const float* z, const float* e, const int64_t* idx, int64_
 int vqk_vq_backward_f32(const float* z, const float* e, const int64_t* idx, const void* dq, int dq_dtype,
                         int64_t n, int k, int d, float cz, float ce, const float* gscale_dev, float* dz, float* de,
                         void* stream);
+/* vqk_vq_backward_f32 as ONE kernel (d == 256): the rows of a 32-row block that share a code are summed in LDS, one
+ * coalesced fp32 atomic row per distinct code and block goes to de (arrival order: not for deterministic mode). */
+int vqk_vq_backward_fused_f32(const float* z, const float* e, const int64_t* idx, const void* dq, int dq_dtype,
+                              int64_t n, int k, int d, float cz, float ce, const float* gscale_dev, float* dz, float* de,
+                              void* stream);
 /* EMA statistics (vector_quantizers.py:159-169): counts[k] += 1, dw[idx] += z (both pre-zeroed) ... */
 int vqk_ema_stats_f32(const float* z, const int64_t* idx, int64_t n, int k, int d,
                       float* counts, float* dw, void* stream);
@@ -211,6 +234,15 @@ int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes);
  * bits every run, so the split is also taken in deterministic mode).  Needs >= 2 * pixels * cout * 4 bytes to be used.
  * ws must be 16-byte aligned (VQK_ERR_ALIGN), ws_bytes >= 0 (VQK_ERR_ARG); the same checks apply to vqk_set_deterministic. */
 int vqk_set_scratch(void* ws, int64_t ws_bytes);
+/* Tuning slots: the launch heuristics that tools/ sweep (formerly read-once environment variables).  name = one of
+ * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4.
+ * A set slot overrides the built-in default at the next launch; vqk_reset_tuning returns every slot to its default.
+ * Process-wide (relaxed atomics); VQK_ERR_ARG for an unknown name.  The Python host maps VQK_<NAME> environment variables
+ * onto these calls when it loads the library (_native.py), so the A/B scripts keep their interface. */
+int vqk_set_tuning(const char* name, int value);
+int vqk_reset_tuning(void);
+int vqk_tuning_count(void);
+const char* vqk_tuning_name(int i);
 /* caps on the persistent grids of the 3x3 fprop/dgrad kernel and of the all-taps wgrad kernel (0 = default: two
  * blocks per CU).  256 = one block per CU, leaving room for a kernel that runs concurrently on another stream
  * (the host overlaps a layer's wgrad with its dgrad and GroupNorm backward).  The caps are THREAD-LOCAL: they apply to the

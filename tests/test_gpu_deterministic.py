@@ -117,3 +117,42 @@ def test_weight_gradient_and_colsum_ordered_equal_atomic(n, cin, cout, h, k):
         assert torch.equal(p, q)
     for p, q in zip(det1, default):
         assert _rel(p, q) < 2e-6
+
+
+def test_graph_captured_on_one_thread_replays_identically_from_another():
+    """include/vqk.h: the mode setters are THREAD-LOCAL and act at launch (= capture) time.  A graph captured after
+    vqk_set_deterministic(1) on thread A holds the ordered kernels and A's workspace pointers: replayed from thread B --
+    which never armed the mode, and whose own setting is 'off' -- it produces the same bits as A's replay and as the
+    eager deterministic step."""
+    import threading
+    box = {}
+
+    def thread_a():
+        torch.cuda.set_device(0)
+        qc = dict(num_embeddings=256, embedding_dim=256, reinit_every_n_epochs=None, type='standard', params=dict(commitment_cost=0.25))
+        torch.manual_seed(7)
+        m = model_mod.VQVAE(64, AE_FULL, qc, None, TC, compute_dtype=torch.bfloat16).to(DEV).train()
+        tr = trainer_mod.MiniTrainer(num_training_batches=8, deterministic=True)
+        opt = tr.attach(m)[0]
+        m.on_train_start()
+        images = torch.rand(8, 3, 64, 64, generator=torch.Generator().manual_seed(3)).to(DEV)
+        tr.capture(m, images, warmup=1, preserve_state=True)
+        tr._graph.replay()
+        torch.cuda.synchronize()
+        box.update(tr=tr, opt=opt, model=m, g_a=opt.flat_g.clone())
+
+    def thread_b():
+        torch.cuda.set_device(0)
+        assert getattr(ops._DET_TLS, 'key', None) is None            # this thread never armed the deterministic mode
+        box['opt'].flat_g.fill_(float('nan'))                        # the graph's own zero_grad must clear this
+        box['tr']._graph.replay()
+        torch.cuda.synchronize()
+        box['g_b'] = box['opt'].flat_g.clone()
+
+    for fn in (thread_a, thread_b):
+        t = threading.Thread(target=fn)
+        t.start()
+        t.join()
+    assert 'g_b' in box and torch.equal(box['g_a'], box['g_b'])
+    g_e = _grads('standard', torch.bfloat16, 64, 8, True)
+    assert torch.equal(box['g_b'], g_e)

@@ -53,3 +53,22 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+
+
+def test_tuning_slots_replace_environment_reads():
+    """VERDICT r3 hygiene: the library reads no environment variable; its launch heuristics are named tuning slots
+    (include/vqk.h: vqk_set_tuning), unknown names are refused, and the Python loader maps VQK_<SLOT> variables onto them"""
+    native = importlib.import_module(PKG + '._native')
+    lib = native.lib()
+    names = [lib.vqk_tuning_name(i).decode() for i in range(lib.vqk_tuning_count())]
+    assert 'MX_HALF' in names and 'GN_BLOCKS_REDUCE' in names and len(names) == len(set(names)) >= 20
+    assert lib.vqk_set_tuning(b'NO_SUCH_SLOT', 1) == -5
+    assert lib.vqk_set_tuning(b'MX_HALF', 0) == 0 and lib.vqk_reset_tuning() == 0
+    got = native.apply_env_tuning(lib, {'VQK_MX_HALF': '0', 'VQK_WGMX_COEF': '0.16', 'VQK_GN_NO_SMALL': '1', 'VQK_UNRELATED': '7'})
+    assert got == {'MX_HALF': 0, 'WGMX_COEF_E4': 1600, 'GN_NO_SMALL': 1}
+    assert lib.vqk_reset_tuning() == 0
+    import glob
+    import os
+    csrc = os.path.join(os.path.dirname(native.__file__), 'csrc')
+    for path in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.cpp')) + glob.glob(os.path.join(csrc, '*.h')):
+        assert 'getenv' not in open(path).read(), path

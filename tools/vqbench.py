@@ -52,6 +52,34 @@ def bench(n, k, d=256, iters=200, scale=0.36, trained=True):
                    us=round(t * 1e6, 2), gbps=round(nbytes / t / 1e9, 1), hbm_frac=round(nbytes / t / 8e12, 4),
                    tflops_bf16=round(flops / t / 1e12, 1), indices_equal_exact_kernel=bool(torch.equal(idx, idx2)),
                    exact_fp32_kernel_us=round(t_exact * 1e6, 2))
+        # round 4: the whole quantizer forward as ONE kernel (codebook derivatives prepared when the codebook changes) and the
+        # whole backward as one -- against the launch sequence they replace
+        lib.vqk_vq_prepare_f32(e.data_ptr(), k, d, ws.data_ptr(), ws.numel(), s)
+        q32 = torch.empty(n, d, device='cuda'); qlo = torch.empty(n, d, dtype=torch.bfloat16, device='cuda')
+        sse = torch.zeros((), device='cuda'); hist = torch.zeros(k, dtype=torch.int32, device='cuda')
+        idx3 = torch.empty(n, dtype=torch.int64, device='cuda')
+        fwd = lambda: lib.vqk_vq_forward_f32(z.data_ptr(), e.data_ptr(), ws.data_ptr(), ws.numel(), n, k, d, 0, idx3.data_ptr(), 0,
+                                             qlo.data_ptr(), sse.data_ptr(), hist.data_ptr(), s)
+        t_fwd = _time(fwd, iters)
+
+        def old_fwd():
+            lib.vqk_row_sqnorm_f32(z.data_ptr(), n, d, z2.data_ptr(), s)
+            lib.vqk_row_sqnorm_f32(e.data_ptr(), k, d, e2.data_ptr(), s)
+            filt()
+            lib.vqk_vq_gather_f32(z.data_ptr(), e.data_ptr(), idx2.data_ptr(), n, k, d, q32.data_ptr(), qlo.data_ptr(), sse.data_ptr(),
+                                  hist.data_ptr(), s)
+        t_old_fwd = _time(old_fwd, iters)
+        dq = torch.randn(n, d, device='cuda').to(torch.bfloat16)
+        dz = torch.empty(n, d, device='cuda'); de = torch.zeros(k, d, device='cuda'); gs = torch.ones((), device='cuda')
+        bw = lambda f: (lambda: f(z.data_ptr(), e.data_ptr(), idx2.data_ptr(), dq.data_ptr(), 1, n, k, d, 1e-7, 4e-7, gs.data_ptr(),
+                                  dz.data_ptr(), de.data_ptr(), s))
+        t_bwd, t_old_bwd = _time(bw(lib.vqk_vq_backward_fused_f32), iters), _time(bw(lib.vqk_vq_backward_f32), iters)
+        fwd_bytes = n * d * 4 + k * d * 2 + n * d * 2 + n * 8          # z read, bf16 codebook read, bf16 q written, idx written
+        out.update(forward_kernel='vq_assign_filter_kernel, fused form (|z|^2 + filter + re-rank + gather + loss sum + histogram)',
+                   forward_us=round(t_fwd * 1e6, 2), forward_equal=bool(torch.equal(idx3, idx)),
+                   forward_gbps=round(fwd_bytes / t_fwd / 1e9, 1), forward_hbm_frac=round(fwd_bytes / t_fwd / 8e12, 4),
+                   forward_round3_sequence_us=round(t_old_fwd * 1e6, 2),
+                   backward_us=round(t_bwd * 1e6, 2), backward_round3_sequence_us=round(t_old_bwd * 1e6, 2))
     else:
         out.update(kernel='vq_assign_reg_kernel (exact fp32 MFMA)', us=round(t_exact * 1e6, 2), gbps=round(nbytes / t_exact / 1e9, 1),
                    hbm_frac=round(nbytes / t_exact / 8e12, 4), tflops_fp32=round(flops / t_exact / 1e12, 1),

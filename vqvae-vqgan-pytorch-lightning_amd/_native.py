@@ -28,6 +28,9 @@ _PROTOS = {
     'vqk_row_sqnorm_f32': [P, L, I, P, P],
     'vqk_vq_assign_f32': [P, P, P, P, L, I, I, I, P, P],
     'vqk_vq_assign_filtered_f32': [P, P, P, P, L, I, I, I, P, P, L, P],
+    'vqk_vq_prepare_f32': [P, I, I, P, L, P],
+    'vqk_vq_forward_f32': [P, P, P, L, L, I, I, I, P, P, P, P, P, P],
+    'vqk_vq_backward_fused_f32': [P, P, P, P, I, L, I, I, F, F, P, P, P, P],
     'vqk_vq_distances_f32': [P, P, P, P, L, I, I, I, P, P, P],
     'vqk_entropy_forward_f32': [P, L, I, F, P, P, P, P, P, P, P],
     'vqk_entropy_backward_f32': [P, P, P, P, L, I, F, F, P, P],
@@ -91,7 +94,9 @@ _PROTOS = {
     'vqk_bias_act': [P, P, P, P, P, P, L, L, I, I, I, F, F, F, P],
     'vqk_upfirdn2d': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, I, P],
 }
-_SPECIAL = {'vqk_conv_packed_elems': (c_int64, [I, I, I, I]), 'vqk_conv2d_wgrad_edge_ws_bytes': (c_int64, []), 'vqk_vq_filter_ws_bytes': (c_int64, [I, I]), 'vqk_status_str': (c_char_p, [I]), 'vqk_version': (I, []), 'vqk_arch': (c_char_p, [])}
+_SPECIAL = {'vqk_set_tuning': (I, [c_char_p, I]), 'vqk_reset_tuning': (I, []), 'vqk_tuning_count': (I, []),
+            'vqk_tuning_name': (c_char_p, [I]),
+            'vqk_conv_packed_elems': (c_int64, [I, I, I, I]), 'vqk_conv2d_wgrad_edge_ws_bytes': (c_int64, []), 'vqk_vq_filter_ws_bytes': (c_int64, [I, I]), 'vqk_status_str': (c_char_p, [I]), 'vqk_version': (I, []), 'vqk_arch': (c_char_p, [])}
 EXPORTS = sorted(list(_PROTOS) + list(_SPECIAL))
 
 
@@ -140,7 +145,33 @@ def lib() -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = cdll
+    apply_env_tuning(cdll)
     return _lib
+
+
+def apply_env_tuning(cdll=None, environ=None) -> dict:
+    """The library reads no environment variable (include/vqk.h); its launch heuristics are tuning slots.  This host layer
+    keeps the interface of the A/B scripts under tools/: every ``VQK_<SLOT>`` found in the environment is handed to
+    ``vqk_set_tuning`` once, when the library is loaded (VQK_WGMX_COEF is a float, its slot counts 1e-4 units; the two
+    formerly presence-only switches VQK_GN_NO_SMALL / VQK_WGRAD_NO_* count as 1 when set to anything but '0')."""
+    cdll = cdll or lib()
+    environ = os.environ if environ is None else environ
+    applied = {}
+    for i in range(cdll.vqk_tuning_count()):
+        name = cdll.vqk_tuning_name(i).decode()
+        env = 'VQK_WGMX_COEF' if name == 'WGMX_COEF_E4' else 'VQK_' + name
+        raw = environ.get(env)
+        if raw is None:
+            continue
+        if name == 'WGMX_COEF_E4':
+            val = int(round(float(raw) * 1e4))
+        elif name in ('GN_NO_SMALL', 'WGRAD_NO_PW16', 'WGRAD_NO_P16K'):
+            val = 0 if raw == '0' else 1
+        else:
+            val = int(raw)
+        check(cdll.vqk_set_tuning(name.encode(), val), f'set_tuning({name})')
+        applied[name] = val
+    return applied
 
 
 ERR_SHAPE = -1          # VQK_ERR_SHAPE (include/vqk.h)

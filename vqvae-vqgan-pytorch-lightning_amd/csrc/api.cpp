@@ -53,3 +53,60 @@ extern "C" int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes) {
     d.bytes = (on && ws) ? ws_bytes : 0;
     return VQK_OK;
 }
+
+// ---------------------------------------------------------------- tuning slots (include/vqk.h: vqk_set_tuning)
+#include <string.h>
+#include <stdlib.h>
+namespace vqkd {
+static TuneSlot g_tune[] = {
+    {"MX", 0, 0},
+    {"MX_1X1", 0, 0},
+    {"TW16", 0, 0},
+    {"STREAM_BLOCKS", 0, 0},
+    {"MX_MIN_TILES", 0, 0},
+    {"FPROP_SPLITK", 0, 0},
+    {"SK_BLOCKS", 0, 0},
+    {"SK_MINSTEPS", 0, 0},
+    {"SK_MAXMB", 0, 0},
+    {"UPS_PHASE", 0, 0},
+    {"WGRAD_BLOCKS", 0, 0},
+    {"WGMX", 0, 0},
+    {"WGRAD_GEN_BLOCKS", 0, 0},
+    {"WGRAD_NO_PW16", 0, 0},
+    {"WGRAD_NO_P16K", 0, 0},
+    {"MX_HALF", 0, 0},
+    {"MX_HALF_HW", 0, 0},
+    {"UPFIRDN_TILE", 0, 0},
+    {"GN_BLOCKS_REDUCE", 0, 0},
+    {"GN_BLOCKS_APPLY", 0, 0},
+    {"GN_NT_MB", 0, 0},
+    {"GN_NO_SMALL", 0, 0},
+    {"WGMX_COEF_E4", 0, 0}
+};
+static constexpr int kTune = (int)(sizeof(g_tune) / sizeof(g_tune[0]));
+TuneSlot* tune_slot(const char* name) {
+    for (int i = 0; i < kTune; ++i)
+        if (strcmp(g_tune[i].name, name) == 0) return &g_tune[i];
+    abort();                                                     // a call site names a slot that is not in the table above
+}
+}  // namespace vqkd
+
+extern "C" int vqk_set_tuning(const char* name, int value) {
+    if (!name) return VQK_ERR_ARG;
+    for (int i = 0; i < vqkd::kTune; ++i)
+        if (strcmp(vqkd::g_tune[i].name, name) == 0) {
+            __atomic_store_n(&vqkd::g_tune[i].value, value, __ATOMIC_RELAXED);
+            __atomic_store_n(&vqkd::g_tune[i].is_set, 1, __ATOMIC_RELEASE);
+            return VQK_OK;
+        }
+    return VQK_ERR_ARG;
+}
+
+extern "C" int vqk_reset_tuning(void) {
+    for (int i = 0; i < vqkd::kTune; ++i) __atomic_store_n(&vqkd::g_tune[i].is_set, 0, __ATOMIC_RELAXED);
+    return VQK_OK;
+}
+
+extern "C" int vqk_tuning_count(void) { return vqkd::kTune; }
+
+extern "C" const char* vqk_tuning_name(int i) { return (i >= 0 && i < vqkd::kTune) ? vqkd::g_tune[i].name : nullptr; }

@@ -96,6 +96,16 @@ struct DetState { int on; float* ws; int64_t bytes; };
 DetState& det_state();
 DetState& scratch_state();      // vqk_set_scratch: zero-initialised fp32 scratch of the current stream (split-K partial sums)
 }
+// launch heuristics that tools/ sweep (include/vqk.h: vqk_set_tuning): process-wide slots, relaxed atomics; a call site
+// resolves its slot once and then reads one int per launch.  The library itself never reads the environment.
+namespace vqkd {
+struct TuneSlot {
+    const char* name; int value; int is_set;
+    int get(int dflt) const { return __atomic_load_n(&is_set, __ATOMIC_RELAXED) ? __atomic_load_n(&value, __ATOMIC_RELAXED) : dflt; }
+};
+TuneSlot* tune_slot(const char* name);      // nullptr-safe: an unknown name aborts at first use (a typo in the source)
+}
+#define VQK_TUNE(name, dflt) ([]() -> const vqkd::TuneSlot* { static const vqkd::TuneSlot* s = vqkd::tune_slot(name); return s; }()->get(dflt))
 #define VQK_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH; } while (0)
 #define VQK_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
 static inline bool vqk_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -2007,8 +2007,8 @@ static thread_local int g_wgrad_blocks = 0;     // kernel running concurrently o
 // 1x1 convs (the ResBlock shortcuts, autoencoder.py:52-55): the NTAP = 1 form of the matrix/auxiliary-wave kernel -- bf16, whole
 // 128-cout tiles, at least two 32-channel chunks, 32-bit buffer offsets
 inline bool mx_serves_1x1(const ConvGeom& g) {
-    static const int mx_on = getenv("VQK_MX") ? atoi(getenv("VQK_MX")) : 1;
-    static const int on = getenv("VQK_MX_1X1") ? atoi(getenv("VQK_MX_1X1")) : 1;
+    const int mx_on = VQK_TUNE("MX", 1);
+    const int on = VQK_TUNE("MX_1X1", 1);
     return mx_on && on && g_force_variant != 5 && (g.cout & 127) == 0 && (g.cpt >> 2) >= 2 && !g.ups &&
            (int64_t)g.n * g.h_in * g.w_in * g.cin * 2 < 0x7fffffffLL && (int64_t)g.m * g.cout * 2 < 0x7fffffffLL;
 }
@@ -2017,7 +2017,7 @@ inline bool mx_serves_1x1(const ConvGeom& g) {
 inline int halo_twlog(const ConvGeom& g) {
     if ((g.ks != 3 && g.ks != 1) || (g.cpt % 8) != 0 || g_force_variant == 0) return 0;
     if (g.ks == 1 && !mx_serves_1x1(g)) return 0;                // 1x1: only the matrix/auxiliary-wave kernel has a pixel-tile form
-    static const int prefer16 = getenv("VQK_TW16") ? atoi(getenv("VQK_TW16")) : 0;      // A/B: 16x16 patches where both fit
+    const int prefer16 = VQK_TUNE("TW16", 0);      // A/B: 16x16 patches where both fit
     if (prefer16 && (g.w % 16) == 0 && (g.h % 16) == 0) return 4;
     if ((g.w % 32) == 0 && (g.h % 8) == 0) return 5;
     if ((g.w % 16) == 0 && (g.h % 16) == 0) return 4;
@@ -2032,7 +2032,7 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         if (!tw) return VQK_ERR_SHAPE;
         const int th = 256 >> tw;
         const int total = g.n * (g.h / th) * (g.w >> tw) * g.tiles_n;
-        static const int persist_env = getenv("VQK_STREAM_BLOCKS") ? atoi(getenv("VQK_STREAM_BLOCKS")) : 512;
+        const int persist_env = VQK_TUNE("STREAM_BLOCKS", 512);
         const int persist = g_stream_blocks > 0 ? g_stream_blocks : persist_env;
         const dim3 grid((unsigned)(total < persist ? total : persist));
         constexpr int lds = 2 * 28 * 1024;
@@ -2041,8 +2041,8 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
             // matrix-wave / auxiliary-wave kernel (conv_mx.hip): whole 128-cout tiles, plain epilogue (bias / residual /
             // pooling).  The choice must not depend on the batch size (a step on B images has to equal the mean of the steps
             // on its halves to bf16 noise -- the two kernels round differently), hence no tile-count threshold by default
-            static const int mx_on = getenv("VQK_MX") ? atoi(getenv("VQK_MX")) : 1;
-            static const int mx_min = getenv("VQK_MX_MIN_TILES") ? atoi(getenv("VQK_MX_MIN_TILES")) : 1;
+            const int mx_on = VQK_TUNE("MX", 1);
+            const int mx_min = VQK_TUNE("MX_MIN_TILES", 1);
             // (bias / residual / pooling; relu or leaky relu with the StyleGAN2 gains: the VGG and discriminator convs)
             const bool plain = (act == 0 || ((act == 2 || act == 3) && !g.pool && !g.gn_ws)) && (g.cout & 127) == 0;
             const bool fits32 = (int64_t)g.n * g.h_in * g.w_in * g.cin * 2 < 0x7fffffffLL && (int64_t)g.m * g.cout * 2 < 0x7fffffffLL;
@@ -2135,11 +2135,11 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
         vqkd::DetState& sc = vqkd::scratch_state();
         const int tiles = g.tiles_m * g.tiles_n, ksteps = (g.kchunks + 7) >> 3;
         const int64_t out_elems = (int64_t)g.m * g.cout;
-        static const int sk_on = getenv("VQK_FPROP_SPLITK") ? atoi(getenv("VQK_FPROP_SPLITK")) : 1;
+        const int sk_on = VQK_TUNE("FPROP_SPLITK", 1);
         // (this kernel runs one k-step at a time per block: below ~4 blocks per CU nothing hides its load -> LDS -> MFMA latency)
-        static const int sk_blocks = getenv("VQK_SK_BLOCKS") ? atoi(getenv("VQK_SK_BLOCKS")) : 2048;
-        static const int sk_minsteps = getenv("VQK_SK_MINSTEPS") ? atoi(getenv("VQK_SK_MINSTEPS")) : 4;
-        static const int sk_maxmb = getenv("VQK_SK_MAXMB") ? atoi(getenv("VQK_SK_MAXMB")) : 32;
+        const int sk_blocks = VQK_TUNE("SK_BLOCKS", 2048);
+        const int sk_minsteps = VQK_TUNE("SK_MINSTEPS", 4);
+        const int sk_maxmb = VQK_TUNE("SK_MAXMB", 32);
         int splits = tiles * 2 <= sk_blocks ? sk_blocks / tiles : 1;
         if (splits > ksteps / sk_minsteps) splits = ksteps / sk_minsteps;
         if ((int64_t)splits * out_elems * 4 > ((int64_t)sk_maxmb << 20)) splits = (int)(((int64_t)sk_maxmb << 20) / (out_elems * 4));
@@ -2326,8 +2326,8 @@ int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* 
     const int rc = make_geom(g, dtype, n, h, w, cin, cout, 3, 0);            // tiles over the LOW-resolution h x w grid
     if (rc) return rc;
     const int tw = halo_twlog(g);
-    static const int mx_on = getenv("VQK_MX") ? atoi(getenv("VQK_MX")) : 1;
-    static const int ph_on = getenv("VQK_UPS_PHASE") ? atoi(getenv("VQK_UPS_PHASE")) : 1;
+    const int mx_on = VQK_TUNE("MX", 1);
+    const int ph_on = VQK_TUNE("UPS_PHASE", 1);
     VQK_REQUIRE(tw && mx_on && ph_on && (cout % 128) == 0 && (g.cpt >> 2) >= 2 && g_force_variant != 5, VQK_ERR_SHAPE);
     VQK_REQUIRE((int64_t)4 * g.m * (backward ? cin : cout) * 2 < 0x7fffffffLL && (int64_t)g.m * (backward ? cout : cin) * 2 < 0x7fffffffLL,
                 VQK_ERR_SHAPE);
@@ -2454,13 +2454,13 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     }
     if (plain && dtype == VQK_BF16 && ksize == 3 && (g.h % 8) == 0 && (g.w % 8) == 0 && g_force_variant != 0) {
         const int tiles = ((cout + 63) / 64) * ((cin + 63) / 64);
-        static const bool no_pw16 = getenv("VQK_WGRAD_NO_PW16") != nullptr;
+        const bool no_pw16 = VQK_TUNE("WGRAD_NO_PW16", 0) != 0;
         const bool pw16 = (g.w % 16) == 0 && !no_pw16;
         const int total_patches = g.n * (g.h / 8) * (g.w / (pw16 ? 16 : 8));
         // split-K over pixel patches.  Cost model fitted on MI355X (tools/convbench.py sweeps): MFMA time falls with the
         // number of resident blocks (up to 2 per CU) while every split adds one fp32 atomic pass over dW (~1.1 TB/s):
         // t(s) = F / (R * min(1, tiles*s/512)) + s * |dW| / B  =>  s* = sqrt(0.16 * pixels / tiles) below the block cap.
-        static const int target = getenv("VQK_WGRAD_BLOCKS") ? atoi(getenv("VQK_WGRAD_BLOCKS")) : 0;
+        const int target = VQK_TUNE("WGRAD_BLOCKS", 0);
         const int cap = g_wgrad_blocks > 0 ? g_wgrad_blocks : 512;
         int splits;
         if (target > 0) splits = (target + tiles - 1) / tiles;
@@ -2474,12 +2474,12 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
         const int pps = (total_patches + splits - 1) / splits;
         splits = (total_patches + pps - 1) / pps;
         const dim3 grid((unsigned)tiles, (unsigned)splits);
-        static const bool no_p16k = getenv("VQK_WGRAD_NO_P16K") != nullptr;
-        static const int wgmx = getenv("VQK_WGMX") ? atoi(getenv("VQK_WGMX")) : 1;
+        const bool no_p16k = VQK_TUNE("WGRAD_NO_P16K", 0) != 0;
+        const int wgmx = VQK_TUNE("WGMX", 1);
         if (pw16 && (cin % 64) == 0 && (cout % 64) == 0 && wgmx && target == 0) {
             // matrix/auxiliary-wave form: ONE 512-thread block per CU, so half as many resident blocks as the cost model
             // above assumes: s* = sqrt(0.08 * pixels / tiles) under half the block cap
-            static const double coef = getenv("VQK_WGMX_COEF") ? atof(getenv("VQK_WGMX_COEF")) : 0.08;
+            const double coef = VQK_TUNE("WGMX_COEF_E4", 800) * 1e-4;          // (knob in units of 1e-4)
             const int capm = cap / 2 > tiles ? cap / 2 : tiles;
             int sm = (int)(sqrt(coef * (double)g.m / tiles) + 0.5);
             if (sm > (capm + tiles - 1) / tiles) sm = (capm + tiles - 1) / tiles;
@@ -2526,7 +2526,7 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     // ends with one: at 2048 blocks the 1x1 shortcut's 128 x 256 gradient cost 134 MB of atomics per launch)
     // (measured, tools/wgrad_gen_bench.py: 1x1 128->256 @128^2 167 -> 67 us; the strided 3x3 gathers are faster on the
     // single-stage kernel with ~2048 blocks -- 421 vs 302 us at 128->256 @257^2 stride 2 -- and keep it)
-    static const int wg_target = getenv("VQK_WGRAD_GEN_BLOCKS") ? atoi(getenv("VQK_WGRAD_GEN_BLOCKS")) : 512;
+    const int wg_target = VQK_TUNE("WGRAD_GEN_BLOCKS", 512);
     const bool db = dtype == VQK_BF16 && ksize == 1;
     const int target_blocks = db ? wg_target : 2048;
     int splits = (target_blocks + tiles - 1) / tiles;
@@ -2575,8 +2575,8 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
 int vqk_conv2d_wgrad_pooled_dy(int dtype, const void* x, const void* dy_pooled, float* dw, int n, int h, int w, int cin,
                                int cout, float scale, const void* zeros, void* stream) {
     VQK_REQUIRE(dtype == VQK_BF16 && (h % 8) == 0 && (w % 16) == 0 && (cin % 64) == 0 && (cout % 64) == 0, VQK_ERR_SHAPE);
-    static const int wgmx = getenv("VQK_WGMX") ? atoi(getenv("VQK_WGMX")) : 1;
-    VQK_REQUIRE(wgmx && g_force_variant != 0 && !getenv("VQK_WGRAD_BLOCKS") && !getenv("VQK_WGRAD_NO_PW16"), VQK_ERR_SHAPE);
+    const int wgmx = VQK_TUNE("WGMX", 1);
+    VQK_REQUIRE(wgmx && g_force_variant != 0 && VQK_TUNE("WGRAD_BLOCKS", 0) == 0 && VQK_TUNE("WGRAD_NO_PW16", 0) == 0, VQK_ERR_SHAPE);
     return wgrad_general(dtype, x, dy_pooled, dw, n, h, w, cin, cout, 3, 1, 1, 0, h, w, zeros, stream, 1, scale);
 }
 

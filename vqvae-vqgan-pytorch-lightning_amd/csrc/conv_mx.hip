@@ -521,8 +521,8 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     (void)zeros;
     // 128-pixel half tiles for the 16x16 maps: a function of the image size only (never of the batch size: per-tile
     // statistics partials group differently), they double the blocks of launches whose 256-pixel tiles fill half the chip
-    static const int half_on = getenv("VQK_MX_HALF") ? atoi(getenv("VQK_MX_HALF")) : 1;
-    static const int half_hw = getenv("VQK_MX_HALF_HW") ? atoi(getenv("VQK_MX_HALF_HW")) : 256;
+    const int half_on = VQK_TUNE("MX_HALF", 1);
+    const int half_hw = VQK_TUNE("MX_HALF_HW", 256);
     const bool half = half_on && g.h * g.w <= half_hw && !g.pool && g.ntap == 9 && (twlog == 4 ? (g.h % 8) == 0 : (g.h % 4) == 0);
     const int th = (half ? 128 : 256) >> twlog;
     const int total = g.n * (g.h / th) * (g.w >> twlog) * g.tiles_n;

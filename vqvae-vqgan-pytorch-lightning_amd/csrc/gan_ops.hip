@@ -826,7 +826,7 @@ int vqk_upfirdn2d_nhwc(int dtype, const void* x, const float* f, void* y, int n,
     VQK_REQUIRE(out_h == (h * upy + pady0 + pady1 - fh + downy) / downy, VQK_ERR_SHAPE);
     VQK_REQUIRE(out_w >= 1 && out_h >= 1, VQK_ERR_SHAPE);
     // LDS-tiled form: 4x4 FIR, (up, down) in {(1,1), (1,2), (2,1)}, whole groups of 8 channel slots
-    static const int tile_on = getenv("VQK_UPFIRDN_TILE") ? atoi(getenv("VQK_UPFIRDN_TILE")) : 1;
+    const int tile_on = VQK_TUNE("UPFIRDN_TILE", 1);
     if (tile_on && fh == 4 && fw == 4 && upx == upy && downx == downy && c % (8 * v) == 0 &&
         ((upx == 1 && downx == 1) || (upx == 2 && downx == 1))) {     // (down 2: the register form below is faster, 189 vs 249 us)
         const int tiles_x = (out_w + 15) / 16, tiles_y = (out_h + 7) / 8;

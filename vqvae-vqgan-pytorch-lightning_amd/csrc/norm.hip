@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const T* __restrict__
 
 // pixels per thread of the small-map form for this problem, or 0 when it does not apply
 inline int gn_small_ppt(int dtype, int64_t hw, int c, int groups, int max_ppt) {
-    static const bool off = getenv("VQK_GN_NO_SMALL") != nullptr;
+    const bool off = VQK_TUNE("GN_NO_SMALL", 0) != 0;
     if (off || c % 32 || (32 % (c / groups))) return 0;
     const int rows = dtype == VQK_F32 ? 32 : 64;
     if (hw % rows) return 0;
@@ -621,8 +621,8 @@ int check_gn(int dtype, int c, int groups) {
 // sums) pay per-block LDS + global atomics for every channel / group, so they want fewer, fatter blocks (~768 total):
 // measured -8...27 % per reducing pass on the 64^2 / 128^2 maps, -2...5 % on 256^2 (sweep 256...4096 blocks).
 inline int pick_ppb(int n, int64_t hw, bool reducing = false) {
-    static const int tot_r = getenv("VQK_GN_BLOCKS_REDUCE") ? atoi(getenv("VQK_GN_BLOCKS_REDUCE")) : 768;
-    static const int tot_a = getenv("VQK_GN_BLOCKS_APPLY") ? atoi(getenv("VQK_GN_BLOCKS_APPLY")) : 2048;
+    const int tot_r = VQK_TUNE("GN_BLOCKS_REDUCE", 768);
+    const int tot_a = VQK_TUNE("GN_BLOCKS_APPLY", 2048);
     const int total = reducing ? tot_r : tot_a;
     int64_t blocks_per_sample = (total + n - 1) / n;
     int64_t ppb = (hw + blocks_per_sample - 1) / blocks_per_sample;
@@ -665,7 +665,7 @@ static int gn_backward_impl(int dtype, const void* x, const float* stats, const 
     const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
     const size_t lds = (size_t)2 * c * sizeof(double) + 256 * 2 * (dtype == VQK_F32 ? 4 : 8) * sizeof(float);
-    static const int64_t nt_mb = getenv("VQK_GN_NT_MB") ? atoll(getenv("VQK_GN_NT_MB")) : 192;
+    const int64_t nt_mb = VQK_TUNE("GN_NT_MB", 192);
     const bool nt = (int64_t)n * hw * c * (dtype == VQK_F32 ? 4 : 2) >= (nt_mb << 20);
     // deterministic mode: group partials [n][groups][nblk][2] doubles, then channel partials [n][nblk][2c] floats, in the workspace
     vqkd::DetState& det = vqkd::det_state();

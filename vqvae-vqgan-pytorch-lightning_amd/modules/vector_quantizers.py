@@ -14,6 +14,9 @@ from .abstract_modules.base_quantizer import BaseVectorQuantizer
 from .autoencoder import Conv2d
 
 
+EMA_COLLECTIVES = [0, 0]        # collectives issued / bytes (bench.py reports both per step)
+
+
 def reduce_ema_stats(stats: torch.Tensor, local_batch: int, force_collective: bool = False) -> float:
     """Collective #2: sum the packed ``[counts(K) | dw(K*D)]`` statistics of every data-parallel rank with
     ONE all-reduce, in place; returns the Laplace-smoothing constant of vector_quantizers.py:164 for the reduced
@@ -22,6 +25,8 @@ def reduce_ema_stats(stats: torch.Tensor, local_batch: int, force_collective: bo
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if world > 1 or (force_collective and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        EMA_COLLECTIVES[0] += 1
+        EMA_COLLECTIVES[1] += stats.numel() * stats.element_size()
     return float(local_batch * world)
 
 

@@ -232,6 +232,7 @@ def repack_owned(owner=None) -> int:
     """Refresh every cached operand whose master weight belongs to ``owner`` (a FlatAdamW; None: every stale entry)
     with one ``vqk_conv_pack_multi`` launch.  Called by ``FlatAdamW.step`` right after the AdamW kernel."""
     global _PACK_TABLE
+    refresh_vq_prepared(owner)                           # the quantizer's prepared codebook follows the same rule
     keys, dead = [], []
     for key, ent in _PACK_CACHE.items():
         weight = ent.wref()
@@ -262,6 +263,7 @@ def repack_owned(owner=None) -> int:
 def clear_pack_cache():
     global _PACK_TABLE
     _PACK_CACHE.clear()
+    _VQ_PREP.clear()
     _PACK_TABLE = None
 
 
@@ -284,6 +286,12 @@ def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_d
         _native.check(st, 'conv2d_thin_out')
         return y
     kname = _fprop_kernel_name(x.dtype, wlayout, (n, h * s, w * s, cin, cout, act, out_dtype))
+    if (x.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and wlayout == 0 and ksize == 3 and cin == 8 and residual is None
+            and not ups and w % 32 == 0 and cout % 8 == 0):
+        # one 16-byte chunk of input channels (the padded 3-channel image): csrc/conv.hip::launch_fprop takes the
+        # thin-input kernel -- it writes 2 * Cout bytes per pixel at memory speed: an HBM line, not an MFMA one
+        kname, flops = kname.replace('conv_fprop_kernel<bf16>', 'conv3x3_thin_in_kernel<bf16> (HBM)'), 0.0
+        nbytes = x.numel() * 2 + y.numel() * 2
     if ksize == 1 and kname.startswith('conv3x3_mx_kernel'):
         # the NTAP = 1 instantiation (ResBlock shortcuts): memory-bound, reported with its bytes like the GroupNorm passes
         kname, flops = kname.replace('conv3x3_mx_kernel<bf16>', 'conv1x1_mx_kernel<bf16> (HBM)'), 0.0
@@ -1119,6 +1127,7 @@ class _MSE(torch.autograd.Function):
 # vector quantizer
 # ------------------------------------------------------------------------------------------------------
 VQ_FILTER = os.environ.get('VQK_VQ_FILTER', '1') != '0'
+VQ_FUSED = os.environ.get('VQK_VQ_FUSED', '1') != '0'      # one forward kernel + one backward kernel (0: the round-3 launch sequence)
 _VQ_WS: dict = {}
 
 
@@ -1128,6 +1137,65 @@ def _vq_filter_ws(device, k: int, d: int) -> torch.Tensor:
     if ws is None:
         ws = _VQ_WS[key] = torch.empty(_native.lib().vqk_vq_filter_ws_bytes(k, d), dtype=torch.uint8, device=device)
     return ws
+
+
+class _VQPrep:
+    __slots__ = ('wref', 'ws', 'stamp', 'k', 'd')
+
+
+_VQ_PREP: dict = {}             # data_ptr of the codebook -> _VQPrep: what vqk_vq_prepare_f32 derived from it
+
+
+def _vq_prepare_now(ent, cb) -> None:
+    _native.check(_native.lib().vqk_vq_prepare_f32(cb.data_ptr(), ent.k, ent.d, ent.ws.data_ptr(), ent.ws.numel(), _stream()),
+                  'vq_prepare')
+
+
+def vq_prepared(codebook) -> torch.Tensor | None:
+    """Workspace of the filtered assignment for ``codebook`` (a Parameter / tensor [K, 256] fp32, contiguous): the bf16
+    fragment-major copy, |e|^2, the filter margins and max |e|^2 -- everything that depends on the codebook only.  Built
+    when the codebook CHANGES, not per step: the entry is stamped like the packed conv operands (in-place version +
+    generation of the owning FlatAdamW), refreshed by :func:`repack_owned` right after the AdamW kernel and by
+    :func:`ema_apply` after the EMA update, so a captured step holds no prepare launch.  None: shape not served."""
+    k, d = codebook.shape
+    if not (VQ_FILTER and VQ_FUSED and d == 256 and k % 32 == 0 and codebook.dtype == torch.float32 and codebook.is_contiguous()):
+        return None
+    cb = codebook.detach()
+    ent = _VQ_PREP.get(cb.data_ptr())
+    if ent is not None and (ent.wref() is not codebook or ent.k != k):
+        ent = None
+    stamp = _pack_stamp(codebook)
+    if ent is None:
+        ent = _VQPrep()
+        ent.wref, ent.k, ent.d, ent.stamp = weakref.ref(codebook), k, d, None
+        ent.ws = torch.empty(_native.lib().vqk_vq_filter_ws_bytes(k, d), dtype=torch.uint8, device=cb.device)
+        _VQ_PREP[cb.data_ptr()] = ent
+    if ent.stamp != stamp:
+        _vq_prepare_now(ent, cb)
+        ent.stamp = stamp
+    return ent.ws
+
+
+def refresh_vq_prepared(owner=None, data_ptr: int | None = None) -> int:
+    """re-derive the prepared workspaces whose codebook belongs to ``owner`` (a FlatAdamW that just stepped), lives at
+    ``data_ptr`` (the EMA update wrote it through the C-ABI: no version bump), or -- both None -- is stale"""
+    n = 0
+    for ptr, ent in list(_VQ_PREP.items()):
+        cbp = ent.wref()
+        if cbp is None or cbp.data_ptr() != ptr:
+            del _VQ_PREP[ptr]
+            continue
+        if data_ptr is not None:
+            hit = ptr == data_ptr
+        elif owner is not None:
+            hit = getattr(cbp, '_vqk_owner', None) is owner
+        else:
+            hit = ent.stamp != _pack_stamp(cbp)
+        if hit:
+            _vq_prepare_now(ent, cbp.detach())
+            ent.stamp = _pack_stamp(cbp)
+            n += 1
+    return n
 
 
 def vq_assign(flat_z: torch.Tensor, codebook: torch.Tensor, assoc: int) -> torch.Tensor:
@@ -1172,14 +1240,24 @@ class VQLookupFn(torch.autograd.Function):
         cb = codebook.detach().contiguous() if codebook_loss else codebook.detach().clone()
         k = cb.shape[0]
         flat = z.permute(0, 2, 3, 1).reshape(n, d)           # a view: NHWC memory is already [N][D]
-        idx = vq_assign(flat, cb, assoc)
-        q32 = empty_nhwc(b, d, h, w, torch.float32, z.device)
         qlo = empty_nhwc(b, d, h, w, torch.bfloat16, z.device) if out_dtype == torch.bfloat16 else None
-        sse = torch.zeros((), dtype=torch.float32, device=z.device)
-        hist = torch.zeros(k, dtype=torch.int32, device=z.device)
-        _native.check(_native.lib().vqk_vq_gather_f32(flat.data_ptr(), cb.data_ptr(), idx.data_ptr(), n, k, d,
-                                                      q32.data_ptr(), _p(qlo), sse.data_ptr(), hist.data_ptr(),
-                                                      _stream()), 'vq_gather')
+        zbuf = torch.zeros(k + 1, dtype=torch.int32, device=z.device)            # histogram | loss sum: one fill launch
+        hist, sse = zbuf[:k], zbuf[k:].view(torch.float32).view(())
+        ws = vq_prepared(codebook) if codebook.is_contiguous() else None
+        if ws is not None:
+            # ONE kernel: |z|^2, bf16 filter + exact re-rank, gather, sum (q - z)^2, histogram (csrc/vq_filter.hip); the
+            # fp32 copy of q is only written when it is the output
+            q32 = empty_nhwc(b, d, h, w, torch.float32, z.device) if qlo is None else None
+            idx = torch.empty(n, dtype=torch.int64, device=z.device)
+            _native.check(_native.lib().vqk_vq_forward_f32(flat.data_ptr(), codebook.detach().data_ptr(), ws.data_ptr(), ws.numel(),
+                                                           n, k, d, assoc, idx.data_ptr(), _p(q32), _p(qlo), sse.data_ptr(),
+                                                           hist.data_ptr(), _stream()), 'vq_forward')
+        else:
+            idx = vq_assign(flat, cb, assoc)
+            q32 = empty_nhwc(b, d, h, w, torch.float32, z.device)
+            _native.check(_native.lib().vqk_vq_gather_f32(flat.data_ptr(), cb.data_ptr(), idx.data_ptr(), n, k, d,
+                                                          q32.data_ptr(), _p(qlo), sse.data_ptr(), hist.data_ptr(),
+                                                          _stream()), 'vq_gather')
         mse = sse / float(n * d)
         loss = (mse + beta * mse) if codebook_loss else beta * mse
         ctx.save_for_backward(z, cb, idx)
@@ -1197,11 +1275,13 @@ class VQLookupFn(torch.autograd.Function):
         gs = dloss.to(torch.float32).contiguous() if dloss is not None else None
         dqc = nhwc(dq) if dq is not None else None
         scale = 2.0 / float(n * d)
-        _native.check(_native.lib().vqk_vq_backward_f32(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), _p(dqc),
-                                                        dcode(dqc.dtype) if dqc is not None else F32, n, k, d,
-                                                        beta * scale if gs is not None else 0.0,
-                                                        scale if gs is not None else 0.0, _p(gs), dz.data_ptr(),
-                                                        _p(de), _stream()), 'vq_backward')
+        fused = VQ_FUSED and d == 256 and not DETERMINISTIC       # (deterministic mode: the ordered two-kernel form)
+        fn = _native.lib().vqk_vq_backward_fused_f32 if fused else _native.lib().vqk_vq_backward_f32
+        _native.check(fn(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), _p(dqc),
+                         dcode(dqc.dtype) if dqc is not None else F32, n, k, d,
+                         beta * scale if gs is not None else 0.0,
+                         scale if gs is not None else 0.0, _p(gs), dz.data_ptr(),
+                         _p(de), _stream()), 'vq_backward')
         return dz, de, None, None, None, None
 
 
@@ -1373,6 +1453,7 @@ def ema_apply(buf, ema_count, ema_weight, codebook, decay: float, eps: float, ba
     _native.check(_native.lib().vqk_ema_update_f32(ema_count.data_ptr(), ema_weight.data_ptr(), codebook.data_ptr(),
                                                    buf.data_ptr(), buf[k:].data_ptr(), k, d, decay, eps, batch, _stream()),
                   'ema_update')
+    refresh_vq_prepared(data_ptr=codebook.data_ptr())      # written through the C-ABI: no version bump to notice
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -158,10 +158,22 @@ class FlatAdamW(torch.optim.Optimizer):
     def collective_on(self) -> bool:
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective)
 
+    # bench.py: collectives issued / bytes handed to RCCL since construction, and a timing-only switch that skips the
+    # collectives (the step then runs exactly as at world 1: step time with - without = the EXPOSED communication time)
+    collectives_issued = 0
+    collective_bytes = 0
+    mute_collectives = False
+
+    def _count(self, numel: int) -> None:
+        self.collectives_issued += 1
+        self.collective_bytes += numel * 4
+
     def all_reduce_grads(self, world_size: int | None = None):
         """ONE collective per optimizer step (replaces DDP's bucketed reducer, vqvae/train.py:128)."""
         if self.collective_on():
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+            if not self.mute_collectives:
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+                self._count(self.flat_g.numel())
             self.grad_scale = 1.0 / dist.get_world_size()
         else:
             self.grad_scale = 1.0
@@ -174,6 +186,9 @@ class FlatAdamW(torch.optim.Optimizer):
             self.grad_scale = 1.0 / dist.get_world_size() if self.collective_on() else 1.0
             return None
         self.grad_scale = 1.0 / dist.get_world_size()
+        if self.mute_collectives:
+            return None
+        self._count(hi - lo)
         return dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
 
     @torch.no_grad()
