@@ -235,7 +235,7 @@ int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes);
  * ws must be 16-byte aligned (VQK_ERR_ALIGN), ws_bytes >= 0 (VQK_ERR_ARG); the same checks apply to vqk_set_deterministic. */
 int vqk_set_scratch(void* ws, int64_t ws_bytes);
 /* Tuning slots: the launch heuristics that tools/ sweep (formerly read-once environment variables).  name = one of
- * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4.
+ * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4, GN_CLUSTER_MAX_HW.
  * A set slot overrides the built-in default at the next launch; vqk_reset_tuning returns every slot to its default.
  * Process-wide (relaxed atomics); VQK_ERR_ARG for an unknown name.  The Python host maps VQK_<NAME> environment variables
  * onto these calls when it loads the library (_native.py), so the A/B scripts keep their interface. */
@@ -297,6 +297,14 @@ int vqk_gn_forward_presummed(int dtype, const void* x, const float* w, const flo
 int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
                     void* dx, float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu,
                     int accumulate, const void* add, void* stream);
+/* vqk_gn_backward / vqk_gn_backward_pooled_add (add_pooled != NULL) with the SIZE of the workspace stated.  With
+ * ws_doubles >= N*G*2 + N + N*(C/32) the mid-size maps (H*W <= the GN_CLUSTER_MAX_HW slot, a multiple of 8 x 64 pixels in
+ * bf16) run as ONE kernel: clusters of blocks per (sample, 32-channel slice) keep x and dy in registers, exchange their group
+ * sums through the workspace (the extra N*(C/32) slots are the clusters' tickets) and apply from the registers -- x and dy are
+ * read once.  Same workspace protocol (zero on entry, zero on exit); deterministic mode keeps the two-kernel form. */
+int vqk_gn_backward_ws(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
+                       void* dx, float* dw, float* db, double* red, int64_t ws_doubles, int n, int h, int wd, int c, int groups,
+                       int silu, int accumulate, const void* add, const void* add_pooled, float add_scale, void* stream);
 /* vqk_gn_backward with dx += add_scale * (add_pooled read at pixel (row/2, col/2)): the skip-branch gradient of a ResBlock
  * whose output went through a fused 2x2 average pool, still at half resolution ([N][h/2][wd/2][C]).  h * wd > 1024. */
 int vqk_gn_backward_pooled_add(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,

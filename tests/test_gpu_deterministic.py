@@ -101,7 +101,9 @@ def test_groupnorm_ordered_sums_equal_atomic_sums(n, c, h):
     default, det1, det2 = _both(fn)
     for p, q in zip(det1, det2):
         assert torch.equal(p, q)
-    for p, q, tol in zip(det1, default, (1e-6, 1e-6, 1e-6, 1e-5, 1e-5)):
+    # (dx: the default mode's mid-size maps run the single-kernel cluster form, whose group sums meet in another order -- a few
+    # bf16 outputs round the other way)
+    for p, q, tol in zip(det1, default, (1e-6, 1e-6, 2e-5, 1e-5, 1e-5)):
         assert _rel(p, q) <= tol
 
 

@@ -1,0 +1,80 @@
+"""The single-kernel 'cluster' form of the GroupNorm(+SiLU) backward for mid-size maps (csrc/norm.hip: gn_cluster_bwd_kernel;
+reference: vqvae/modules/autoencoder.py:25-39 differentiated) against the two-kernel form it replaces and
+against fp64 autograd of the reference formula (unbiased variance): dx, d gamma, d beta, with and without the skip addend,
+with the half-resolution addend of a pooled ResBlock, bf16 and fp32, and the workspace left zero (protocol of
+include/vqk.h: vqk_gn_backward_ws) so that back-to-back calls and the other GroupNorm kernels keep working."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
+DEV = 'cuda:0'
+CL = torch.channels_last
+
+
+def _ref(x, w, b, dy, groups, add=None):
+    x = x.double().requires_grad_(True)
+    w, b = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    n, c, h, wd = x.shape
+    xg = x.reshape(n, groups, -1)
+    mean, var = xg.mean(-1, keepdim=True), xg.var(-1, keepdim=True)          # torch.var: unbiased (autoencoder.py:33)
+    xh = ((xg - mean) / torch.sqrt(var + 1e-6)).reshape(n, c, h, wd)
+    y = torch.nn.functional.silu(xh * w.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+    y.backward(dy.double())
+    dx = x.grad if add is None else x.grad + add.double()
+    return dx, w.grad, b.grad
+
+
+def _run(x, st, w, b, dy, groups, add=None, pooled=None):
+    dw, db = torch.zeros_like(w), torch.zeros_like(b)
+    if pooled is not None:
+        dx = ops.raw_gn_backward_pooled_add(x, st, w, b, dy, groups, True, dw, db, pooled, 0.25)
+    else:
+        dx, _, _ = ops.raw_gn_backward(x, st, w, b, dy, groups, True, dw, db, add=add)
+    return dx, dw, db
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('n,c,h', [(4, 128, 64), (3, 256, 64), (4, 256, 32), (2, 512, 32), (2, 128, 48)])
+@pytest.mark.parametrize('mode', ['plain', 'add', 'pooled'])
+def test_cluster_backward_equals_two_kernel_form_and_fp64(dtype, n, c, h, mode):
+    if mode == 'pooled' and h * h <= 1024:
+        pytest.skip('the pooled addend exists for maps above 32x32 only')
+    g = torch.Generator().manual_seed(n * c + h)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    x32, dy32 = mk(n, c, h, h), mk(n, c, h, h)
+    x = x32.to(dtype).to(DEV).contiguous(memory_format=CL)
+    dy = dy32.to(dtype).to(DEV).contiguous(memory_format=CL)
+    w = (mk(c) * 0.2 + 1).to(DEV); b = (mk(c) * 0.2).to(DEV)
+    add = mk(n, c, h, h).to(dtype).to(DEV).contiguous(memory_format=CL) if mode == 'add' else None
+    pooled = mk(n, c, h // 2, h // 2).to(dtype).to(DEV).contiguous(memory_format=CL) if mode == 'pooled' else None
+    _, st = ops.raw_gn_forward(x, w, b, 32, 1e-6, True)
+    lib = native.lib()
+    saved, ops.GN_CLUSTER_MAX_HW = ops.GN_CLUSTER_MAX_HW, 1 << 20
+    lib.vqk_set_tuning(b'GN_CLUSTER_MAX_HW', 1 << 20)                   # (the shipped default keeps the cluster form to <= 32x32 maps)
+    assert ops._gn_cluster(dtype, h * h, c, 32)
+    got = _run(x, st, w, b, dy, 32, add, pooled)
+    ws = ops._gn_ws(x.device, 0)
+    torch.cuda.synchronize()
+    assert float(ws.abs().max()) == 0.0                                   # sums AND tickets are back to zero
+    got2 = _run(x, st, w, b, dy, 32, add, pooled)                           # ... so the next call works
+    lib.vqk_set_tuning(b'GN_CLUSTER_MAX_HW', 0)
+    try:
+        want = _run(x, st, w, b, dy, 32, add, pooled)
+    finally:
+        lib.vqk_reset_tuning()
+        ops.GN_CLUSTER_MAX_HW = saved
+    full_add = add
+    if pooled is not None:
+        full_add = 0.25 * pooled.float().repeat_interleave(2, 2).repeat_interleave(2, 3)
+    ref = _ref(x.float().cpu(), w.cpu(), b.cpu(), dy.float().cpu(), 32, None if full_add is None else full_add.float().cpu())
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    for a, a2, t, r in zip(got, got2, want, ref):
+        rel = lambda p, q: float((p.double().cpu() - q.double().cpu()).norm() / (q.double().cpu().norm() + 1e-30))
+        assert rel(a, t) < (1e-6 if dtype == torch.float32 else 3e-3), rel(a, t)      # two-kernel form (bf16: one output rounding)
+        assert rel(a, a2) < 1e-6
+        assert rel(a, r) < tol, rel(a, r)

@@ -57,30 +57,39 @@ template <> struct Vec16<float> {
         __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
     }
 };
+// two fp32 -> packed bf16 pair in ONE instruction (v_cvt_pk_bf16_f32: hardware round-to-nearest-even, NaN stays NaN).  The
+// software form above costs ~12 VALU instructions per element with an exec-masked NaN branch: it made the bf16 stores of the
+// GroupNorm passes the largest single item of their instruction count (round 4).
+__device__ __forceinline__ unsigned vqk_pack_bf16x2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
+}
+typedef __attribute__((ext_vector_type(4))) unsigned int vqk_u32x4;
+__device__ __forceinline__ vqk_u32x4 vqk_pack_bf16x8(const float (&o)[8]) {
+    const vqk_u32x4 v = {vqk_pack_bf16x2(o[0], o[1]), vqk_pack_bf16x2(o[2], o[3]), vqk_pack_bf16x2(o[4], o[5]), vqk_pack_bf16x2(o[6], o[7])};
+    return v;
+}
+
 template <> struct Vec16<bf16_raw> {
     static constexpr int N = 8;
-    __device__ static __forceinline__ void load(const bf16_raw* p, float (&o)[8]) {
-        u16x8 v = *reinterpret_cast<const u16x8*>(p);
+    __device__ static __forceinline__ void unpack(const vqk_u32x4& v, float (&o)[8]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(v[i]);
+        for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(v[i] << 16); o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+    }
+    __device__ static __forceinline__ void load(const bf16_raw* p, float (&o)[8]) {
+        unpack(*reinterpret_cast<const vqk_u32x4*>(p), o);
     }
     __device__ static __forceinline__ void load_nt(const bf16_raw* p, float (&o)[8]) {
-        u16x8 v = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(v[i]);
+        unpack(__builtin_nontemporal_load(reinterpret_cast<const vqk_u32x4*>(p)), o);
     }
     __device__ static __forceinline__ void store(bf16_raw* p, const float (&o)[8]) {
-        u16x8 v;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = f32_to_bf16(o[i]);
-        *reinterpret_cast<u16x8*>(p) = v;
+        *reinterpret_cast<vqk_u32x4*>(p) = vqk_pack_bf16x8(o);
     }
     // streaming store (nt): the line is not kept in L2 / Infinity Cache on its way to HBM
     __device__ static __forceinline__ void store_nt(bf16_raw* p, const float (&o)[8]) {
-        u16x8 v;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = f32_to_bf16(o[i]);
-        __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(p));
+        __builtin_nontemporal_store(vqk_pack_bf16x8(o), reinterpret_cast<vqk_u32x4*>(p));
     }
 };
 

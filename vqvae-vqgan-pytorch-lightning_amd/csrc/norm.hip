@@ -5,6 +5,9 @@
 // Thread mapping: a thread owns one 16-byte channel vector slot (fixed channels) and strides over pixels,
 // so per-channel affine terms / partial sums live in registers.
 #include "common.h"
+#ifndef GN_CL_SLEEP
+#define GN_CL_SLEEP 8     // s_sleep argument (x 64 cycles) between two polls of a cluster's ticket
+#endif
 #ifndef GN_UNROLL
 #define GN_UNROLL 2
 #endif
@@ -16,6 +19,30 @@
 #include <stdlib.h>
 
 namespace {
+
+template <typename T> struct Raw16;
+template <> struct Raw16<float> {
+    typedef f32x4 type;
+    __device__ static __forceinline__ void unpack(const f32x4& v, float (&o)[4]) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+};
+template <> struct Raw16<bf16_raw> {
+    typedef vqk_u32x4 type;
+    __device__ static __forceinline__ void unpack(const vqk_u32x4& v, float (&o)[8]) { Vec16<bf16_raw>::unpack(v, o); }
+};
+// raw 16-byte load of one channel vector (NT: nontemporal)
+template <typename T, bool NT>
+__device__ __forceinline__ typename Raw16<T>::type gn_ld(const T* p) {
+    typedef typename Raw16<T>::type raw_t;
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(p));
+    return *reinterpret_cast<const raw_t*>(p);
+}
+// The streaming passes walk a thread's pixels p, p + pstep, ... as a software pipeline: GN_DEPTH vectors per tensor are in
+// flight AHEAD of the one being computed; the loads are unconditional (the address is clamped to the block's last pixel), so
+// the compiler waits with counted vmcnt instead of draining the queue at every conditional (round 4: the skip-addend load
+// of the backward was issued and waited for inside the loop -- one exposed HBM round trip per pixel vector).
+#ifndef GN_DEPTH
+#define GN_DEPTH 3
+#endif
 
 // Block-level reduction shared by the two reducing kernels: every thread parks its 2V partial sums in LDS (lane-linear,
 // 16-byte stores), then thread `col` adds up its column over the rows.  The previous form issued 2V LDS atomics per
@@ -96,7 +123,7 @@ __global__ void gn_finalize_kernel(const double* __restrict__ acc, float* __rest
 __device__ __forceinline__ float sigmoid_f(float y) { return __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
 __device__ __forceinline__ float silu_f(float y) { return y * sigmoid_f(y); }
 
-template <typename T>
+template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ w, const float* __restrict__ b,
                                                        T* __restrict__ y, int64_t hw, int c, int groups, int silu,
@@ -122,7 +149,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float t = __fmaf_rn(v[i], scale[i], shift[i]);
-            v[i] = silu ? silu_f(t) : t;
+            v[i] = SILU ? silu_f(t) : t;
         }
         GN_STORE_FWD(y + off + p * c, v);
     }
@@ -146,7 +173,7 @@ __device__ __forceinline__ void ws_release(double* __restrict__ ws, int n_sample
 
 // gn_finalize + gn_apply in one pass: every thread derives (mean, rstd) of its channels' groups from the double
 // sums; the first pixel block of each sample also stores them as fp32 stats for the backward.
-template <typename T>
+template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_fin_kernel(const T* __restrict__ x, double* __restrict__ ws,
                                                            float* __restrict__ stats, const float* __restrict__ w,
                                                            const float* __restrict__ b, T* __restrict__ y, int64_t hw,
@@ -189,23 +216,36 @@ __global__ __launch_bounds__(256) void gn_apply_fin_kernel(const T* __restrict__
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     const int64_t off = (int64_t)n * hw * c + slot * V;
-#pragma unroll GN_UNROLL
-    for (int64_t p = p0 + prow; p < p1; p += pstep) {
-        float v[V];
-        Vec16<T>::load(x + off + p * c, v);
+    {
+        typedef typename Raw16<T>::type raw_t;
+        constexpr int D = GN_DEPTH + 1;
+        const int64_t last = p1 - 1, step = pstep;
+        raw_t buf[D];
+        int64_t p = p0 + prow;
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float t = __fmaf_rn(v[i], scale[i], shift[i]);
-            v[i] = silu ? silu_f(t) : t;
+        for (int u = 0; u < D; ++u) buf[u] = gn_ld<T, false>(x + off + min(p + u * step, last) * c);
+        for (; p < p1; p += D * step) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int64_t q = p + u * step;
+                float v[V];
+                Raw16<T>::unpack(buf[u], v);
+                buf[u] = gn_ld<T, false>(x + off + min(q + D * step, last) * c);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float t = __fmaf_rn(v[i], scale[i], shift[i]);
+                    v[i] = SILU ? silu_f(t) : t;
+                }
+                if (q < p1) GN_STORE_FWD(y + off + q * c, v);
+            }
         }
-        GN_STORE_FWD(y + off + p * c, v);
     }
     if (!part) ws_release(ws, gridDim.y, groups);
 }
 
 // pass 1 of the backward: per-channel sums of dy_pre and dy_pre*xhat (-> dw, db) and the per-group
 // sums of dxhat and dxhat*xhat (-> red[n][g][2], double).
-template <typename T>
+template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             const T* __restrict__ dy, float* __restrict__ dw,
@@ -229,22 +269,40 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     const int64_t off = (int64_t)n * hw * c + slot * V;
-#pragma unroll GN_UNROLL
-    for (int64_t p = p0 + prow; p < p1; p += pstep) {
-        float xv[V], gv[V];
-        Vec16<T>::load(x + off + p * c, xv);
-        Vec16<T>::load(dy + off + p * c, gv);
+    {
+        typedef typename Raw16<T>::type raw_t;
+        constexpr int D = GN_DEPTH;
+        const int64_t last = p1 - 1, step = pstep;
+        raw_t bx[D], bg[D];
+        int64_t p = p0 + prow;
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const float xh = (xv[i] - mean[i]) * rstd[i];
-            float g = gv[i];
-            if (silu) {
-                const float yv = __fmaf_rn(xh, wv[i], bv[i]);
-                const float sg = sigmoid_f(yv);
-                g *= sg * (1.0f + yv * (1.0f - sg));
+        for (int u = 0; u < D; ++u) {
+            const int64_t q = min(p + u * step, last) * c;
+            bx[u] = gn_ld<T, false>(x + off + q); bg[u] = gn_ld<T, false>(dy + off + q);
+        }
+        for (; p < p1; p += D * step) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int64_t q = p + u * step;
+                float xv[V], gv[V];
+                Raw16<T>::unpack(bx[u], xv);
+                Raw16<T>::unpack(bg[u], gv);
+                const int64_t qn = min(q + D * step, last) * c;
+                bx[u] = gn_ld<T, false>(x + off + qn); bg[u] = gn_ld<T, false>(dy + off + qn);
+                const float live = q < p1 ? 1.0f : 0.0f;          // (beyond the block: the clamped re-read counts for nothing)
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float xh = (xv[i] - mean[i]) * rstd[i];
+                    float g = gv[i] * live;
+                    if constexpr (SILU) {
+                        const float yv = __fmaf_rn(xh, wv[i], bv[i]);
+                        const float sg = sigmoid_f(yv);
+                        g *= sg * (1.0f + yv * (1.0f - sg));
+                    }
+                    a[i] += g;
+                    bb[i] = __fmaf_rn(g, xh, bb[i]);
+                }
             }
-            a[i] += g;
-            bb[i] = __fmaf_rn(g, xh, bb[i]);
         }
     }
     block_colsum<V>(a, bb, part, sh, c);
@@ -298,7 +356,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finish_kernel(const float* __restr
 // NT: x and dy are read for the last time here; for tensors beyond the Infinity Cache (>= 192 MB) nontemporal loads keep
 // them from evicting what the next kernel reads (backward pair 530 -> 485 us at 128 ch @256^2, 272 -> 248 us at 256 ch
 // @128^2); for cache-sized tensors they are slower (127 -> 137 us at 128 ch @128^2), so the host picks.
-template <typename T, bool NT>
+// ADD: 0 no addend, 1 addend at the same resolution (`add`, or dx itself when add == NULL), 2 addend at half resolution
+template <typename T, bool NT, bool SILU, int ADD>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const T* __restrict__ dy, T* __restrict__ dx,
@@ -337,34 +396,60 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = min(hw, p0 + pix_per_block);
     const int64_t off = (int64_t)n * hw * c + slot * V;
-#pragma unroll GN_UNROLL
-    for (int64_t p = p0 + prow; p < p1; p += pstep) {
-        float xv[V], gv[V], ov[V];
-        if (NT) { Vec16<T>::load_nt(x + off + p * c, xv); Vec16<T>::load_nt(dy + off + p * c, gv); }
-        else { Vec16<T>::load(x + off + p * c, xv); Vec16<T>::load(dy + off + p * c, gv); }
-        if (accumulate) {
-            if (add_w) {                                    // `add` at HALF resolution: pixel (r, q) reads pooled pixel (r/2, q/2)
-                const int64_t row = p / add_w, col = p - row * add_w;
-                Vec16<T>::load(add + ((int64_t)n * (hw >> 2) + (row >> 1) * (add_w >> 1) + (col >> 1)) * c + slot * V, ov);
+    {
+        typedef typename Raw16<T>::type raw_t;
+        constexpr int D = GN_DEPTH;
+        const int64_t last = p1 - 1, step = pstep;
+        const T* ap = ADD == 1 ? (add ? add : dx) : add;
+        const int64_t aoff = (int64_t)n * (hw >> 2) * c + slot * V;     // ADD == 2: the half-resolution addend of this sample
+        auto add_ptr = [&](int64_t q) -> const T* {
+            if (ADD == 2) {
+                const int qi = (int)q, row = qi / add_w, col = qi - row * add_w;
+                return ap + aoff + (int64_t)((row >> 1) * (add_w >> 1) + (col >> 1)) * c;
+            }
+            return ap + off + q * c;
+        };
+        raw_t bx[D], bg[D], ba[ADD ? D : 1];
+        int64_t p = p0 + prow;
 #pragma unroll
-                for (int i = 0; i < V; ++i) ov[i] *= add_scale;
-            } else {
-                Vec16<T>::load((add ? add : dx) + off + p * c, ov);
+        for (int u = 0; u < D; ++u) {
+            const int64_t q = min(p + u * step, last);
+            bx[u] = gn_ld<T, NT>(x + off + q * c); bg[u] = gn_ld<T, NT>(dy + off + q * c);
+            if (ADD) ba[u] = gn_ld<T, false>(add_ptr(q));
+        }
+        (void)accumulate;
+        for (; p < p1; p += D * step) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int64_t q = p + u * step;
+                float xv[V], gv[V], ov[V];
+                Raw16<T>::unpack(bx[u], xv);
+                Raw16<T>::unpack(bg[u], gv);
+                if (ADD) {
+                    Raw16<T>::unpack(ba[ADD ? u : 0], ov);
+                    if (ADD == 2) {
+#pragma unroll
+                        for (int i = 0; i < V; ++i) ov[i] *= add_scale;
+                    }
+                }
+                const int64_t qn = min(q + D * step, last);
+                bx[u] = gn_ld<T, NT>(x + off + qn * c); bg[u] = gn_ld<T, NT>(dy + off + qn * c);
+                if (ADD) ba[ADD ? u : 0] = gn_ld<T, false>(add_ptr(qn));
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float xh = (xv[i] - mean[i]) * rstd[i];
+                    float g = gv[i];
+                    if constexpr (SILU) {
+                        const float yv = __fmaf_rn(xh, wv[i], bv[i]);
+                        const float sg = sigmoid_f(yv);
+                        g *= sg * (1.0f + yv * (1.0f - sg));
+                    }
+                    const float r = (g * wv[i] - k1[i] - xh * k2[i]) * rstd[i];
+                    ov[i] = ADD ? ov[i] + r : r;
+                }
+                if (q < p1) GN_STORE_BWD(dx + off + q * c, ov);
             }
         }
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const float xh = (xv[i] - mean[i]) * rstd[i];
-            float g = gv[i];
-            if (silu) {
-                const float yv = __fmaf_rn(xh, wv[i], bv[i]);
-                const float sg = sigmoid_f(yv);
-                g *= sg * (1.0f + yv * (1.0f - sg));
-            }
-            const float r = (g * wv[i] - k1[i] - xh * k2[i]) * rstd[i];
-            ov[i] = accumulate ? ov[i] + r : r;
-        }
-        GN_STORE_BWD(dx + off + p * c, ov);
     }
     if (!gpart) ws_release(red, gridDim.y, groups);
 }
@@ -375,20 +460,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
 // vectors), reduces inside the block (no global atomics for the statistics, no workspace, no second read) and applies from
 // the registers.  The two-kernel form spent most of its 20-60 us per call on launches, global atomics and the round trip.
 // ------------------------------------------------------------------------------------------------
-template <typename T> struct Raw16;
-template <> struct Raw16<float> {
-    typedef f32x4 type;
-    __device__ static __forceinline__ void unpack(const f32x4& v, float (&o)[4]) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
-};
-template <> struct Raw16<bf16_raw> {
-    typedef u16x8 type;
-    __device__ static __forceinline__ void unpack(const u16x8& v, float (&o)[8]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(v[i]);
-    }
-};
-
-template <typename T, int PPT>
+template <typename T, int PPT, bool SILU>
 __global__ __launch_bounds__(256) void gn_small_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, T* __restrict__ y,
                                                            float* __restrict__ stats, int c, int groups, int silu, float eps) {
@@ -465,7 +537,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const float t = __fmaf_rn(v[i], scale[i], shift[i]);
-            v[i] = silu ? silu_f(t) : t;
+            v[i] = SILU ? silu_f(t) : t;
         }
         Vec16<T>::store(y + off + (int64_t)(prow + k * ROWS) * c, v);
     }
@@ -473,7 +545,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd_kernel(const T* __restrict__
 
 // KEEP = false (16 pixels per thread, the 32^2 maps): x / dy do not fit the registers twice, the second pass re-reads the
 // block's own 128 KiB from L2 instead.
-template <typename T, int PPT, bool KEEP>
+template <typename T, int PPT, bool KEEP, bool SILU>
 __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const T* __restrict__ dy, T* __restrict__ dx,
@@ -505,7 +577,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const T* __restrict__
     }
     auto pre = [&](float xv, float gv, int i, float& xh) -> float {      // dy before the SiLU, xhat
         xh = (xv - mean[i]) * rstd[i];
-        if (silu) {
+        if constexpr (SILU) {
             const float yv = __fmaf_rn(xh, wv[i], bv[i]);
             const float sg = sigmoid_f(yv);
             gv *= sg * (1.0f + yv * (1.0f - sg));
@@ -597,6 +669,172 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Mid-size maps (round 4): the single-kernel backward for maps that do not fit ONE block's registers.  CL blocks form a
+// cluster per (sample, 32-channel slice); each keeps its PPT x 64 pixels of x and dy in registers, adds its group sums to the
+// stream's fp64 workspace (the slots of the two-kernel form), arrives at the cluster's ticket and spins until all CL blocks
+// have arrived, then applies from the registers: x and dy are read ONCE (3 tensor passes instead of 5), one launch instead
+// of two.  The blocks of a cluster are consecutive block ids (dispatched in order: the oldest incomplete cluster is always
+// fully resident before any younger one holds the slots it needs), the last block to LEAVE zeroes the cluster's sums and
+// tickets again (workspace protocol of the other passes: zero on entry, zero on exit).  Not for deterministic mode (fp64
+// atomics in arrival order); `add` at half resolution (add_w) as in gn_bwd_apply_kernel.
+// ------------------------------------------------------------------------------------------------
+// SL: channels per slice -- 64 (a pixel's slice is one whole 128-byte line in bf16) or 32
+template <typename T, int PPT, int SL, bool SILU>
+__global__ __launch_bounds__(256) void gn_cluster_bwd_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             const T* __restrict__ dy, T* __restrict__ dx,
+                                                             const T* __restrict__ add, float* __restrict__ dw,
+                                                             float* __restrict__ db, double* __restrict__ red,
+                                                             unsigned* __restrict__ tickets, int64_t hw, int c, int groups,
+                                                             int silu, int accumulate, int cl, int add_w, float add_scale) {
+    constexpr int V = Vec16<T>::N, SLOTS = SL / V, ROWS = 256 / SLOTS;
+    typedef typename Raw16<T>::type raw_t;
+    __shared__ float sh[2][SL];
+    __shared__ float shw[4][2][SL];
+    __shared__ float kk[SL][2];
+    const int slot = threadIdx.x % SLOTS, prow = threadIdx.x / SLOTS;
+    const int slices = c / SL;
+    const int slice = (int)blockIdx.x / cl, rank = (int)blockIdx.x - slice * cl;
+    const int n = blockIdx.y, ch0 = slice * SL, cpg = c / groups;
+    const int64_t pix0 = (int64_t)rank * (PPT * ROWS) + prow;
+    const int64_t off = (int64_t)n * hw * c + ch0 + slot * V;
+    raw_t rx[PPT], rg[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        rx[k] = *reinterpret_cast<const raw_t*>(x + off + (pix0 + k * ROWS) * c);      // (ordinary loads: a 128-byte line holds
+        rg[k] = *reinterpret_cast<const raw_t*>(dy + off + (pix0 + k * ROWS) * c);     // two slices -- the sibling cluster wants it too)
+    }
+    float mean[V], rstd[V], wv[V], bv[V], a[V], bb[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = ch0 + slot * V + i, g = ch / cpg;
+        mean[i] = stats[((int64_t)n * groups + g) * 2]; rstd[i] = stats[((int64_t)n * groups + g) * 2 + 1];
+        wv[i] = w[ch]; bv[i] = b[ch]; a[i] = 0.f; bb[i] = 0.f;
+    }
+    auto pre = [&](float xv, float gv, int i, float& xh) -> float {      // dy before the SiLU, xhat
+        xh = (xv - mean[i]) * rstd[i];
+        if constexpr (SILU) {
+            const float yv = __fmaf_rn(xh, wv[i], bv[i]);
+            const float sg = sigmoid_f(yv);
+            gv *= sg * (1.0f + yv * (1.0f - sg));
+        }
+        return gv;
+    };
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        float xv[V], gv[V];
+        Raw16<T>::unpack(rx[k], xv);
+        Raw16<T>::unpack(rg[k], gv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float xh;
+            const float g = pre(xv[i], gv[i], i, xh);
+            a[i] += g;
+            bb[i] = __fmaf_rn(g, xh, bb[i]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) { asm volatile("" : "+v"(rx[k])); asm volatile("" : "+v"(rg[k])); }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+#pragma unroll
+        for (int o = 32; o >= SLOTS; o >>= 1) { a[i] += __shfl_xor(a[i], o, 64); bb[i] += __shfl_xor(bb[i], o, 64); }
+    }
+    if ((threadIdx.x & 63) < SLOTS) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            shw[threadIdx.x >> 6][0][slot * V + i] = a[i];
+            shw[threadIdx.x >> 6][1][slot * V + i] = bb[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * SL) {
+        const int j = threadIdx.x / SL, cl_ = threadIdx.x % SL;
+        sh[j][cl_] = ((shw[0][j][cl_] + shw[1][j][cl_]) + shw[2][j][cl_]) + shw[3][j][cl_];
+    }
+    __syncthreads();
+    // Cross-block exchange WITHOUT acquire / release fences: on this multi-die part an agent-scope release writes the die's
+    // whole L2 back and an acquire invalidates it (measured: the fenced form ran 3-6x slower than the two-kernel passes).
+    // Every access to the sums and tickets is an agent-scope atomic (performed at the memory side, past the per-die L2s);
+    // the sums are RETURNING atomics, so the wave has their results -- they have been performed -- before its arrival is
+    // counted, and a block that sees all CL arrivals reads the complete sums.
+    unsigned* arrive = tickets + ((int64_t)n * slices + slice) * 2;
+    if (threadIdx.x < SL) {
+        const int ci = threadIdx.x, ch = ch0 + ci;
+        atomicAdd(db + ch, sh[0][ci]);
+        atomicAdd(dw + ch, sh[1][ci]);
+        const int g0 = (ci / cpg) * cpg;
+        double seen = 0.0;
+        if (ci == g0) {                                          // one thread per group of the slice: its sums into the workspace
+            double s1 = 0.0, s2 = 0.0;
+            for (int i = 0; i < cpg; ++i) {
+                s1 += (double)sh[0][g0 + i] * (double)w[ch0 + g0 + i];
+                s2 += (double)sh[1][g0 + i] * (double)w[ch0 + g0 + i];
+            }
+            const int g = (ch0 + g0) / cpg;
+            seen = __hip_atomic_fetch_add(&red[((int64_t)n * groups + g) * 2 + 0], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen += __hip_atomic_fetch_add(&red[((int64_t)n * groups + g) * 2 + 1], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("" :: "v"(seen));                           // the returned values are waited for before the barrier below
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cl) __builtin_amdgcn_s_sleep(GN_CL_SLEEP);
+    }
+    __syncthreads();
+    if (threadIdx.x < SL) {
+        const int ci = threadIdx.x, g = (ch0 + ci) / cpg;
+        const double m = (double)hw * cpg;
+        const double s1 = __hip_atomic_load(&red[((int64_t)n * groups + g) * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double s2 = __hip_atomic_load(&red[((int64_t)n * groups + g) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        kk[ci][0] = (float)(s1 / m); kk[ci][1] = (float)(s2 / (m - 1.0));
+    }
+    __syncthreads();                                             // (every thread's loads above have returned: kk is written)
+    if (threadIdx.x == 0) {
+        // the last block to leave (every block has READ the sums by then) restores the workspace: sums and tickets zero
+        const unsigned left = __hip_atomic_fetch_add(arrive + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (unsigned)cl - 1) {
+            for (int g = ch0 / cpg; g < (ch0 + SL) / cpg; ++g) {
+                __hip_atomic_store(&red[((int64_t)n * groups + g) * 2 + 0], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&red[((int64_t)n * groups + g) * 2 + 1], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(arrive + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    float k1[V], k2[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { k1[i] = kk[slot * V + i][0]; k2[i] = kk[slot * V + i][1]; }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        float xv[V], gv[V], ov[V];
+        const int64_t p = pix0 + k * ROWS;
+        const int64_t o = off + p * c;
+        Raw16<T>::unpack(rx[k], xv);
+        Raw16<T>::unpack(rg[k], gv);
+        if (accumulate) {
+            if (add_w) {
+                const int64_t row = p / add_w, col = p - row * add_w;
+                Vec16<T>::load(add + ((int64_t)n * (hw >> 2) + (row >> 1) * (add_w >> 1) + (col >> 1)) * c + ch0 + slot * V, ov);
+#pragma unroll
+                for (int i = 0; i < V; ++i) ov[i] *= add_scale;
+            } else {
+                Vec16<T>::load((add ? add : dx) + o, ov);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float xh;
+            const float g = pre(xv[i], gv[i], i, xh);
+            const float r = (g * wv[i] - k1[i] - xh * k2[i]) * rstd[i];
+            ov[i] = accumulate ? ov[i] + r : r;
+        }
+        Vec16<T>::store(dx + o, ov);
+    }
+}
+
 // pixels per thread of the small-map form for this problem, or 0 when it does not apply
 inline int gn_small_ppt(int dtype, int64_t hw, int c, int groups, int max_ppt) {
     const bool off = VQK_TUNE("GN_NO_SMALL", 0) != 0;
@@ -634,7 +872,7 @@ inline int pick_ppb(int n, int64_t hw, bool reducing = false) {
 
 static int gn_backward_impl(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy, void* dx,
                             float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu, int accumulate,
-                            const void* add, int add_w, float add_scale, void* stream) {
+                            const void* add, int add_w, float add_scale, void* stream, int64_t ws_doubles = 0) {
     VQK_REQUIRE(x && stats && w && b && dy && dx && dw && db && red, VQK_ERR_ARG);
     VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
     const int rc = check_gn(dtype, c, groups);
@@ -652,15 +890,42 @@ static int gn_backward_impl(int dtype, const void* x, const float* stats, const 
             VQK_REQUIRE(det.ws && (int64_t)n * 2 * c * 4 <= det.bytes, VQK_ERR_WORKSPACE);
             cpart = det.ws;
         }
-#define VQK_GN_SMALL_BWD(T, P) hipLaunchKernelGGL((gn_small_bwd_kernel<T, P, (P < 16)>), sgrid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, dw, db, c, groups, silu, acc, cpart)
+#define VQK_GN_SMALL_BWD_S(T, P, S) hipLaunchKernelGGL((gn_small_bwd_kernel<T, P, (P < 16), S>), sgrid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, dw, db, c, groups, silu, acc, cpart)
+#define VQK_GN_SMALL_BWD(T, P) do { if (silu) VQK_GN_SMALL_BWD_S(T, P, true); else VQK_GN_SMALL_BWD_S(T, P, false); } while (0)
 #define VQK_GN_SMALL_BWD_T(T) do { switch (ppt) { case 1: VQK_GN_SMALL_BWD(T, 1); break; case 2: VQK_GN_SMALL_BWD(T, 2); break; \
         case 4: VQK_GN_SMALL_BWD(T, 4); break; case 8: VQK_GN_SMALL_BWD(T, 8); break; default: VQK_GN_SMALL_BWD(T, 16); } } while (0)
         if (dtype == VQK_F32) VQK_GN_SMALL_BWD_T(float); else VQK_GN_SMALL_BWD_T(bf16_raw);
 #undef VQK_GN_SMALL_BWD_T
 #undef VQK_GN_SMALL_BWD
+#undef VQK_GN_SMALL_BWD_S
         if (cpart) hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((unsigned)((2 * c + 7) / 8)), dim3(256), 0, st, (const float*)cpart, n, c, dw, db);
         VQK_CHECK_LAUNCH();
         return VQK_OK;
+    }
+    {
+        // cluster form: 64-channel slices (32 when c is no multiple of 64), hw = cl * 8 * rows, workspace with the ticket
+        // region (ws_doubles says so)
+        const int v = dtype == VQK_F32 ? 4 : 8;
+        const int sl = (c % 64 == 0 && 64 % (c / groups) == 0) ? 64 : 32;
+        const int rows = 256 / (sl / v);
+        const int64_t max_hw = VQK_TUNE("GN_CLUSTER_MAX_HW", 1024);
+        vqkd::DetState& det0 = vqkd::det_state();
+        if (!det0.on && ws_doubles >= (int64_t)n * groups * 2 + n + (int64_t)n * (c / 32) && hw <= max_hw && c % sl == 0 &&
+            sl % (c / groups) == 0 && hw % (8 * rows) == 0 && (!add_w || (add_w % 2 == 0 && hw % add_w == 0))) {
+            const int cl = (int)(hw / (8 * rows));
+            unsigned* tickets = reinterpret_cast<unsigned*>(red + (int64_t)n * groups * 2 + n);
+            const dim3 cgrid((unsigned)(c / sl * cl), (unsigned)n);
+            const int acc = (accumulate || add) ? 1 : 0;
+#define VQK_GN_CL_U(T, S, U) hipLaunchKernelGGL((gn_cluster_bwd_kernel<T, 8, S, U>), cgrid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, \
+                                           (T*)dx, (const T*)add, dw, db, red, tickets, hw, c, groups, silu, acc, cl, add_w, add_scale)
+#define VQK_GN_CL(T, S) do { if (silu) VQK_GN_CL_U(T, S, true); else VQK_GN_CL_U(T, S, false); } while (0)
+            if (dtype == VQK_F32) { if (sl == 64) VQK_GN_CL(float, 64); else VQK_GN_CL(float, 32); }
+            else { if (sl == 64) VQK_GN_CL(bf16_raw, 64); else VQK_GN_CL(bf16_raw, 32); }
+#undef VQK_GN_CL
+#undef VQK_GN_CL_U
+            VQK_CHECK_LAUNCH();
+            return VQK_OK;
+        }
     }
     const int ppb = pick_ppb(n, hw), rppb = pick_ppb(n, hw, true);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n), rgrid((unsigned)((hw + rppb - 1) / rppb), (unsigned)n);
@@ -679,13 +944,18 @@ static int gn_backward_impl(int dtype, const void* x, const float* stats, const 
         cpart = reinterpret_cast<float*>(reinterpret_cast<char*>(det.ws) + gbytes);
     }
     const int acc = (accumulate || add) ? 1 : 0;
-#define VQK_GN_BWD(T) do { \
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, rgrid, dim3(256), lds, st, (const T*)x, stats, w, b, (const T*)dy, dw, db, red, hw, c, groups, silu, rppb, gpart, cpart); \
-        if (nt) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, red, hw, c, groups, silu, acc, ppb, add_w, add_scale, (const double*)gpart, nblk); \
-        else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, red, hw, c, groups, silu, acc, ppb, add_w, add_scale, (const double*)gpart, nblk); \
+#define VQK_GN_BWD_A(T, S, N, A) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, N, S, A>), grid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, red, hw, c, groups, silu, acc, ppb, add_w, add_scale, (const double*)gpart, nblk)
+#define VQK_GN_BWD_N(T, S, N) do { if (!acc) VQK_GN_BWD_A(T, S, N, 0); else if (add_w) VQK_GN_BWD_A(T, S, N, 2); else VQK_GN_BWD_A(T, S, N, 1); } while (0)
+#define VQK_GN_BWD_S(T, S) do { \
+        hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, S>), rgrid, dim3(256), lds, st, (const T*)x, stats, w, b, (const T*)dy, dw, db, red, hw, c, groups, silu, rppb, gpart, cpart); \
+        if (nt) VQK_GN_BWD_N(T, S, true); else VQK_GN_BWD_N(T, S, false); \
     } while (0)
+#define VQK_GN_BWD(T) do { if (silu) VQK_GN_BWD_S(T, true); else VQK_GN_BWD_S(T, false); } while (0)
     if (dtype == VQK_F32) VQK_GN_BWD(float); else VQK_GN_BWD(bf16_raw);
 #undef VQK_GN_BWD
+#undef VQK_GN_BWD_S
+#undef VQK_GN_BWD_N
+#undef VQK_GN_BWD_A
     if (cpart) hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((unsigned)((2 * c + 7) / 8)), dim3(256), 0, st, (const float*)cpart, n * nblk, c, dw, db);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
@@ -724,8 +994,8 @@ int vqk_gn_apply(int dtype, const void* x, const float* stats, const float* w, c
     const int ppb = pick_ppb(n, hw);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
     hipStream_t st = vqk_stream(stream);
-    if (dtype == VQK_F32) hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, w, b, (float*)y, hw, c, groups, silu, ppb);
-    else hipLaunchKernelGGL(gn_apply_kernel<bf16_raw>, grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb);
+    if (dtype == VQK_F32) { if (silu) hipLaunchKernelGGL((gn_apply_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (float*)y, hw, c, groups, silu, ppb); else hipLaunchKernelGGL((gn_apply_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, stats, w, b, (float*)y, hw, c, groups, silu, ppb); }
+    else { if (silu) hipLaunchKernelGGL((gn_apply_kernel<bf16_raw, true>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb); else hipLaunchKernelGGL((gn_apply_kernel<bf16_raw, false>), grid, dim3(256), 0, st, (const bf16_raw*)x, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb); }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }
@@ -740,12 +1010,14 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
     hipStream_t st = vqk_stream(stream);
     if (const int ppt = gn_small_ppt(dtype, hw, c, groups, 16)) {
         const dim3 sgrid((unsigned)(c / 32), (unsigned)n);
-#define VQK_GN_SMALL_FWD(T, P) hipLaunchKernelGGL((gn_small_fwd_kernel<T, P>), sgrid, dim3(256), 0, st, (const T*)x, w, b, (T*)y, stats, c, groups, silu, eps)
+#define VQK_GN_SMALL_FWD_S(T, P, S) hipLaunchKernelGGL((gn_small_fwd_kernel<T, P, S>), sgrid, dim3(256), 0, st, (const T*)x, w, b, (T*)y, stats, c, groups, silu, eps)
+#define VQK_GN_SMALL_FWD(T, P) do { if (silu) VQK_GN_SMALL_FWD_S(T, P, true); else VQK_GN_SMALL_FWD_S(T, P, false); } while (0)
 #define VQK_GN_SMALL_FWD_T(T) do { switch (ppt) { case 1: VQK_GN_SMALL_FWD(T, 1); break; case 2: VQK_GN_SMALL_FWD(T, 2); break; \
         case 4: VQK_GN_SMALL_FWD(T, 4); break; case 8: VQK_GN_SMALL_FWD(T, 8); break; default: VQK_GN_SMALL_FWD(T, 16); } } while (0)
         if (dtype == VQK_F32) VQK_GN_SMALL_FWD_T(float); else VQK_GN_SMALL_FWD_T(bf16_raw);
 #undef VQK_GN_SMALL_FWD_T
 #undef VQK_GN_SMALL_FWD
+#undef VQK_GN_SMALL_FWD_S
         VQK_CHECK_LAUNCH();
         return VQK_OK;
     }
@@ -761,10 +1033,10 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
     }
     if (dtype == VQK_F32) {
         hipLaunchKernelGGL(gn_stats_kernel<float>, rgrid, dim3(256), lds, st, (const float*)x, hw, c, groups, rppb, ws, part);
-        hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk);
+        { if (silu) hipLaunchKernelGGL((gn_apply_fin_kernel<float, true>), grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk); else hipLaunchKernelGGL((gn_apply_fin_kernel<float, false>), grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk); }
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, rppb, ws, part);
-        hipLaunchKernelGGL(gn_apply_fin_kernel<bf16_raw>, grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk);
+        { if (silu) hipLaunchKernelGGL((gn_apply_fin_kernel<bf16_raw, true>), grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk); else hipLaunchKernelGGL((gn_apply_fin_kernel<bf16_raw, false>), grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk); }
     }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
@@ -781,9 +1053,9 @@ int vqk_gn_forward_presummed(int dtype, const void* x, const float* w, const flo
     const int ppb = pick_ppb(n, hw);
     const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
     if (dtype == VQK_F32)
-        hipLaunchKernelGGL(gn_apply_fin_kernel<float>, grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps);
+        { if (silu) hipLaunchKernelGGL((gn_apply_fin_kernel<float, true>), grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps); else hipLaunchKernelGGL((gn_apply_fin_kernel<float, false>), grid, dim3(256), (size_t)groups * 8, st, (const float*)x, ws, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps); }
     else
-        hipLaunchKernelGGL(gn_apply_fin_kernel<bf16_raw>, grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps);
+        { if (silu) hipLaunchKernelGGL((gn_apply_fin_kernel<bf16_raw, true>), grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps); else hipLaunchKernelGGL((gn_apply_fin_kernel<bf16_raw, false>), grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps); }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }
@@ -796,6 +1068,21 @@ int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w
                     float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu, int accumulate,
                     const void* add, void* stream) {
     return gn_backward_impl(dtype, x, stats, w, b, dy, dx, dw, db, red, n, hw, c, groups, silu, accumulate, add, 0, 1.0f, stream);
+}
+
+int vqk_gn_backward_ws(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
+                       void* dx, float* dw, float* db, double* red, int64_t ws_doubles, int n, int h, int wd, int c, int groups,
+                       int silu, int accumulate, const void* add, const void* add_pooled, float add_scale, void* stream) {
+    VQK_REQUIRE(h > 0 && wd > 0 && ws_doubles >= (int64_t)n * groups * 2 + n, VQK_ERR_ARG);
+    VQK_REQUIRE(!(add && add_pooled), VQK_ERR_ARG);
+    if (add_pooled) {
+        VQK_REQUIRE((h % 2) == 0 && (wd % 2) == 0, VQK_ERR_ARG);
+        VQK_REQUIRE((int64_t)h * wd > 1024, VQK_ERR_SHAPE);
+        return gn_backward_impl(dtype, x, stats, w, b, dy, dx, dw, db, red, n, (int64_t)h * wd, c, groups, silu, 1, add_pooled, wd,
+                                add_scale, stream, ws_doubles);
+    }
+    return gn_backward_impl(dtype, x, stats, w, b, dy, dx, dw, db, red, n, (int64_t)h * wd, c, groups, silu, accumulate, add, 0, 1.0f,
+                            stream, ws_doubles);
 }
 
 int vqk_gn_backward_pooled_add(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,

@@ -502,6 +502,25 @@ def raw_cast(src_f32, dtype) -> torch.Tensor:
 _GN_WS: dict = {}
 
 
+GN_CLUSTER_MAX_HW = int(os.environ.get('VQK_GN_CLUSTER_MAX_HW', '1024'))    # (mirrors the library's tuning slot: event bytes only)
+
+
+def _gn_ws_doubles(n: int, c: int, groups: int) -> int:
+    """sums [N][G][2] + one counter slot per sample + one ticket slot per (sample, 32-channel slice) (include/vqk.h:
+    vqk_gn_backward_ws)"""
+    return n * groups * 2 + n + n * (c // 32)
+
+
+def _gn_cluster(dtype, hw: int, c: int, groups: int) -> bool:
+    """does vqk_gn_backward_ws take its single-kernel cluster form for this map?  (bench statistics: 3 tensor passes, not 5)"""
+    v = 4 if dtype == torch.float32 else 8
+    sl = 64 if (c % 64 == 0 and 64 % (c // groups) == 0) else 32
+    rows = 256 // (sl // v)
+    small = 256 if dtype == torch.float32 else 512               # up to here: the one-block-per-slice kernels
+    return (not DETERMINISTIC and small < hw <= GN_CLUSTER_MAX_HW and c % sl == 0 and sl % (c // groups) == 0
+            and hw % (8 * rows) == 0)
+
+
 def _gn_ws(device, n_doubles: int) -> torch.Tensor:
     """Persistent fp64 workspace of the GroupNorm kernels for the current stream (include/vqk.h: zero on entry, the
     consumer kernel leaves it zero again -> no memset launch per call)."""
@@ -597,14 +616,15 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
     dw = dw if dw is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     db = db if db is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     _claim_presummed(x, -1)                                      # (clears a stale note + workspace; never matches)
-    red = _gn_ws(x.device, n * groups * 2 + n)
+    red = _gn_ws(x.device, _gn_ws_doubles(n, c, groups))
     nb = x.numel() * x.element_size()
-    passes = (3 if h * wd <= 512 else 5) + (1 if add is not None else 0)     # x, dy (twice on the two-kernel path), dx, skip
+    one_pass = h * wd <= 512 or _gn_cluster(x.dtype, h * wd, c, groups)
+    passes = (3 if one_pass else 5) + (1 if add is not None else 0)     # x, dy (twice on the two-kernel path), dx, skip
     st = _timed('group_norm_bwd (HBM)' + (f' {c}@{h}x{wd}' if _EVENT_SHAPES else ''), 0.0,
-                lambda: _native.lib().vqk_gn_backward(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
-                                                      b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-                                                      db.data_ptr(), red.data_ptr(), n, h * wd, c, groups, int(silu), 0,
-                                                      _p(add), _stream()), passes * nb)
+                lambda: _native.lib().vqk_gn_backward_ws(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
+                                                         b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                         db.data_ptr(), red.data_ptr(), red.numel(), n, h, wd, c, groups,
+                                                         int(silu), 0, _p(add), 0, 1.0, _stream()), passes * nb)
     _native.check(st, 'gn_backward')
     return dx, dw, db
 
@@ -614,13 +634,15 @@ def raw_gn_backward_pooled_add(x, stats, w, b, dy, groups: int, silu: bool, dw, 
     n, c, h, wd = x.shape
     dx = torch.empty_like(x, memory_format=_CL)
     _claim_presummed(x, -1)
-    red = _gn_ws(x.device, n * groups * 2 + n)
+    red = _gn_ws(x.device, _gn_ws_doubles(n, c, groups))
     nb = x.numel() * x.element_size()
+    passes = 3.25 if _gn_cluster(x.dtype, h * wd, c, groups) else 5.25
     st = _timed('group_norm_bwd (HBM)' + (f' {c}@{h}x{wd} pooled-add' if _EVENT_SHAPES else ''), 0.0,
-                lambda: _native.lib().vqk_gn_backward_pooled_add(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
-                                                                 b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-                                                                 db.data_ptr(), red.data_ptr(), n, h, wd, c, groups, int(silu),
-                                                                 add_pooled.data_ptr(), float(add_scale), _stream()), 5.25 * nb)
+                lambda: _native.lib().vqk_gn_backward_ws(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
+                                                         b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                         db.data_ptr(), red.data_ptr(), red.numel(), n, h, wd, c, groups,
+                                                         int(silu), 1, 0, add_pooled.data_ptr(), float(add_scale), _stream()),
+                passes * nb)
     _native.check(st, 'gn_backward_pooled_add')
     return dx
 
