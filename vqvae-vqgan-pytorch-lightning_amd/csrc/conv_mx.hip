@@ -34,7 +34,7 @@ using vqkd::pack_bf16x2;
 using vqkd::xcd_remap;
 
 #ifndef VQK_MXABL
-#define VQK_MXABL 0          // timing-only ablation bits (tools/ab_build.sh): never set in the shipped build
+#define VQK_MXABL 0          // timing-only ablation bits (tools/ab_build.sh): never set in the shipped build (32: half the weight stream)
 #endif
 #ifndef VQK_MX_RD
 #define VQK_MX_RD 6          // weight ring depth in phases ((tap, k-substep) pairs; divides 18)
@@ -195,7 +195,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const int soff = (ph + RD >= NPH) ? wnxt[j] + (ph + RD - NPH) * 1024 : wcur[j] + (ph + RD) * 1024;
-                        bw[ph % RD][j] = wload(soff);
+                        // VQK_MXABL & 32 (timing only, round 4): the two pixel-half waves of a cout half load the SAME weight
+                        // fragments -- here the second wave keeps its stale ring instead: the kernel's L2 -> VGPR weight stream is
+                        // halved (L2 side) at NO cost for whatever would share it, i.e. an upper bound on what a shared stream can win
+                        // (same instruction stream: the second wave re-reads ONE fragment -- an L1 hit -- instead of skipping the load;
+                        // skipping it put a branch into the pinned phase and cost 7-10 %)
+                        bw[ph % RD][j] = wload(((VQK_MXABL & 32) && g.n > 0 && wm == 1) ? (soff & 1023) : soff);
                     }
                     if (VQK_MX_PIN) {
                         if (reads) {

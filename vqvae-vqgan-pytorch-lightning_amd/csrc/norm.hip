@@ -41,7 +41,7 @@ __device__ __forceinline__ typename Raw16<T>::type gn_ld(const T* p) {
 // the compiler waits with counted vmcnt instead of draining the queue at every conditional (round 4: the skip-addend load
 // of the backward was issued and waited for inside the loop -- one exposed HBM round trip per pixel vector).
 #ifndef GN_DEPTH
-#define GN_DEPTH 3
+#define GN_DEPTH 5        // swept 2 ... 5 (tools/ab_gn_depth.sh): 128 ch @256^2 backward 466 / 470 / 451 / 454 us, step 28.57 / 28.56 / 28.55 / 28.40 ms
 #endif
 
 // Block-level reduction shared by the two reducing kernels: every thread parks its 2V partial sums in LDS (lane-linear,
