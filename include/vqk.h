@@ -85,6 +85,14 @@ int vqk_vq_forward_f32(const float* z, const float* e, const void* ws, int64_t w
 /* Same search, additionally writing the full fp32 distance matrix dmat[N][K] (Entropy quantizer). */
 int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const float* e2,
                          int64_t n, int k, int d, int assoc, int64_t* idx, float* dmat, void* stream);
+/* vqk_vq_distances_f32 (d == 256) that also leaves the softmax row statistics of a = -d / temperature: lse[N], hrow[N] (sample
+ * entropies) and hsum[0] += sum_i h_i (pre-zeroed) -- an online log-sum-exp under the distance MFMAs; follow it with
+ * vqk_entropy_forward_presummed_f32 (column means + finalize) instead of vqk_entropy_forward_f32. */
+int vqk_vq_distances_stats_f32(const float* z, const float* e, const float* z2, const float* e2, int64_t n, int k, int d,
+                               int assoc, int64_t* idx, float* dmat, float temperature, float* lse, float* hrow, float* hsum,
+                               void* stream);
+int vqk_entropy_forward_presummed_f32(const float* dmat, int64_t n, int k, float temperature, const float* lse, float* psum,
+                                      float* u, float* avg_term, void* stream);
 /* Entropy loss on dmat (vector_quantizers.py:296-328, 'softmax' type): per row lse[N], hrow[N] (sample entropies),
  * hsum[0] += sum_i h_i, psum[K] += sum_i p_ik, u[K] = log(pbar+1e-5) + pbar/(pbar+1e-5), avg_term[0] += sum_k pbar
  * log(pbar+1e-5) (pbar = psum/N).  hsum, psum, avg_term pre-zeroed.  loss_ent = ratio * (hsum/N + avg_term). */
@@ -235,7 +243,7 @@ int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes);
  * ws must be 16-byte aligned (VQK_ERR_ALIGN), ws_bytes >= 0 (VQK_ERR_ARG); the same checks apply to vqk_set_deterministic. */
 int vqk_set_scratch(void* ws, int64_t ws_bytes);
 /* Tuning slots: the launch heuristics that tools/ sweep (formerly read-once environment variables).  name = one of
- * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4, GN_CLUSTER_MAX_HW.
+ * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4, GN_CLUSTER_MAX_HW, COMM_CUS.
  * A set slot overrides the built-in default at the next launch; vqk_reset_tuning returns every slot to its default.
  * Process-wide (relaxed atomics); VQK_ERR_ARG for an unknown name.  The Python host maps VQK_<NAME> environment variables
  * onto these calls when it loads the library (_native.py), so the A/B scripts keep their interface. */
@@ -249,6 +257,10 @@ const char* vqk_tuning_name(int i);
  * launches the calling thread issues afterwards (set, launch, reset in one place), never to another thread or device
  * context.  vqk_conv_set_variant above is a process-wide TEST hook and not meant for product code. */
 int vqk_conv_set_block_caps(int stream_blocks, int wgrad_blocks);
+/* DIAGNOSTIC (tools/comm_probe.py): a stand-in for a collective's kernel -- `blocks` persistent 256-thread blocks stream
+ * dst[i] += src[i] over `bytes` (16-byte aligned, a multiple of 16) `passes` times, sleeping `sleep` x 64 cycles between
+ * 4-KiB pieces, so that a chosen number of CUs stays occupied for a chosen time while the train step runs on another stream. */
+int vqk_probe_stream_add(const float* src, float* dst, int64_t bytes, int blocks, int passes, int sleep, void* stream);
 /* w [Cout][ks][ks][Cin] -> wt [Cin][ks][ks][Cout] with both taps flipped; src fp32, dst `dtype`. */
 int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, int ksize, void* stream);
 /* dw[Cout][ks][ks][Cin] (fp32) += sum_pix dy[pix][co] * x[pix (+) tap][ci].  dw must be pre-zeroed

@@ -103,6 +103,31 @@ def test_config5_entropy_k8192(golden, tag, temp):
     close_norm(de[::64], g[f'{tag}.de_rows'], 5 * tol_de)
 
 
+def test_config5_entropy_keeps_no_n_by_k_tensor_between_forward_and_backward():
+    """the forward reduces the [N][K] distance matrix to lse[N] / hrow[N] / u[K] and frees it; what stays
+    allocated until the backward does not grow with N x K (round 3 saved the matrix: 134 MB here, 537 MB at BASELINE size)"""
+    i = S.entropy_full_inputs(0.05)
+    q = vqm.EntropyVectorQuantizer(8192, 256, i['ratio'], 0.05, 'softmax', i['beta']).to(DEV)
+    with torch.no_grad():
+        q.codebook.weight.copy_(dev(i['e']))
+    z = dev(i['z']).requires_grad_(True)
+    n, k = z.shape[0] * z.shape[2] * z.shape[3], 8192
+    qz, idx, loss = q(z)                                             # (warm-up: workspaces, lazily built operands)
+    torch.autograd.grad([qz, loss], [z, q.codebook.weight], [dev(i['dq']), ONE()])
+    del qz, idx, loss
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    qz, idx, loss = q(z)
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated() - base
+    peak_fwd = torch.cuda.max_memory_allocated() - base
+    assert peak_fwd >= n * k * 4                                    # the matrix existed (transient) ...
+    assert held < 0.25 * n * k * 4, (held, n * k * 4)               # ... and is gone: z-sized tensors and [N] / [K] statistics remain
+    dz, de = torch.autograd.grad([qz, loss], [z, q.codebook.weight], [dev(i['dq']), ONE()])
+    assert torch.isfinite(dz).all() and torch.isfinite(de).all()
+
+
 def test_config5_entropy_baseline_size_vs_chunked_oracle():
     """N = 16,384 (bs=64), K = 8192: loss, indices and both gradients against the chunked CPU oracle (which
     test_oracle_full.py pins to the reference at N = 4096); the cotangent of the distances sums to zero per row, so

@@ -28,10 +28,13 @@ _PROTOS = {
     'vqk_row_sqnorm_f32': [P, L, I, P, P],
     'vqk_vq_assign_f32': [P, P, P, P, L, I, I, I, P, P],
     'vqk_vq_assign_filtered_f32': [P, P, P, P, L, I, I, I, P, P, L, P],
+    'vqk_probe_stream_add': [P, P, L, I, I, I, P],
     'vqk_vq_prepare_f32': [P, I, I, P, L, P],
     'vqk_vq_forward_f32': [P, P, P, L, L, I, I, I, P, P, P, P, P, P],
     'vqk_vq_backward_fused_f32': [P, P, P, P, I, L, I, I, F, F, P, P, P, P],
     'vqk_vq_distances_f32': [P, P, P, P, L, I, I, I, P, P, P],
+    'vqk_vq_distances_stats_f32': [P, P, P, P, L, I, I, I, P, P, F, P, P, P, P],
+    'vqk_entropy_forward_presummed_f32': [P, L, I, F, P, P, P, P, P],
     'vqk_entropy_forward_f32': [P, L, I, F, P, P, P, P, P, P, P],
     'vqk_entropy_backward_f32': [P, P, P, P, L, I, F, F, P, P],
     'vqk_entropy_argmax_forward_f32': [P, P, P, L, I, F, P, P, P, P, P, P, P, P],

@@ -2480,7 +2480,8 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
             // matrix/auxiliary-wave form: ONE 512-thread block per CU, so half as many resident blocks as the cost model
             // above assumes: s* = sqrt(0.08 * pixels / tiles) under half the block cap
             const double coef = VQK_TUNE("WGMX_COEF_E4", 800) * 1e-4;          // (knob in units of 1e-4)
-            const int capm = cap / 2 > tiles ? cap / 2 : tiles;
+            const int comm = VQK_TUNE("COMM_CUS", 0);               // CUs left to a running collective (conv_mx.hip)
+            const int capm = cap / 2 - comm > tiles ? cap / 2 - comm : tiles;
             int sm = (int)(sqrt(coef * (double)g.m / tiles) + 0.5);
             if (sm > (capm + tiles - 1) / tiles) sm = (capm + tiles - 1) / tiles;
             if (sm > (total_patches + 3) / 4) sm = (total_patches + 3) / 4;          // >= 4 patches per block

@@ -531,7 +531,11 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     const bool half = half_on && g.h * g.w <= half_hw && !g.pool && g.ntap == 9 && (twlog == 4 ? (g.h % 8) == 0 : (g.h % 4) == 0);
     const int th = (half ? 128 : 256) >> twlog;
     const int total = g.n * (g.h / th) * (g.w >> twlog) * g.tiles_n;
-    const int cus = device_cus();
+    // COMM_CUS (data parallel, world > 1): CUs left to the collective's kernels.  A persistent grid of one block per CU that
+    // finds some CUs taken runs its last blocks as a SECOND wave (up to 2x the kernel time); a grid of cus - COMM_CUS blocks
+    // runs as one wave on what is free (tools/comm_probe.py, profiles/round4_comm_probe.txt)
+    int cus = device_cus() - VQK_TUNE("COMM_CUS", 0);
+    if (cus < 1) cus = 1;
     const dim3 grid((unsigned)(total < cus ? total : cus));
     constexpr int lds5 = 3 * (((256 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
     constexpr int lds4 = 3 * (((256 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;

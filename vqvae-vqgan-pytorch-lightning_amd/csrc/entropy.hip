@@ -167,6 +167,21 @@ int vqk_entropy_forward_f32(const float* dmat, int64_t n, int k, float temperatu
     return VQK_OK;
 }
 
+// vqk_entropy_forward_f32 when lse / hrow / hsum were produced by vqk_vq_distances_stats_f32: the column pass and the finalize only
+int vqk_entropy_forward_presummed_f32(const float* dmat, int64_t n, int k, float temperature, const float* lse, float* psum,
+                                      float* u, float* avg_term, void* stream) {
+    VQK_REQUIRE(dmat && lse && psum && u && avg_term, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && k > 0 && temperature > 0.f, VQK_ERR_SHAPE);
+    hipStream_t st = vqk_stream(stream);
+    const float inv_t = 1.0f / temperature;
+    int rpb = (int)((n + 255) / 256); if (rpb < 16) rpb = 16;
+    const dim3 grid((unsigned)((k + 255) / 256), (unsigned)((n + rpb - 1) / rpb));
+    hipLaunchKernelGGL(entropy_colsum_kernel, grid, dim3(256), 0, st, dmat, lse, n, k, inv_t, rpb, psum);
+    hipLaunchKernelGGL(entropy_finalize_kernel, dim3(vqk_grid_1d(k, 256, 64)), dim3(256), 0, st, psum, k, 1.0f / (float)n, u, avg_term);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
 int vqk_entropy_backward_f32(float* dmat, const float* lse, const float* hrow, const float* u, int64_t n, int k,
                              float temperature, float ratio, const float* gscale_dev, void* stream) {
     VQK_REQUIRE(dmat && lse && hrow && u, VQK_ERR_ARG);

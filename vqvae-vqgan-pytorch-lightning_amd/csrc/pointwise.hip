@@ -390,3 +390,33 @@ int vqk_ssim_sum(const float* pred, const float* target, int n, int c, int h, in
 }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------------
+// DIAGNOSTIC: stand-in for a collective's kernel (include/vqk.h: vqk_probe_stream_add, tools/comm_probe.py)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void probe_stream_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t vecs,
+                                                               int passes, int sleep) {
+    const int64_t per = (vecs + gridDim.x - 1) / gridDim.x;
+    const int64_t v0 = (int64_t)blockIdx.x * per, v1 = min(vecs, v0 + per);
+    for (int p = 0; p < passes; ++p)
+        for (int64_t v = v0 + threadIdx.x; v < v1; v += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + 4 * v);
+            f32x4 b = *reinterpret_cast<const f32x4*>(dst + 4 * v);
+            b += a;
+            *reinterpret_cast<f32x4*>(dst + 4 * v) = b;
+            for (int s = 0; s < sleep; ++s) __builtin_amdgcn_s_sleep(64);
+        }
+}
+}  // namespace
+
+extern "C" int vqk_probe_stream_add(const float* src, float* dst, int64_t bytes, int blocks, int passes, int sleep, void* stream) {
+    VQK_REQUIRE(src && dst, VQK_ERR_ARG);
+    VQK_REQUIRE(bytes > 0 && (bytes % 16) == 0 && blocks > 0 && passes > 0 && sleep >= 0, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(src) && vqk_aligned16(dst), VQK_ERR_ALIGN);
+    hipLaunchKernelGGL(probe_stream_add_kernel, dim3((unsigned)blocks), dim3(256), 0, vqk_stream(stream), src, dst, bytes / 16, passes,
+                       sleep);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}

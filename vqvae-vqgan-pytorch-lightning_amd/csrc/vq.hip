@@ -113,14 +113,22 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
 // double-buffered half tiles (the loads of the next 64 MFMAs are in flight during the current 64).  Same MFMA
 // sequence, same k order, same comparisons as vq_assign_kernel => identical indices.
 // ------------------------------------------------------------------------------------------------
-template <int ASSOC, bool WRITE_D, int DD>
+// STATS (Entropy quantizer, vector_quantizers.py:296-310): the row statistics of the softmax over a = -d / T ride along as an
+// ONLINE log-sum-exp per lane (running max m, s = sum exp(a - m), sa = sum exp(a - m) a; one rescale per 32-code tile), merged
+// over the row's eight partial states at the end: lse_i = m + log s, h_i = lse_i - sa / s, hsum += h_i -- the separate pass
+// over the [N][K] matrix (entropy_rows_kernel: 0.36 ms at N = 16,384, K = 8,192) disappears under the fp32 MFMAs.
+template <int ASSOC, bool WRITE_D, int DD, bool STATS = false>
 __global__ __launch_bounds__(256) void vq_assign_reg_kernel(const float* __restrict__ z, const float* __restrict__ e,
                                                             const float* __restrict__ z2, const float* __restrict__ e2,
                                                             int64_t n, int k, int64_t* __restrict__ idx,
-                                                            float* __restrict__ dmat) {
+                                                            float* __restrict__ dmat, float inv_t = 0.0f,
+                                                            float* __restrict__ lse = nullptr, float* __restrict__ hrow = nullptr,
+                                                            float* __restrict__ hsum = nullptr) {
     constexpr int NF = DD / 8, HF = NF / 2;                      // float4 fragments per row slice / per half tile
     __shared__ float red_d[128];
     __shared__ int red_i[128];
+    __shared__ float red_s[STATS ? 3 * 128 : 1];
+    float m_run = -INFINITY, s_run = 0.0f, sa_run = 0.0f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n0 = (int64_t)blockIdx.x * 32;
     const int j = lane & 31, half = lane >> 5;
@@ -178,9 +186,11 @@ __global__ __launch_bounds__(256) void vq_assign_reg_kernel(const float* __restr
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][3], zr[HF + i][3], acc, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        float av[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            av[r] = -INFINITY;
             if (code < k) {
                 const float ab2 = 2.0f * acc[r];
                 float dist;
@@ -188,8 +198,42 @@ __global__ __launch_bounds__(256) void vq_assign_reg_kernel(const float* __restr
                 else            dist = __fadd_rn(__fsub_rn(zz, ab2), e2v[r]);
                 if (dist < best) { best = dist; best_i = code; }
                 if (WRITE_D && n0 + j < n) dmat[(n0 + j) * (int64_t)k + code] = dist;
+                if (STATS) av[r] = -dist * inv_t;
             }
         }
+        if (STATS) {
+            float tmax = av[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, av[r]);
+            const float mn = fmaxf(m_run, tmax);
+            if (mn > -INFINITY) {                                // (a lane whose codes are all beyond K has nothing to add)
+                const float sc = __expf(m_run - mn);             // exp(-inf) = 0 on the first tile
+                float ts = 0.0f, tsa = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ex = __expf(av[r] - mn);         // 0 for the padded entries
+                    ts += ex;
+                    tsa = __fmaf_rn(ex, av[r] > -INFINITY ? av[r] : 0.0f, tsa);
+                }
+                s_run = __fmaf_rn(s_run, sc, ts);
+                sa_run = __fmaf_rn(sa_run, sc, tsa);
+                m_run = mn;
+            }
+        }
+    }
+    if (STATS) {
+        // merge the row's partial states: the two half-waves, then the four waves
+        auto merge = [](float& m, float& s_, float& sa, float om, float os, float osa) {
+            const float mn = fmaxf(m, om);
+            if (mn > -INFINITY) {
+                const float c0 = __expf(m - mn), c1 = __expf(om - mn);
+                s_ = s_ * c0 + os * c1;
+                sa = sa * c0 + osa * c1;
+                m = mn;
+            }
+        };
+        merge(m_run, s_run, sa_run, __shfl_xor(m_run, 32, 64), __shfl_xor(s_run, 32, 64), __shfl_xor(sa_run, 32, 64));
+        if (half == 0) { red_s[wave * 32 + j] = m_run; red_s[128 + wave * 32 + j] = s_run; red_s[256 + wave * 32 + j] = sa_run; }
     }
     {
         const float od = __shfl_xor(best, 32, 64);
@@ -206,6 +250,23 @@ __global__ __launch_bounds__(256) void vq_assign_reg_kernel(const float* __restr
             if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
         }
         idx[n0 + tid] = (bi == 0x7fffffff) ? 0 : (int64_t)bi;
+        if (STATS) {
+            float m = red_s[tid], s_ = red_s[128 + tid], sa = red_s[256 + tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float om = red_s[w * 32 + tid], os = red_s[128 + w * 32 + tid], osa = red_s[256 + w * 32 + tid];
+                const float mn = fmaxf(m, om);
+                if (mn > -INFINITY) {
+                    const float c0 = __expf(m - mn), c1 = __expf(om - mn);
+                    s_ = s_ * c0 + os * c1; sa = sa * c0 + osa * c1; m = mn;
+                }
+            }
+            const float l = m + __logf(s_);
+            const float h = l - sa / s_;
+            lse[n0 + tid] = l;
+            hrow[n0 + tid] = h;
+            atomicAdd(hsum, h);
+        }
     }
 }
 
@@ -429,6 +490,22 @@ int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const 
     }
     if (assoc == 0) hipLaunchKernelGGL((vq_assign_kernel<0, true>), grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx, dmat);
     else hipLaunchKernelGGL((vq_assign_kernel<1, true>), grid, dim3(256), lds, vqk_stream(stream), z, e, z2, e2, n, k, d, idx, dmat);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_vq_distances_stats_f32(const float* z, const float* e, const float* z2, const float* e2, int64_t n, int k, int d,
+                               int assoc, int64_t* idx, float* dmat, float temperature, float* lse, float* hrow, float* hsum,
+                               void* stream) {
+    VQK_REQUIRE(z && e && z2 && e2 && idx && dmat && lse && hrow && hsum, VQK_ERR_ARG);
+    VQK_REQUIRE(n >= 0 && k > 0 && d == 256 && temperature > 0.0f, VQK_ERR_SHAPE);
+    VQK_REQUIRE(assoc == 0 || assoc == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(z) && vqk_aligned16(e), VQK_ERR_ALIGN);
+    if (n == 0) return VQK_OK;
+    const dim3 grid((unsigned)((n + 31) / 32));
+    const float inv_t = 1.0f / temperature;
+    if (assoc == 0) hipLaunchKernelGGL((vq_assign_reg_kernel<0, true, 256, true>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat, inv_t, lse, hrow, hsum);
+    else hipLaunchKernelGGL((vq_assign_reg_kernel<1, true, 256, true>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat, inv_t, lse, hrow, hsum);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

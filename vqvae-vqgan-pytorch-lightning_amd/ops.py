@@ -1307,12 +1307,16 @@ class VQLookupFn(torch.autograd.Function):
         return dz, de, None, None, None, None
 
 
+ENTROPY_FUSED_ROWS = os.environ.get('VQK_ENTROPY_FUSED_ROWS', '1') != '0'
+
+
 class EntropyVQFn(torch.autograd.Function):
     """Entropy-regularised lookup (vector_quantizers.py:290-356, ent_loss_type='softmax'):
     loss = beta*mse(q.detach(), z) + mse(q, z.detach()) + ratio*(mean_i H(p_i) - H(mean_i p_i)),  p = softmax(-d/T).
-    The fp32 distance matrix is materialised once (N*K*4 bytes: 0.5 GB at N=16384, K=8192, against 288 GB of
-    HBM) and overwritten in place by its cotangent in backward; dz / dE come from two fp32-MFMA GEMMs that
-    reuse the 1x1 conv kernels.  Returns (q, idx [B,HW], loss, hist)."""
+    The fp32 distance matrix is a TRANSIENT of each direction (N*K*4 bytes: 0.5 GB at N=16384, K=8192): the forward
+    reduces it to lse[N], hrow[N], u[K] and frees it, the backward recomputes it once (same kernel, same bits) and
+    overwrites it in place by its cotangent; dz / dE come from two fp32-MFMA GEMMs that reuse the 1x1 conv kernels.
+    Returns (q, idx [B,HW], loss, hist)."""
 
     @staticmethod
     def forward(ctx, z, codebook, beta: float, ratio: float, temperature: float, out_dtype, loss_type: str = 'softmax'):
@@ -1334,17 +1338,27 @@ class EntropyVQFn(torch.autograd.Function):
         dmat = torch.empty((n, k), **f32)
         _native.check(lib.vqk_row_sqnorm_f32(flat.data_ptr(), n, d, z2.data_ptr(), st), 'row_sqnorm(z)')
         _native.check(lib.vqk_row_sqnorm_f32(cb.data_ptr(), k, d, e2.data_ptr(), st), 'row_sqnorm(e)')
-        _native.check(lib.vqk_vq_distances_f32(flat.data_ptr(), cb.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d, 1,
-                                               idx.data_ptr(), dmat.data_ptr(), st), 'vq_distances')
+        scal = torch.zeros(3, **f32)                           # sse, hsum, avg_term
+        lse, hrow = torch.empty(n, **f32), torch.empty(n, **f32)
+        fused_rows = loss_type == 'softmax' and d == 256 and ENTROPY_FUSED_ROWS
+        if fused_rows:                                         # the row statistics ride under the distance MFMAs (csrc/vq.hip)
+            _native.check(lib.vqk_vq_distances_stats_f32(flat.data_ptr(), cb.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d, 1,
+                                                         idx.data_ptr(), dmat.data_ptr(), temperature, lse.data_ptr(),
+                                                         hrow.data_ptr(), scal[1:2].data_ptr(), st), 'vq_distances_stats')
+        else:
+            _native.check(lib.vqk_vq_distances_f32(flat.data_ptr(), cb.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d, 1,
+                                                   idx.data_ptr(), dmat.data_ptr(), st), 'vq_distances')
         q32 = empty_nhwc(b, d, h, w, torch.float32, dev)
         qlo = empty_nhwc(b, d, h, w, torch.bfloat16, dev) if out_dtype == torch.bfloat16 else None
-        scal = torch.zeros(3, **f32)                           # sse, hsum, avg_term
         hist = torch.zeros(k, dtype=torch.int32, device=dev)
         _native.check(lib.vqk_vq_gather_f32(flat.data_ptr(), cb.data_ptr(), idx.data_ptr(), n, k, d, q32.data_ptr(),
                                             _p(qlo), scal[0:1].data_ptr(), hist.data_ptr(), st), 'vq_gather')
-        lse, hrow = torch.empty(n, **f32), torch.empty(n, **f32)
         psum, u = torch.zeros(k, **f32), torch.empty(k, **f32)
-        if loss_type == 'softmax':
+        if fused_rows:
+            _native.check(lib.vqk_entropy_forward_presummed_f32(dmat.data_ptr(), n, k, temperature, lse.data_ptr(), psum.data_ptr(),
+                                                                u.data_ptr(), scal[2:3].data_ptr(), st), 'entropy_forward_presummed')
+            ent = scal[1] / float(n) + scal[2]
+        elif loss_type == 'softmax':
             _native.check(lib.vqk_entropy_forward_f32(dmat.data_ptr(), n, k, temperature, lse.data_ptr(), hrow.data_ptr(),
                                                       scal[1:2].data_ptr(), psum.data_ptr(), u.data_ptr(),
                                                       scal[2:3].data_ptr(), st), 'entropy_forward')
@@ -1358,14 +1372,18 @@ class EntropyVQFn(torch.autograd.Function):
             ent = s2[1] / float(n) + scal[2]
         mse = scal[0] / float(n * d)
         loss = beta * mse + mse + ent * ratio
-        ctx.save_for_backward(z, cb, idx, dmat, lse, hrow, u)
+        # Nothing of size N x K survives the forward: the backward recomputes the distance matrix ONCE (the same kernel, the same
+        # bits) into a transient buffer; what is kept is z, the codebook, idx and the row / column statistics lse[N], hrow[N], u[K]
+        # (round 3 saved dmat: 537 MB at N = 16,384, K = 8,192, growing with N x K)
+        del dmat
+        ctx.save_for_backward(z, cb, idx, lse, hrow, u, z2, e2)
         ctx.cfg = (beta, ratio, temperature, n, k, d, loss_type)
         ctx.mark_non_differentiable(idx, hist)
         return (qlo if qlo is not None else q32), idx.view(b, h * w), loss, hist
 
     @staticmethod
     def backward(ctx, dq, _didx, dloss, _dhist):
-        z, cb, idx, dmat, lse, hrow, u = ctx.saved_tensors
+        z, cb, idx, lse, hrow, u, z2, e2 = ctx.saved_tensors
         beta, ratio, temperature, n, k, d, loss_type = ctx.cfg
         lib, st = _native.lib(), _stream()
         flat = z.permute(0, 2, 3, 1).reshape(n, d)
@@ -1374,12 +1392,18 @@ class EntropyVQFn(torch.autograd.Function):
         scale = 2.0 / float(n * d) if gs is not None else 0.0
         dz = torch.empty_like(z, memory_format=_CL)
         de = torch.zeros_like(cb)
-        _native.check(lib.vqk_vq_backward_f32(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), _p(dqc),
-                                              dcode(dqc.dtype) if dqc is not None else F32, n, k, d, beta * scale, scale,
-                                              _p(gs), dz.data_ptr(), de.data_ptr(), st), 'vq_backward')
+        fused = VQ_FUSED and d == 256 and not DETERMINISTIC       # one kernel (csrc/vq_filter.hip); K = 8192: 41 against 235 us
+        fn = lib.vqk_vq_backward_fused_f32 if fused else lib.vqk_vq_backward_f32
+        _native.check(fn(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), _p(dqc),
+                         dcode(dqc.dtype) if dqc is not None else F32, n, k, d, beta * scale, scale,
+                         _p(gs), dz.data_ptr(), de.data_ptr(), st), 'vq_backward')
         if gs is None:
             return dz, de, None, None, None, None, None
-        # dmat <- dL_ent/dd  (rows sum to zero)
+        # the distance matrix again (transient), then dmat <- dL_ent/dd  (rows sum to zero)
+        dmat = torch.empty((n, k), dtype=torch.float32, device=z.device)
+        idx2 = torch.empty(n, dtype=torch.int64, device=z.device)
+        _native.check(lib.vqk_vq_distances_f32(flat.data_ptr(), cb.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d, 1,
+                                               idx2.data_ptr(), dmat.data_ptr(), st), 'vq_distances (backward recompute)')
         if loss_type == 'softmax':
             _native.check(lib.vqk_entropy_backward_f32(dmat.data_ptr(), lse.data_ptr(), hrow.data_ptr(), u.data_ptr(), n, k,
                                                        temperature, ratio, gs.data_ptr(), st), 'entropy_backward')
