@@ -317,6 +317,12 @@ int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w
 int vqk_gn_backward_ws(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
                        void* dx, float* dw, float* db, double* red, int64_t ws_doubles, int n, int h, int wd, int c, int groups,
                        int silu, int accumulate, const void* add, const void* add_pooled, float add_scale, void* stream);
+/* vqk_gn_backward_ws (same-resolution addend) that also accumulates the per-channel sums of the dx it writes into
+ * dx_colsum[C] (fp32): when x is the output of a conv with a bias, that is the conv's bias gradient -- no column-sum pass over
+ * the gradient tensor.  Two-kernel form only; not in deterministic mode (VQK_ERR_ARG). */
+int vqk_gn_backward_colsum(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
+                           void* dx, float* dw, float* db, double* red, int64_t ws_doubles, int n, int h, int wd, int c, int groups,
+                           int silu, int accumulate, const void* add, float* dx_colsum, void* stream);
 /* vqk_gn_backward with dx += add_scale * (add_pooled read at pixel (row/2, col/2)): the skip-branch gradient of a ResBlock
  * whose output went through a fused 2x2 average pool, still at half resolution ([N][h/2][wd/2][C]).  h * wd > 1024. */
 int vqk_gn_backward_pooled_add(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,

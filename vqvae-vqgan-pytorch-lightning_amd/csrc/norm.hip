@@ -365,12 +365,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            double* __restrict__ red, int64_t hw, int c,
                                                            int groups, int silu, int accumulate, int pix_per_block,
                                                            int add_w, float add_scale,
-                                                           const double* __restrict__ gpart = nullptr, int nblk = 0) {
+                                                           const double* __restrict__ gpart = nullptr, int nblk = 0,
+                                                           float* __restrict__ dx_colsum = nullptr) {
+    // dx_colsum (optional, fp32 [C], accumulated into): the per-channel sums of the dx this pass writes -- the BIAS gradient of
+    // the conv that produced x (the Upsample convs: autoencoder.py:102-105), which was a separate 185-us column-sum pass over
+    // the 537-MB gradient at 128 ch @256^2.  A thread owns fixed channels, so the sums live in 8 registers.
     constexpr int V = Vec16<T>::N;
     const int vpp = c / V, slot = threadIdx.x % vpp, prow = threadIdx.x / vpp, pstep = 256 / vpp;
     const int n = blockIdx.y, cpg = c / groups;
     const double m = (double)hw * cpg;
     float mean[V], rstd[V], wv[V], bv[V], k1[V], k2[V];
+    float csum[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) csum[i] = 0.0f;
     __shared__ float gk[256][2];                            // deterministic mode: (k1, k2) per group, summed once per block
     if (gpart) {                                            // the reduce blocks' partials, in block order
         for (int g = threadIdx.x; g < groups; g += 256) {
@@ -447,8 +454,26 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                     const float r = (g * wv[i] - k1[i] - xh * k2[i]) * rstd[i];
                     ov[i] = ADD ? ov[i] + r : r;
                 }
-                if (q < p1) GN_STORE_BWD(dx + off + q * c, ov);
+                if (q < p1) {
+                    GN_STORE_BWD(dx + off + q * c, ov);
+                    if (dx_colsum) {                             // kernel-uniform
+#pragma unroll
+                        for (int i = 0; i < V; ++i) csum[i] += ov[i];
+                    }
+                }
             }
+        }
+    }
+    if (dx_colsum) {
+        // the block's rows of a slot are added through LDS ([prow][channel], reusing nothing else), one atomic per channel
+        __shared__ float cs_part[256 * 8];
+#pragma unroll
+        for (int i = 0; i < V; ++i) cs_part[prow * c + slot * V + i] = csum[i];      // vpp * V = c columns, 256 / vpp rows: 256 * V floats
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < c; ch += 256) {
+            float a = 0.0f;
+            for (int r = 0; r < pstep; ++r) a += cs_part[r * c + ch];
+            atomicAdd(dx_colsum + ch, a);
         }
     }
     if (!gpart) ws_release(red, gridDim.y, groups);
@@ -872,7 +897,8 @@ inline int pick_ppb(int n, int64_t hw, bool reducing = false) {
 
 static int gn_backward_impl(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy, void* dx,
                             float* dw, float* db, double* red, int n, int64_t hw, int c, int groups, int silu, int accumulate,
-                            const void* add, int add_w, float add_scale, void* stream, int64_t ws_doubles = 0) {
+                            const void* add, int add_w, float add_scale, void* stream, int64_t ws_doubles = 0,
+                            float* dx_colsum = nullptr) {
     VQK_REQUIRE(x && stats && w && b && dy && dx && dw && db && red, VQK_ERR_ARG);
     VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
     const int rc = check_gn(dtype, c, groups);
@@ -881,7 +907,7 @@ static int gn_backward_impl(int dtype, const void* x, const float* stats, const 
     hipStream_t st = vqk_stream(stream);
     // 16 pixels per thread (the 32^2 maps, re-read form) measured 106 us per call inside the step against 93 for the
     // two-kernel form next to the weight-gradient kernels: the single-kernel backward is used up to 8 pixels per thread
-    if (const int ppt = add_w ? 0 : gn_small_ppt(dtype, hw, c, groups, 8)) {
+    if (const int ppt = (add_w || dx_colsum) ? 0 : gn_small_ppt(dtype, hw, c, groups, 8)) {
         const dim3 sgrid((unsigned)(c / 32), (unsigned)n);
         const int acc = (accumulate || add) ? 1 : 0;
         vqkd::DetState& det = vqkd::det_state();
@@ -910,7 +936,7 @@ static int gn_backward_impl(int dtype, const void* x, const float* stats, const 
         const int rows = 256 / (sl / v);
         const int64_t max_hw = VQK_TUNE("GN_CLUSTER_MAX_HW", 1024);
         vqkd::DetState& det0 = vqkd::det_state();
-        if (!det0.on && ws_doubles >= (int64_t)n * groups * 2 + n + (int64_t)n * (c / 32) && hw <= max_hw && c % sl == 0 &&
+        if (!det0.on && !dx_colsum && ws_doubles >= (int64_t)n * groups * 2 + n + (int64_t)n * (c / 32) && hw <= max_hw && c % sl == 0 &&
             sl % (c / groups) == 0 && hw % (8 * rows) == 0 && (!add_w || (add_w % 2 == 0 && hw % add_w == 0))) {
             const int cl = (int)(hw / (8 * rows));
             unsigned* tickets = reinterpret_cast<unsigned*>(red + (int64_t)n * groups * 2 + n);
@@ -944,7 +970,7 @@ static int gn_backward_impl(int dtype, const void* x, const float* stats, const 
         cpart = reinterpret_cast<float*>(reinterpret_cast<char*>(det.ws) + gbytes);
     }
     const int acc = (accumulate || add) ? 1 : 0;
-#define VQK_GN_BWD_A(T, S, N, A) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, N, S, A>), grid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, red, hw, c, groups, silu, acc, ppb, add_w, add_scale, (const double*)gpart, nblk)
+#define VQK_GN_BWD_A(T, S, N, A) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, N, S, A>), grid, dim3(256), 0, st, (const T*)x, stats, w, b, (const T*)dy, (T*)dx, (const T*)add, red, hw, c, groups, silu, acc, ppb, add_w, add_scale, (const double*)gpart, nblk, dx_colsum)
 #define VQK_GN_BWD_N(T, S, N) do { if (!acc) VQK_GN_BWD_A(T, S, N, 0); else if (add_w) VQK_GN_BWD_A(T, S, N, 2); else VQK_GN_BWD_A(T, S, N, 1); } while (0)
 #define VQK_GN_BWD_S(T, S) do { \
         hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, S>), rgrid, dim3(256), lds, st, (const T*)x, stats, w, b, (const T*)dy, dw, db, red, hw, c, groups, silu, rppb, gpart, cpart); \
@@ -1083,6 +1109,15 @@ int vqk_gn_backward_ws(int dtype, const void* x, const float* stats, const float
     }
     return gn_backward_impl(dtype, x, stats, w, b, dy, dx, dw, db, red, n, (int64_t)h * wd, c, groups, silu, accumulate, add, 0, 1.0f,
                             stream, ws_doubles);
+}
+
+int vqk_gn_backward_colsum(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
+                           void* dx, float* dw, float* db, double* red, int64_t ws_doubles, int n, int h, int wd, int c, int groups,
+                           int silu, int accumulate, const void* add, float* dx_colsum, void* stream) {
+    VQK_REQUIRE(h > 0 && wd > 0 && ws_doubles >= (int64_t)n * groups * 2 + n && dx_colsum, VQK_ERR_ARG);
+    VQK_REQUIRE(vqkd::det_state().on == 0, VQK_ERR_ARG);          // (atomics in arrival order: the ordered mode keeps vqk_colsum)
+    return gn_backward_impl(dtype, x, stats, w, b, dy, dx, dw, db, red, n, (int64_t)h * wd, c, groups, silu, accumulate, add, 0, 1.0f,
+                            stream, ws_doubles, dx_colsum);
 }
 
 int vqk_gn_backward_pooled_add(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,

@@ -74,6 +74,7 @@ def set_deterministic(on: bool) -> None:
     global DETERMINISTIC, _DET_GEN, FUSE_GN_STATS
     DETERMINISTIC = bool(on)
     _DET_GEN += 1
+    _DB_DONE.clear()
     FUSE_GN_STATS = False if on else os.environ.get('VQK_FUSE_GN_STATS', '1') != '0'
 
 
@@ -610,7 +611,9 @@ def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool
     return y, stats
 
 
-def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None, add=None):
+def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None, add=None, dx_colsum=None):
+    """``dx_colsum``: fp32 [C] buffer that also receives the per-channel sums of the dx written (the bias gradient of the conv
+    that produced x: vqk_gn_backward_colsum); the caller checks :func:`gn_colsum_ok` first"""
     n, c, h, wd = x.shape
     dx = torch.empty_like(x, memory_format=_CL)
     dw = dw if dw is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
@@ -620,6 +623,15 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
     nb = x.numel() * x.element_size()
     one_pass = h * wd <= 512 or _gn_cluster(x.dtype, h * wd, c, groups)
     passes = (3 if one_pass else 5) + (1 if add is not None else 0)     # x, dy (twice on the two-kernel path), dx, skip
+    if dx_colsum is not None:
+        st = _timed('group_norm_bwd (HBM)' + (f' {c}@{h}x{wd} +bias-grad' if _EVENT_SHAPES else ''), 0.0,
+                    lambda: _native.lib().vqk_gn_backward_colsum(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
+                                                                 b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                                 db.data_ptr(), red.data_ptr(), red.numel(), n, h, wd, c, groups,
+                                                                 int(silu), 0, _p(add), dx_colsum.data_ptr(), _stream()),
+                    (5 + (1 if add is not None else 0)) * nb)
+        _native.check(st, 'gn_backward_colsum')
+        return dx, dw, db
     st = _timed('group_norm_bwd (HBM)' + (f' {c}@{h}x{wd}' if _EVENT_SHAPES else ''), 0.0,
                 lambda: _native.lib().vqk_gn_backward_ws(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
                                                          b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
@@ -627,6 +639,32 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
                                                          int(silu), 0, _p(add), 0, 1.0, _stream()), passes * nb)
     _native.check(st, 'gn_backward')
     return dx, dw, db
+
+
+# The bias gradient of a conv whose output feeds a ResBlock rides in that block's LAST GroupNorm-backward pass (the pass that
+# writes d(block input) = the conv's dy): Conv2dFn.forward notes (output tensor, bias parameter), ResBlockFn.forward claims the
+# note when that very tensor is its input, its backward hands the bias's arena gradient to the kernel and marks the bias as
+# done; Conv2dFn.backward then skips its column-sum pass over dy (185 us for the 537-MB gradient of the last Upsample conv).
+FUSE_BIAS_COLSUM = os.environ.get('VQK_FUSE_BIAS_COLSUM', '1') != '0'
+_PENDING_DB = None
+_DB_DONE: set = set()
+
+
+def gn_colsum_ok(h: int, w: int) -> bool:
+    return FUSE_BIAS_COLSUM and not DETERMINISTIC and h * w > 1024
+
+
+def _note_bias_colsum(y, bias) -> None:
+    global _PENDING_DB
+    _PENDING_DB = (weakref.ref(y), bias)
+
+
+def _claim_bias_colsum(x):
+    global _PENDING_DB
+    p, _PENDING_DB = _PENDING_DB, None
+    if p is not None and p[0]() is x:
+        return p[1]
+    return None
 
 
 def raw_gn_backward_pooled_add(x, stats, w, b, dy, groups: int, silu: bool, dw, db, add_pooled, add_scale: float):
@@ -771,6 +809,9 @@ class Conv2dFn(torch.autograd.Function):
         ctx.bias_ref, ctx.weight_ref = bias, weight
         ctx.cfg = (k, ups, act, o, i, cin, cout_pad, bias is not None, residual is not None, dt)
         ctx.phase = phase
+        if (bias is not None and act == 0 and cout_pad == o and out_dtype == dt and gn_colsum_ok(y.shape[2], y.shape[3])
+                and direct_grad(bias) is not None):
+            _note_bias_colsum(y, bias)                           # a ResBlock reading y next computes db in its backward
         return y
 
     @staticmethod
@@ -809,7 +850,9 @@ class Conv2dFn(torch.autograd.Function):
                 dw = None                                        # already accumulated in the flat arena
             elif padded:
                 dw = dw[:o, :i]
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and id(ctx.bias_ref) in _DB_DONE:
+            _DB_DONE.discard(id(ctx.bias_ref))                   # the consumer's GroupNorm backward summed dy's columns already
+        elif has_bias and ctx.needs_input_grad[2]:
             n, c, h, w = dyc.shape
             tgt = None if padded else direct_grad(ctx.bias_ref)
             db = raw_colsum(n * h * w, c, dyc, out=tgt)
@@ -904,6 +947,7 @@ class ResBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n1w, n1b, c1w, n2w, n2b, c2w, scw, groups: int, eps: float, pool: bool = False, next_gn: int = 0):
         _require_gpu(x)
+        ctx.db_param = _claim_bias_colsum(x)                     # x = output of a conv with a bias: its db rides in our backward
         x = nhwc(x)
         dt = x.dtype
         n, cin, h, w = x.shape
@@ -1014,11 +1058,16 @@ class ResBlockFn(torch.autograd.Function):
             dw = raw_conv_wgrad(inp, dy, k, False, out=tgt)
             return dx, (None if tgt is not None else dw)
 
-        def gn_bwd(inp, st, wv, bv, dy, wparam, bparam, add=None):
+        def gn_bwd(inp, st, wv, bv, dy, wparam, bparam, add=None, colsum_of=None):
             tw, tb = direct_grad(wparam), direct_grad(bparam)
             direct = tw is not None and tb is not None
+            cs = None
+            if colsum_of is not None and gn_colsum_ok(h, w) and not torch.is_grad_enabled():
+                cs = direct_grad(colsum_of)
+                if cs is not None:
+                    _DB_DONE.add(id(colsum_of))
             dx, dw, db = raw_gn_backward(inp, st, wv, bv, dy, groups, True, tw if direct else None,
-                                         tb if direct else None, add=add)
+                                         tb if direct else None, add=add, dx_colsum=cs)
             if direct:
                 return dx, None, None
             return dx, dw.view(wparam.shape), db.view(bparam.shape)
@@ -1064,7 +1113,7 @@ class ResBlockFn(torch.autograd.Function):
                 dskip, dwsc = dout, None
                 if scw is not None:
                     dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
-                dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip)
+                dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip, colsum_of=ctx.db_param)
                 if OVERLAP_MODE != 1 and CHAIN_FIRST:
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
@@ -1079,7 +1128,7 @@ class ResBlockFn(torch.autograd.Function):
         dskip, dwsc = dout, None
         if scw is not None:
             dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
-        dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip)
+        dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip, colsum_of=ctx.db_param)
         return dx, dn1w, dn1b, dw1, dn2w, dn2b, dw2, dwsc, None, None, None, None
 
 
