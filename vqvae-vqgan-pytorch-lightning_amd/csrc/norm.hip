@@ -884,8 +884,11 @@ int check_gn(int dtype, int c, int groups) {
 // sums) pay per-block LDS + global atomics for every channel / group, so they want fewer, fatter blocks (~768 total):
 // measured -8...27 % per reducing pass on the 64^2 / 128^2 maps, -2...5 % on 256^2 (sweep 256...4096 blocks).
 inline int pick_ppb(int n, int64_t hw, bool reducing = false) {
-    const int tot_r = VQK_TUNE("GN_BLOCKS_REDUCE", 768);
-    const int tot_a = VQK_TUNE("GN_BLOCKS_APPLY", 2048);
+    // round 4, re-swept with the pipelined loops (tools/gn_grid_sweep.py): fewer, fatter blocks -- a block now opens with
+    // GN_DEPTH loads in flight, so short blocks are mostly prologue.  Reduce 512 (256 on <= 64x64 maps: 128 ch @64^2 backward
+    // 73 -> 53 us, 256 ch @64^2 88 -> 75), apply 1024 (64^2 forward apply 29.8 -> 25.8 / 23.3 -> 17.7 us; large maps flat)
+    const int tot_r = VQK_TUNE("GN_BLOCKS_REDUCE", hw <= 4096 ? 256 : 512);
+    const int tot_a = VQK_TUNE("GN_BLOCKS_APPLY", 1024);
     const int total = reducing ? tot_r : tot_a;
     int64_t blocks_per_sample = (total + n - 1) / n;
     int64_t ppb = (hw + blocks_per_sample - 1) / blocks_per_sample;
