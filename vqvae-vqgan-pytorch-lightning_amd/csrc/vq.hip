@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restric
 __global__ __launch_bounds__(256) void vq_code_grad_kernel(const float* __restrict__ z, const float* __restrict__ e,
                                                            const int64_t* __restrict__ idx, int64_t n, int d,
                                                            int64_t span, float ce, const float* __restrict__ gs,
-                                                           float* __restrict__ de, int ordered) {
+                                                           float* __restrict__ de, int ordered, float* __restrict__ part = nullptr) {
     constexpr int CAP = 2048;
     __shared__ int rows[CAP];
     __shared__ int nrows;
@@ -395,12 +395,32 @@ __global__ __launch_bounds__(256) void vq_code_grad_kernel(const float* __restri
         }
         __syncthreads();
     }
+    if (part) {
+        // deterministic mode with row splits (round 4: one block per code walked all N rows of a collapsed codebook -- 0.58 ms):
+        // every (split, code) block STORES its partial row (zeros when it has no rows); vq_code_grad_reduce_kernel adds the
+        // splits in index order
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            if (c < d) part[((int64_t)blockIdx.y * gridDim.x + k) * d + c] = ce * acc[j];
+        }
+        return;
+    }
     if (any)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = threadIdx.x + 256 * j;
             if (c < d) atomicAdd(de + (int64_t)k * d + c, ce * acc[j]);
         }
+}
+
+__global__ __launch_bounds__(256) void vq_code_grad_reduce_kernel(const float* __restrict__ part, int64_t elems, int splits,
+                                                                  float* __restrict__ de) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    float s = 0.f;
+    for (int q = 0; q < splits; ++q) s += part[(int64_t)q * elems + i];
+    de[i] += s;
 }
 
 __global__ __launch_bounds__(256) void ema_stats_kernel(const float* __restrict__ z, const int64_t* __restrict__ idx,
@@ -538,11 +558,23 @@ int vqk_vq_backward_f32(const float* z, const float* e, const int64_t* idx, cons
     if (de) {
         int splits = (int)((n + 255) / 256);              // <= 256 rows per block even when every row hits one code
         if (splits > 64) splits = 64;
-        const int det = vqkd::det_state().on;
-        if (det) splits = 1;                              // deterministic mode: one block per code, rows added in row order
+        vqkd::DetState& dst = vqkd::det_state();
+        const int det = dst.on;
+        float* part = nullptr;
+        if (det) {
+            // deterministic mode: rows of a (code, split) block added in row order, the splits' partial rows through the
+            // workspace in split order; without a workspace that holds them: one block per code
+            if (splits > 32) splits = 32;
+            while (splits > 1 && (int64_t)splits * k * d * 4 > dst.bytes) splits >>= 1;
+            part = (splits > 1 && dst.ws) ? dst.ws : nullptr;
+            if (!part) splits = 1;
+        }
         const int64_t span = (n + splits - 1) / splits;
         hipLaunchKernelGGL(vq_code_grad_kernel, dim3((unsigned)k, (unsigned)splits), dim3(256), 0, vqk_stream(stream), z, e,
-                           idx, n, d, span, ce, gscale_dev, de, det);
+                           idx, n, d, span, ce, gscale_dev, de, det, part);
+        if (part)
+            hipLaunchKernelGGL(vq_code_grad_reduce_kernel, dim3((unsigned)(((int64_t)k * d + 255) / 256)), dim3(256), 0,
+                               vqk_stream(stream), (const float*)part, (int64_t)k * d, splits, de);
     }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
