@@ -303,6 +303,13 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
 /* the same when the sums of x are already in ws (vqk_conv2d_fprop_gnstats of the producing conv): one launch */
 int vqk_gn_forward_presummed(int dtype, const void* x, const float* w, const float* b, void* y, float* stats, double* ws,
                              int n, int64_t hw, int c, int groups, float eps, int silu, void* stream);
+/* deterministic mode: the producing conv (vqk_conv2d_fprop_gnstats / vqk_conv2d_ups_phase while vqk_set_deterministic is on)
+ * left the sums as ONE SLOT PER 256-pixel TILE, parts[((n * G + g) * nblk + tile) * 2 + j], nblk = (conv-resolution H * W) / 256
+ * (plain stores, no zero-on-entry protocol: `ws` handed to the conv is `parts`, >= N*G*nblk*2 doubles).  The slots are added in
+ * a fixed order into sums[N*G*2] (scratch), then the apply pass runs as in vqk_gn_forward_presummed. */
+int vqk_gn_forward_presummed_parts(int dtype, const void* x, const float* w, const float* b, void* y, float* stats,
+                                   const double* parts, int nblk, double* sums, int n, int64_t hw, int c, int groups, float eps,
+                                   int silu, void* stream);
 /* backward of y = act(GN(x)): needs x, stats, w, b and dy.  red = N*G*2+N doubles scratch with the vqk_gn_forward
  * workspace protocol (zero on entry, zero again on exit); dw/db [C] fp32 pre-zeroed (accumulated into).  accumulate != 0: dx += result; add != NULL: dx = result + add (the residual-branch
  * gradient of a ResBlock, fused instead of a separate add pass). */

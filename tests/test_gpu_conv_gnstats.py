@@ -119,3 +119,45 @@ def test_conv_and_fused_sums_are_deterministic_and_batch_split_exact(cin, cout, 
     assert torch.equal(yf, yf2) and torch.equal(sf, sf2)
     assert torch.equal(yf, torch.cat([ya, yb], 0))
     assert torch.equal(sf, torch.cat([sa, sb], 0))
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,ups,hb,hr,pool', [CASES[0], CASES[2], CASES[5], CASES[8], CASES[13], CASES[14]])
+def test_fused_stats_in_deterministic_mode_use_one_slot_per_tile(n, cin, cout, h, w, ups, hb, hr, pool):
+    """deterministic mode (round 4): the drain STORES its tile's sums in the tile's own slot and the consumer adds the slots in a
+    fixed order (vqk_gn_forward_presummed_parts) -- (mean, rstd) equal to the separate pass to fp32 rounding, and two runs give
+    the same bits; the upsample conv in phase form (four launches into four slot ranges) included"""
+    g = torch.Generator(device=DEV).manual_seed(cin + cout + h + 3 * ups + hb + 2 * hr + 4 * pool)
+    x = (torch.randn(n, cin, h, w, device=DEV, generator=g) + 0.3).to(BF).contiguous(memory_format=CL)
+    wt = (torch.randn(cout, 3, 3, cin, device=DEV, generator=g) / (3 * cin ** 0.5)).reshape(-1)
+    bias = torch.randn(cout, device=DEV, generator=g) if hb else None
+    s = 2 if ups else 1
+    res = torch.randn(n, cout, h * s, w * s, device=DEV, generator=g).to(BF).contiguous(memory_format=CL) if hr else None
+    layout = ops.weight_layout(BF, n, h, w, cin, cout, 3, bool(ups))
+    wq = ops.pack_weights(wt, BF, cout, cin, 3, False, layout)
+    gw = torch.randn(cout, device=DEV, generator=g); gb = torch.randn(cout, device=DEV, generator=g)
+    y_ref = ops.raw_conv_fprop_pooled(x, wq, bias, res, 3, bool(ups), cout, 0.25) if pool else \
+        ops.raw_conv_fprop(x, wq, bias, res, 3, bool(ups), 0, BF, cout, layout)
+    _, st_ref = ops.raw_gn_forward(y_ref, gw, gb, 32, 1e-6, True)
+    ops.set_deterministic(True)
+    try:
+        runs = []
+        for _ in range(2):
+            y = ops.raw_conv_fprop_gnstats(x, wq, bias, res, bool(ups), cout, 32, pool=bool(pool), pool_scale=0.25)
+            assert y is not None
+            a, st = ops.raw_gn_forward(y, gw, gb, 32, 1e-6, True, presummed=True, conv_hw=h * s * w * s)
+            runs.append((y.clone(), a.clone(), st.clone()))
+        if ups and cin % 128 == 0 and res is None:                  # the phase form of the upsample conv: four slot ranges
+            w4 = ops.pack_weights(wt, BF, cout, cin, 3, False, 2)
+            yp = ops.raw_conv_ups_phase(x, w4, bias, cout, False, 32)
+            assert yp is not None
+            _, stp = ops.raw_gn_forward(yp, gw, gb, 32, 1e-6, True)   # claims the note left by the phase launches
+            _, stp_ref = ops.raw_gn_stats(yp, 32, 1e-6), None
+            torch.testing.assert_close(stp.view(-1, 2)[:, 0], ops.raw_gn_stats(yp, 32, 1e-6).view(-1, 2)[:, 0], rtol=0, atol=2e-5)
+    finally:
+        ops.set_deterministic(False)
+    torch.cuda.synchronize()
+    for p, q in zip(runs[0], runs[1]):
+        assert torch.equal(p, q)
+    assert torch.equal(runs[0][0], y_ref)
+    torch.testing.assert_close(runs[0][2].view(-1, 2)[:, 0], st_ref.view(-1, 2)[:, 0], rtol=0, atol=2e-5)
+    torch.testing.assert_close(runs[0][2].view(-1, 2)[:, 1], st_ref.view(-1, 2)[:, 1], rtol=2e-5, atol=0)

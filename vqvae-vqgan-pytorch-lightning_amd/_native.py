@@ -70,6 +70,7 @@ _PROTOS = {
     'vqk_gn_apply': [I, P, P, P, P, P, I, L, I, I, I, P],
     'vqk_gn_forward': [I, P, P, P, P, P, P, I, L, I, I, F, I, P],
     'vqk_gn_forward_presummed': [I, P, P, P, P, P, P, I, L, I, I, F, I, P],
+    'vqk_gn_forward_presummed_parts': [I, P, P, P, P, P, P, I, P, I, L, I, I, F, I, P],
     'vqk_gn_backward': [I, P, P, P, P, P, P, P, P, P, I, L, I, I, I, I, P, P],
     'vqk_gn_backward_pooled_add': [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, F, P],
     'vqk_gn_backward_ws': [I, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, I, P, P, F, P],

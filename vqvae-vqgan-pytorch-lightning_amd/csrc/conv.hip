@@ -2223,7 +2223,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.cin = cin; g.cout = cout; g.ks = ksize; g.ups = ups;
     g.stride = 1; g.pad = ksize >> 1; g.zs = 0; g.vh = g.h; g.vw = g.w;
     g.acc_scale = 1.0f; g.out_gain = 1.0f; g.pool = 0; g.pool_scale = 1.0f;
-    g.gn_ws = nullptr; g.gn_cpg = 0;
+    g.gn_ws = nullptr; g.gn_cpg = 0; g.gn_part_nblk = 0; g.gn_part_base = 0;
     g.act = 0; g.dy_pool = 0;
     g.ntap = ksize == 1 ? 1 : 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
@@ -2354,6 +2354,7 @@ int vqk_conv2d_fprop_gnstats(int dtype, const void* x, const void* w, const floa
     VQK_REQUIRE(halo_twlog(g) && (cout % 128) == 0 && g_force_variant != 3 && g_force_variant != 2, VQK_ERR_SHAPE);
     g.pool = pool; g.pool_scale = pool ? pool_scale : 1.0f;
     g.gn_ws = gn_ws; g.gn_cpg = cout / groups;
+    if (g_det) g.gn_part_nblk = (g.h * g.w) / 256;          // deterministic mode: one slot per 256-pixel tile of the image
     return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, 0, 1, vqk_stream(stream));
 }
 
@@ -2384,6 +2385,7 @@ int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* 
             gp.tap_oy = a; gp.tap_ox = b;
             gp.dst_s = 2; gp.dst_a = a; gp.dst_b = b;
             gp.gn_ws = gn_ws; gp.gn_cpg = gn_ws ? cout / groups : 0;
+            if (gn_ws && g_det) { gp.gn_part_nblk = 4 * ((g.h * g.w) / 256); gp.gn_part_base = ph * ((g.h * g.w) / 256); }
         } else {                                             // dx[i][j] += mirrored 2x2 window of the phase (a, b) of dy
             gp.tap_oy = 1 - a; gp.tap_ox = 1 - b;
             gp.src_s = 2; gp.src_a = a; gp.src_b = b;

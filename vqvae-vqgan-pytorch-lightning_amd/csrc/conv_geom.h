@@ -26,6 +26,9 @@ struct ConvGeom {
     // sums of y and y*y (y as stored, i.e. rounded to bf16) are added to gn_ws[n][group][2] (vqk_gn_forward's workspace)
     double* gn_ws;
     int gn_cpg;     // channels per group (cout / groups): a multiple of 4
+    // deterministic mode: gn_part_nblk > 0 -- the tile's sums are STORED at gn_ws[((n * groups + g) * gn_part_nblk + gn_part_base +
+    // tile_in_image) * 2 + j] (one slot per tile: no atomics, no zero-on-entry protocol); the consumer adds the slots in order
+    int gn_part_nblk, gn_part_base;
     // matrix/auxiliary-wave kernel, nearest-x2 upsample convs in PHASE form (conv_mx.hip): output pixel (2i+a, 2j+b) of a 3x3
     // conv over the upsampled image sees only a 2x2 window of the low-resolution input, with pre-summed weights -- four
     // 2x2-tap launches (16 tap-GEMMs per low-resolution pixel instead of 36).  ntap = 4: the taps (r, s), r, s in {0, 1},

@@ -282,9 +282,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     const int slot = xt & 15;                                    // 8 couts = one 16-byte piece of the 256-byte pixel row
     constexpr int NP = POOL ? 4 : NQ;                            // output pieces per thread and tile
     constexpr int NR = NQ;                                       // residual pieces per thread and tile
-    struct OutPos { int pix0, ppix0, co, img; };
+    struct OutPos { int pix0, ppix0, co, img, tile; };
     auto out_pos = [&](const TilePos& tp) -> OutPos {
         OutPos o;
+        o.tile = (tp.py0 / TH) * tiles_x + (tp.px0 >> TWLOG);   // tile of its image (deterministic GroupNorm sums: one slot per tile)
         o.pix0 = ((tp.img * g.h + tp.py0) * g.dst_s + g.dst_a) * (g.w * g.dst_s) + tp.px0 * g.dst_s + g.dst_b;
         o.ppix0 = (tp.img * (g.h >> 1) + (tp.py0 >> 1)) * (g.w >> 1) + (tp.px0 >> 1);
         o.co = tp.nt * 128 + slot * 8;
@@ -308,7 +309,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             float v = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v += *reinterpret_cast<const float*>(smem + SCR + (k * 64 + lane) * 4);
-            if (stat_idx >= 0) atomicAdd(g.gn_ws + stat_idx, (double)v);
+            if (g.gn_part_nblk) {
+                // deterministic mode: this tile's own slot.  Groups wider than a lane's 8 channels (16 / 32 channels per group: 2 / 4
+                // neighbouring lanes hold parts of one group) are folded in lane order first; the first lane of a group stores
+                const int span = g.gn_cpg >> 3;
+                if (span >= 2) v += __shfl_xor(v, 1, 64);
+                if (span >= 4) v += __shfl_xor(v, 2, 64);
+                if (stat_idx >= 0 && (span < 2 || (lane & (span - 1)) == 0)) g.gn_ws[stat_idx] = (double)v;
+            } else if (stat_idx >= 0) {
+                atomicAdd(g.gn_ws + stat_idx, (double)v);
+            }
         }
     };
     auto drain = [&](const OutPos& o, const u32x4 (&rv)[NR]) {
@@ -444,7 +454,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             const float val = q == 0 ? ga : q == 1 ? qa : q == 2 ? gb : qb;
             *reinterpret_cast<float*>(smem + SCR + (xw * 64 + lane) * 4) = val;
             const int grp = (o.co + (q >> 1) * 4) / g.gn_cpg;
-            stat_idx = (split || q < 2) ? ((o.img * (g.cout / g.gn_cpg) + grp) * 2 + (q & 1)) : -1;
+            const int gslot = o.img * (g.cout / g.gn_cpg) + grp;
+            stat_idx = (split || q < 2) ? ((g.gn_part_nblk ? gslot * g.gn_part_nblk + g.gn_part_base + o.tile : gslot) * 2 + (q & 1)) : -1;
         }
     };
 

@@ -860,6 +860,17 @@ __global__ __launch_bounds__(256) void gn_cluster_bwd_kernel(const T* __restrict
     }
 }
 
+// deterministic mode, GroupNorm sums left by a conv's drain as ONE SLOT PER TILE (conv_mx.hip: gn_part_nblk): block (sample, group)
+// adds its nblk slot pairs in a FIXED order -- lane l: slots l, l + 64, ...; then the xor tree 32 .. 1 -- into sums[(n * G + g) * 2 + j]
+__global__ __launch_bounds__(64) void gn_parts_reduce_kernel(const double* __restrict__ parts, int nblk, double* __restrict__ sums) {
+    const double* q = parts + (int64_t)blockIdx.x * nblk * 2;
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) { a += q[2 * k]; b += q[2 * k + 1]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    if (threadIdx.x == 0) { sums[(int64_t)blockIdx.x * 2] = a; sums[(int64_t)blockIdx.x * 2 + 1] = b; }
+}
+
 // pixels per thread of the small-map form for this problem, or 0 when it does not apply
 inline int gn_small_ppt(int dtype, int64_t hw, int c, int groups, int max_ppt) {
     const bool off = VQK_TUNE("GN_NO_SMALL", 0) != 0;
@@ -1067,6 +1078,26 @@ int vqk_gn_forward(int dtype, const void* x, const float* w, const float* b, voi
         hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, rgrid, dim3(256), lds, st, (const bf16_raw*)x, hw, c, groups, rppb, ws, part);
         { if (silu) hipLaunchKernelGGL((gn_apply_fin_kernel<bf16_raw, true>), grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk); else hipLaunchKernelGGL((gn_apply_fin_kernel<bf16_raw, false>), grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, ws, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps, (const double*)part, nblk); }
     }
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_gn_forward_presummed_parts(int dtype, const void* x, const float* w, const float* b, void* y, float* stats,
+                                   const double* parts, int nblk, double* sums, int n, int64_t hw, int c, int groups, float eps,
+                                   int silu, void* stream) {
+    VQK_REQUIRE(x && w && b && y && stats && parts && sums && nblk > 0, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && hw > 0, VQK_ERR_SHAPE);
+    const int rc = check_gn(dtype, c, groups);
+    if (rc) return rc;
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    hipStream_t st = vqk_stream(stream);
+    hipLaunchKernelGGL(gn_parts_reduce_kernel, dim3((unsigned)(n * groups)), dim3(64), 0, st, parts, nblk, sums);
+    const int ppb = pick_ppb(n, hw);
+    const dim3 grid((unsigned)((hw + ppb - 1) / ppb), (unsigned)n);
+    if (dtype == VQK_F32)
+        { if (silu) hipLaunchKernelGGL((gn_apply_fin_kernel<float, true>), grid, dim3(256), (size_t)groups * 8, st, (const float*)x, sums, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps, (const double*)sums, 1); else hipLaunchKernelGGL((gn_apply_fin_kernel<float, false>), grid, dim3(256), (size_t)groups * 8, st, (const float*)x, sums, stats, w, b, (float*)y, hw, c, groups, silu, ppb, eps, (const double*)sums, 1); }
+    else
+        { if (silu) hipLaunchKernelGGL((gn_apply_fin_kernel<bf16_raw, true>), grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, sums, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps, (const double*)sums, 1); else hipLaunchKernelGGL((gn_apply_fin_kernel<bf16_raw, false>), grid, dim3(256), (size_t)groups * 8, st, (const bf16_raw*)x, sums, stats, w, b, (bf16_raw*)y, hw, c, groups, silu, ppb, eps, (const double*)sums, 1); }
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

@@ -75,7 +75,8 @@ def set_deterministic(on: bool) -> None:
     DETERMINISTIC = bool(on)
     _DET_GEN += 1
     _DB_DONE.clear()
-    FUSE_GN_STATS = False if on else os.environ.get('VQK_FUSE_GN_STATS', '1') != '0'
+    FUSE_GN_STATS = os.environ.get('VQK_FUSE_GN_STATS', '1') != '0'     # (deterministic mode: per-tile slots instead of atomics)
+    _GN_WS.clear(); _GN_PARTS.clear()
 
 
 def _p(t):
@@ -331,7 +332,7 @@ def raw_conv_fprop_pooled(x, wq, bias, residual, ksize: int, ups: bool, cout: in
 
 FUSE_GN_STATS = os.environ.get('VQK_FUSE_GN_STATS', '1') != '0'
 if os.environ.get('VQK_DETERMINISTIC') == '1':          # same as set_deterministic(True), from the environment
-    DETERMINISTIC, FUSE_GN_STATS = True, False
+    DETERMINISTIC = True
 
 
 def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: int, pool: bool = False,
@@ -348,7 +349,7 @@ def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: 
     if _PENDING_GN is not None:                                  # sums nobody claimed (the consumer was not a GroupNorm)
         _claim_presummed(x, -1)
     y = empty_nhwc(n, cout, ho, wo, x.dtype, x.device)
-    ws = _gn_ws(x.device, n * groups * 2 + n)
+    ws = _gn_sum_target(x.device, n, groups, h * s * w * s)
     flops = 2.0 * n * h * s * w * s * cout * cin * 9
     nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size()
               + (residual.numel() * residual.element_size() if residual is not None else 0) + cout * cin * 9 * x.element_size())
@@ -383,7 +384,7 @@ def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int =
     if gn_groups and not backward and FUSE_GN_STATS and 4 * h * w > 1024:
         if _PENDING_GN is not None:
             _claim_presummed(x, -1)
-        ws = _gn_ws(x.device, n * gn_groups * 2 + n)
+        ws = _gn_sum_target(x.device, n, gn_groups, 4 * h * w)
     flops = 2.0 * n * 4 * h * w * cout * cin * 9                 # ALGORITHMIC: the 3x3 conv over the upsampled image
     nbytes = x.numel() * x.element_size() + y.numel() * y.element_size() + cout * cin * 9 * x.element_size()
     st = _timed('conv3x3_mx_kernel<bf16>' + (f' {cin}->{cout}@{y.shape[2]}x{y.shape[3]} phase-{"dgrad" if backward else "fwd"}' if _EVENT_SHAPES else ''), flops,
@@ -522,6 +523,28 @@ def _gn_cluster(dtype, hw: int, c: int, groups: int) -> bool:
             and hw % (8 * rows) == 0)
 
 
+_GN_PARTS: dict = {}
+
+
+def _gn_parts(device, n_doubles: int) -> torch.Tensor:
+    """deterministic mode: the per-tile slots a conv's drain leaves its GroupNorm sums in (+ N*G*2 doubles of scratch in front for
+    their ordered total): plain stores, every slot written before it is read -- no zero protocol"""
+    key = (device, _stream())
+    ws = _GN_PARTS.get(key)
+    if ws is None or ws.numel() < n_doubles:
+        ws = _GN_PARTS[key] = torch.empty(max(n_doubles, 1 << 20), dtype=torch.float64, device=device)
+    return ws
+
+
+def _gn_sum_target(device, n: int, groups: int, conv_hw: int) -> torch.Tensor:
+    """where the conv's drain puts the GroupNorm sums of its output: the stream's fp64 workspace (atomics, zero protocol), or in
+    deterministic mode one slot per 256-pixel tile behind N*G*2 doubles of scratch (include/vqk.h: vqk_gn_forward_presummed_parts)"""
+    if DETERMINISTIC:
+        nblk = conv_hw // 256
+        return _gn_parts(device, n * groups * 2 * (nblk + 1))[n * groups * 2:]
+    return _gn_ws(device, n * groups * 2 + n)
+
+
 def _gn_ws(device, n_doubles: int) -> torch.Tensor:
     """Persistent fp64 workspace of the GroupNorm kernels for the current stream (include/vqk.h: zero on entry, the
     consumer kernel leaves it zero again -> no memset launch per call)."""
@@ -538,13 +561,15 @@ def _gn_ws(device, n_doubles: int) -> torch.Tensor:
 # that tensor claims them and skips its statistics pass.  Anything else arriving first finds the workspace dirty: it is
 # cleared and the note dropped (the unfused sequence runs), so a changed call order costs a memset, never a wrong result.
 _PENDING_GN = None
+_PENDING_GN_HW = [0]        # conv-resolution pixels per image of the noted tensor's producer (deterministic mode: slots = that / 256)
 
 
-def _note_presummed(y, groups: int) -> None:
+def _note_presummed(y, groups: int, conv_hw: int = 0) -> None:
     """the note is keyed by the tensor OBJECT (weak reference), not by its address: a freed tensor whose memory the caching
     allocator hands to another tensor of the same shape can never claim stale sums"""
     global _PENDING_GN
     _PENDING_GN = (weakref.ref(y), groups, _stream(), y.device)
+    _PENDING_GN_HW[0] = conv_hw if conv_hw else y.shape[2] * y.shape[3]
 
 
 def _claim_presummed(x, groups: int) -> bool:
@@ -556,8 +581,8 @@ def _claim_presummed(x, groups: int) -> bool:
     ref, g, stream, device = p
     if ref() is x and g == groups and stream == _stream():
         return True
-    ws = _GN_WS.get((device, stream))          # only the workspace the unclaimed sums were left in -- never another stream's,
-    if ws is not None:                         # which a GroupNorm kernel of that stream may be using right now
+    ws = None if DETERMINISTIC else _GN_WS.get((device, stream))   # (deterministic mode: per-tile slots, nothing to clear)
+    if ws is not None:                         # only the workspace the unclaimed sums were left in -- never another stream's
         if stream == _stream():
             ws.zero_()
         else:
@@ -585,7 +610,7 @@ def raw_gn_apply(x, stats, w, b, groups: int, silu: bool) -> torch.Tensor:
     return y
 
 
-def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool = False):
+def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool = False, conv_hw: int = 0):
     """(y, stats): sums kernel + finalize-and-apply kernel on the persistent workspace; ``presummed``: the sums of x were
     left in the workspace by the conv that produced x (``raw_conv_fprop_gnstats``), only the apply pass runs"""
     n, c, h, wd = x.shape
@@ -593,7 +618,20 @@ def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool
     stats = torch.empty(n * groups * 2, dtype=torch.float32, device=x.device)
     ws = _gn_ws(x.device, n * groups * 2 + n)
     nb = x.numel() * x.element_size()
-    presummed = presummed or _claim_presummed(x, groups)
+    claimed = (not presummed) and _claim_presummed(x, groups)
+    if claimed:
+        conv_hw = _PENDING_GN_HW[0]                               # (a pooled producer: 4x the pixels of x)
+    presummed = presummed or claimed
+    if presummed and DETERMINISTIC:
+        nblk = (conv_hw or h * wd) // 256
+        buf = _gn_parts(x.device, n * groups * 2 * (nblk + 1))
+        st = _timed('group_norm_fwd (HBM)' + (f' {c}@{h}x{wd} presummed' if _EVENT_SHAPES else ''), 0.0,
+                    lambda: _native.lib().vqk_gn_forward_presummed_parts(dcode(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                                         y.data_ptr(), stats.data_ptr(), buf[n * groups * 2:].data_ptr(),
+                                                                         nblk, buf.data_ptr(), n, h * wd, c, groups, eps, int(silu),
+                                                                         _stream()), 2 * nb)
+        _native.check(st, 'gn_forward_presummed_parts')
+        return y, stats
     if presummed:
         st = _timed('group_norm_fwd (HBM)' + (f' {c}@{h}x{wd} presummed' if _EVENT_SHAPES else ''), 0.0,
                     lambda: _native.lib().vqk_gn_forward_presummed(dcode(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(),
@@ -976,7 +1014,7 @@ class ResBlockFn(torch.autograd.Function):
         if next_gn and l2 == 1 and cout % 128 == 0:              # the sums for the GroupNorm that reads `out` next
             out = raw_conv_fprop_gnstats(a2, wq2, None, skip, False, cout, next_gn, pool=pool, pool_scale=0.25)
             if out is not None:
-                _note_presummed(out, next_gn)
+                _note_presummed(out, next_gn, conv_hw=h * w)
         if out is not None:
             pass
         elif pool and can_pool_epilogue(dt, cout, l2):
