@@ -86,3 +86,81 @@ def test_scratch_and_deterministic_setters_validate():
     assert lib.vqk_set_deterministic(0, 0, 0) == OK
     assert lib.vqk_set_scratch(0, 0) == OK
     ops._DET_TLS.scratch = None                                   # this thread re-arms its scratch on the next op
+
+
+def test_round4_quantizer_entry_points_validate_before_launching():
+    """vqk_vq_prepare_f32 / vqk_vq_forward_f32 / vqk_vq_backward_fused_f32 / vqk_vq_distances_stats_f32: shape, alignment, argument and
+    workspace checks; a rejected call launches nothing"""
+    lib, s = native.lib(), torch.cuda.current_stream().cuda_stream
+    n, k, d = 96, 64, 256
+    z = torch.randn(n, d, device='cuda'); e = torch.randn(k, d, device='cuda')
+    need = lib.vqk_vq_filter_ws_bytes(k, d)
+    ws = torch.zeros(need, dtype=torch.uint8, device='cuda')
+    prep = lambda **o: lib.vqk_vq_prepare_f32(_ptr(o.get('e', e)), o.get('k', k), o.get('d', d), _ptr(o.get('ws', ws)), o.get('wb', need), s)
+    assert prep(d=128) == SHAPE and prep(k=40) == SHAPE and prep(ws=None) == ARG and prep(wb=need - 1) == WORKSPACE
+    assert prep(ws=ws[1:]) == ALIGN
+    torch.cuda.synchronize()
+    assert int(ws.sum()) == 0
+    assert prep() == OK
+    idx = torch.full((n,), -7, dtype=torch.int64, device='cuda')
+    q = torch.empty(n, d, device='cuda'); ql = torch.empty(n, d, dtype=torch.bfloat16, device='cuda')
+    sse = torch.zeros((), device='cuda'); hist = torch.zeros(k, dtype=torch.int32, device='cuda')
+    fwd = lambda **o: lib.vqk_vq_forward_f32(_ptr(o.get('z', z)), _ptr(e), _ptr(o.get('ws', ws)), o.get('wb', need), o.get('n', n), o.get('k', k),
+                                             o.get('d', d), o.get('assoc', 0), _ptr(o.get('idx', idx)), _ptr(o.get('q', q)), _ptr(ql), _ptr(sse),
+                                             _ptr(hist), s)
+    assert fwd(d=64) == SHAPE and fwd(k=33) == SHAPE and fwd(assoc=3) == ARG and fwd(idx=None) == ARG and fwd(wb=16) == WORKSPACE
+    assert fwd(z=z.view(-1)[1:]) == ALIGN and fwd(q=q.view(-1)[1:]) == ALIGN
+    torch.cuda.synchronize()
+    assert int((idx == -7).sum()) == n and int(hist.sum()) == 0
+    assert fwd(n=0) == OK and fwd() == OK
+    torch.cuda.synchronize()
+    assert int(hist.sum()) == n and int(idx.min()) >= 0 and torch.equal(q, e[idx])
+    dq = torch.randn(n, d, device='cuda'); dz = torch.zeros(n, d, device='cuda'); de = torch.zeros(k, d, device='cuda')
+    bwd = lambda **o: lib.vqk_vq_backward_fused_f32(_ptr(z), _ptr(e), _ptr(idx), _ptr(o.get('dq', dq)), o.get('dt', F32), n, k, o.get('d', d), 0.1, 0.2,
+                                                    0, _ptr(o.get('dz', dz)), _ptr(de), s)
+    assert bwd(d=128) == SHAPE and bwd(dt=7) == DTYPE and bwd(dz=None) == ARG and bwd(dq=dq.view(-1)[1:]) == ALIGN
+    torch.cuda.synchronize()
+    assert float(dz.abs().sum()) == 0.0 and float(de.abs().sum()) == 0.0
+    assert bwd() == OK
+    z2 = torch.empty(n, device='cuda'); e2 = torch.empty(k, device='cuda')
+    lib.vqk_row_sqnorm_f32(_ptr(z), n, d, _ptr(z2), s); lib.vqk_row_sqnorm_f32(_ptr(e), k, d, _ptr(e2), s)
+    dm = torch.empty(n, k, device='cuda'); lse = torch.empty(n, device='cuda'); hr = torch.empty(n, device='cuda'); hs = torch.zeros(1, device='cuda')
+    dst = lambda **o: lib.vqk_vq_distances_stats_f32(_ptr(z), _ptr(e), _ptr(z2), _ptr(e2), n, k, o.get('d', d), 1, _ptr(idx), _ptr(dm),
+                                                     o.get('t', 0.5), _ptr(o.get('lse', lse)), _ptr(hr), _ptr(hs), s)
+    assert dst(d=128) == SHAPE and dst(t=0.0) == SHAPE and dst(lse=None) == ARG
+    assert dst() == OK
+    torch.cuda.synchronize()
+    a = -dm / 0.5
+    torch.testing.assert_close(lse, torch.logsumexp(a, 1), rtol=1e-5, atol=1e-5)
+
+
+def test_round4_groupnorm_and_tuning_entry_points_validate():
+    lib, s = native.lib(), torch.cuda.current_stream().cuda_stream
+    n, c, h = 2, 128, 32
+    x = torch.randn(n * h * h * c, device='cuda').to(torch.bfloat16); dy = torch.randn_like(x); dx = torch.zeros_like(x)
+    w = torch.ones(c, device='cuda'); b = torch.zeros(c, device='cuda'); st = torch.zeros(n * 32 * 2, device='cuda'); st[1::2] = 1.0
+    dw = torch.zeros(c, device='cuda'); db = torch.zeros(c, device='cuda'); cs = torch.zeros(c, device='cuda')
+    need = n * 32 * 2 + n + n * (c // 32)
+    red = torch.zeros(need, dtype=torch.float64, device='cuda')
+    bw = lambda **o: lib.vqk_gn_backward_ws(BF16, _ptr(x), _ptr(st), _ptr(w), _ptr(b), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), _ptr(red),
+                                            o.get('wsd', need), n, h, h, c, o.get('groups', 32), 1, 0, _ptr(o.get('add')), _ptr(o.get('pooled')), 1.0, s)
+    assert bw(wsd=n * 32 * 2) == ARG                                  # smaller than the sums + counters
+    assert bw(groups=24) == SHAPE
+    assert bw(add=dy, pooled=dy) == ARG                               # one addend, full or half resolution
+    cl = lambda **o: lib.vqk_gn_backward_colsum(BF16, _ptr(x), _ptr(st), _ptr(w), _ptr(b), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), _ptr(red), need,
+                                                n, h, h, c, 32, 1, 0, 0, _ptr(o.get('cs', cs)), s)
+    assert cl(cs=None) == ARG
+    buf = torch.empty(1 << 16, dtype=torch.uint8, device='cuda')
+    assert lib.vqk_set_deterministic(1, buf.data_ptr(), buf.numel()) == OK
+    try:
+        assert cl() == ARG                                            # arrival-order atomics: refused in deterministic mode
+    finally:
+        assert lib.vqk_set_deterministic(0, 0, 0) == OK
+        ops._DET_TLS.key = None
+    torch.cuda.synchronize()
+    assert float(dx.float().abs().sum()) == 0.0 and float(cs.abs().sum()) == 0.0
+    assert bw() == OK and cl() == OK
+    torch.cuda.synchronize()
+    assert float(red.abs().max()) == 0.0 and float(cs.abs().sum()) > 0.0
+    assert lib.vqk_set_tuning(None, 1) == ARG and lib.vqk_set_tuning(b'nope', 1) == ARG and lib.vqk_reset_tuning() == OK
+    assert lib.vqk_probe_stream_add(0, 0, 16, 1, 1, 0, s) == ARG and lib.vqk_probe_stream_add(_ptr(dw), _ptr(db), 20, 1, 1, 0, s) == ARG
