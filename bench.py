@@ -119,7 +119,7 @@ def parity_cost(run: dict, image_size: int, oracle_step, device) -> dict:
             recon, _, idx = m(m.preprocess_batch(images.to(device)))
         out[label] = dict(indices_equal_pct=round(100.0 * float((idx.cpu().reshape(-1) == r['idx'].reshape(-1)).float().mean()), 2),
                           recon_rel_err=float(f"{float((recon.float().cpu() - r['recon']).norm() / r['recon'].norm()):.3e}"),
-                          loss=round(float(loss), 6), oracle_loss=round(float(r['loss']), 6),
+                          loss=round(float(loss.detach()), 6), oracle_loss=round(float(r['loss']), 6),
                           gradient_cosine=round(num / (da * db) ** 0.5, 6), gradient_norm_ratio=round((da / db) ** 0.5, 4))
         del m, tr, opt
     out['sample'] = f'batch {images.shape[0]} at {image_size}x{image_size}, random-init weights, the CPU oracle step of cpu_baseline'
@@ -292,6 +292,9 @@ def main():
     trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
     model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
     ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+    if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+        # the capture's settling steps run on the capture stream, the eager event pass on the default stream: intended
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
     rank, local, world = trainer_mod.init_distributed('nccl')
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (the launcher started {world} ranks); '
