@@ -143,6 +143,9 @@ int vqk_vq_backward_fused_f32(const float* z, const float* e, const int64_t* idx
 /* EMA statistics (vector_quantizers.py:159-169): counts[k] += 1, dw[idx] += z (both pre-zeroed) ... */
 int vqk_ema_stats_f32(const float* z, const int64_t* idx, int64_t n, int k, int d,
                       float* counts, float* dw, void* stream);
+/* vqk_ema_stats_f32 with the rows of a 32-row block that share a code summed in LDS first (d == 256): one coalesced atomic row
+ * per distinct code and block instead of one atomic per (row, channel). */
+int vqk_ema_stats_fused_f32(const float* z, const int64_t* idx, int64_t n, int k, int d, float* counts, float* dw, void* stream);
 /* ... and the update: count' = smooth(decay*count + (1-decay)*n_k), weight' = decay*weight + (1-decay)*dw,
  * codebook = weight'/count'.  `batch` is the smoothing constant b (global image batch). */
 int vqk_ema_update_f32(float* ema_count, float* ema_weight, float* codebook, const float* counts, const float* dw,

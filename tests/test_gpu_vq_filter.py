@@ -224,3 +224,25 @@ def test_prepared_codebook_follows_the_codebook():
     cnt = torch.ones(k, device=DEV); wgt = cb.detach().clone()
     ops.ema_apply(stats, cnt, wgt, cb.data, 0.5, 1e-5, 8.0)          # raw pointer write: ema_apply refreshes the entry
     assert torch.equal(lookup(), exact())
+
+
+@pytest.mark.parametrize('case', ['trained', 'few_codes', 'ragged'])
+def test_fused_ema_statistics_equal_the_per_element_form(case):
+    """vqk_ema_stats_fused_f32 (rows of a block that share a code summed in LDS, one atomic row per distinct code) against
+    vqk_ema_stats_f32 and an fp64 evaluation of vector_quantizers.py:159-163 (counts, dw = one_hot^T z)"""
+    g = torch.Generator().manual_seed(sum(map(ord, case)) + 1)
+    z, e, n, k = _cases(case, g)
+    zd, ed = z.to(DEV).contiguous(), e.to(DEV).contiguous()
+    idx = ops.vq_assign(zd, ed, 0)
+    lib, s = native.lib(), torch.cuda.current_stream().cuda_stream
+    out = {}
+    for name in ('vqk_ema_stats_fused_f32', 'vqk_ema_stats_f32'):
+        buf = torch.zeros(k + k * 256, device=DEV)
+        native.check(getattr(lib, name)(zd.data_ptr(), idx.data_ptr(), n, k, 256, buf.data_ptr(), buf[k:].data_ptr(), s), name)
+        out[name] = buf
+    counts_ref = torch.bincount(idx, minlength=k).double()
+    dw_ref = torch.zeros(k, 256, dtype=torch.float64, device=DEV).index_add_(0, idx, zd.double())
+    for name, buf in out.items():
+        assert torch.equal(buf[:k].double(), counts_ref), name
+        err = float((buf[k:].view(k, 256).double() - dw_ref).norm() / dw_ref.norm())
+        assert err < 2e-6, (name, err)

@@ -45,6 +45,7 @@ _PROTOS = {
     'vqk_vq_gather_f32': [P, P, P, L, I, I, P, P, P, P, P],
     'vqk_vq_backward_f32': [P, P, P, P, I, L, I, I, F, F, P, P, P, P],
     'vqk_ema_stats_f32': [P, P, L, I, I, P, P, P],
+    'vqk_ema_stats_fused_f32': [P, P, L, I, I, P, P, P],
     'vqk_ema_update_f32': [P, P, P, P, P, I, I, F, F, F, P],
     'vqk_conv2d_fprop': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     'vqk_conv2d_fprop_pooled': [I, P, P, P, P, P, I, I, I, I, I, I, I, F, P, P],

@@ -1575,8 +1575,8 @@ def ema_stats(flat_z, idx, k: int, out=None) -> torch.Tensor:
     n, d = flat_z.shape
     buf = out if out is not None else torch.empty(k + k * d, dtype=torch.float32, device=flat_z.device)
     buf.zero_()
-    _native.check(_native.lib().vqk_ema_stats_f32(flat_z.data_ptr(), idx.data_ptr(), n, k, d, buf.data_ptr(),
-                                                  buf[k:].data_ptr(), _stream()), 'ema_stats')
+    fn = _native.lib().vqk_ema_stats_fused_f32 if (VQ_FUSED and d == 256) else _native.lib().vqk_ema_stats_f32
+    _native.check(fn(flat_z.data_ptr(), idx.data_ptr(), n, k, d, buf.data_ptr(), buf[k:].data_ptr(), _stream()), 'ema_stats')
     return buf
 
 
