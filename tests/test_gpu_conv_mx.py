@@ -18,7 +18,9 @@ CASES = [(2, 128, 128, 64, 64, 0, 0, 0, 0), (2, 128, 128, 64, 64, 0, 1, 1, 0), (
          (2, 128, 128, 48, 48, 0, 1, 1, 1), (8, 128, 128, 128, 128, 0, 0, 1, 0), (3, 512, 512, 32, 32, 0, 0, 0, 0),
          (1, 128, 128, 8, 32, 0, 0, 0, 0),
          # 16x16 maps: 128-pixel half tiles
-         (4, 512, 512, 16, 16, 0, 0, 1, 0), (2, 256, 512, 16, 16, 0, 1, 0, 0), (3, 128, 128, 16, 16, 0, 0, 0, 0)]
+         (4, 512, 512, 16, 16, 0, 0, 1, 0), (2, 256, 512, 16, 16, 0, 1, 0, 0), (3, 128, 128, 16, 16, 0, 0, 0, 0),
+         # ... and 64-pixel quarter tiles when the layer has <= 256 output channels (round 4)
+         (4, 256, 256, 16, 16, 0, 1, 1, 0), (2, 512, 256, 16, 16, 0, 0, 0, 0), (5, 256, 128, 8, 32, 0, 0, 1, 0)]
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,ups,hb,hr,pool', CASES)

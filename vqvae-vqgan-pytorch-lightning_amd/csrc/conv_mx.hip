@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     constexpr int NI = PIX / 64, NJ = 2;                         // a matrix wave: NI x 32 pixels x 64 couts (PIX = 128: the half tile of the
                                                                  // 16x16 maps, twice as many blocks for a chip that their 256-pixel tiles leave half empty)
     constexpr int NQ = PIX / 16;                                 // 16-byte staging pieces per auxiliary thread and tile
-    static_assert(PIX == 256 || (PIX == 128 && !POOL && NTAP == 9), "256-pixel tiles, or plain 128-pixel half tiles");
+    static_assert(PIX == 256 || ((PIX == 128 || PIX == 64) && !POOL && NTAP == 9), "256-pixel tiles, or plain 128- / 64-pixel part tiles");
     constexpr int NPH = NTAP * 2;                                // phases ((tap, k-substep) pairs) and weight fragments per unit
     static_assert(NTAP == 9 || ((NTAP == 4 || NTAP == 1) && !POOL), "3x3 taps, the 2x2 taps of an upsample phase, or a 1x1 conv");
     constexpr int XS = (PIECES + 3) / 4;                         // pieces per X wave
@@ -540,7 +540,10 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     const int half_on = VQK_TUNE("MX_HALF", 1);
     const int half_hw = VQK_TUNE("MX_HALF_HW", 256);
     const bool half = half_on && g.h * g.w <= half_hw && !g.pool && g.ntap == 9 && (twlog == 4 ? (g.h % 8) == 0 : (g.h % 4) == 0);
-    const int th = (half ? 128 : 256) >> twlog;
+    // 64-pixel quarter tiles (round 4): the 16x16 maps with <= 256 output channels (256 -> 256, 512 -> 256 @16^2: 128 half tiles for
+    // 256 CUs at bs 32, 412-513 TF) -- again a function of the layer shape only
+    const bool quarter = half && VQK_TUNE("MX_QUARTER", 1) && g.tiles_n <= 2 && (twlog == 4 ? (g.h % 4) == 0 : (g.h % 2) == 0);
+    const int th = (quarter ? 64 : half ? 128 : 256) >> twlog;
     const int total = g.n * (g.h / th) * (g.w >> twlog) * g.tiles_n;
     // COMM_CUS (data parallel, world > 1): CUs left to the collective's kernels.  A persistent grid of one block per CU that
     // finds some CUs taken runs its last blocks as a SECOND wave (up to 2x the kernel time); a grid of cus - COMM_CUS blocks
@@ -553,7 +556,11 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     constexpr int lds4h = 3 * (((128 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
     constexpr int lds5h = 3 * (((128 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
 #define MXL(K, L) return mx_launch<K>(grid, L, st, x, w, bias, res, y, g)
-    if (half) {
+    constexpr int lds4q = 3 * (((64 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 64 * 272 + 1024;
+    constexpr int lds5q = 3 * (((64 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 64 * 272 + 1024;
+    if (quarter) {
+        if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 9, 64>), lds5q); else MXL((conv3x3_mx_kernel<4, false, 9, 64>), lds4q);
+    } else if (half) {
         if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 9, 128>), lds5h); else MXL((conv3x3_mx_kernel<4, false, 9, 128>), lds4h);
     } else if (g.ntap == 4) {
         if (g.pool) return VQK_ERR_ARG;
