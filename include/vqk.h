@@ -206,6 +206,22 @@ int vqk_conv2d_wgrad_pooled_dy(int dtype, const void* x, const void* dy_pooled, 
 int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
                              int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out,
                              const void* zeros, void* stream);
+/* The STRIDE-2 3x3 conv without padding of the StyleGAN2 discriminator's down-sampling layers (the reference's
+ * conv2d_resample.py:119-122: upfirdn2d blur with padding, then F.conv2d(stride=2)) and its data gradient on the
+ * matrix/auxiliary-wave kernel (bf16).  vqk_conv2d_s2_supported: 1 when the shape is served (backward = 0: the conv, Cin % 64
+ * == 0, Cout % 128 == 0, W_out % 32 == 0 && H_out % 4 == 0 or W_out % 16 == 0 && H_out % 8 == 0; backward = 1: its data gradient,
+ * Cout % 64 == 0, Cin % 128 == 0, maps of 32x32 and more), 0 otherwise (callers use vqk_conv2d_general).
+ * vqk_conv2d_s2_fprop: x [N][2 H_out + 1][2 W_out + 1][Cin] -> y [N][H_out][W_out][Cout] = out_gain * act(acc_scale * conv + bias);
+ * wq = vqk_conv_pack_weights(..., transpose 0, layout 1).  The four parity sub-images of an input patch are staged side by
+ * side in LDS, so every tap reads at unit stride.
+ * vqk_conv2d_s2_dgrad: dy [N][H_out][W_out][Cout] -> dx [N][2 H_out + 1][2 W_out + 1][Cin] = acc_scale * gradient, EVERY element
+ * written; w3 = vqk_conv_pack_weights(..., transpose 1, layout 3) (the four output parities' 4 / 2 / 2 / 1 taps), wt0 = the same
+ * weights with transpose 1, layout 0 (the last row and the last column of dx run as parity classes of the im2col kernel). */
+int vqk_conv2d_s2_supported(int dtype, int n, int h_out, int w_out, int cin, int cout, int backward);
+int vqk_conv2d_s2_fprop(int dtype, const void* x, const void* wq, const float* bias, void* y, int n, int h_out, int w_out,
+                        int cin, int cout, int act, float acc_scale, float out_gain, const void* zeros, void* stream);
+int vqk_conv2d_s2_dgrad(int dtype, const void* dy, const void* w3, const void* wt0, void* dx, int n, int h_out, int w_out,
+                        int cin, int cout, float acc_scale, const void* zeros, void* stream);
 /* Weight operand layouts.  0: [Cout][ks][ks][Cin] (any shape).  1: "fragment-major" for the register-weight halo
  * kernel (3x3, Cin a whole 128-byte chunk, W%32==0 && H%8==0 or W%16==0 && H%16==0): Cout padded to a multiple of
  * 128, element order [Cout/32][64-byte Cin chunk][tap][k-substep 0..1][lane 0..63][16 bytes]: every MFMA operand
@@ -246,7 +262,7 @@ int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes);
  * ws must be 16-byte aligned (VQK_ERR_ALIGN), ws_bytes >= 0 (VQK_ERR_ARG); the same checks apply to vqk_set_deterministic. */
 int vqk_set_scratch(void* ws, int64_t ws_bytes);
 /* Tuning slots: the launch heuristics that tools/ sweep (formerly read-once environment variables).  name = one of
- * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4, GN_CLUSTER_MAX_HW, COMM_CUS, MX_QUARTER.
+ * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4, GN_CLUSTER_MAX_HW, COMM_CUS, MX_QUARTER, MX_S2, MX_S2_DGRAD_MIN.
  * A set slot overrides the built-in default at the next launch; vqk_reset_tuning returns every slot to its default.
  * Process-wide (relaxed atomics); VQK_ERR_ARG for an unknown name.  The Python host maps VQK_<NAME> environment variables
  * onto these calls when it loads the library (_native.py), so the A/B scripts keep their interface. */

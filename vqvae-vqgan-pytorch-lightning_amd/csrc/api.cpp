@@ -84,7 +84,9 @@ static TuneSlot g_tune[] = {
     {"WGMX_COEF_E4", 0, 0},
     {"GN_CLUSTER_MAX_HW", 0, 0},
     {"COMM_CUS", 0, 0},
-    {"MX_QUARTER", 0, 0}
+    {"MX_QUARTER", 0, 0},
+    {"MX_S2", 0, 0},
+    {"MX_S2_DGRAD_MIN", 0, 0}
 };
 static constexpr int kTune = (int)(sizeof(g_tune) / sizeof(g_tune[0]));
 TuneSlot* tune_slot(const char* name) {

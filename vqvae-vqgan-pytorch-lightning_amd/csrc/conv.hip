@@ -1853,6 +1853,41 @@ __device__ __forceinline__ void pack_any(const float* __restrict__ w, TD* __rest
         }
         return;
     }
+    if (layout == 3) {
+        // data gradient of a STRIDE-2 3x3 conv without padding, by output parity (vqk_conv2d_s2_dgrad): dx[2i+a][2j+b] sums the
+        // taps ky = a (mod 2), kx = b (mod 2) -- 4 / 2 / 2 / 1 of them for (a, b) = (0,0) / (0,1) / (1,0) / (1,1), nine in all.
+        // Four fragment-major blocks (output channels = ci, input = co) in that order; the window tap (wy, wx) of a phase
+        // reads dy[i - 1 + wy] when the phase has two rows (wy = 0: ky = 2, wy = 1: ky = 0), dy[i] (ky = 1) otherwise.
+        const int dcout = cin, dcin = cout;
+        const int cot_tiles = ((dcout + 127) / 128) * 4;
+        const int ncc = dcin / (4 * E);
+        const int64_t per_tap = (int64_t)cot_tiles * ncc * 2 * 64;       // 16-byte pieces
+        for (int64_t o = tid; o < 9 * per_tap; o += nthr) {
+            const int ph = o < 4 * per_tap ? 0 : o < 6 * per_tap ? 1 : o < 8 * per_tap ? 2 : 3;
+            const int pa = ph >> 1, pb = ph & 1, nb = pb ? 1 : 2, nt = (pa ? 1 : 2) * nb;
+            int64_t r = o - (ph == 0 ? 0 : ph == 1 ? 4 : ph == 2 ? 6 : 8) * per_tap;
+            const int co32 = (int)(r & 31); r >>= 5;
+            const int kg = (int)(r & 1); r >>= 1;
+            const int ks = (int)(r & 1); r >>= 1;
+            const int tap = (int)(r % nt); r /= nt;
+            const int cc = (int)(r % ncc);
+            const int cot = (int)(r / ncc);
+            const int wy = tap / nb, wx = tap - wy * nb;
+            const int ky = pa ? 1 : (wy == 0 ? 2 : 0), kx = pb ? 1 : (wx == 0 ? 2 : 0);
+            const int co = cot * 32 + co32;                              // output channel of the gradient = input channel of the layer
+            const int ci = ((cc * 2 + ks) * 2 + kg) * E;                 // first of E input channels = output channels of the layer
+            float v[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = 0.0f;
+            if (co < dcout) {
+                const float* src = w + ((int64_t)ci * 9 + ky * 3 + kx) * cin + co;
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = src[(int64_t)e * 9 * cin];
+            }
+            Vec16<TD>::store(out + o * E, v);
+        }
+        return;
+    }
     // fragment-major: one thread builds one 16-byte piece (E consecutive input channels of one output channel)
     const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
     const int cot_tiles = ((dcout + 127) / 128) * 4;
@@ -2226,6 +2261,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.gn_ws = nullptr; g.gn_cpg = 0; g.gn_part_nblk = 0; g.gn_part_base = 0;
     g.act = 0; g.dy_pool = 0;
     g.ntap = ksize == 1 ? 1 : 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
+    g.tapw = 0; g.dst_h = g.dst_w = 0; g.s2 = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
     g.m = (int)m;
@@ -2398,6 +2434,96 @@ int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* 
     return VQK_OK;
 }
 
+// ---- the stride-2 3x3 conv without padding of the StyleGAN2 discriminator (conv2d_resample.py:119-122: blur, then
+// F.conv2d(stride=2)) on the matrix/auxiliary-wave kernel.  Input (2 h_out + 1) x (2 w_out + 1), output h_out x w_out.
+static int s2_twlog(int h_out, int w_out, int pix) {
+    if ((w_out % 32) == 0 && (h_out % (pix / 32)) == 0) return 5;
+    if ((w_out % 16) == 0 && (h_out % (pix / 16)) == 0) return 4;
+    return 0;
+}
+
+int vqk_conv2d_s2_supported(int dtype, int n, int h_out, int w_out, int cin, int cout, int backward) {
+    if (dtype != VQK_BF16 || n <= 0 || h_out <= 0 || w_out <= 0 || cin <= 0 || cout <= 0) return 0;
+    if (!VQK_TUNE("MX", 1) || !VQK_TUNE("MX_S2", 1) || g_force_variant == 0 || g_force_variant == 5) return 0;
+    const int64_t big = (int64_t)n * (2 * h_out + 1) * (2 * w_out + 1) * cin * 2, small = (int64_t)n * h_out * w_out * cout * 2;
+    if (big >= 0x7fffffffLL || small >= 0x7fffffffLL) return 0;
+    if (!backward) return (cin % 64) == 0 && (cout % 128) == 0 && s2_twlog(h_out, w_out, 128) != 0;
+    // the data gradient: dy's channels are the reduction, the layer's input channels the output tile; 32x32 maps and larger
+    // (below, the four phases are a handful of tiles each and the im2col kernel's parity classes do as well)
+    return (cout % 64) == 0 && (cin % 128) == 0 && s2_twlog(h_out, w_out, 256) != 0 && w_out >= VQK_TUNE("MX_S2_DGRAD_MIN", 32);
+}
+
+int vqk_conv2d_s2_fprop(int dtype, const void* x, const void* wq, const float* bias, void* y, int n, int h_out, int w_out,
+                        int cin, int cout, int act, float acc_scale, float out_gain, const void* zeros, void* stream) {
+    VQK_REQUIRE(x && wq && y && zeros, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(wq) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    VQK_REQUIRE(act == 0 || act == 2 || act == 3, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_conv2d_s2_supported(dtype, n, h_out, w_out, cin, cout, 0), VQK_ERR_SHAPE);
+    ConvGeom g;
+    const int rc = make_geom(g, dtype, n, h_out, w_out, cin, cout, 3, 0);      // tiles over the OUTPUT grid
+    if (rc) return rc;
+    g.h_in = 2 * h_out + 1; g.w_in = 2 * w_out + 1;
+    g.src_s = 2; g.s2 = 1;
+    g.act = act; g.acc_scale = acc_scale; g.out_gain = out_gain;
+    return vqkd::launch_conv3x3_mx(x, wq, bias, nullptr, y, zeros, g, s2_twlog(h_out, w_out, 128), vqk_stream(stream));
+}
+
+int vqk_conv2d_s2_dgrad(int dtype, const void* dy, const void* w3, const void* wt0, void* dx, int n, int h_out, int w_out,
+                        int cin, int cout, float acc_scale, const void* zeros, void* stream) {
+    VQK_REQUIRE(dy && w3 && wt0 && dx && zeros, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(dy) && vqk_aligned16(w3) && vqk_aligned16(wt0) && vqk_aligned16(dx) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
+    VQK_REQUIRE(vqk_conv2d_s2_supported(dtype, n, h_out, w_out, cin, cout, 1), VQK_ERR_SHAPE);
+    hipStream_t st = vqk_stream(stream);
+    const int H = 2 * h_out + 1, W = 2 * w_out + 1;
+    // (1) the h_out x w_out interior of every output parity: whole tiles on the matrix/auxiliary-wave kernel
+    ConvGeom g;
+    int rc = make_geom(g, dtype, n, h_out, w_out, cout, cin, 3, 0);
+    if (rc) return rc;
+    const int tw = s2_twlog(h_out, w_out, 256);
+    g.acc_scale = acc_scale;
+    g.dst_s = 2; g.dst_h = H; g.dst_w = W;
+    const int64_t tap_elems = (int64_t)((cin + 127) / 128) * 128 * cout;
+    const int tap0[4] = {0, 4, 6, 8};
+    for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1, na = a ? 1 : 2, nb = b ? 1 : 2;
+        ConvGeom gp = g;
+        gp.ntap = na * nb; gp.tapw = gp.ntap == 2 ? nb : 0;
+        gp.tap_oy = (gp.ntap > 1 && a) ? 1 : 0;                   // a one-row window sits on the halo's centre row
+        gp.tap_ox = (gp.ntap > 1 && b) ? 1 : 0;
+        gp.dst_a = a; gp.dst_b = b;
+        rc = vqkd::launch_conv3x3_mx(dy, (const bf16_raw*)w3 + tap0[ph] * tap_elems, nullptr, nullptr, dx, zeros, gp, tw, st);
+        if (rc != VQK_OK) return rc;
+    }
+    // (2) the last row (2 h_out) and the last column (2 w_out) of the gradient: the im2col kernel's parity classes, cut down to them
+    ConvGeom e;
+    rc = make_geom(e, dtype, n, h_out, w_out, cout, cin, 3, 1);
+    if (rc) return rc;
+    e.zs = 1; e.vh = 2 * h_out - 1; e.vw = 2 * w_out - 1; e.stride = 1; e.pad = 2;
+    e.h = H; e.w = W; e.m = n * H * W; e.tiles_m = (e.m + 127) / 128;
+    e.acc_scale = acc_scale;
+    const int saved = g_force_variant;
+    g_force_variant = 0;
+    const int edge[4][4] = {{2 * h_out, 1, 0, w_out + 1},        // {sub_py, sub_h, sub_px, sub_w}: row 2h, every even column
+                            {0, h_out, 2 * w_out, 1},            // column 2w, the even rows above the corner
+                            {2 * h_out, 1, 1, w_out},            // row 2h, odd columns
+                            {1, h_out, 2 * w_out, 1}};           // column 2w, odd rows
+    for (int k = 0; k < 4 && rc == VQK_OK; ++k) {
+        ConvGeom gs = e;
+        gs.sub = 1; gs.sub_py = edge[k][0]; gs.sub_h = edge[k][1]; gs.sub_px = edge[k][2]; gs.sub_w = edge[k][3];
+        gs.nkh = gs.nkw = 0;
+        for (int kk = 0; kk < 3; ++kk) {
+            if (((gs.sub_py + kk - 2) & 1) == 0) gs.khl[gs.nkh++] = kk;
+            if (((gs.sub_px + kk - 2) & 1) == 0) gs.kwl[gs.nkw++] = kk;
+        }
+        gs.kchunks = gs.nkh * gs.nkw * gs.cpt;
+        gs.m = n * gs.sub_h * gs.sub_w;
+        gs.tiles_m = (gs.m + 127) / 128;
+        rc = launch_fprop<bf16_raw, bf16_raw>(dy, wt0, nullptr, nullptr, dx, zeros, gs, 0, 0, st);
+    }
+    g_force_variant = saved;
+    return rc;
+}
+
 int vqk_conv2d_general(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                        int out_dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int stride, int pad,
                        int mode, int h_out, int w_out, int act, float acc_scale, float out_gain, int wlayout,
@@ -2417,6 +2543,7 @@ int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int co
 int64_t vqk_conv_packed_elems(int cout, int cin, int ksize, int layout) {
     if (layout == 0) return (int64_t)cout * cin * ksize * ksize;
     if (layout == 2) return (int64_t)4 * ((cout + 127) / 128) * 128 * cin * 4;      // four phases x four taps
+    if (layout == 3) return (int64_t)((cout + 127) / 128) * 128 * cin * 9;          // four phases, 4 + 2 + 2 + 1 taps
     return (int64_t)((cout + 127) / 128) * 128 * cin * ksize * ksize;
 }
 
@@ -2446,9 +2573,9 @@ int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int ci
         const dim3 grid(vqk_grid_1d(total, 256));
         if (dtype == VQK_F32) hipLaunchKernelGGL(pack_frag_kernel<float>, grid, dim3(256), 0, st, w, (float*)out, cout, cin, taps, transpose, cot_tiles);
         else hipLaunchKernelGGL(pack_frag_kernel<bf16_raw>, grid, dim3(256), 0, st, w, (bf16_raw*)out, cout, cin, taps, transpose, cot_tiles);
-    } else if (layout == 2) {
+    } else if (layout == 2 || layout == 3) {
         const int dcin = transpose ? cout : cin;
-        VQK_REQUIRE(ksize == 3 && dtype == VQK_BF16 && dcin % 64 == 0, VQK_ERR_SHAPE);
+        VQK_REQUIRE(ksize == 3 && dtype == VQK_BF16 && dcin % 64 == 0 && (layout == 2 || transpose), VQK_ERR_SHAPE);
         hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, out, dtype, cout, cin, ksize, transpose, layout);
     } else return VQK_ERR_ARG;
     VQK_CHECK_LAUNCH();

@@ -36,6 +36,10 @@ struct ConvGeom {
     // pixel (dst_s*i + dst_a, dst_s*j + dst_b) of a (dst_s*h) x (dst_s*w) tensor (fprop: dst_s = 2); the input is read at
     // pixel (src_s*i + src_a, src_s*j + src_b) of an h_in x w_in tensor (the data gradient reads the phase of dy: src_s = 2).
     int ntap, tap_oy, tap_ox, src_s, src_a, src_b, dst_s, dst_a, dst_b;
+    // ntap = 2: tapw names the window (2: 1x2, 1: 2x1).  dst_h x dst_w: extent of the destination tensor (0: dst_s*h x dst_s*w;
+    // the data gradient of a stride-2 conv without padding writes the phases of a (2h+1) x (2w+1) tensor).
+    // s2 = 1: the stride-2 3x3 conv itself (input (2h+1) x (2w+1), output h x w): conv3x3_mx_kernel<..., S2 = true>.
+    int tapw, dst_h, dst_w, s2;
     int dy_pool;    // weight-gradient mx kernel: dy is given at HALF resolution (the gradient of a fused 2x2 average pool: every
                     // pooled pixel stands for its 2x2 block), dW is scaled by acc_scale
     int act;        // matrix/auxiliary-wave kernel: epilogue activation (0 none, 2 relu, 3 leaky relu 0.2), with acc_scale / out_gain

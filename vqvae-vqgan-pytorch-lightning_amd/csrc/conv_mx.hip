@@ -57,22 +57,39 @@ using vqkd::xcd_remap;
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
-template <int TWLOG, bool POOL, int NTAP, int PIXELS = 256>
+// tap -> pixel offset inside a halo buffer.  Plain form: window position (tap / TWD, tap % TWD) of the (TH+2) x (TW+2) halo.
+// Stride-2 form (S2): the halo buffer holds the FOUR parity sub-images of the (2 TH + 1) x (2 TW + 1) input patch, each
+// (TH+1) x (TW+1) pixels; tap (ky, kx) reads sub-image (ky & 1, kx & 1) at unit stride, shifted by (ky >> 1, kx >> 1).
+__host__ __device__ constexpr int mx_tap_pix(bool s2, int tap, int twd, int hw2, int shp) {
+    return s2 ? (((tap / 3) & 1) * 2 + ((tap % 3) & 1)) * shp + ((tap / 3) >> 1) * hw2 + ((tap % 3) >> 1)
+              : (tap / twd) * hw2 + (tap % twd);
+}
+
+// TAPW: taps per window row when NTAP = 2 (2: a 1x2 window, 1: a 2x1 window -- the mixed-parity phases of a stride-2 conv's
+// data gradient).  S2: the stride-2 3x3 conv without padding of the StyleGAN2 discriminator (input (2h+1) x (2w+1)).
+template <int TWLOG, bool POOL, int NTAP, int PIXELS = 256, int TAPW = 0, bool S2 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ wp,
                                                             const float* __restrict__ bias,
                                                             const bf16_raw* __restrict__ res, bf16_raw* __restrict__ y,
                                                             ConvGeom g) {
     constexpr int HM = NTAP == 1 ? 0 : 1;                        // halo margin: a 1x1 conv (NTAP = 1) reads the tile's own pixels only
-    constexpr int PIX = PIXELS, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2 * HM, HROWS = (TH + 2 * HM) * HW2;
+    constexpr int PIX = PIXELS, TW = 1 << TWLOG, TH = PIX / TW;
+    constexpr int HW2 = S2 ? TW + 1 : TW + 2 * HM;               // pixels per halo row
+    constexpr int SHP = (TH + 1) * (TW + 1);                     // S2: pixels of one parity sub-image
+    constexpr int HROWS = S2 ? 4 * SHP : (TH + 2 * HM) * HW2;
     constexpr int RS = 80;                                       // bytes per halo pixel: 64 data + 16 pad
     constexpr int PIECES = (HROWS * 5 + 63) / 64;                // 1-KiB LDS-DMA pieces per halo
-    constexpr int BUF = PIECES * 1024, STG = 3 * BUF, SPITCH = 272, SCR = STG + PIX * SPITCH;   // SCR: 1 KiB of statistics partials
+    constexpr int NBUF = S2 ? 2 : 3;                             // halo buffers (S2: a halo is 2.5x the bytes -- two fit)
+    constexpr int BUF = PIECES * 1024, STG = NBUF * BUF, SPITCH = 272, SCR = STG + PIX * SPITCH;   // SCR: 1 KiB of statistics partials
+    constexpr int TWD = TAPW ? TAPW : NTAP == 9 ? 3 : NTAP == 4 ? 2 : 1;      // taps per window row
     constexpr int NI = PIX / 64, NJ = 2;                         // a matrix wave: NI x 32 pixels x 64 couts (PIX = 128: the half tile of the
                                                                  // 16x16 maps, twice as many blocks for a chip that their 256-pixel tiles leave half empty)
     constexpr int NQ = PIX / 16;                                 // 16-byte staging pieces per auxiliary thread and tile
     static_assert(PIX == 256 || ((PIX == 128 || PIX == 64) && !POOL && NTAP == 9), "256-pixel tiles, or plain 128- / 64-pixel part tiles");
     constexpr int NPH = NTAP * 2;                                // phases ((tap, k-substep) pairs) and weight fragments per unit
-    static_assert(NTAP == 9 || ((NTAP == 4 || NTAP == 1) && !POOL), "3x3 taps, the 2x2 taps of an upsample phase, or a 1x1 conv");
+    static_assert(NTAP == 9 || ((NTAP == 4 || NTAP == 2 || NTAP == 1) && !POOL), "3x3 taps, the 2x2 / 1x2 / 2x1 taps of a phase, or a 1x1 conv");
+    static_assert(!S2 || (NTAP == 9 && !POOL && PIX == 128), "stride 2: 3x3 taps, 128-pixel tiles");
+    static_assert(TAPW == 0 || (NTAP == 2 && (TAPW == 1 || TAPW == 2)), "TAPW names the orientation of a 2-tap window");
     constexpr int XS = (PIECES + 3) / 4;                         // pieces per X wave
     constexpr int OOB = (int)0x80000000;
     typedef bf16x8_t frag_t;
@@ -158,8 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tap = 0; tap < NTAP; ++tap) {
-                constexpr int TWD = NTAP == 9 ? 3 : NTAP == 4 ? 2 : 1;      // taps per window row
-                const int toff = ((tap / TWD) * HW2 + (tap % TWD)) * RS;
+                const int toff = mx_tap_pix(S2, tap, TWD, HW2, SHP) * RS;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bool reads = ks == 0 || tap < NTAP - 1;
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
 #pragma unroll
                         for (int i = 0; i < NI; ++i) a[1][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
                     } else if (tap < NTAP - 1) {
-                        const int toff1 = (((tap + 1) / TWD) * HW2 + ((tap + 1) % TWD)) * RS;
+                        const int toff1 = mx_tap_pix(S2, tap + 1, TWD, HW2, SHP) * RS;
 #pragma unroll
                         for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(lbase[i] + toff1);
                     }
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             }
             unit_barrier();
             cur_nt = nxt_nt; tj = ntj; c = nc;
-            bi = bi == 2 ? 0 : bi + 1;
+            bi = bi == NBUF - 1 ? 0 : bi + 1;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) wcur[j] = wnxt[j];
         }
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     const int xt = tid - 256, xw = wave - 4;
     const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_raw*>(x), 0, (int)((int64_t)g.n * g.h_in * g.w_in * g.cin * 2), 0x00020000);
-    const int out_bytes = (int)((int64_t)g.m * g.cout * 2) * g.dst_s * g.dst_s;     // (dst_s h) x (dst_s w) output pixels
+    const int out_bytes = (int)((int64_t)g.n * g.dst_h * g.dst_w * g.cout * 2);    // dst_h x dst_w output pixels (dst_s h x dst_s w, or odd: +1)
     const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw*>(res), 0, res ? out_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(y, 0, out_bytes >> (POOL ? 2 : 0), 0x00020000);
 
@@ -253,14 +269,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     for (int sl = 0; sl < XS; ++sl) {
         const int s = (xw + 4 * sl) * 64 + lane;
         const int hp = s / 5, cp = s - hp * 5;
-        const int hy = hp / HW2, hx = hp - hy * HW2;
-        rel[sl] = (((((hy - HM) * g.src_s) >> g.ups) * g.w_in + (((hx - HM) * g.src_s) >> g.ups)) * g.cin + cp * 8) * 2;
-        flg[sl] = (HM && hy == 0 ? 1 : 0) | (HM && hy == TH + 1 ? 2 : 0) | (HM && hx == 0 ? 4 : 0) | (HM && hx == TW + 1 ? 8 : 0) |
-                  ((cp == 4 || hp >= HROWS) ? 16 : 0);
+        if constexpr (S2) {
+            // sub-image (a, b) of the patch: input pixel (2 hy + a, 2 hx + b); the odd sub-images have no row TH / column TW
+            const int sh = hp / SHP, q = hp - sh * SHP;
+            const int hy = q / HW2, hx = q - hy * HW2, pa = sh >> 1, pb = sh & 1;
+            rel[sl] = (((2 * hy + pa) * g.w_in + 2 * hx + pb) * g.cin + cp * 8) * 2;
+            flg[sl] = (cp == 4 || hp >= HROWS || (pa && hy == TH) || (pb && hx == TW)) ? 16 : 0;
+        } else {
+            const int hy = hp / HW2, hx = hp - hy * HW2;
+            rel[sl] = (((((hy - HM) * g.src_s) >> g.ups) * g.w_in + (((hx - HM) * g.src_s) >> g.ups)) * g.cin + cp * 8) * 2;
+            flg[sl] = (HM && hy == 0 ? 1 : 0) | (HM && hy == TH + 1 ? 2 : 0) | (HM && hx == 0 ? 4 : 0) | (HM && hx == TW + 1 ? 8 : 0) |
+                      ((cp == 4 || hp >= HROWS) ? 16 : 0);
+        }
     }
     auto issue_halo = [&](const TilePos& tp, int c, int bufi) {
         const int base = (((tp.img * g.h_in + ((tp.py0 * g.src_s + g.src_a) >> g.ups)) * g.w_in + ((tp.px0 * g.src_s + g.src_b) >> g.ups)) * g.cin + c * 32) * 2;
-        const int tb = (tp.py0 == 0 ? 1 : 0) | (tp.py0 + TH == g.h ? 2 : 0) | (tp.px0 == 0 ? 4 : 0) | (tp.px0 + TW == g.w ? 8 : 0) | 16;
+        const int tb = S2 ? 16 : ((tp.py0 == 0 ? 1 : 0) | (tp.py0 + TH == g.h ? 2 : 0) | (tp.px0 == 0 ? 4 : 0) | (tp.px0 + TW == g.w ? 8 : 0) | 16);
 #pragma unroll
         for (int sl = 0; sl < XS; ++sl) {
             if (xw + 4 * sl < PIECES) {                          // wave-uniform
@@ -286,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     auto out_pos = [&](const TilePos& tp) -> OutPos {
         OutPos o;
         o.tile = (tp.py0 / TH) * tiles_x + (tp.px0 >> TWLOG);   // tile of its image (deterministic GroupNorm sums: one slot per tile)
-        o.pix0 = ((tp.img * g.h + tp.py0) * g.dst_s + g.dst_a) * (g.w * g.dst_s) + tp.px0 * g.dst_s + g.dst_b;
+        o.pix0 = (tp.img * g.dst_h + tp.py0 * g.dst_s + g.dst_a) * g.dst_w + tp.px0 * g.dst_s + g.dst_b;
         o.ppix0 = (tp.img * (g.h >> 1) + (tp.py0 >> 1)) * (g.w >> 1) + (tp.px0 >> 1);
         o.co = tp.nt * 128 + slot * 8;
         o.img = tp.img;
@@ -296,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         int ty, tx;
         if constexpr (!POOL) { const int pp = k * 16 + (xt >> 4); ty = pp >> TWLOG; tx = pp & (TW - 1); }
         else { const int opp = (k >> 2) * 16 + (xt >> 4); ty = 2 * (opp >> (TWLOG - 1)) + ((k >> 1) & 1); tx = 2 * (opp & (TW / 2 - 1)) + (k & 1); }
-        return ((o.pix0 + (ty * g.w * g.dst_s + tx) * g.dst_s) * g.cout + o.co) * 2;
+        return ((o.pix0 + (ty * g.dst_w + tx) * g.dst_s) * g.cout + o.co) * 2;
     };
     auto load_res = [&](const OutPos& o, u32x4 (&rv)[NR]) {
 #pragma unroll
@@ -459,15 +483,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         }
     };
 
-    // position of the unit whose halo is requested next (two units ahead of the M waves)
+    // position of the unit whose halo is requested next (NBUF - 1 units ahead of the M waves)
     int ltj = 0, lc = 0, lbuf = 0;
     TilePos ltp = tile_pos(0);
     auto advance = [&]() {
         if (++lc == nch) { lc = 0; ++ltj; ltp = tile_pos(ltj < my_tiles ? ltj : my_tiles - 1); }
-        lbuf = lbuf == 2 ? 0 : lbuf + 1;
+        lbuf = lbuf == NBUF - 1 ? 0 : lbuf + 1;
     };
     issue_halo(ltp, lc, lbuf); advance();                        // unit 0
-    issue_halo(ltp, lc, lbuf); advance();                        // unit 1 (nch >= 2: it exists)
+    if constexpr (NBUF == 3) { issue_halo(ltp, lc, lbuf); advance(); }      // unit 1 (nch >= 2: it exists)
     int tj = 0, c = 0;
     TilePos cur = tile_pos(0);
     OutPos done = out_pos(cur);
@@ -482,6 +506,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         // every vector-memory operation of the previous interval has completed: the halo of unit u+1 is in LDS (published
         // to the M waves by the barrier that ends this interval), the residual pieces are in registers
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NBUF == 2) {
+            // two halo buffers: the buffer of unit u+1 is the one unit u-1 was computed from -- free since the last barrier.
+            // Requested first, it has this whole interval to land and is awaited before the barrier that publishes it
+            if (u + 1 < units) issue_halo(ltp, lc, lbuf);
+            advance();
+        }
         if (flush) { flush_stats(); flush = false; }
         if (pending && !((VQK_MXABL & 2) && g.n > 0)) { drain(done, rv); flush = g.gn_ws != nullptr; }   // tile parked during unit u-1
         pending = (c == nch - 1);                                // unit u ends a tile: its residual is requested now,
@@ -489,8 +519,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             done = out_pos(cur);
             if (res) load_res(done, rv);
         }
-        if (u + 2 < units && !((VQK_MXABL & 1) && g.n > 0)) issue_halo(ltp, lc, lbuf);      // unit u+2
-        advance();
+        if constexpr (NBUF == 3) {
+            if (u + 2 < units && !((VQK_MXABL & 1) && g.n > 0)) issue_halo(ltp, lc, lbuf);      // unit u+2
+            advance();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         unit_barrier();
         if (++c == nch) { c = 0; ++tj; if (tj < my_tiles) cur = tile_pos(tj); }
     }
@@ -533,8 +567,10 @@ int device_cus() {                                               // persistent g
 }  // namespace
 
 int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
-                      const ConvGeom& g, int twlog, hipStream_t st) {
+                      const ConvGeom& g_in, int twlog, hipStream_t st) {
     (void)zeros;
+    ConvGeom g = g_in;
+    if (!g.dst_h) { g.dst_h = g.h * g.dst_s; g.dst_w = g.w * g.dst_s; }
     // 128-pixel half tiles for the 16x16 maps: a function of the image size only (never of the batch size: per-tile
     // statistics partials group differently), they double the blocks of launches whose 256-pixel tiles fill half the chip
     const int half_on = VQK_TUNE("MX_HALF", 1);
@@ -542,7 +578,8 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     const bool half = half_on && g.h * g.w <= half_hw && !g.pool && g.ntap == 9 && (twlog == 4 ? (g.h % 8) == 0 : (g.h % 4) == 0);
     // 64-pixel quarter tiles (round 4): the 16x16 maps with <= 256 output channels (256 -> 256, 512 -> 256 @16^2: 128 half tiles for
     // 256 CUs at bs 32, 412-513 TF) -- again a function of the layer shape only
-    const bool quarter = half && VQK_TUNE("MX_QUARTER", 1) && g.tiles_n <= 2 && (twlog == 4 ? (g.h % 4) == 0 : (g.h % 2) == 0);
+    const int qmode = VQK_TUNE("MX_QUARTER", 1);   // 1: layers with <= 2 output-channel tiles, 2: every half-tile layer
+    const bool quarter = half && qmode && (g.tiles_n <= 2 || qmode >= 2) && (twlog == 4 ? (g.h % 4) == 0 : (g.h % 2) == 0);
     const int th = (quarter ? 64 : half ? 128 : 256) >> twlog;
     const int total = g.n * (g.h / th) * (g.w >> twlog) * g.tiles_n;
     // COMM_CUS (data parallel, world > 1): CUs left to the collective's kernels.  A persistent grid of one block per CU that
@@ -558,6 +595,22 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
 #define MXL(K, L) return mx_launch<K>(grid, L, st, x, w, bias, res, y, g)
     constexpr int lds4q = 3 * (((64 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 64 * 272 + 1024;
     constexpr int lds5q = 3 * (((64 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 64 * 272 + 1024;
+    if (g.s2) {
+        // stride-2 3x3 conv: 128-pixel tiles, TWO halo buffers of four (TH+1) x (TW+1) parity sub-images
+        constexpr int lds5s = 2 * ((4 * (128 / 32 + 1) * 33 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
+        constexpr int lds4s = 2 * ((4 * (128 / 16 + 1) * 17 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
+        if (g.pool || g.ntap != 9 || (twlog == 4 ? (g.h % 8) : (g.h % 4)) != 0) return VQK_ERR_ARG;
+        const int tot2 = g.n * (g.h / (128 >> twlog)) * (g.w >> twlog) * g.tiles_n;
+        const dim3 grid2((unsigned)(tot2 < cus ? tot2 : cus));
+        if (twlog == 5) return mx_launch<conv3x3_mx_kernel<5, false, 9, 128, 0, true>>(grid2, lds5s, st, x, w, bias, res, y, g);
+        return mx_launch<conv3x3_mx_kernel<4, false, 9, 128, 0, true>>(grid2, lds4s, st, x, w, bias, res, y, g);
+    }
+    if (g.ntap == 2) {
+        if (g.pool) return VQK_ERR_ARG;
+        if (g.tapw == 2) { if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 2, 256, 2>), lds5); else MXL((conv3x3_mx_kernel<4, false, 2, 256, 2>), lds4); }
+        if (g.tapw == 1) { if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 2, 256, 1>), lds5); else MXL((conv3x3_mx_kernel<4, false, 2, 256, 1>), lds4); }
+        return VQK_ERR_ARG;
+    }
     if (quarter) {
         if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 9, 64>), lds5q); else MXL((conv3x3_mx_kernel<4, false, 9, 64>), lds4q);
     } else if (half) {

@@ -29,6 +29,7 @@ from .modules.abstract_modules.base_autoencoder import BaseVQVAE
 from .modules.autoencoder import Decoder, Encoder, GroupNorm, Conv2d, set_compute_dtype
 from .modules.vector_quantizers import (EMAVectorQuantizer, EntropyVectorQuantizer, GumbelVectorQuantizer,
                                         VectorQuantizer)
+from .modules.loss import loss as loss_mod
 from .modules.loss.loss import VQLPIPSWithDiscriminator
 from .optim import FlatAdamW
 from .schedulers import CosineScheduler, LinearCosineScheduler, LinearScheduler
@@ -207,15 +208,25 @@ class VQVAE(BaseVQVAE, _LightningBase):
         # away by the reference too (model.py:258 zeroes them before the discriminator step) -- not computing them saves every
         # weight-gradient kernel of one of the step's three discriminator passes
         disc_params = [p for p in self.criterion.discriminator.parameters() if p.requires_grad]
-        for p in disc_params:
-            p.requires_grad_(False)
-        try:
+        share = loss_mod.SHARE_FAKE_PASS and self.current_epoch >= self.criterion.adversarial_start_epoch
+        if share:
+            # the discriminator half reuses THIS pass over the reconstruction (loss.SHARE_FAKE_PASS): its parameters stay in the
+            # graph, the generator's backward skips their gradients (ops.no_param_grads) and keeps the saved activations
+            self.criterion.shared_fake_logits = None
             res = self.criterion.forward_autoencoder(q_loss, target, recon_pad, self.current_epoch,
                                                      last_layer=self.decoder.conv_out.weight)
-        finally:
+            with ops.no_param_grads():
+                res[0].backward(retain_graph=True)
+        else:
             for p in disc_params:
-                p.requires_grad_(True)
-        self.manual_backward(res[0])
+                p.requires_grad_(False)
+            try:
+                res = self.criterion.forward_autoencoder(q_loss, target, recon_pad, self.current_epoch,
+                                                         last_layer=self.decoder.conv_out.weight)
+            finally:
+                for p in disc_params:
+                    p.requires_grad_(True)
+            self.manual_backward(res[0])
         self._gan_state = (target, recon_pad, q_loss, res)
         return res
 
@@ -226,7 +237,12 @@ class VQVAE(BaseVQVAE, _LightningBase):
         loss, d_loss, r1_penalty = self.criterion.forward_discriminator(target, recon_pad, self.current_epoch, step)
         if loss is not None:
             disc_opt.zero_grad()
-            self.manual_backward(loss)
+            if getattr(self.criterion, 'shared_fake_logits', None) is not None:
+                # the fake half of the loss hangs on the generator half's graph: only the discriminator's leaves are wanted
+                # (retain_graph: the graph-capturing trainer runs this half twice on one generator half -- with and without R1)
+                loss.backward(inputs=[p for p in self.criterion.discriminator.parameters() if p.requires_grad], retain_graph=True)
+            else:
+                self.manual_backward(loss)
         return loss, d_loss, r1_penalty
 
     def _gan_log(self, res, q_loss, d_loss, r1_penalty):

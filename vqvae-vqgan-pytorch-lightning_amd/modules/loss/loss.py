@@ -14,6 +14,12 @@ from .lpips import LPIPS
 from ..autoencoder import _to_internal
 
 BATCHED_DISC = os.environ.get('VQK_BATCHED_DISC', '1') == '1'    # discriminator step: real | fake in one pass (0: two passes)
+# The reference evaluates D(fake) twice per step on the SAME reconstruction with the SAME discriminator weights: for the
+# generator loss (loss.py:63 of the reference) and again, detached, for the discriminator loss (:83) -- the discriminator's
+# optimizer steps only after both.  1: the second evaluation is not run; the discriminator loss backpropagates through the
+# activations the first one saved (same logits bit for bit, same gradients up to the summation order of the weight gradients:
+# two batches of n instead of one of 2n).  0: the two-pass form.
+SHARE_FAKE_PASS = os.environ.get('VQK_SHARE_FAKE_PASS', '1') == '1'
 
 _MODE = {'hinge': 0, 'non-saturating': 1}
 
@@ -58,6 +64,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
         nll_loss = l1_loss * self.l1_weight + l2_loss * self.l2_weight + p_loss * self.perceptual_weight
         if current_epoch >= self.adversarial_start_epoch:
             logits_fake = self.discriminator(reconstructions)
+            self.shared_fake_logits = logits_fake if (SHARE_FAKE_PASS and self.training) else None
             g_loss = generator_loss(logits_fake, loss_type=self.adversarial_loss_type)
             if self.training and self.use_adaptive_g_weight:
                 g_weight = self.calculate_adaptive_weight(p_loss, g_loss, last_layer=last_layer)   # p_loss, as the reference
@@ -84,7 +91,13 @@ class VQLPIPSWithDiscriminator(nn.Module):
             compute_r1 = (self.training and current_step % self.r1_regularization_every == 0
                           and self.r1_regularization_cost is not None)
             images = images.detach().requires_grad_(compute_r1)
-            if BATCHED_DISC and not compute_r1 and images.shape[0] == reconstructions.shape[0] and images.shape[2:] == reconstructions.shape[2:]:
+            shared = getattr(self, 'shared_fake_logits', None) if SHARE_FAKE_PASS else None
+            if shared is not None and shared.shape[0] == reconstructions.shape[0]:
+                # (the caller restricts the backward to the discriminator's parameters: the graph behind `shared` also leads
+                # into the decoder)
+                logits_real = self.discriminator(images)
+                logits_fake = shared
+            elif BATCHED_DISC and not compute_r1 and images.shape[0] == reconstructions.shape[0] and images.shape[2:] == reconstructions.shape[2:]:
                 # real | fake through the discriminator as ONE batch (same logits: only the minibatch-stddev layer couples
                 # samples and it groups inside each half): half the launches, no per-parameter gradient accumulation
                 dt = self.discriminator.compute_dtype

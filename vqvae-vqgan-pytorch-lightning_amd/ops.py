@@ -416,6 +416,24 @@ class no_direct_grad:
         _DIRECT_GRAD = self._prev
 
 
+_PARAM_GRADS = True
+
+
+class no_param_grads:
+    """context: ConvActFn's backward computes the DATA gradient only (the weight / bias gradients are neither computed nor
+    returned).  The generator loss backpropagates through the discriminator for the sake of the decoder alone (the reference
+    zeroes the discriminator gradients of that pass before its discriminator step, model.py:258); with the fake pass shared
+    between the two halves of the step the discriminator's parameters must keep requires_grad, so freezing them is no option."""
+
+    def __enter__(self):
+        global _PARAM_GRADS
+        self._prev, _PARAM_GRADS = _PARAM_GRADS, False
+
+    def __exit__(self, *exc):
+        global _PARAM_GRADS
+        _PARAM_GRADS = self._prev
+
+
 def direct_grad(param):
     """The flat-arena gradient view of ``param`` when the HIP kernels may accumulate straight into it
     (FlatAdamW marks its parameters; the arena is zeroed once per step by ``zero_grad``), else None."""
@@ -1729,6 +1747,27 @@ def _conv_general_raw(x, wq, bias, residual, cout, k, stride, pad, mode, h_out, 
     return y
 
 
+def _s2_served(dt, out_dtype, n, h, w, h_out, w_out, cin, cout, k, stride, pad, backward: bool) -> bool:
+    """the stride-2 3x3 conv without padding on a (2 h_out + 1) x (2 w_out + 1) input (the discriminator's down-sampling conv
+    after its blur, discriminator.py:95 / conv2d_resample.py:119-122) has a matrix/auxiliary-wave form (vqk_conv2d_s2_*)"""
+    if not (k == 3 and stride == 2 and pad == 0 and dt == torch.bfloat16 and out_dtype == torch.bfloat16
+            and h == 2 * h_out + 1 and w == 2 * w_out + 1):
+        return False
+    return bool(_native.lib().vqk_conv2d_s2_supported(dcode(dt), n, h_out, w_out, cin, cout, int(backward)))
+
+
+def _conv_s2_fprop_raw(x, wq, bias, cout, h_out, w_out, act, acc_scale, out_gain):
+    n, cin, h, w = x.shape
+    y = empty_nhwc(n, cout, h_out, w_out, x.dtype, x.device)
+    flops = 2.0 * n * h_out * w_out * cout * cin * 9
+    st = _timed('conv3x3_mx_kernel<bf16> (stride 2)', flops,
+                lambda: _native.lib().vqk_conv2d_s2_fprop(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias), y.data_ptr(), n,
+                                                          h_out, w_out, cin, cout, act, float(acc_scale), float(out_gain),
+                                                          zero_page(x.device).data_ptr(), _stream()))
+    _native.check(st, 'conv2d_s2_fprop')
+    return y
+
+
 def _packed_w4(weight, w4, cin, cout_pad, dt, k, transpose, layout):
     """cached operand for 4-D conv parameters; 2-D (fully connected) weights viewed as 1x1 convs are packed per call"""
     if weight.dim() == 4:
@@ -1760,7 +1799,8 @@ class ConvActFn(torch.autograd.Function):
         h_out = (h + 2 * pad - k) // stride + 1
         w_out = (w + 2 * pad - k) // stride + 1
         plain = stride == 1 and pad == k // 2
-        layout = weight_layout(dt, n, h, w, cin, cout_pad, k, False, out_dtype) if plain else 0
+        s2 = _s2_served(dt, out_dtype, n, h, w, h_out, w_out, cin, cout_pad, k, stride, pad, False)
+        layout = weight_layout(dt, n, h, w, cin, cout_pad, k, False, out_dtype) if plain else (1 if s2 else 0)
         w4 = weight.reshape(o, i, k, k)
         wq = _packed_w4(weight, w4, cin, cout_pad, dt, k, False, layout)
         b32 = None
@@ -1777,6 +1817,8 @@ class ConvActFn(torch.autograd.Function):
             w3[:o, 1, 1, :i] = weight.detach().reshape(o, i)
             wq3 = pack_weights(w3.reshape(-1), dt, cout_pad, 8, 3, False, 0)
             y = _conv_general_raw(x, wq3, b32, None, cout_pad, 3, 1, 1, 0, h_out, w_out, act, wgain, out_gain, out_dtype, 0)
+        elif s2:
+            y = _conv_s2_fprop_raw(x, wq, b32, cout_pad, h_out, w_out, act, wgain, out_gain)
         else:
             y = _conv_general_raw(x, wq, b32, None, cout_pad, k, stride, pad, 0, h_out, w_out, act, wgain, out_gain, out_dtype,
                                   layout)
@@ -1793,7 +1835,8 @@ class ConvActFn(torch.autograd.Function):
         lib, st = _native.lib(), _stream()
         # t and dx are built from differentiable Functions so that R1 (autograd.grad(..., create_graph=True) through
         # this backward, loss.py:98-112) can differentiate them again; in an ordinary backward they record nothing.
-        want_db = bias is not None and ctx.needs_input_grad[2]
+        want_db = bias is not None and ctx.needs_input_grad[2] and _PARAM_GRADS
+        want_dw = ctx.needs_input_grad[1] and _PARAM_GRADS
         dyn = nhwc(dy)
         dbsum = None
         gscale = 1.0
@@ -1801,7 +1844,7 @@ class ConvActFn(torch.autograd.Function):
         # 1/sqrt(fan_in) weight gain then rides in t (t' = wgain * t: dx = dgrad(t', W), dW += wgrad(x, t'), db = colsum(t') / wgain)
         # -- no zero-filled temporary, no scale pass, no accumulate pass per parameter
         tgt = None
-        if (ctx.needs_input_grad[1] and act != 0 and dyn.dtype == dt and cout_pad == o and cin == i and wgain > 0.0
+        if (want_dw and act != 0 and dyn.dtype == dt and cout_pad == o and cin == i and wgain > 0.0
                 and not torch.is_grad_enabled()):            # (a create_graph pass -- R1's inner autograd.grad -- must not touch .grad)
             tgt = direct_grad(weight)
         fold = float(wgain) if tgt is not None else 1.0
@@ -1823,7 +1866,7 @@ class ConvActFn(torch.autograd.Function):
             _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tc.detach().data_ptr(), tgt.data_ptr(), n, h, w, cin,
                                                        cout_pad, k, stride, pad, 0, h_out, w_out,
                                                        zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
-        elif ctx.needs_input_grad[1]:
+        elif want_dw:
             tcd = tc.detach()
             dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=x.device)
             _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tcd.data_ptr(), dwp.data_ptr(), n, h, w, cin,
@@ -1888,6 +1931,15 @@ class ConvDgradFn(torch.autograd.Function):
             layout = weight_layout(dt, n, h_out, w_out, cout_pad, cin, k, False)
             wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, layout)
             dx = _conv_general_raw(t, wt, None, None, cin, k, 1, k // 2, 0, h, w, 0, wgain, 1.0, dt, layout)
+        elif _s2_served(dt, dt, n, h, w, h_out, w_out, cin, cout_pad, k, stride, pad, True):
+            wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 0)
+            w3 = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 3)
+            dx = empty_nhwc(n, cin, h, w, dt, t.device)
+            st = _timed('conv3x3_mx_kernel<bf16> (stride-2 dgrad phases)', 2.0 * n * h_out * w_out * cout_pad * cin * 9,
+                        lambda: _native.lib().vqk_conv2d_s2_dgrad(dcode(dt), t.data_ptr(), w3.data_ptr(), wt.data_ptr(), dx.data_ptr(),
+                                                                  n, h_out, w_out, cin, cout_pad, float(wgain),
+                                                                  zero_page(t.device).data_ptr(), _stream()))
+            _native.check(st, 'conv2d_s2_dgrad')
         else:
             wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 0)
             dx = _conv_general_raw(t, wt, None, None, cin, k, 1, k - 1 - pad, 2 if stride == 2 else 0, h, w, 0, wgain, 1.0,
@@ -1909,7 +1961,10 @@ class ConvDgradFn(torch.autograd.Function):
         w4 = weight.detach().reshape(o, i, k, k)
         lib, st = _native.lib(), _stream()
         d_t = d_w = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and _s2_served(dt, dt, n, h, w, h_out, w_out, cin, cout_pad, k, stride, pad, False):
+            d_t = _conv_s2_fprop_raw(v, _packed_w4(weight, w4, cin, cout_pad, dt, k, False, 1), None, cout_pad, h_out, w_out, 0,
+                                     wgain, 1.0)
+        elif ctx.needs_input_grad[0]:
             wq = _packed_w4(weight, w4, cin, cout_pad, dt, k, False, 0)
             d_t = _conv_general_raw(v, wq, None, None, cout_pad, k, stride, pad, 0, h_out, w_out, 0, wgain, 1.0, dt, 0)
         if ctx.needs_input_grad[1]:
