@@ -425,6 +425,13 @@ int vqk_act_backward_colsum(int dtype, const void* dy, const void* y, void* dx, 
 int vqk_upfirdn2d_nhwc(int dtype, const void* x, const float* f, void* y, int n, int h, int w, int c, int fh, int fw,
                        int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip,
                        float gain, int out_h, int out_w, void* stream);
+/* The backward of "relu / leaky-relu, then a 4x4 FIR blur" as ONE pass (up = down = 1; the reference runs bias_act's gradient
+ * after upfirdn2d's, discriminator.py:104-120 / conv2d_resample.py:119): out = gain * act'(y_act) * upfirdn2d(x, f, pad, flip),
+ * the slope taken from the sign of the activated tensor y_act [N][out_h][out_w][C] (act 2 = relu, 3 = leaky relu 0.2).
+ * C a multiple of 8 sixteen-byte slots; VQK_ERR_SHAPE otherwise (callers run vqk_upfirdn2d_nhwc + vqk_act_backward). */
+int vqk_upfirdn2d_act_backward(int dtype, const void* x, const float* f, const void* y_act, void* out, int n, int h, int w, int c,
+                                int padx0, int padx1, int pady0, int pady1, int flip, float gain, int act, int out_h, int out_w,
+                                void* stream);
 /* 2x2/stride-2 max pool: backward = 0: out[N][H/2][W/2][C] = max ; backward = 1: out[N][H][W][C] = dy routed to the
  * first maximum of each window (x is the forward input). */
 int vqk_maxpool2x2(int dtype, const void* x, const void* dy, void* out, int n, int h, int w, int c, int backward,

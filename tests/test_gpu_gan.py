@@ -423,3 +423,31 @@ def test_discriminator_step_batched_equals_two_passes():
     assert abs(l1.item() - l2.item()) < 1e-5 * max(1.0, abs(l2.item()))
     for a, b in zip(g1, g2):
         assert rel(a, b) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_discriminator_block_equals_layer_by_layer(dtype):
+    """ops.DiscBlockFn (one autograd node per resnet block: activation gradient fused into the blur's adjoint, skip-branch
+    gradient added in the data-gradient kernel's epilogue) against the layer-by-layer nodes it replaces (discriminator.py:233-262):
+    same logits bit for bit (same forward launches), input and parameter gradients to the rounding of the two passes it skips"""
+    torch.manual_seed(7)
+    d = disc.Discriminator(64, channel_base=4096, channel_max=64).to(DEV)
+    d.compute_dtype = dtype
+    img = torch.randn(4, 3, 64, 64, device=DEV)
+    out = []
+    for fused in (True, False):
+        ops.FUSE_DISC_BLOCK = fused
+        try:
+            d.zero_grad()
+            x = img.clone().requires_grad_(True)
+            logits = d(x)
+            torch.nn.functional.softplus(-logits).mean().backward()
+            out.append((logits.detach().clone(), x.grad.clone(), [p.grad.detach().clone() for p in d.parameters()]))
+        finally:
+            ops.FUSE_DISC_BLOCK = True
+    (l1, gx1, gp1), (l2, gx2, gp2) = out
+    assert torch.equal(l1, l2)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel(gx1, gx2) < tol
+    for (name, _), a, b in zip(d.named_parameters(), gp1, gp2):
+        assert rel(a, b, floor=1e-9) < tol, name

@@ -93,6 +93,7 @@ _PROTOS = {
     'vqk_act_backward': [I, P, P, P, L, I, F, P],
     'vqk_act_backward_colsum': [I, P, P, P, L, I, I, F, P, P],
     'vqk_upfirdn2d_nhwc': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, I, P],
+    'vqk_upfirdn2d_act_backward': [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, P],
     'vqk_maxpool2x2': [I, P, P, P, I, I, I, I, I, P],
     'vqk_channel_affine': [I, P, P, P, P, L, I, P],
     'vqk_lpips_tap': [I, P, P, P, I, L, I, P, P, F, P, P],

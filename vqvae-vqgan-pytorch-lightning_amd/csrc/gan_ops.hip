@@ -678,10 +678,14 @@ __global__ __launch_bounds__(256) void upfirdn_fir4_kernel(const T* __restrict__
 // from L1/L2 and reached 1.5 TB/s of algorithmic bytes (354 us for 128 ch @256^2, bs 16); here a block stages the input
 // footprint of an 8 x 16 output tile x 8 channel slots (16 B each) in LDS once, with zero fill outside the image, and every
 // thread produces four consecutive output pixels of one slot from LDS.
-template <typename T, int UP, int DOWN>
+// MASK: the result is multiplied by the slope of a relu / leaky-relu taken from the sign of `mask` (an activated tensor of the
+// output's shape) -- the backward of "activation, then blur" (discriminator.py:104-120 followed by conv2d_resample.py:119) as ONE
+// pass: t = act'(y0) * blur^T(dB) without storing blur^T(dB).
+template <typename T, int UP, int DOWN, bool MASK = false>
 __global__ __launch_bounds__(256) void upfirdn_tile_kernel(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ y,
                                                            int n, int h, int w, int c, int px0, int py0, int flip, float gain,
-                                                           int oh, int ow, int tiles_x, int tiles_y) {
+                                                           int oh, int ow, int tiles_x, int tiles_y,
+                                                           const T* __restrict__ mask = nullptr, float slope = 1.0f) {
     constexpr int V = Vec16<T>::N, TOH = 8, TOW = 16;
     constexpr int IH = ((TOH - 1) * DOWN + 3) / UP + 2, IW = ((TOW - 1) * DOWN + 3) / UP + 2;     // input rows / columns per tile
     typedef typename Raw16<T>::type raw_t;
@@ -767,7 +771,17 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(const T* __restrict__
     };
     if (UP == 2 && (ux_first & 1)) body(std::integral_constant<int, 1>{});
     else body(std::integral_constant<int, 0>{});
-    T* yrow = y + (((int64_t)img * oh + oy) * ow + ox0 + 4 * oxq) * c + cs * 8 * V + slot * V;
+    const int64_t yoff = (((int64_t)img * oh + oy) * ow + ox0 + 4 * oxq) * c + cs * 8 * V + slot * V;
+    T* yrow = y + yoff;
+    if constexpr (MASK) {
+        float mv[4][V];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) Vec16<T>::load(mask + yoff + (int64_t)min(o, ow - 1 - (ox0 + 4 * oxq)) * c, mv[o]);   // (clamped: no load beyond the row)
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[o][k] = mv[o][k] > 0.0f ? acc[o][k] : slope * acc[o][k];
+    }
 #pragma unroll
     for (int o = 0; o < 4; ++o)
         if (ox0 + 4 * oxq + o < ow) Vec16<T>::store(yrow + (int64_t)o * c, acc[o]);
@@ -864,6 +878,32 @@ int vqk_upfirdn2d_nhwc(int dtype, const void* x, const float* f, void* y, int n,
     if (dtype == VQK_F32) hipLaunchKernelGGL(upfirdn_nhwc_kernel<float>, grid, dim3(256), 0, vqk_stream(stream), (const float*)x, f, (float*)y, n, h, w, c, fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain, out_h, out_w);
     else if (dtype == VQK_BF16) hipLaunchKernelGGL(upfirdn_nhwc_kernel<bf16_raw>, grid, dim3(256), 0, vqk_stream(stream), (const bf16_raw*)x, f, (bf16_raw*)y, n, h, w, c, fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain, out_h, out_w);
     else return VQK_ERR_DTYPE;
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_upfirdn2d_act_backward(int dtype, const void* x, const float* f, const void* y_act, void* out, int n, int h, int w, int c,
+                                int padx0, int padx1, int pady0, int pady1, int flip, float gain, int act, int out_h, int out_w,
+                                void* stream) {
+    VQK_REQUIRE(x && f && y_act && out, VQK_ERR_ARG);
+    VQK_REQUIRE(dtype == VQK_F32 || dtype == VQK_BF16, VQK_ERR_DTYPE);
+    VQK_REQUIRE(act == 2 || act == 3, VQK_ERR_ARG);
+    const int v = dtype == VQK_F32 ? 4 : 8;
+    VQK_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % (8 * v) == 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(out_w == w + padx0 + padx1 - 3 && out_h == h + pady0 + pady1 - 3 && out_w >= 1 && out_h >= 1, VQK_ERR_SHAPE);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(y_act) && vqk_aligned16(out), VQK_ERR_ALIGN);
+    const int tiles_x = (out_w + 15) / 16, tiles_y = (out_h + 7) / 8;
+    const int64_t blocks = (int64_t)n * tiles_y * tiles_x * (c / (8 * v));
+    VQK_REQUIRE(blocks < 0x7fffffff, VQK_ERR_SHAPE);
+    const float slope = act == 3 ? 0.2f : 0.0f;
+    hipStream_t st = vqk_stream(stream);
+    constexpr int ih = 7 + 3 + 2, iw = 15 + 3 + 2;
+    if (dtype == VQK_F32)
+        hipLaunchKernelGGL((upfirdn_tile_kernel<float, 1, 1, true>), dim3((unsigned)blocks), dim3(256), (size_t)ih * iw * 8 * 16, st, (const float*)x, f,
+                           (float*)out, n, h, w, c, padx0, pady0, flip, gain, out_h, out_w, tiles_x, tiles_y, (const float*)y_act, slope);
+    else
+        hipLaunchKernelGGL((upfirdn_tile_kernel<bf16_raw, 1, 1, true>), dim3((unsigned)blocks), dim3(256), (size_t)ih * iw * 8 * 16, st, (const bf16_raw*)x, f,
+                           (bf16_raw*)out, n, h, w, c, padx0, pady0, flip, gain, out_h, out_w, tiles_x, tiles_y, (const bf16_raw*)y_act, slope);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

@@ -98,9 +98,20 @@ class DiscriminatorBlock(nn.Module):
                                 resample_filter=resample_filter)
         self.num_layers += 3
 
-    def forward(self, x, img):
+    def forward(self, x, img, double_backward: bool = False):
         if self.in_channels == 0:
             x = self.fromrgb(img)
+        c0, c1, sk = self.conv0, self.conv1, self.skip
+        if (ops.FUSE_DISC_BLOCK and not double_backward and torch.is_grad_enabled() and c0.activation == 'lrelu'
+                and c1.resample_filter.shape == (4, 4)):
+            # one autograd node per block (ops.DiscBlockFn): same forward launches, fused backward passes
+            fw = c1.resample_filter.shape[0]
+            pb0, pb1 = c1.padding + (fw - 1) // 2, c1.padding + (fw - 2) // 2      # Conv2dLayer.forward's p0 / p1 with down = 2
+            ps0, ps1 = sk.padding + (fw - 1) // 2, sk.padding + (fw - 2) // 2
+            cfg = (float(c0.weight_gain), float(c1.weight_gain), float(sk.weight_gain), ops.ACT_CODE['lrelu'], float(c0.act_gain),
+                   float(np.sqrt(0.5)), (pb0, pb1, pb0, pb1), (ps0, ps1, ps0, ps1))
+            return ops.DiscBlockFn.apply(x, c0.weight, c0.bias, c1.weight, c1.bias, sk.weight,
+                                         c1.resample_filter.to(torch.float32).contiguous(), cfg), None
         y = self.skip(x, gain=np.sqrt(0.5))
         x = self.conv0(x)
         x = self.conv1(x, gain=np.sqrt(0.5))
@@ -166,10 +177,12 @@ class Discriminator(nn.Module):
         self.b4 = DiscriminatorEpilogue(ch[4], cmap_dim=0, resolution=4, img_channels=img_channels,
                                         architecture=architecture, **(epilogue_kwargs or {}))
 
-    def forward(self, img, halves: int = 1, **_):
-        """halves: number of independent batches concatenated along dim 0 (only the minibatch-stddev layer couples samples)"""
+    def forward(self, img, halves: int = 1, double_backward: bool = False, **_):
+        """halves: number of independent batches concatenated along dim 0 (only the minibatch-stddev layer couples samples);
+        double_backward: this pass will be differentiated twice (R1, loss.py:98-112): layer-by-layer autograd nodes instead of
+        the fused block nodes, whose backward is first-order only"""
         img = _to_internal(img, self.compute_dtype)
         x = None
         for res in self.block_resolutions:
-            x, _unused = getattr(self, f'b{res}')(x, img)
+            x, _unused = getattr(self, f'b{res}')(x, img, double_backward)
         return self.b4(x, halves=halves)

@@ -95,7 +95,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
             if shared is not None and shared.shape[0] == reconstructions.shape[0]:
                 # (the caller restricts the backward to the discriminator's parameters: the graph behind `shared` also leads
                 # into the decoder)
-                logits_real = self.discriminator(images)
+                logits_real = self.discriminator(images, double_backward=compute_r1)
                 logits_fake = shared
             elif BATCHED_DISC and not compute_r1 and images.shape[0] == reconstructions.shape[0] and images.shape[2:] == reconstructions.shape[2:]:
                 # real | fake through the discriminator as ONE batch (same logits: only the minibatch-stddev layer couples
@@ -104,7 +104,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
                 both = torch.cat([_to_internal(images, dt), _to_internal(reconstructions.detach(), dt)], 0)
                 logits_real, logits_fake = self.discriminator(both, halves=2).chunk(2, 0)
             else:
-                logits_real = self.discriminator(images)
+                logits_real = self.discriminator(images, double_backward=compute_r1)
                 logits_fake = self.discriminator(reconstructions.detach())
             d_loss = discriminator_loss(logits_real, logits_fake, loss_type=self.adversarial_loss_type)
             r1_term = self.calculate_r1_regularization_term(logits_real, images, compute_r1)

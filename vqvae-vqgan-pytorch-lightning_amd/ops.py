@@ -1830,57 +1830,72 @@ class ConvActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
-        weight, bias = ctx.refs
-        k, stride, pad, act, wgain, out_gain, o, i, cin, cout_pad, dt = ctx.cfg
-        lib, st = _native.lib(), _stream()
-        # t and dx are built from differentiable Functions so that R1 (autograd.grad(..., create_graph=True) through
-        # this backward, loss.py:98-112) can differentiate them again; in an ordinary backward they record nothing.
-        want_db = bias is not None and ctx.needs_input_grad[2] and _PARAM_GRADS
-        want_dw = ctx.needs_input_grad[1] and _PARAM_GRADS
-        dyn = nhwc(dy)
-        dbsum = None
-        gscale = 1.0
-        # weight gradient straight into the optimizer's flat gradient arena (unpadded layers of a FlatAdamW-owned module): the
-        # 1/sqrt(fan_in) weight gain then rides in t (t' = wgain * t: dx = dgrad(t', W), dW += wgrad(x, t'), db = colsum(t') / wgain)
-        # -- no zero-filled temporary, no scale pass, no accumulate pass per parameter
-        tgt = None
-        if (want_dw and act != 0 and dyn.dtype == dt and cout_pad == o and cin == i and wgain > 0.0
-                and not torch.is_grad_enabled()):            # (a create_graph pass -- R1's inner autograd.grad -- must not touch .grad)
-            tgt = direct_grad(weight)
-        fold = float(wgain) if tgt is not None else 1.0
-        if act == 0 and dyn.dtype == dt:
-            # linear layer (the discriminator's skip convs, its last fully connected layer): t = out_gain * dy is no pass over
-            # the tensor -- the scalar rides in the data- / weight-gradient scale (and on the bias sum)
-            t, gscale = dyn, float(out_gain)
-        else:
-            if want_db and dyn.dtype == dt:                  # the bias gradient rides in the act-backward pass
-                dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
-            t = ActBwdFn.apply(dyn, y, act, float(out_gain) * fold, dbsum)
-        tc = t if t.dtype == dt else nhwc(t.to(dt))
-        n, _, h, w = x.shape
-        _, _, h_out, w_out = tc.shape
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = ConvDgradFn.apply(tc, weight, k, stride, pad, 1.0 if tgt is not None else float(wgain) * gscale, cin, cout_pad, h, w)
-        if tgt is not None:
-            _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tc.detach().data_ptr(), tgt.data_ptr(), n, h, w, cin,
-                                                       cout_pad, k, stride, pad, 0, h_out, w_out,
-                                                       zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
-        elif want_dw:
-            tcd = tc.detach()
-            dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=x.device)
-            _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tcd.data_ptr(), dwp.data_ptr(), n, h, w, cin,
-                                                       cout_pad, k, stride, pad, 0, h_out, w_out,
-                                                       zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
-            if wgain * gscale != 1.0:
-                _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain) * gscale, 0.0, dwp.numel(), st), 'axpby')
-            dw = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
-        if want_db:
-            fused = dbsum is not None and cout_pad % (4 if dt == torch.float32 else 8) == 0 and cout_pad // (4 if dt == torch.float32 else 8) <= 256
-            db = (dbsum if fused else raw_colsum(n * h_out * w_out, cout_pad, tc.detach()))[:o]
-            if gscale != 1.0 or fold != 1.0:
-                db = db * (gscale / fold)
+        dx, dw, db = _conv_act_backward(x, y, ctx.refs, ctx.cfg, ctx.needs_input_grad, dy)
         return dx, dw, db, None, None, None, None, None, None, None
+
+
+def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None):
+    """ConvActFn's backward as a plain function (DiscBlockFn composes three of them).  ``make_t(scale, dbsum)``: the caller
+    produces t = scale * act'(y) * dy itself (fused into the pass that produces dy) and adds t's column sums to ``dbsum`` when that
+    is not None; ``dx_residual``: added to the data gradient in the conv kernel's epilogue."""
+    weight, bias = refs
+    k, stride, pad, act, wgain, out_gain, o, i, cin, cout_pad, dt = cfg
+    lib, st = _native.lib(), _stream()
+    # t and dx are built from differentiable Functions so that R1 (autograd.grad(..., create_graph=True) through
+    # this backward, loss.py:98-112) can differentiate them again; in an ordinary backward they record nothing.
+    want_db = bias is not None and needs[2] and _PARAM_GRADS
+    want_dw = needs[1] and _PARAM_GRADS
+    dyn = nhwc(dy) if dy is not None else None
+    dy_dtype = dyn.dtype if dyn is not None else dt
+    dbsum = None
+    gscale = 1.0
+    # weight gradient straight into the optimizer's flat gradient arena (unpadded layers of a FlatAdamW-owned module): the
+    # 1/sqrt(fan_in) weight gain then rides in t (t' = wgain * t: dx = dgrad(t', W), dW += wgrad(x, t'), db = colsum(t') / wgain)
+    # -- no zero-filled temporary, no scale pass, no accumulate pass per parameter
+    tgt = None
+    if (want_dw and act != 0 and dy_dtype == dt and cout_pad == o and cin == i and wgain > 0.0
+            and not torch.is_grad_enabled()):            # (a create_graph pass -- R1's inner autograd.grad -- must not touch .grad)
+        tgt = direct_grad(weight)
+    fold = float(wgain) if tgt is not None else 1.0
+    if make_t is not None:
+        if want_db:
+            dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
+        t = make_t(float(out_gain) * fold, dbsum)
+    elif act == 0 and dyn.dtype == dt:
+        # linear layer (the discriminator's skip convs, its last fully connected layer): t = out_gain * dy is no pass over
+        # the tensor -- the scalar rides in the data- / weight-gradient scale (and on the bias sum)
+        t, gscale = dyn, float(out_gain)
+    else:
+        if want_db and dyn.dtype == dt:                  # the bias gradient rides in the act-backward pass
+            dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
+        t = ActBwdFn.apply(dyn, y, act, float(out_gain) * fold, dbsum)
+    tc = t if t.dtype == dt else nhwc(t.to(dt))
+    n, _, h, w = x.shape
+    _, _, h_out, w_out = tc.shape
+    dx = dw = db = None
+    if needs[0]:
+        dx = ConvDgradFn.apply(tc, weight, k, stride, pad, 1.0 if tgt is not None else float(wgain) * gscale, cin, cout_pad, h, w,
+                               dx_residual)
+    if tgt is not None:
+        _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tc.detach().data_ptr(), tgt.data_ptr(), n, h, w, cin,
+                                                   cout_pad, k, stride, pad, 0, h_out, w_out,
+                                                   zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
+    elif want_dw:
+        tcd = tc.detach()
+        dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=x.device)
+        _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tcd.data_ptr(), dwp.data_ptr(), n, h, w, cin,
+                                                   cout_pad, k, stride, pad, 0, h_out, w_out,
+                                                   zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
+        if wgain * gscale != 1.0:
+            _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain) * gscale, 0.0, dwp.numel(), st), 'axpby')
+        dw = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
+    if want_db:
+        fused = dbsum is not None and (make_t is not None or (cout_pad % (4 if dt == torch.float32 else 8) == 0
+                                                               and cout_pad // (4 if dt == torch.float32 else 8) <= 256))
+        db = (dbsum if fused else raw_colsum(n * h_out * w_out, cout_pad, tc.detach()))[:o]
+        if gscale != 1.0 or fold != 1.0:
+            db = db * (gscale / fold)
+    return dx, dw, db
 
 
 class ActBwdFn(torch.autograd.Function):
@@ -1922,7 +1937,9 @@ class ConvDgradFn(torch.autograd.Function):
     cotangent and a wgrad with the cotangent in the role of the layer input."""
 
     @staticmethod
-    def forward(ctx, t, weight, k: int, stride: int, pad: int, wgain: float, cin: int, cout_pad: int, h: int, w: int):
+    def forward(ctx, t, weight, k: int, stride: int, pad: int, wgain: float, cin: int, cout_pad: int, h: int, w: int,
+                residual=None):
+        """residual (a constant of the differentiation: DiscBlockFn's other branch gradient) is added in the kernel's epilogue"""
         dt = t.dtype
         o, i = weight.shape[0], weight.shape[1]
         w4 = weight.detach().reshape(o, i, k, k)
@@ -1930,7 +1947,8 @@ class ConvDgradFn(torch.autograd.Function):
         if stride == 1 and pad == k // 2:
             layout = weight_layout(dt, n, h_out, w_out, cout_pad, cin, k, False)
             wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, layout)
-            dx = _conv_general_raw(t, wt, None, None, cin, k, 1, k // 2, 0, h, w, 0, wgain, 1.0, dt, layout)
+            dx = _conv_general_raw(t, wt, None, residual, cin, k, 1, k // 2, 0, h, w, 0, wgain, 1.0, dt, layout)
+            residual = None
         elif _s2_served(dt, dt, n, h, w, h_out, w_out, cin, cout_pad, k, stride, pad, True):
             wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 0)
             w3 = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 3)
@@ -1944,6 +1962,8 @@ class ConvDgradFn(torch.autograd.Function):
             wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 0)
             dx = _conv_general_raw(t, wt, None, None, cin, k, 1, k - 1 - pad, 2 if stride == 2 else 0, h, w, 0, wgain, 1.0,
                                    dt, 0)
+        if residual is not None:                         # (the strided / padded forms have no residual operand)
+            dx = AddFn.apply(dx, residual)
         ctx.save_for_backward(t)
         ctx.refs = (weight,)
         ctx.cfg = (k, stride, pad, wgain, cin, cout_pad, o, i)
@@ -1975,7 +1995,7 @@ class ConvDgradFn(torch.autograd.Function):
             if wgain != 1.0:
                 _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain), 0.0, dwp.numel(), st), 'axpby')
             d_w = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
-        return d_t, d_w, None, None, None, None, None, None, None, None
+        return d_t, d_w, None, None, None, None, None, None, None, None, None
 
 
 def conv_act(x, weight, bias=None, k=3, stride=1, pad=None, act='linear', wgain=1.0, out_gain=1.0, out_dtype=None):
@@ -2159,6 +2179,99 @@ class AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return dy, dy
+
+
+FUSE_DISC_BLOCK = os.environ.get('VQK_FUSE_DISC_BLOCK', '1') != '0'
+
+
+def _conv_act_cfg(x, weight, k, stride, pad, act, wgain, out_gain):
+    """the ``ctx.cfg`` tuple ConvActFn.forward builds for this call (channel counts already whole 16-byte chunks)"""
+    o, i = weight.shape[0], weight.shape[1]
+    e = epc(x.dtype)
+    return (k, stride, pad, act, float(wgain), float(out_gain), o, i, x.shape[1], -(-o // e) * e, x.dtype)
+
+
+class DiscBlockFn(torch.autograd.Function):
+    """One resnet DiscriminatorBlock (discriminator.py:233-262: y = skip(x) * sqrt(1/2) + conv1(conv0(x)) * sqrt(1/2)) as ONE
+    autograd node.  Forward: the same five launches as the layer-by-layer form.  Backward, in an order autograd cannot choose:
+    (1) conv1 (activation gradient, stride-2 data gradient, weight gradient), (2) the skip branch down to the block input's
+    resolution, (3) conv0's activation gradient FUSED into the blur's adjoint (vqk_upfirdn2d_act_backward: blur^T(dB) is never
+    stored), (4) conv0's data gradient with the skip branch's gradient added IN ITS EPILOGUE (no accumulation pass).
+    First-order only: the R1 pass (autograd.grad(..., create_graph=True), loss.py:98-112) uses the layer-by-layer form."""
+
+    @staticmethod
+    def layers(x, w0, b0, w1, b1, ws, f, cfg):
+        """the block layer by layer (DiscriminatorBlock.forward's un-fused form); returns the intermediates as well"""
+        wg0, wg1, wgs, act, act_gain, gain, pad_blur, pad_skip = cfg
+        ys = UpfirdnNhwcFn.apply(x, f, 1, 2, pad_skip, False, 1.0)
+        ysk = ConvActFn.apply(ys, ws, None, 1, 1, 0, 0, wgs, gain, None)
+        y0 = ConvActFn.apply(x, w0, b0, 3, 1, 1, act, wg0, act_gain, None)
+        blur = UpfirdnNhwcFn.apply(y0, f, 1, 1, pad_blur, False, 1.0)
+        y1 = ConvActFn.apply(blur, w1, b1, 3, 2, 0, act, wg1, act_gain * gain, None)
+        return AddFn.apply(ysk, y1), ys, y0, blur, y1
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, ws, f, cfg):
+        wg0, wg1, wgs, act, act_gain, gain, pad_blur, pad_skip = cfg
+        x_in, x = x, nhwc(x)
+        out, ys, y0, blur, y1 = DiscBlockFn.layers(x, w0, b0, w1, b1, ws, f, cfg)
+        ctx.block_cfg = cfg
+        ctx.save_for_backward(x_in, ys, y0, blur, y1, f)        # (the INPUT itself: a double backward differentiates through it)
+        ctx.refs = (w0, b0, w1, b1, ws)
+        ctx.cfgs = (_conv_act_cfg(x, w0, 3, 1, 1, act, wg0, act_gain), _conv_act_cfg(blur, w1, 3, 2, 0, act, wg1, act_gain * gain),
+                    _conv_act_cfg(ys, ws, 1, 1, 0, 0, wgs, gain), pad_blur, pad_skip)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ys, y0, blur, y1, f = ctx.saved_tensors
+        w0, b0, w1, b1, ws = ctx.refs
+        cfg0, cfg1, cfgs, pad_blur, pad_skip = ctx.cfgs
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            # this backward is itself being differentiated (create_graph=True, e.g. R1 on a pass that was not announced with
+            # double_backward=True): the fused passes below record nothing, so the block is evaluated again layer by layer and
+            # ITS differentiable backward is used (costs one forward of the block)
+            with torch.enable_grad():
+                ins = [x, w0, b0, w1, b1, ws]
+                out = DiscBlockFn.layers(x, w0, b0, w1, b1, ws, f, ctx.block_cfg)[0]
+                idx = [i for i in range(6) if need[i] and ins[i] is not None]
+                got = torch.autograd.grad(out, [ins[i] for i in idx], g, create_graph=True, allow_unused=True)
+            res = [None] * 8
+            for i, v in zip(idx, got):
+                res[i] = v
+            return tuple(res)
+        x = nhwc(x)
+        g = nhwc(g)
+        n, c, h, w = x.shape
+        fh, fw = f.shape
+        # (1) conv1
+        d_blur, dw1, db1 = _conv_act_backward(blur, y1, (w1, b1), cfg1, (True, need[3], need[4]), g)
+        # (2) skip: 1x1 data gradient at half resolution, then the adjoint of blur + decimate (upfirdn2d.py:259-268)
+        g_lo, dws, _ = _conv_act_backward(ys, None, (ws, None), cfgs, (need[0], need[5], False), g)
+        u = None
+        if need[0]:
+            _, _, oh, ow = ys.shape
+            ps = (fw - pad_skip[0] - 1, w - ow * 2 + pad_skip[0], fh - pad_skip[2] - 1, h - oh * 2 + pad_skip[2])
+            u = UpfirdnNhwcFn.apply(g_lo, f, 2, 1, ps, True, 1.0)
+        # (3) + (4) conv0
+        _, _, bh, bw = blur.shape
+        pb = (fw - pad_blur[0] - 1, w - bw + pad_blur[0], fh - pad_blur[2] - 1, h - bh + pad_blur[2])
+        act = cfg0[3]
+
+        def make_t(scale, dbsum):
+            t0 = torch.empty_like(y0, memory_format=_CL)
+            st = _native.lib().vqk_upfirdn2d_act_backward(dcode(x.dtype), d_blur.data_ptr(), f.data_ptr(), y0.data_ptr(), t0.data_ptr(),
+                                                          n, bh, bw, c, pb[0], pb[1], pb[2], pb[3], 1, float(scale), act, h, w,
+                                                          _stream()) if (act in (2, 3) and fh == 4 and fw == 4) else -1
+            if st != 0:                                  # shapes outside the fused kernel: blur^T, then the activation gradient
+                t0 = ActBwdFn.apply(UpfirdnNhwcFn.apply(d_blur, f, 1, 1, pb, True, 1.0), y0, act, float(scale), None)
+            if dbsum is not None:
+                raw_colsum(n * h * w, c, t0, out=dbsum)
+            return t0
+
+        gx, dw0, db0 = _conv_act_backward(x, y0, (w0, b0), cfg0, (need[0], need[1], need[2]), None, make_t=make_t, dx_residual=u)
+        return gx, dw0, db0, dw1, db1, dws, None, None
 
 
 class ReconLossFn(torch.autograd.Function):
