@@ -421,6 +421,10 @@ int vqk_act_backward(int dtype, const void* dy, const void* y, void* dx, int64_t
  * number of 16-byte vectors, at most 256 of them. */
 int vqk_act_backward_colsum(int dtype, const void* dy, const void* y, void* dx, int64_t rows, int c, int act, float scale,
                             float* colsum, void* stream);
+/* the same with the column sums scaled before they are ADDED to colsum (colsum += colsum_scale * sum_rows dx): the bias gradient
+ * goes straight into an optimizer's gradient arena when dx carries a folded weight gain (colsum_scale = 1 / gain) */
+int vqk_act_backward_colsum_scaled(int dtype, const void* dy, const void* y, void* dx, int64_t rows, int c, int act, float scale,
+                                   float colsum_scale, float* colsum, void* stream);
 /* upfirdn2d (upfirdn2d.cpp:16 argument meaning) on NHWC tensors of `dtype`, C a whole 16-byte chunk. */
 int vqk_upfirdn2d_nhwc(int dtype, const void* x, const float* f, void* y, int n, int h, int w, int c, int fh, int fw,
                        int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip,

@@ -38,6 +38,20 @@ def test_argument_validation_without_gpu():
     assert lib.vqk_gn_stats(0, 16, 1, 16, 30, 32, 1e-6, 16, 16, 0) == -1                          # C % groups
 
 
+def test_stride2_entry_points_validate_without_gpu():
+    """round 4: the discriminator's stride-2 conv / data gradient (vqk_conv2d_s2_*) and the fused blur-adjoint + activation
+    gradient refuse unsupported shapes and NULL pointers before any launch"""
+    lib = importlib.import_module(PKG + '._native').lib()
+    assert lib.vqk_conv2d_s2_supported(1, 16, 128, 128, 128, 256, 0) == 1 and lib.vqk_conv2d_s2_supported(1, 16, 128, 128, 128, 256, 1) == 1
+    assert lib.vqk_conv2d_s2_supported(1, 16, 8, 8, 512, 512, 0) == 0            # 17x17 -> 8x8 stays on the im2col kernel
+    assert lib.vqk_conv2d_s2_supported(0, 16, 128, 128, 128, 256, 0) == 0        # fp32
+    assert lib.vqk_conv2d_s2_supported(1, 64, 128, 128, 512, 256, 0) == 0        # 32-bit buffer offsets
+    assert lib.vqk_conv2d_s2_fprop(1, 0, 0, 0, 0, 16, 128, 128, 128, 256, 3, 1.0, 1.0, 0, 0) == -5
+    assert lib.vqk_conv2d_s2_dgrad(1, 0, 0, 0, 0, 16, 128, 128, 128, 256, 1.0, 0, 0) == -5
+    assert lib.vqk_upfirdn2d_act_backward(1, 0, 0, 0, 0, 2, 33, 33, 64, 1, 1, 1, 1, 1, 1.0, 3, 32, 32, 0) == -5
+    assert lib.vqk_conv_packed_elems(256, 128, 3, 3) == 256 * 128 * 9            # layout 3: the nine taps, grouped by parity
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     ops = importlib.import_module(PKG + '.ops')

@@ -92,6 +92,7 @@ _PROTOS = {
     'vqk_adamw': [P, P, P, P, L, P, P, I, F, F, F, F, I, F, P, P],
     'vqk_act_backward': [I, P, P, P, L, I, F, P],
     'vqk_act_backward_colsum': [I, P, P, P, L, I, I, F, P, P],
+    'vqk_act_backward_colsum_scaled': [I, P, P, P, L, I, I, F, F, P, P],
     'vqk_upfirdn2d_nhwc': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, I, P],
     'vqk_upfirdn2d_act_backward': [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, P],
     'vqk_maxpool2x2': [I, P, P, P, I, I, I, I, I, P],

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
                                                              int64_t rows, int c, int64_t rows_per_block, int act, float scale,
-                                                             float* __restrict__ colsum) {
+                                                             float* __restrict__ colsum, float cs_scale) {
     constexpr int V = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sh = reinterpret_cast<float*>(smem);            // [c]
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T* __restrict
         for (int k = 0; k < V; ++k) atomicAdd(sh + slot * V + k, a[k]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < c; i += 256) atomicAdd(colsum + i, sh[i]);
+    for (int i = threadIdx.x; i < c; i += 256) atomicAdd(colsum + i, sh[i] * cs_scale);
 }
 
 // y[n,oy,ox,:] = gain * sum_{fy,fx} F[fy][fx] * U[oy*down + fy - pad0][...]; U = zero-stuffed x
@@ -809,8 +809,15 @@ int vqk_act_backward(int dtype, const void* dy, const void* y, void* dx, int64_t
     return VQK_OK;
 }
 
+int vqk_act_backward_colsum_scaled(int dtype, const void* dy, const void* y, void* dx, int64_t rows, int c, int act, float scale,
+                                   float colsum_scale, float* colsum, void* stream);
 int vqk_act_backward_colsum(int dtype, const void* dy, const void* y, void* dx, int64_t rows, int c, int act, float scale,
                             float* colsum, void* stream) {
+    return vqk_act_backward_colsum_scaled(dtype, dy, y, dx, rows, c, act, scale, 1.0f, colsum, stream);
+}
+
+int vqk_act_backward_colsum_scaled(int dtype, const void* dy, const void* y, void* dx, int64_t rows, int c, int act, float scale,
+                                   float colsum_scale, float* colsum, void* stream) {
     VQK_REQUIRE(dy && y && dx && colsum, VQK_ERR_ARG);
     VQK_REQUIRE(act >= 0 && act <= 3 && rows >= 0 && c > 0, VQK_ERR_ARG);
     VQK_REQUIRE(dtype == VQK_F32 || dtype == VQK_BF16, VQK_ERR_DTYPE);
@@ -823,8 +830,8 @@ int vqk_act_backward_colsum(int dtype, const void* dy, const void* y, void* dx, 
     blocks = (rows + rpb - 1) / rpb;
     const size_t lds = (size_t)c * 4;
     hipStream_t st = vqk_stream(stream);
-    if (dtype == VQK_F32) hipLaunchKernelGGL(act_bwd_colsum_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, (const float*)dy, (const float*)y, (float*)dx, rows, c, rpb, act, scale, colsum);
-    else hipLaunchKernelGGL(act_bwd_colsum_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_raw*)dy, (const bf16_raw*)y, (bf16_raw*)dx, rows, c, rpb, act, scale, colsum);
+    if (dtype == VQK_F32) hipLaunchKernelGGL(act_bwd_colsum_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, (const float*)dy, (const float*)y, (float*)dx, rows, c, rpb, act, scale, colsum, colsum_scale);
+    else hipLaunchKernelGGL(act_bwd_colsum_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_raw*)dy, (const bf16_raw*)y, (bf16_raw*)dx, rows, c, rpb, act, scale, colsum, colsum_scale);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

@@ -1847,7 +1847,7 @@ def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None
     want_dw = needs[1] and _PARAM_GRADS
     dyn = nhwc(dy) if dy is not None else None
     dy_dtype = dyn.dtype if dyn is not None else dt
-    dbsum = None
+    dbsum = db_tgt = None
     gscale = 1.0
     # weight gradient straight into the optimizer's flat gradient arena (unpadded layers of a FlatAdamW-owned module): the
     # 1/sqrt(fan_in) weight gain then rides in t (t' = wgain * t: dx = dgrad(t', W), dW += wgrad(x, t'), db = colsum(t') / wgain)
@@ -1867,8 +1867,11 @@ def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None
         t, gscale = dyn, float(out_gain)
     else:
         if want_db and dyn.dtype == dt:                  # the bias gradient rides in the act-backward pass
-            dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
-        t = ActBwdFn.apply(dyn, y, act, float(out_gain) * fold, dbsum)
+            vec = 4 if dt == torch.float32 else 8
+            if DIRECT_BIAS_GRAD and cout_pad == o and cout_pad % vec == 0 and cout_pad // vec <= 256 and not torch.is_grad_enabled():
+                db_tgt = direct_grad(bias)               # ... straight into the optimizer's arena (no zero fill, scale, add)
+            dbsum = db_tgt if db_tgt is not None else torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
+        t = ActBwdFn.apply(dyn, y, act, float(out_gain) * fold, dbsum, 1.0 / fold if db_tgt is not None else 1.0)
     tc = t if t.dtype == dt else nhwc(t.to(dt))
     n, _, h, w = x.shape
     _, _, h_out, w_out = tc.shape
@@ -1889,7 +1892,7 @@ def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None
         if wgain * gscale != 1.0:
             _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain) * gscale, 0.0, dwp.numel(), st), 'axpby')
         dw = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
-    if want_db:
+    if want_db and db_tgt is None:
         fused = dbsum is not None and (make_t is not None or (cout_pad % (4 if dt == torch.float32 else 8) == 0
                                                                and cout_pad // (4 if dt == torch.float32 else 8) <= 256))
         db = (dbsum if fused else raw_colsum(n * h_out * w_out, cout_pad, tc.detach()))[:o]
@@ -1903,15 +1906,15 @@ class ActBwdFn(torch.autograd.Function):
     its own backward is the same op (bias_act.py:197-198: lrelu / relu have no second-order term)"""
 
     @staticmethod
-    def forward(ctx, dy, y, act: int, scale: float, colsum=None):
-        """colsum: fp32 [C] buffer that ALSO receives the column sums of the result (the conv's bias gradient) -- one pass"""
+    def forward(ctx, dy, y, act: int, scale: float, colsum=None, colsum_scale: float = 1.0):
+        """colsum: fp32 [C] buffer that ALSO receives colsum_scale * the column sums of the result (the conv's bias gradient) -- one pass"""
         t = torch.empty_like(dy, memory_format=_CL)
         n, c, h, w = dy.shape
         v = 4 if dy.dtype == torch.float32 else 8
         if colsum is not None and c % v == 0 and c // v <= 256:
-            _native.check(_native.lib().vqk_act_backward_colsum(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(),
-                                                                n * h * w, c, act, scale, colsum.data_ptr(), _stream()),
-                          'act_backward_colsum')
+            _native.check(_native.lib().vqk_act_backward_colsum_scaled(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(),
+                                                                       n * h * w, c, act, scale, float(colsum_scale),
+                                                                       colsum.data_ptr(), _stream()), 'act_backward_colsum')
             ctx.fused_colsum = True
         else:
             _native.check(_native.lib().vqk_act_backward(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(), dy.numel(),
@@ -1929,7 +1932,7 @@ class ActBwdFn(torch.autograd.Function):
         act, scale = ctx.cfg
         if act == 1:
             raise NotImplementedError('second-order tanh epilogue is not on any path')
-        return ActBwdFn.apply(nhwc(v), y, act, scale), None, None, None, None
+        return ActBwdFn.apply(nhwc(v), y, act, scale), None, None, None, None, None
 
 
 class ConvDgradFn(torch.autograd.Function):
@@ -2182,6 +2185,7 @@ class AddFn(torch.autograd.Function):
 
 
 FUSE_DISC_BLOCK = os.environ.get('VQK_FUSE_DISC_BLOCK', '1') != '0'
+DIRECT_BIAS_GRAD = os.environ.get('VQK_DIRECT_BIAS_GRAD', '1') != '0'    # ConvActFn: bias gradient straight into the optimizer's arena
 
 
 def _conv_act_cfg(x, weight, k, stride, pad, act, wgain, out_gain):
