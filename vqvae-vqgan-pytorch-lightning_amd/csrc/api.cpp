@@ -86,7 +86,8 @@ static TuneSlot g_tune[] = {
     {"COMM_CUS", 0, 0},
     {"MX_QUARTER", 0, 0},
     {"MX_S2", 0, 0},
-    {"MX_S2_DGRAD_MIN", 0, 0}
+    {"MX_S2_DGRAD_MIN", 0, 0},
+    {"UPS_MERGE", 0, 0}
 };
 static constexpr int kTune = (int)(sizeof(g_tune) / sizeof(g_tune[0]));
 TuneSlot* tune_slot(const char* name) {

@@ -2261,7 +2261,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.gn_ws = nullptr; g.gn_cpg = 0; g.gn_part_nblk = 0; g.gn_part_base = 0;
     g.act = 0; g.dy_pool = 0;
     g.ntap = ksize == 1 ? 1 : 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
-    g.tapw = 0; g.dst_h = g.dst_w = 0; g.s2 = 0;
+    g.tapw = 0; g.dst_h = g.dst_w = 0; g.s2 = 0; g.phase_mode = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
     g.m = (int)m;
@@ -2413,6 +2413,21 @@ int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* 
     g.ntap = 4;
     const int64_t phase_elems = (int64_t)((cout + 127) / 128) * 128 * cin * 4;
     hipStream_t st = vqk_stream(stream);
+    if (VQK_TUNE("UPS_MERGE", 1)) {
+        // one launch for the four phases (conv_mx.hip: ConvGeom::phase_mode)
+        ConvGeom gp = g;
+        if (!backward) {
+            gp.phase_mode = 1;
+            gp.dst_s = 2;
+            gp.gn_ws = gn_ws; gp.gn_cpg = gn_ws ? cout / groups : 0;
+            if (gn_ws && g_det) { gp.gn_part_nblk = 4 * ((g.h * g.w) / 256); gp.gn_part_base = 0; }
+        } else {
+            gp.phase_mode = 2;
+            gp.src_s = 2;
+            gp.h_in = 2 * h; gp.w_in = 2 * w;
+        }
+        return vqkd::launch_conv3x3_mx(x, w4, backward ? nullptr : bias, nullptr, y, zeros, gp, tw, st);
+    }
     for (int ph = 0; ph < 4; ++ph) {
         const int a = ph >> 1, b = ph & 1;
         ConvGeom gp = g;

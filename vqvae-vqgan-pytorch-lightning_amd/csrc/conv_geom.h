@@ -40,6 +40,8 @@ struct ConvGeom {
     // the data gradient of a stride-2 conv without padding writes the phases of a (2h+1) x (2w+1) tensor).
     // s2 = 1: the stride-2 3x3 conv itself (input (2h+1) x (2w+1), output h x w): conv3x3_mx_kernel<..., S2 = true>.
     int tapw, dst_h, dst_w, s2;
+    int phase_mode; // ntap = 4, the four phases of an upsample conv in one launch: 1 forward (phase = a tile dimension), 2 data
+                    // gradient (phase = a unit dimension: the tile accumulates all four in registers); weights: the four blocks of layout 2
     int dy_pool;    // weight-gradient mx kernel: dy is given at HALF resolution (the gradient of a fused 2x2 average pool: every
                     // pooled pixel stands for its 2x2 block), dW is scaled by acc_scale
     int act;        // matrix/auxiliary-wave kernel: epilogue activation (0 none, 2 relu, 3 leaky relu 0.2), with acc_scale / out_gain

@@ -100,18 +100,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = g.w >> TWLOG, tiles_y = g.h / TH;
-    const int total_tiles = g.n * tiles_y * tiles_x * g.tiles_n;
-    const int nch = g.cpt >> 2;                                  // 32-channel chunks per tile
+    // The four phases of an upsample conv in ONE launch (NTAP = 4, g.phase_mode): 1 (forward): the phase is a dimension of the
+    // TILE index, next to the cout tile -- the blocks that share an input halo run side by side; the window offset, the destination
+    // parity and the weight block follow the tile's phase.  2 (data gradient): the phase is a dimension of the UNIT index -- a
+    // tile accumulates its four phases x chunks in registers (fp32) and is stored once (the four-launch form added the phases
+    // through the bf16 tensor in memory: three more passes over it).
+    const int pmode = NTAP == 4 ? g.phase_mode : 0;
+    const int total_tiles = g.n * tiles_y * tiles_x * g.tiles_n * (pmode == 1 ? 4 : 1);
+    const int nch = g.cpt >> 2;                                  // 32-channel chunks per tile (and phase)
+    const int nun = pmode == 2 ? 4 * nch : nch;                  // units per tile
     const int vbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int my_tiles = (total_tiles - vbid + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int units = my_tiles * nch;
+    const int units = my_tiles * nun;
     if (units <= 0) return;
 
-    struct TilePos { int img, py0, px0, nt; };
+    struct TilePos { int img, py0, px0, nt, ph; };
     auto tile_pos = [&](int j) -> TilePos {
         int t = vbid + j * (int)gridDim.x;
         TilePos tp;
         tp.nt = t % g.tiles_n; t /= g.tiles_n;
+        tp.ph = 0;
+        if (pmode == 1) { tp.ph = t & 3; t >>= 2; }
         const int txi = t % tiles_x; t /= tiles_x;
         const int tyi = t % tiles_y;
         tp.img = t / tiles_y; tp.py0 = tyi * TH; tp.px0 = txi * TW;
@@ -130,14 +139,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             int ty, tx;
             if (TWLOG == 5) { ty = wm * NI + i; tx = p; }
             else { ty = wm * 2 * NI + 2 * i + (p >> 4); tx = p & 15; }
-            abase[i] = (unsigned)(((ty + g.tap_oy) * HW2 + tx + g.tap_ox) * RS + kg * 16);
+            abase[i] = (unsigned)(((ty + (pmode ? 0 : g.tap_oy)) * HW2 + tx + (pmode ? 0 : g.tap_ox)) * RS + kg * 16);
             sbase[i] = (unsigned)(STG + (ty * TW + tx) * SPITCH + (wn * 64 + 4 * kg) * 2);
         }
         const int lane16 = lane * 16;
+        const int phase_bytes = (g.cout >> 5) * nch * (NPH * 1024);
         const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_raw*>(wp), 0, (g.cout >> 5) * nch * (NPH * 1024), 0x00020000);
-        auto unit_w = [&](int nt, int c, int j) -> int { return ((nt * 4 + wn * 2 + j) * nch + c) * (NPH * 1024); };
-        auto tile_nt = [&](int j) -> int { return (vbid + j * (int)gridDim.x) % g.tiles_n; };
+            const_cast<bf16_raw*>(wp), 0, phase_bytes * (pmode ? 4 : 1), 0x00020000);
+        // tile key: cout tile | phase << 16 (pmode 1); c: unit of the tile = chunk (+ nch * phase in pmode 2)
+        auto unit_ph = [&](int key, int c) -> int { return pmode == 2 ? c / nch : (key >> 16); };
+        auto unit_w = [&](int key, int c, int j) -> int {
+            const int ph = unit_ph(key, c), cc = pmode == 2 ? c - ph * nch : c;
+            return ph * phase_bytes + (((key & 0xffff) * 4 + wn * 2 + j) * nch + cc) * (NPH * 1024);
+        };
+        // window offset of a phase inside the halo: forward (a, b), data gradient (1 - a, 1 - b) (vqk_conv2d_ups_phase)
+        auto phase_off = [&](int ph) -> int {
+            const int a = ph >> 1, b = ph & 1;
+            return pmode == 1 ? (a * HW2 + b) * RS : pmode == 2 ? ((1 - a) * HW2 + (1 - b)) * RS : 0;
+        };
+        auto tile_nt = [&](int j) -> int {
+            const int t = vbid + j * (int)gridDim.x;
+            return (t % g.tiles_n) | (pmode == 1 ? ((t / g.tiles_n) & 3) << 16 : 0);
+        };
         auto wload = [&](int soff) -> frag_t {
             return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(wsrd, lane16, soff, 0));
         };
@@ -159,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         int tj = 0, c = 0, bi = 0;
         for (int u = 0; u < units; ++u) {
             int ntj = tj, nc = c + 1;
-            if (nc == nch) { nc = 0; ntj = tj + 1; }
+            if (nc == nun) { nc = 0; ntj = tj + 1; }
             if (u + 1 >= units) { ntj = tj; nc = c; }            // clamp: the weight prefetch stays unconditional
             const int nxt_nt = (ntj == tj) ? cur_nt : tile_nt(ntj);
             int wnxt[NJ];
@@ -167,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             for (int j = 0; j < NJ; ++j) wnxt[j] = unit_w(nxt_nt, nc, j);
             const char* lbase[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) lbase[i] = smem + bi * BUF + abase[i];
+            for (int i = 0; i < NI; ++i) lbase[i] = smem + bi * BUF + abase[i] + (NTAP == 4 ? phase_off(unit_ph(cur_nt, c)) : 0);
 
             frag_t a[2][NI];
 #pragma unroll
@@ -231,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (c == nch - 1 && !((VQK_MXABL & 4) && g.n > 0)) {
+            if (c == nun - 1 && !((VQK_MXABL & 4) && g.n > 0)) {
                 // park the tile: lane (pixel p, half kg) holds couts j*32 + 8*rq + 4*kg + e of its wave's 64 -> 8-byte pieces
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
@@ -282,8 +305,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                       ((cp == 4 || hp >= HROWS) ? 16 : 0);
         }
     }
-    auto issue_halo = [&](const TilePos& tp, int c, int bufi) {
-        const int base = (((tp.img * g.h_in + ((tp.py0 * g.src_s + g.src_a) >> g.ups)) * g.w_in + ((tp.px0 * g.src_s + g.src_b) >> g.ups)) * g.cin + c * 32) * 2;
+    auto issue_halo = [&](const TilePos& tp, int cu, int bufi) {
+        // pmode 2: unit cu = phase * nch + chunk reads the phase (a, b) of the full-resolution gradient
+        const int uph = pmode == 2 ? cu / nch : 0, c = pmode == 2 ? cu - uph * nch : cu;
+        const int sa = pmode == 2 ? (uph >> 1) : g.src_a, sb = pmode == 2 ? (uph & 1) : g.src_b;
+        const int base = (((tp.img * g.h_in + ((tp.py0 * g.src_s + sa) >> g.ups)) * g.w_in + ((tp.px0 * g.src_s + sb) >> g.ups)) * g.cin + c * 32) * 2;
         const int tb = S2 ? 16 : ((tp.py0 == 0 ? 1 : 0) | (tp.py0 + TH == g.h ? 2 : 0) | (tp.px0 == 0 ? 4 : 0) | (tp.px0 + TW == g.w ? 8 : 0) | 16);
 #pragma unroll
         for (int sl = 0; sl < XS; ++sl) {
@@ -309,8 +335,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     struct OutPos { int pix0, ppix0, co, img, tile; };
     auto out_pos = [&](const TilePos& tp) -> OutPos {
         OutPos o;
-        o.tile = (tp.py0 / TH) * tiles_x + (tp.px0 >> TWLOG);   // tile of its image (deterministic GroupNorm sums: one slot per tile)
-        o.pix0 = (tp.img * g.dst_h + tp.py0 * g.dst_s + g.dst_a) * g.dst_w + tp.px0 * g.dst_s + g.dst_b;
+        o.tile = (tp.py0 / TH) * tiles_x + (tp.px0 >> TWLOG) + (pmode == 1 ? tp.ph * tiles_y * tiles_x : 0);   // tile of its image (deterministic GroupNorm sums: one slot per tile)
+        const int da = pmode == 1 ? (tp.ph >> 1) : g.dst_a, db = pmode == 1 ? (tp.ph & 1) : g.dst_b;
+        o.pix0 = (tp.img * g.dst_h + tp.py0 * g.dst_s + da) * g.dst_w + tp.px0 * g.dst_s + db;
         o.ppix0 = (tp.img * (g.h >> 1) + (tp.py0 >> 1)) * (g.w >> 1) + (tp.px0 >> 1);
         o.co = tp.nt * 128 + slot * 8;
         o.img = tp.img;
@@ -487,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     int ltj = 0, lc = 0, lbuf = 0;
     TilePos ltp = tile_pos(0);
     auto advance = [&]() {
-        if (++lc == nch) { lc = 0; ++ltj; ltp = tile_pos(ltj < my_tiles ? ltj : my_tiles - 1); }
+        if (++lc == nun) { lc = 0; ++ltj; ltp = tile_pos(ltj < my_tiles ? ltj : my_tiles - 1); }
         lbuf = lbuf == NBUF - 1 ? 0 : lbuf + 1;
     };
     issue_halo(ltp, lc, lbuf); advance();                        // unit 0
@@ -514,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         }
         if (flush) { flush_stats(); flush = false; }
         if (pending && !((VQK_MXABL & 2) && g.n > 0)) { drain(done, rv); flush = g.gn_ws != nullptr; }   // tile parked during unit u-1
-        pending = (c == nch - 1);                                // unit u ends a tile: its residual is requested now,
+        pending = (c == nun - 1);                                // unit u ends a tile: its residual is requested now,
         if (pending) {                                           // the tile itself is drained in the next interval
             done = out_pos(cur);
             if (res) load_res(done, rv);
@@ -526,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         unit_barrier();
-        if (++c == nch) { c = 0; ++tj; if (tj < my_tiles) cur = tile_pos(tj); }
+        if (++c == nun) { c = 0; ++tj; if (tj < my_tiles) cur = tile_pos(tj); }
     }
     if (flush) flush_stats();
     if (pending) {
@@ -581,7 +608,7 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     const int qmode = VQK_TUNE("MX_QUARTER", 1);   // 1: layers with <= 2 output-channel tiles, 2: every half-tile layer
     const bool quarter = half && qmode && (g.tiles_n <= 2 || qmode >= 2) && (twlog == 4 ? (g.h % 4) == 0 : (g.h % 2) == 0);
     const int th = (quarter ? 64 : half ? 128 : 256) >> twlog;
-    const int total = g.n * (g.h / th) * (g.w >> twlog) * g.tiles_n;
+    const int total = g.n * (g.h / th) * (g.w >> twlog) * g.tiles_n * ((g.ntap == 4 && g.phase_mode == 1) ? 4 : 1);
     // COMM_CUS (data parallel, world > 1): CUs left to the collective's kernels.  A persistent grid of one block per CU that
     // finds some CUs taken runs its last blocks as a SECOND wave (up to 2x the kernel time); a grid of cus - COMM_CUS blocks
     // runs as one wave on what is free (tools/comm_probe.py, profiles/round4_comm_probe.txt)
