@@ -132,6 +132,7 @@ _MX_ON = os.environ.get('VQK_MX', '1') != '0'
 _THIN_OUT = os.environ.get('VQK_THIN_OUT', '1') != '0'
 _MX_MIN_TILES = int(os.environ.get('VQK_MX_MIN_TILES', '1'))
 _WGMX_ON = os.environ.get('VQK_WGMX', '1') != '0'
+_UPS_MERGE = os.environ.get('VQK_UPS_MERGE', '1') != '0'      # (the library's tuning slot of the same name: one launch per phase-form conv)
 
 
 def _fprop_kernel_name(dtype, wlayout: int, shape=None) -> str:
@@ -390,7 +391,7 @@ def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int =
     st = _timed('conv3x3_mx_kernel<bf16>' + (f' {cin}->{cout}@{y.shape[2]}x{y.shape[3]} phase-{"dgrad" if backward else "fwd"}' if _EVENT_SHAPES else ''), flops,
                 lambda: _native.lib().vqk_conv2d_ups_phase(dcode(x.dtype), x.data_ptr(), wq4.data_ptr(), _p(bias), y.data_ptr(),
                                                            n, h, w, cin, cout, int(backward), _p(ws), gn_groups,
-                                                           zero_page(x.device).data_ptr(), _stream()), nbytes, launches=4,
+                                                           zero_page(x.device).data_ptr(), _stream()), nbytes, launches=1 if _UPS_MERGE else 4,
                 exec_flops=flops * 4.0 / 9.0)
     if st == _native.ERR_SHAPE:
         return None
