@@ -20,6 +20,8 @@ BATCHED_DISC = os.environ.get('VQK_BATCHED_DISC', '1') == '1'    # discriminator
 # activations the first one saved (same logits bit for bit, same gradients up to the summation order of the weight gradients:
 # two batches of n instead of one of 2n).  0: the two-pass form.
 SHARE_FAKE_PASS = os.environ.get('VQK_SHARE_FAKE_PASS', '1') == '1'
+LPIPS_SIDE_STREAM = os.environ.get('VQK_LPIPS_SIDE_STREAM', '1') == '1'
+DISC_REAL_SIDE_STREAM = os.environ.get('VQK_DISC_REAL_SIDE_STREAM', '1') == '1'
 
 _MODE = {'hinge': 0, 'non-saturating': 1}
 
@@ -60,10 +62,24 @@ class VQLPIPSWithDiscriminator(nn.Module):
     def forward_autoencoder(self, quantizer_loss, images, reconstructions, current_epoch: int, last_layer=None):
         n, c, h, w = reconstructions.shape
         l1_loss, l2_loss = ops.ReconLossFn.apply(reconstructions, images, float(n * 3 * h * w))
-        p_loss = self.perceptual_loss(images, reconstructions)
-        nll_loss = l1_loss * self.l1_weight + l2_loss * self.l2_weight + p_loss * self.perceptual_weight
-        if current_epoch >= self.adversarial_start_epoch:
+        adversarial = current_epoch >= self.adversarial_start_epoch
+        side = None
+        if LPIPS_SIDE_STREAM and adversarial and reconstructions.is_cuda:
+            # LPIPS (two VGG16 passes) and the discriminator pass over the reconstruction are independent until their gradients
+            # meet at the reconstruction: LPIPS is issued on a second stream -- autograd runs its backward on that stream too --
+            # so the under-filled small-map launches and the bandwidth-bound passes of one chain run next to the other's convs
+            main, side = torch.cuda.current_stream(), ops.aux_stream(reconstructions.device, 'lpips')
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                p_loss = self.perceptual_loss(images, reconstructions)
+        else:
+            p_loss = self.perceptual_loss(images, reconstructions)
+        if adversarial:
             logits_fake = self.discriminator(reconstructions)
+        if side is not None:
+            main.wait_stream(side)
+        nll_loss = l1_loss * self.l1_weight + l2_loss * self.l2_weight + p_loss * self.perceptual_weight
+        if adversarial:
             self.shared_fake_logits = logits_fake if (SHARE_FAKE_PASS and self.training) else None
             g_loss = generator_loss(logits_fake, loss_type=self.adversarial_loss_type)
             if self.training and self.use_adaptive_g_weight:
@@ -95,8 +111,19 @@ class VQLPIPSWithDiscriminator(nn.Module):
             if shared is not None and shared.shape[0] == reconstructions.shape[0]:
                 # (the caller restricts the backward to the discriminator's parameters: the graph behind `shared` also leads
                 # into the decoder)
-                logits_real = self.discriminator(images, double_backward=compute_r1)
                 logits_fake = shared
+                if DISC_REAL_SIDE_STREAM and images.is_cuda:
+                    # the real pass on a second stream: autograd runs its backward there, next to the backward of the fake pass
+                    # (whose forward ran on the main stream in the generator half) -- two independent chains through the same weights
+                    main, side = torch.cuda.current_stream(), ops.aux_stream(images.device, 'disc_real')
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        logits_real = self.discriminator(images, double_backward=compute_r1)
+                        r1_term = self.calculate_r1_regularization_term(logits_real, images, compute_r1)
+                    main.wait_stream(side)
+                    d_loss = discriminator_loss(logits_real, logits_fake, loss_type=self.adversarial_loss_type)
+                    return d_loss + r1_term, d_loss, r1_term
+                logits_real = self.discriminator(images, double_backward=compute_r1)
             elif BATCHED_DISC and not compute_r1 and images.shape[0] == reconstructions.shape[0] and images.shape[2:] == reconstructions.shape[2:]:
                 # real | fake through the discriminator as ONE batch (same logits: only the minibatch-stddev layer couples
                 # samples and it groups inside each half): half the launches, no per-parameter gradient accumulation

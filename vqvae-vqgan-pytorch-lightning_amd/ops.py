@@ -967,6 +967,14 @@ def _side_stream(device) -> torch.cuda.Stream:
     return st
 
 
+def aux_stream(device, tag: str) -> torch.cuda.Stream:
+    """a named extra stream per device (independent branches of a step, e.g. LPIPS next to the discriminator)"""
+    st = _SIDE_STREAMS.get((device, tag))
+    if st is None:
+        st = _SIDE_STREAMS[(device, tag)] = torch.cuda.Stream(device=device)
+    return st
+
+
 # hipGraph replay maps the captured nodes to hardware queues by a depth-first walk in which the FIRST successor of a node
 # (in capture order) inherits its queue and every further successor gets another one.  The weight-gradient launch is
 # captured right behind the data-gradient conv it forks from, so the replay runs conv -> wgrad -> conv on one queue and the
