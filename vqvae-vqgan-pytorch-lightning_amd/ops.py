@@ -190,7 +190,7 @@ class _PackEntry:
 
 
 _PACK_CACHE: dict = {}          # (data_ptr, o, i, k, transpose, layout, dtype) -> _PackEntry
-_PACK_TABLE = None              # (tuple of keys, device int64 [n, 8]) of the last repack launch
+_PACK_TABLE = None              # {tuple of keys: device int64 [n, 8]} descriptor tables of the repack launches
 
 
 def _pack_stamp(weight):
@@ -251,11 +251,14 @@ def repack_owned(owner=None) -> int:
     if not keys:
         return 0
     keys = tuple(keys)
-    if _PACK_TABLE is None or _PACK_TABLE[0] != keys:
+    if _PACK_TABLE is None:
+        _PACK_TABLE = {}
+    table = _PACK_TABLE.get(keys)                        # one device table per set of operands (two optimizers alternate: VQ-GAN)
+    if table is None:
+        if len(_PACK_TABLE) >= 8:
+            _PACK_TABLE.clear()
         dev = _PACK_CACHE[keys[0]].dst.device
-        table = torch.tensor([_PACK_CACHE[k].desc for k in keys], dtype=torch.int64).to(dev)
-        _PACK_TABLE = (keys, table)
-    table = _PACK_TABLE[1]
+        table = _PACK_TABLE[keys] = torch.tensor([_PACK_CACHE[k].desc for k in keys], dtype=torch.int64).to(dev)
     _native.check(_native.lib().vqk_conv_pack_multi(table.data_ptr(), len(keys), 32, _stream()), 'conv_pack_multi')
     for k in keys:
         ent = _PACK_CACHE[k]
