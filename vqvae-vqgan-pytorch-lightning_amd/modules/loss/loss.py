@@ -112,7 +112,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
                 # (the caller restricts the backward to the discriminator's parameters: the graph behind `shared` also leads
                 # into the decoder)
                 logits_fake = shared
-                if DISC_REAL_SIDE_STREAM and images.is_cuda:
+                if DISC_REAL_SIDE_STREAM and images.is_cuda and not ops.DETERMINISTIC:     # (deterministic mode: the two chains' weight-gradient sums must meet in a fixed order)
                     # the real pass on a second stream: autograd runs its backward there, next to the backward of the fake pass
                     # (whose forward ran on the main stream in the generator half) -- two independent chains through the same weights
                     main, side = torch.cuda.current_stream(), ops.aux_stream(images.device, 'disc_real')

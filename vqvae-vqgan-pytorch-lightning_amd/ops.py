@@ -253,12 +253,15 @@ def repack_owned(owner=None) -> int:
     keys = tuple(keys)
     if _PACK_TABLE is None:
         _PACK_TABLE = {}
-    table = _PACK_TABLE.get(keys)                        # one device table per set of operands (two optimizers alternate: VQ-GAN)
+    # one device table per set of DESCRIPTORS (two optimizers alternate in the VQ-GAN step).  Keyed by the descriptors themselves:
+    # a later model may get the same parameter addresses (same keys) with other destination buffers
+    sig = tuple(tuple(int(v) for v in _PACK_CACHE[k].desc) for k in keys)
+    table = _PACK_TABLE.get(sig)
     if table is None:
         if len(_PACK_TABLE) >= 8:
             _PACK_TABLE.clear()
         dev = _PACK_CACHE[keys[0]].dst.device
-        table = _PACK_TABLE[keys] = torch.tensor([_PACK_CACHE[k].desc for k in keys], dtype=torch.int64).to(dev)
+        table = _PACK_TABLE[sig] = torch.tensor([list(d) for d in sig], dtype=torch.int64).to(dev)
     _native.check(_native.lib().vqk_conv_pack_multi(table.data_ptr(), len(keys), 32, _stream()), 'conv_pack_multi')
     for k in keys:
         ent = _PACK_CACHE[k]
