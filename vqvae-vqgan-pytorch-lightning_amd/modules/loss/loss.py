@@ -88,6 +88,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
                 g_weight = self.generator_weight
             loss = nll_loss + g_loss * g_weight + quantizer_loss
         else:
+            self.shared_fake_logits = None                   # (no discriminator pass in this step: nothing to share, nothing kept alive)
             g_loss = torch.zeros_like(nll_loss, requires_grad=False)
             g_weight = 0.
             loss = nll_loss + quantizer_loss
