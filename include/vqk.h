@@ -206,6 +206,11 @@ int vqk_conv2d_wgrad_pooled_dy(int dtype, const void* x, const void* dy_pooled, 
 int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
                              int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out,
                              const void* zeros, void* stream);
+/* the same with dW += scale * (the gradient): a layer whose backward carries a scalar gain (the discriminator's linear skip convs:
+ * weight gain x output gain) accumulates straight into an optimizer's gradient arena -- no zeroed temporary, scale pass and add */
+int vqk_conv2d_wgrad_general_scaled(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
+                                    int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out, float scale,
+                                    const void* zeros, void* stream);
 /* The STRIDE-2 3x3 conv without padding of the StyleGAN2 discriminator's down-sampling layers (the reference's
  * conv2d_resample.py:119-122: upfirdn2d blur with padding, then F.conv2d(stride=2)) and its data gradient on the
  * matrix/auxiliary-wave kernel (bf16).  vqk_conv2d_s2_supported: 1 when the shape is served (backward = 0: the conv, Cin % 64

@@ -56,6 +56,7 @@ _PROTOS = {
     'vqk_conv2d_s2_dgrad': [I, P, P, P, P, I, I, I, I, I, F, P, P],
     'vqk_conv2d_general': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, I, P, P],
     'vqk_conv2d_wgrad_general': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P],
+    'vqk_conv2d_wgrad_general_scaled': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, P, P],
     'vqk_conv_weight_layout': [I, I, I, I, I, I, I, I],
     'vqk_conv_pack_weights': [P, P, I, I, I, I, I, I, P],
     'vqk_conv_pack_multi': [P, I, I, P],

@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<bf16_raw>(const bf16
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < g.cout) atomicAdd(dw + ((int64_t)co * taps + tap) * g.cin + ci, acc[i][j][r]);
+                if (co < g.cout) atomicAdd(dw + ((int64_t)co * taps + tap) * g.cin + ci, acc[i][j][r] * g.acc_scale);
             }
     }
 }
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_db_kernel(const bf16_raw* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < g.cout) atomicAdd(dw + ((int64_t)co * taps + tap) * g.cin + ci, acc[i][j][r]);
+                if (co < g.cout) atomicAdd(dw + ((int64_t)co * taps + tap) * g.cin + ci, acc[i][j][r] * g.acc_scale);
             }
     }
 }
@@ -1435,7 +1435,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel<float>(const float* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < g.cout) atomicAdd(dw + ((int64_t)co * taps + tap) * g.cin + ci, acc[i][j][r]);
+                if (co < g.cout) atomicAdd(dw + ((int64_t)co * taps + tap) * g.cin + ci, acc[i][j][r] * g.acc_scale);
             }
     }
 }
@@ -1615,7 +1615,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(const bf16_r
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
-                if (co < g.cout) atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r]);
+                if (co < g.cout) atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r] * g.acc_scale);
             }
     }
 }
@@ -1763,7 +1763,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(const bf16_ra
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
-            atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r]);
+            atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r] * g.acc_scale);
         }
 }
 
@@ -2629,6 +2629,7 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
     if (rc) return rc;
     const int epc = dtype == VQK_F32 ? 4 : 8;
     VQK_REQUIRE(cout % epc == 0, VQK_ERR_SHAPE);
+    g.acc_scale = dy_scale;                                      // dW += dy_scale * (x^T dy): every kernel below scales its partial sums
     const bool plain = stride == 1 && pad == (ksize >> 1) && h_out == g.h && w_out == g.w;
     if (!plain) {
         g.stride = stride; g.pad = pad;
@@ -2771,6 +2772,12 @@ int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw
                              int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out, const void* zeros,
                              void* stream) {
     return wgrad_general(dtype, x, dy, dw, n, h_in, w_in, cin, cout, ksize, stride, pad, mode, h_out, w_out, zeros, stream);
+}
+
+int vqk_conv2d_wgrad_general_scaled(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
+                                    int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out, float scale,
+                                    const void* zeros, void* stream) {
+    return wgrad_general(dtype, x, dy, dw, n, h_in, w_in, cin, cout, ksize, stride, pad, mode, h_out, w_out, zeros, stream, 0, scale);
 }
 
 int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream) {

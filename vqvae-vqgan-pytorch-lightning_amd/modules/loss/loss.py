@@ -113,7 +113,12 @@ class VQLPIPSWithDiscriminator(nn.Module):
                 # (the caller restricts the backward to the discriminator's parameters: the graph behind `shared` also leads
                 # into the decoder)
                 logits_fake = shared
-                if DISC_REAL_SIDE_STREAM and images.is_cuda and not ops.DETERMINISTIC:     # (deterministic mode: the two chains' weight-gradient sums must meet in a fixed order)
+                # Not in R1 steps: there the real pass is layer-by-layer and differentiated twice, so one parameter can receive a
+                # RETURNED gradient (autograd's read-modify-write accumulation) from one chain while the other chain's kernels add
+                # to it atomically from the other stream -- lost updates (seen as a 10-80 % error of b8.conv0.weight's gradient in
+                # 8 of 30 golden steps).  Without R1 both chains run the same nodes: a parameter is accumulated atomically by both
+                # or returned by both (one AccumulateGrad node, one stream).  Not in deterministic mode either (fixed summation order).
+                if DISC_REAL_SIDE_STREAM and images.is_cuda and not ops.DETERMINISTIC and not compute_r1:
                     # the real pass on a second stream: autograd runs its backward there, next to the backward of the fake pass
                     # (whose forward ran on the main stream in the generator half) -- two independent chains through the same weights
                     main, side = torch.cuda.current_stream(), ops.aux_stream(images.device, 'disc_real')

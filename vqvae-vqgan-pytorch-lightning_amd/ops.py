@@ -186,7 +186,30 @@ def pack_weights(w_mem_f32, dtype, cout, cin, ksize, transpose: bool, layout: in
 
 
 class _PackEntry:
-    __slots__ = ('wref', 'src', 'dst', 'desc', 'stamp')
+    __slots__ = ('wref', 'src', 'dst', 'desc', 'stamp', 'ready')
+
+
+def _pack_written(entries) -> None:
+    """``entries`` were (re)written by a launch on the current stream: a use from ANOTHER stream has to wait for it.  (The VQ-GAN
+    step runs LPIPS and the discriminator's real pass on second streams; a backward operand packed lazily by one of two
+    concurrent chains was read by the other while the pack kernel was still running -- one golden-step failure in twelve runs.)"""
+    if torch.cuda.is_current_stream_capturing():
+        ready = None                                     # (captured work is ordered by the capture; settled steps pack nothing lazily)
+    else:
+        ev = torch.cuda.Event()
+        ev.record()
+        ready = (torch.cuda.current_stream(), ev)
+    for ent in entries:
+        ent.ready = ready
+
+
+def _pack_use(ent) -> torch.Tensor:
+    r = ent.ready
+    if r is not None:
+        cur = torch.cuda.current_stream()
+        if cur != r[0] and not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(r[1])
+    return ent.dst
 
 
 _PACK_CACHE: dict = {}          # (data_ptr, o, i, k, transpose, layout, dtype) -> _PackEntry
@@ -217,18 +240,20 @@ def packed_weight(weight, cin_pad: int, cout_pad: int, dtype, ksize: int, transp
     if ent is not None and ent.wref() is not weight:
         ent = None                                       # the address was recycled by another parameter
     if ent is not None and ent.stamp == stamp:
-        return ent.dst
+        return _pack_use(ent)
     if ent is None:
         dc, di = (i, o) if transpose else (o, i)
         ent = _PackEntry()
         ent.wref, ent.src = weakref.ref(weight), w.permute(0, 2, 3, 1).reshape(-1)
         ent.dst = torch.empty(_native.lib().vqk_conv_packed_elems(dc, di, ksize, layout), dtype=dtype, device=w.device)
         ent.desc = [ent.src.data_ptr(), ent.dst.data_ptr(), dcode(dtype), o, i, ksize, int(transpose), layout]
+        ent.ready = None
         _PACK_CACHE[key] = ent
     st = _native.lib().vqk_conv_pack_weights(ent.src.data_ptr(), ent.dst.data_ptr(), dcode(dtype), o, i, ksize,
                                              int(transpose), layout, _stream())
     _native.check(st, 'conv_pack_weights')
     ent.stamp = stamp
+    _pack_written((ent,))
     return ent.dst
 
 
@@ -267,6 +292,7 @@ def repack_owned(owner=None) -> int:
     for k in keys:
         ent = _PACK_CACHE[k]
         ent.stamp = _pack_stamp(ent.wref())
+    _pack_written([_PACK_CACHE[k] for k in keys])
     return len(keys)
 
 
@@ -1868,10 +1894,15 @@ def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None
     # weight gradient straight into the optimizer's flat gradient arena (unpadded layers of a FlatAdamW-owned module): the
     # 1/sqrt(fan_in) weight gain then rides in t (t' = wgain * t: dx = dgrad(t', W), dW += wgrad(x, t'), db = colsum(t') / wgain)
     # -- no zero-filled temporary, no scale pass, no accumulate pass per parameter
-    tgt = None
-    if (want_dw and act != 0 and dy_dtype == dt and cout_pad == o and cin == i and wgain > 0.0
+    tgt = tgt_lin = None
+    if (want_dw and dy_dtype == dt and cout_pad == o and cin == i and wgain > 0.0
             and not torch.is_grad_enabled()):            # (a create_graph pass -- R1's inner autograd.grad -- must not touch .grad)
-        tgt = direct_grad(weight)
+        if act != 0:
+            tgt = direct_grad(weight)
+        elif make_t is None and DIRECT_LINEAR_WGRAD:
+            # linear layer (skip convs, the last fully connected layer): t = dy is no pass, the gains ride in the weight-gradient
+            # kernel's own scale (vqk_conv2d_wgrad_general_scaled) -- also straight into the arena
+            tgt_lin = direct_grad(weight)
     fold = float(wgain) if tgt is not None else 1.0
     if make_t is not None:
         if want_db:
@@ -1899,6 +1930,10 @@ def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None
         _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tc.detach().data_ptr(), tgt.data_ptr(), n, h, w, cin,
                                                    cout_pad, k, stride, pad, 0, h_out, w_out,
                                                    zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
+    elif tgt_lin is not None:
+        _native.check(lib.vqk_conv2d_wgrad_general_scaled(dcode(dt), x.data_ptr(), tc.detach().data_ptr(), tgt_lin.data_ptr(), n, h, w,
+                                                          cin, cout_pad, k, stride, pad, 0, h_out, w_out, float(wgain) * gscale,
+                                                          zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
     elif want_dw:
         tcd = tc.detach()
         dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=x.device)
@@ -2201,6 +2236,7 @@ class AddFn(torch.autograd.Function):
 
 
 FUSE_DISC_BLOCK = os.environ.get('VQK_FUSE_DISC_BLOCK', '1') != '0'
+DIRECT_LINEAR_WGRAD = os.environ.get('VQK_DIRECT_LINEAR_WGRAD', '1') != '0'   # linear ConvActFn layers: scaled weight gradient straight into the arena
 DIRECT_BIAS_GRAD = os.environ.get('VQK_DIRECT_BIAS_GRAD', '1') != '0'    # ConvActFn: bias gradient straight into the optimizer's arena
 
 
