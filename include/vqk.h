@@ -179,6 +179,12 @@ int vqk_conv2d_fprop_pooled(int dtype, const void* x, const void* w, const float
 int vqk_conv2d_fprop_gnstats(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* y,
                              int n, int h_in, int w_in, int cin, int cout, int ksize, int ups, int pool, float pool_scale,
                              double* gn_ws, int groups, const void* zeros, void* stream);
+/* The 3x3 conv on the padded 3-channel image (the encoder's first conv, autoencoder.py:132; x [N][H][W][8], w [Cout][3][3][8] in the compute
+ * dtype, layout 0) with the GroupNorm sums of its output left in gn_ws as vqk_conv2d_fprop_gnstats leaves them.  Served: bf16,
+ * Cout = 128 in 32 groups, W % 32 == 0, not in deterministic mode; VQK_ERR_SHAPE otherwise (nothing launched: callers run
+ * vqk_conv2d_fprop and vqk_gn_forward). */
+int vqk_conv2d_thin_in_gnstats(int dtype, const void* x, const void* w, const float* bias, void* y, int n, int h, int wd, int cout,
+                               double* gn_ws, int groups, void* stream);
 /* The nearest-x2 upsample + 3x3 conv of autoencoder.py:104-106 in PHASE form: output pixel (2i+a, 2j+b) only sees a 2x2
  * window of the low-resolution input with pre-summed weights, so the conv runs as four 2x2-tap launches (4/9 of the
  * multiply-adds).  w4: the operand of vqk_conv_pack_weights(..., layout 2) -- transpose = 0 for backward = 0 (x [N][h][w][Cin]

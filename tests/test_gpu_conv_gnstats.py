@@ -54,6 +54,33 @@ def test_fused_stats_match_separate_pass(n, cin, cout, h, w, ups, hb, hr, pool):
     assert float(ws.abs().max()) == 0.0, 'the GroupNorm workspace must be left zero'
 
 
+@pytest.mark.parametrize('n,h,w', [(4, 128, 128), (32, 64, 64), (3, 96, 64), (2, 256, 256)])
+def test_thin_in_conv_leaves_the_sums_of_its_output(n, h, w):
+    """the encoder's first conv (padded 3-channel image -> 128 channels, autoencoder.py:132) with the sums for the first
+    ResBlock's GroupNorm in its store loop (vqk_conv2d_thin_in_gnstats) against conv + separate statistics pass"""
+    g = torch.Generator(device=DEV).manual_seed(n + h)
+    x = torch.zeros(n, 8, h, w, device=DEV)
+    x[:, :3] = torch.randn(n, 3, h, w, device=DEV, generator=g)
+    x = x.to(BF).contiguous(memory_format=CL)
+    wt = torch.zeros(128, 3, 3, 8, device=DEV)
+    wt[..., :3] = torch.randn(128, 3, 3, 3, device=DEV, generator=g) / 5.0
+    wq = ops.pack_weights(wt.reshape(-1), BF, 128, 8, 3, False, 0)
+    gw = torch.randn(128, device=DEV, generator=g)
+    gb = torch.randn(128, device=DEV, generator=g)
+    y_ref = ops.raw_conv_fprop(x, wq, None, None, 3, False, 0, BF, 128, 0)
+    a_ref, st_ref = ops.raw_gn_forward(y_ref, gw, gb, 32, 1e-6, True)
+    y = ops.raw_conv_thin_in_gnstats(x, wq, None, 128, 32)
+    assert y is not None, 'the fused kernel must serve this shape'
+    a, st = ops.raw_gn_forward(y, gw, gb, 32, 1e-6, True, presummed=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    torch.testing.assert_close(st.view(-1, 2)[:, 0], st_ref.view(-1, 2)[:, 0], rtol=0, atol=2e-5)
+    torch.testing.assert_close(st.view(-1, 2)[:, 1], st_ref.view(-1, 2)[:, 1], rtol=2e-5, atol=0)
+    assert float((a.float() - a_ref.float()).norm() / a_ref.float().norm()) < 1e-4
+    ws = ops._gn_ws(x.device, n * 32 * 2 + n)
+    assert float(ws.abs().max()) == 0.0, 'the GroupNorm workspace must be left zero'
+
+
 def test_not_served_returns_none():
     x = torch.randn(1, 128, 32, 32, device=DEV).to(BF).contiguous(memory_format=CL)     # 32x32 map: single-kernel GroupNorm territory
     wq = ops.pack_weights(torch.randn(128 * 9 * 128, device=DEV) * 0.03, BF, 128, 128, 3, False, 1)

@@ -988,7 +988,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(const bf16_raw* 
 // per lane (tap 2s + lane/32; neighbours hit L1/L2), the weights live in registers for the whole kernel, and the
 // output tile is transposed through LDS so that every store instruction writes 1 KiB of consecutive bytes.
 // ------------------------------------------------------------------------------------------------
-template <int NJ>
+// STATS (round 4: the encoder's first conv, autoencoder.py:132 -> the first ResBlock's GroupNorm): the GroupNorm sums of the stored
+// output ride in the store loop (g.gn_ws, 4 channels per group, Cout = NJ*32).  A wave then owns tiles of ONE image (waves_per_image
+// waves sweep an image together) and adds its sums once, at the end: 64 fp64 atomics per wave.
+template <int NJ, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(const bf16_raw* __restrict__ x,
                                                                  const bf16_raw* __restrict__ wgt,
                                                                  const float* __restrict__ bias,
@@ -1036,17 +1039,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(const bf16_raw*
             a[s5] = __builtin_bit_cast(bf16x8_t, ok ? ld : zero4);
         }
     };
-    int t = (int)blockIdx.x * 4 + wave;
+    int t = (int)blockIdx.x * 4 + wave, t_step = nw, t_end = total, img_s = 0;
+    if constexpr (STATS) {                                       // (the launcher made nw a multiple of n and of the tiles of an image)
+        const int wpi = nw / g.n, tpi = g.h * xb;
+        img_s = t / wpi;
+        t = img_s * tpi + (t - img_s * wpi); t_step = wpi; t_end = (img_s + 1) * tpi;
+    }
+    float sga = 0.f, sqa = 0.f, sgb = 0.f, sqb = 0.f;            // STATS: sum / sum of squares of channels 0-3 / 4-7 of this lane's slot
     float* bl = reinterpret_cast<float*>(smem + 4 * 32 * RS);     // the block's NJ*32 biases (read as float4 in the epilogue)
     if (tid < NJ * 32) bl[tid] = (bias && cout_base + tid < g.cout) ? bias[cout_base + tid] : 0.0f;
     __syncthreads();
-    if (t >= total) return;
+    if (t >= t_end) return;
     bf16x8_t a[5], an[5];
     load_a(t, a);
-    for (; t < total; t += nw) {
+    for (; t < t_end; t += t_step) {
         const int xs = t % xb;
         const int row = t / xb;
-        const int tn = t + nw < total ? t + nw : t;              // next tile's operand in flight during this one
+        const int tn = t + t_step < t_end ? t + t_step : t;      // next tile's operand in flight during this one
         load_a(tn, an);
         f32x16 acc[NJ];
 #pragma unroll
@@ -1091,6 +1100,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(const bf16_raw*
                 const int pr = o / (NJ * 64), pb = o - pr * (NJ * 64);
                 const u32x4 v = *reinterpret_cast<const u32x4*>(lds + pr * RS + pb);
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(ybase + o));   // whole lines, written once: 146 -> 105 us
+                if constexpr (STATS) {
+                    // the lane's slot (lane & 15: 8 channels = two groups) is the same in every iteration; packed-pair dot
+                    // products against (1, 1) / against itself, as in the role-split kernel's drain (conv_mx.hip)
+                    const unsigned ones2 = 0x3f803f80u;
+                    const unsigned d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];
+                    asm("v_dot2c_f32_bf16 %0, %4, %8\n\tv_dot2c_f32_bf16 %1, %4, %4\n\tv_dot2c_f32_bf16 %2, %6, %8\n\t"
+                        "v_dot2c_f32_bf16 %3, %6, %6\n\tv_dot2c_f32_bf16 %0, %5, %8\n\tv_dot2c_f32_bf16 %1, %5, %5\n\t"
+                        "v_dot2c_f32_bf16 %2, %7, %8\n\tv_dot2c_f32_bf16 %3, %7, %7\n\ts_nop 0"
+                        : "+v"(sga), "+v"(sqa), "+v"(sgb), "+v"(sqb) : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(ones2));
+                }
             }
         } else {
 #pragma unroll
@@ -1105,6 +1124,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(const bf16_raw*
         }
 #pragma unroll
         for (int s5 = 0; s5 < 5; ++s5) a[s5] = an[s5];
+    }
+    if constexpr (STATS) {
+        asm volatile("s_nop 3" : "+v"(sga), "+v"(sqa), "+v"(sgb), "+v"(sqb));       // (the dot chain is closed before the sums are read)
+        sga += __shfl_xor(sga, 16, 64); sga += __shfl_xor(sga, 32, 64);
+        sqa += __shfl_xor(sqa, 16, 64); sqa += __shfl_xor(sqa, 32, 64);
+        sgb += __shfl_xor(sgb, 16, 64); sgb += __shfl_xor(sgb, 32, 64);
+        sqb += __shfl_xor(sqb, 16, 64); sqb += __shfl_xor(sqb, 32, 64);
+        if (lane < 16) {
+            const int groups = g.cout >> 2;
+            double* dst = g.gn_ws + ((int64_t)img_s * groups + ((cout_base >> 2) + 2 * lane)) * 2;
+            atomicAdd(dst, (double)sga); atomicAdd(dst + 1, (double)sqa);
+            atomicAdd(dst + 2, (double)sgb); atomicAdd(dst + 3, (double)sqb);
+        }
     }
 }
 
@@ -2392,6 +2424,30 @@ int vqk_conv2d_fprop_gnstats(int dtype, const void* x, const void* w, const floa
     g.gn_ws = gn_ws; g.gn_cpg = cout / groups;
     if (g_det) g.gn_part_nblk = (g.h * g.w) / 256;          // deterministic mode: one slot per 256-pixel tile of the image
     return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, 0, 1, vqk_stream(stream));
+}
+
+int vqk_conv2d_thin_in_gnstats(int dtype, const void* x, const void* w, const float* bias, void* y, int n, int h, int wd, int cout,
+                               double* gn_ws, int groups, void* stream) {
+    VQK_REQUIRE(x && w && y && gn_ws, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w) && vqk_aligned16(y), VQK_ERR_ALIGN);
+    VQK_REQUIRE(dtype == VQK_BF16, VQK_ERR_DTYPE);
+    VQK_REQUIRE(n > 0 && h > 0 && wd > 0, VQK_ERR_SHAPE);
+    // served: 128 output channels in 32 groups (4 channels per group), whole 32-pixel row segments, not in deterministic mode
+    // (its per-tile slots exist on the role-split kernel only), and a wave count that splits evenly over images and over an image's tiles
+    VQK_REQUIRE(cout == 128 && groups == 32 && (wd % 32) == 0 && !g_det && g_force_variant != 0, VQK_ERR_SHAPE);
+    ConvGeom g;
+    const int rc = make_geom(g, dtype, n, h, wd, 8, cout, 3, 0);
+    if (rc) return rc;
+    const int tpi = h * (wd >> 5);
+    int wpi = 0;
+    for (int c = 4096 / n; c >= 1; --c)
+        if (tpi % c == 0 && ((n * c) & 3) == 0) { wpi = c; break; }
+    VQK_REQUIRE(wpi > 0, VQK_ERR_SHAPE);
+    g.gn_ws = gn_ws; g.gn_cpg = 4;
+    hipLaunchKernelGGL((conv3x3_thin_in_kernel<4, true>), dim3((unsigned)(n * wpi / 4)), dim3(256), 4 * 32 * (4 * 64 + 8) + 4 * 128,
+                       vqk_stream(stream), (const bf16_raw*)x, (const bf16_raw*)w, bias, (bf16_raw*)y, g, 0, 0);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
 }
 
 int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w,

@@ -156,11 +156,12 @@ class Encoder(nn.Module):
         """``cut_after``: index into ``self.blocks`` (``shallow_split()``): the autograd graph is cut behind that module and
         the pair (tensor before the cut, detached leaf after it) is left in ``self.last_cut``"""
         x = _to_internal(x, self.compute_dtype)
-        x = self.conv_in(x)
         mods = list(self.blocks)
         i = 0
         # every ResBlock / pooled output is read next by a 32-group GroupNorm (the next block's norm1, finally self.norm)
         gn = self.norm.num_groups
+        # ... and so is conv_in's output when a ResBlock follows (its norm1): the sums ride in the first conv's store loop
+        x = self.conv_in(x, next_gn=gn if (mods and isinstance(mods[0], ResBlock)) else 0)
         self.last_cut = None
         while i < len(mods):                                  # ResBlock + Downsample pairs run as one fused op
             step = 2 if (isinstance(mods[i], ResBlock) and i + 1 < len(mods) and isinstance(mods[i + 1], Downsample)) else 1

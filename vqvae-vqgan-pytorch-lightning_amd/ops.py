@@ -398,6 +398,31 @@ def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: 
     return y
 
 
+THIN_IN_GNSTATS = os.environ.get('VQK_THIN_IN_GNSTATS', '1') != '0'
+
+
+def raw_conv_thin_in_gnstats(x, wq, bias, cout: int, groups: int):
+    """the 3x3 conv on the padded 3-channel image (the encoder's first conv) with the GroupNorm sums of its output in the
+    stream's workspace (vqk_conv2d_thin_in_gnstats); None when not served (nothing launched)"""
+    _require_gpu(x)
+    n, cin, h, w = x.shape
+    if (not FUSE_GN_STATS or not THIN_IN_GNSTATS or DETERMINISTIC or x.dtype != torch.bfloat16 or cin != 8 or h * w <= 1024):
+        return None
+    if _PENDING_GN is not None:
+        _claim_presummed(x, -1)
+    y = empty_nhwc(n, cout, h, w, x.dtype, x.device)
+    ws = _gn_sum_target(x.device, n, groups, h * w)
+    nbytes = x.numel() * x.element_size() + y.numel() * y.element_size()
+    st = _timed('conv3x3_thin_in_kernel<bf16> (HBM)' + (f' {cin}->{cout}@{h}x{w} +gn-sums' if _EVENT_SHAPES else ''),
+                0.0,
+                lambda: _native.lib().vqk_conv2d_thin_in_gnstats(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias), y.data_ptr(),
+                                                                 n, h, w, cout, ws.data_ptr(), groups, _stream()), nbytes)
+    if st == _native.ERR_SHAPE:
+        return None
+    _native.check(st, 'conv2d_thin_in_gnstats')
+    return y
+
+
 UPS_PHASE = int(os.environ.get('VQK_UPS_PHASE', '1'))      # 0 off, 1 forward + data gradient, 2 forward only
 
 
@@ -891,6 +916,11 @@ class Conv2dFn(torch.autograd.Function):
             phase = y is not None
         if y is None and next_gn and k == 3 and act == 0 and layout == 1 and out_dtype == dt and cout_pad % 128 == 0 and cout_pad == o:
             y = raw_conv_fprop_gnstats(x, wq, b32, res, ups, cout_pad, next_gn)
+            if y is not None:
+                _note_presummed(y, next_gn)
+        if (y is None and next_gn and k == 3 and act == 0 and layout == 0 and cin == 8 and cout_pad == o and res is None and not ups
+                and out_dtype == dt):
+            y = raw_conv_thin_in_gnstats(x, wq, b32, cout_pad, next_gn)      # the encoder's first conv: sums for the first ResBlock's norm1
             if y is not None:
                 _note_presummed(y, next_gn)
         if y is None:
