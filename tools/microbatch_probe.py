@@ -1,6 +1,9 @@
 #!/usr/bin/env python
-"""Feasibility probe: the 32-image step as TWO independent 16-image chains (forward + backward each) on two streams inside one
-hipGraph, against the ordinary one-chain graph.  Timing only (the probe does not check the numerics)."""
+"""Feasibility probe: the 32-image step as NSPLIT independent chains (forward + backward each), against the ordinary one-chain graph.
+Timing only (the probe does not check the numerics).  Default: the chains one after the other on ONE stream, eager and captured
+(round 4: 2 chains 32.6 ms against 28.2 ms for one -- half the tiles per launch, twice the launches -- so interleaving them on two
+streams would have to hide more than 4.4 ms).  TWO_STREAMS=1: one stream per chain; the eager form runs, capturing it died inside
+hipStreamEndCapture on ROCm 7.2 (segmentation fault), which is why this is opt-in."""
 import importlib, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,7 +38,7 @@ def main():
     xs = [c.clone() for c in x.chunk(nsplit, 0)]
     cap = torch.cuda.Stream()
     streams = [torch.cuda.Stream() for _ in range(nsplit)]
-    if os.environ.get('SAME_STREAM'):
+    if not os.environ.get('TWO_STREAMS'):
         streams = [cap] * nsplit
     m.defer_usage_accumulation = True
 
