@@ -2350,7 +2350,9 @@ class DiscBlockFn(torch.autograd.Function):
             st = _native.lib().vqk_upfirdn2d_act_backward(dcode(x.dtype), d_blur.data_ptr(), f.data_ptr(), y0.data_ptr(), t0.data_ptr(),
                                                           n, bh, bw, c, pb[0], pb[1], pb[2], pb[3], 1, float(scale), act, h, w,
                                                           _stream()) if (act in (2, 3) and fh == 4 and fw == 4) else -1
-            if st != 0:                                  # shapes outside the fused kernel: blur^T, then the activation gradient
+            if st not in (-1, _native.ERR_SHAPE):
+                _native.check(st, 'upfirdn2d_act_backward')
+            else:                                        # shapes outside the fused kernel: blur^T, then the activation gradient
                 t0 = ActBwdFn.apply(UpfirdnNhwcFn.apply(d_blur, f, 1, 1, pb, True, 1.0), y0, act, float(scale), None)
             if dbsum is not None:
                 raw_colsum(n * h * w, c, t0, out=dbsum)
