@@ -6,7 +6,7 @@
  *     synchronised, and a call's RESULT depends on its arguments only.  The library reads no environment variable.
  *     What state it does keep, all of it launch POLICY (which kernel / grid / accumulation order serves a call), and its scope:
  *       THREAD-LOCAL (applies to the launches the calling host thread issues afterwards; another thread -- e.g. autograd's
- *       backward worker -- arms its own): vqk_set_deterministic (+ its workspace), vqk_set_scratch, vqk_conv_set_block_caps,
+ *       backward worker -- arms its own): vqk_set_deterministic (+ its workspace), vqk_set_scratch, vqk_set_tile_queue, vqk_conv_set_block_caps,
  *       vqk_conv_set_variant.  These act at LAUNCH (= graph capture) time: a hipGraph captured under them replays the
  *       captured kernels and workspace pointers from any thread, whatever that thread's own settings are
  *       (tests/test_gpu_deterministic.py::test_graph_captured_on_one_thread_replays_identically_from_another);
@@ -272,8 +272,17 @@ int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes);
  * bits every run, so the split is also taken in deterministic mode).  Needs >= 2 * pixels * cout * 4 bytes to be used.
  * ws must be 16-byte aligned (VQK_ERR_ALIGN), ws_bytes >= 0 (VQK_ERR_ARG); the same checks apply to vqk_set_deterministic. */
 int vqk_set_scratch(void* ws, int64_t ws_bytes);
+/* DYNAMIC TILE QUEUE of the persistent matrix/auxiliary-wave conv kernel (csrc/conv_mx.hip; tuning slot TILE_QUEUE: 0 = off,
+ * the static share; 1 = a block's first tile is its static one, the rest are drawn; 2 = every tile is drawn).  ws: >= 64 bytes
+ * of int32 words, ZERO on the first use; the kernels leave them zero again (the last block of a launch to run out of tiles
+ * resets them), so launches that follow each other on ONE stream may share them -- launches that can run CONCURRENTLY (other
+ * streams) need words of their own: the pointer is THREAD-LOCAL like vqk_set_scratch and is meant to follow the caller's
+ * current stream.  ws = NULL: static share.  Results do not depend on the mode (a tile's arithmetic and its destination are
+ * functions of the tile index only).  VQK_ERR_WORKSPACE below 64 bytes, VQK_ERR_ALIGN unless 16-byte aligned.
+ * A kernel that is KILLED mid-way leaves the words dirty: re-zero them before the next launch. */
+int vqk_set_tile_queue(void* ws, int64_t ws_bytes);
 /* Tuning slots: the launch heuristics that tools/ sweep (formerly read-once environment variables).  name = one of
- * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4, GN_CLUSTER_MAX_HW, COMM_CUS, MX_QUARTER, MX_S2, MX_S2_DGRAD_MIN, UPS_MERGE.
+ * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4, GN_CLUSTER_MAX_HW, COMM_CUS, MX_QUARTER, MX_S2, MX_S2_DGRAD_MIN, UPS_MERGE, TILE_QUEUE.
  * A set slot overrides the built-in default at the next launch; vqk_reset_tuning returns every slot to its default.
  * Process-wide (relaxed atomics); VQK_ERR_ARG for an unknown name.  The Python host maps VQK_<NAME> environment variables
  * onto these calls when it loads the library (_native.py), so the A/B scripts keep their interface. */

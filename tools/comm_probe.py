@@ -5,9 +5,10 @@ all-reduce launches no ring kernel and moves no peer traffic, so it says nothing
 The headline step is captured as usual (three hipGraphs with the gradient all-reduces issued between them,
 trainer.MiniTrainer.train_batch_graphed).  Here every `all_reduce_range` is replaced by a STAND-IN for RCCL's kernel: `blocks`
 persistent 256-thread blocks on a side stream that stream-add the range (bytes x 2 (N-1)/N of a ring all-reduce) at a throttled
-rate, so that the chosen number of CUs stays occupied for the time the collective would take at a given bus bandwidth.  Printed:
-ms per step without collectives, with the stand-in, and with the stand-in when the persistent conv grids leave those CUs free
-(tuning slot COMM_CUS).  Usage: python tools/comm_probe.py [--steps 30]"""
+rate, so that the chosen number of CUs stays occupied for the time the collective would take at a given bus bandwidth.  Printed,
+per tile-assignment mode of the persistent conv kernels (tuning slot TILE_QUEUE: 0 static share, 1 / 2 dynamic queue): ms per
+step without collectives and with the stand-in.  (Round 4 also measured smaller persistent grids -- tuning slot COMM_CUS --
+and found them harmful: profiles/round4_comm_probe.txt.)  Usage: python tools/comm_probe.py [--steps 30] [--modes 0,1,2]"""
 import argparse, importlib, os, sys, time
 import torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,6 +33,9 @@ class Work:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--modes', type=str, default='0,1,2', help='TILE_QUEUE modes to compare')
+    ap.add_argument('--blocks', type=str, default='16,32,64', help='CUs held by the stand-in')
+    ap.add_argument('--ms', type=str, default='0.5,1.5', help='minimum duration of the largest range (ms)')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     trainer_mod.init_distributed('nccl')
@@ -65,13 +69,16 @@ def main():
         return Work(ev)
     opt.all_reduce_range = fake_range
 
+    cur = dict(tr=tr)
+
     def steps(n):
+        t_ = cur['tr']
         for i in range(5):
-            tr.train_batch_graphed(model, images, i)
+            t_.train_batch_graphed(model, images, i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n):
-            tr.train_batch_graphed(model, images, i)
+            t_.train_batch_graphed(model, images, i)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
@@ -86,48 +93,35 @@ def main():
     ranges = tr._ranges(opt, 3 if getattr(tr, '_graph3', None) is not None else 2)
     mb = [(hi - lo) * 4 / 1e6 for lo, hi in ranges]
     print(f'arena ranges (MB): {[round(m, 1) for m in mb]}  -- all-reduced after graph 1 / 2 / 3', flush=True)
-    base = steps(a.steps)
-    print(f'no collectives: {base:.3f} ms/step', flush=True)
     big = int(max(hi - lo for lo, hi in ranges)) * 4
     big -= big % 16
     # target: the LARGEST range takes `ms` (bus bandwidth = 1.75 x bytes / ms for an 8-GPU ring); the throttle is found by search
-    for blocks in (16, 32, 64):
-        for ms in (0.5, 1.5):
+    cases = []
+    for blocks in [int(b) for b in a.blocks.split(',')]:
+        for ms in [float(m) for m in a.ms.split(',')]:
             sleep, passes = 0, 1
             t = kernel_ms(big, blocks, passes, sleep)
             while t < ms and sleep < 64:
                 sleep = max(1, sleep * 2)
                 t = kernel_ms(big, blocks, passes, sleep)
+            cases.append((blocks, passes, sleep, t))
+    # the tile assignment of the persistent conv kernels is part of the captured graphs: one capture per TILE_QUEUE mode
+    names = {0: 'static share', 1: 'queue, first tile static', 2: 'queue, every tile'}
+    for mode in [int(m) for m in a.modes.split(',')]:
+        lib.vqk_set_tuning(b'TILE_QUEUE', mode)
+        tr2 = trainer_mod.MiniTrainer(num_training_batches=1000)
+        tr2.optimizers = tr.optimizers
+        model.trainer = tr2
+        tr2.capture(model, images, warmup=1)
+        cur['tr'] = tr2
+        state['mode'] = 'off'
+        base = steps(a.steps)
+        print(f'TILE_QUEUE={mode} ({names[mode]}): no collectives {base:.3f} ms/step', flush=True)
+        for blocks, passes, sleep, t in cases:
             state.update(mode='on', blocks=blocks, passes=passes, sleep=sleep)
-            lib.vqk_reset_tuning()
             on = steps(a.steps)
-            lib.vqk_set_tuning(b'COMM_CUS', blocks)
-            # (the grids are part of the captured graphs: re-capture with the reduced grids)
-            tr2 = trainer_mod.MiniTrainer(num_training_batches=1000)
-            tr2.optimizers = tr.optimizers
-            model.trainer = tr2
-            tr2.capture(model, images, warmup=1)
-            keep, globals()['_keep'] = tr, None
-            t_red = None
-            try:
-                saved = tr
-                def steps2(n):
-                    for i in range(5):
-                        tr2.train_batch_graphed(model, images, i)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for i in range(n):
-                        tr2.train_batch_graphed(model, images, i)
-                    torch.cuda.synchronize()
-                    return (time.perf_counter() - t0) / n * 1e3
-                t_red = steps2(a.steps)
-                state['mode'] = 'off'
-                t_red_alone = steps2(a.steps)
-            finally:
-                lib.vqk_reset_tuning()
-                model.trainer = tr
-            print(f'stand-in on {blocks:3d} CUs, largest range {t:.2f} ms (throttle {sleep}): {on:.3f} ms/step (+{on - base:.3f}); '
-                  f'with COMM_CUS={blocks}: {t_red:.3f} ms/step (+{t_red - base:.3f}; the reduced grids alone: {t_red_alone:.3f})', flush=True)
+            print(f'  stand-in on {blocks:3d} CUs, largest range {t:.2f} ms (throttle {sleep}): {on:.3f} ms/step (+{on - base:.3f})', flush=True)
+    lib.vqk_reset_tuning()
 
 
 if __name__ == '__main__':

@@ -2,6 +2,7 @@
 """Timeline view of ONE train step from a rocprofv3 rocpd kernel trace: wall time, union of busy intervals,
 time with two kernels in flight, idle gaps (with the kernels either side) and per-queue sums.
 Usage: python tools/timeline.py results.db [step_index_from_end=2] [min_gap_us=3]"""
+import os
 import sqlite3
 import sys
 
@@ -45,6 +46,11 @@ def main(path, back=2, min_gap=3.0):
         qs.setdefault(q, [0, 0]); qs[q][0] += 1; qs[q][1] += e - s
     for q, (c, t) in qs.items():
         print(f'  queue {q}: {c} kernels, {t / 1e3:.1f} us')
+    mark = os.environ.get('TL_MARK')                            # kernels to place on the step's time axis (e.g. TL_MARK=probe)
+    if mark:
+        for n, s, e, q in step:
+            if mark in n:
+                print(f'  mark q{q} {short(n):40s} start {(s - t0) / 1e3:9.1f} us  end {(e - t0) / 1e3:9.1f} us  ({(e - s) / 1e3:.1f} us)')
     # idle gaps
     gaps = []
     depth, idle_start, prev = 0, t0, 'AdamW(prev)'

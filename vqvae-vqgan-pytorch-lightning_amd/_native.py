@@ -65,6 +65,7 @@ _PROTOS = {
     'vqk_conv_set_block_caps': [I, I],
     'vqk_set_deterministic': [I, P, L],
     'vqk_set_scratch': [P, L],
+    'vqk_set_tile_queue': [P, L],
     'vqk_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
     'vqk_conv2d_wgrad_pooled_dy': [I, P, P, P, I, I, I, I, I, F, P, P],

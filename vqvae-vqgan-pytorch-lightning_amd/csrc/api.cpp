@@ -32,7 +32,21 @@ DetState& scratch_state() {
     static thread_local DetState st = {0, nullptr, 0};
     return st;
 }
+DetState& tile_queue_state() {
+    static thread_local DetState st = {0, nullptr, 0};
+    return st;
+}
 }  // namespace vqkd
+
+extern "C" int vqk_set_tile_queue(void* ws, int64_t ws_bytes) {
+    if (ws && ws_bytes < 64) return VQK_ERR_WORKSPACE;           // eight per-XCD counters + the census word
+    if (ws && (reinterpret_cast<uintptr_t>(ws) & 15)) return VQK_ERR_ALIGN;
+    vqkd::DetState& d = vqkd::tile_queue_state();
+    d.on = ws ? 1 : 0;
+    d.ws = reinterpret_cast<float*>(ws);
+    d.bytes = ws ? ws_bytes : 0;
+    return VQK_OK;
+}
 
 extern "C" int vqk_set_scratch(void* ws, int64_t ws_bytes) {
     if (ws && ws_bytes < 0) return VQK_ERR_ARG;
@@ -87,7 +101,8 @@ static TuneSlot g_tune[] = {
     {"MX_QUARTER", 0, 0},
     {"MX_S2", 0, 0},
     {"MX_S2_DGRAD_MIN", 0, 0},
-    {"UPS_MERGE", 0, 0}
+    {"UPS_MERGE", 0, 0},
+    {"TILE_QUEUE", 0, 0}
 };
 static constexpr int kTune = (int)(sizeof(g_tune) / sizeof(g_tune[0]));
 TuneSlot* tune_slot(const char* name) {

@@ -104,6 +104,7 @@ namespace vqkd {
 struct DetState { int on; float* ws; int64_t bytes; };
 DetState& det_state();
 DetState& scratch_state();      // vqk_set_scratch: zero-initialised fp32 scratch of the current stream (split-K partial sums)
+DetState& tile_queue_state();   // vqk_set_tile_queue: the current stream's tile-queue words (conv_geom.h: ConvGeom::tq)
 }
 // launch heuristics that tools/ sweep (include/vqk.h: vqk_set_tuning): process-wide slots, relaxed atomics; a call site
 // resolves its slot once and then reads one int per launch.  The library itself never reads the environment.

@@ -2291,7 +2291,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.stride = 1; g.pad = ksize >> 1; g.zs = 0; g.vh = g.h; g.vw = g.w;
     g.acc_scale = 1.0f; g.out_gain = 1.0f; g.pool = 0; g.pool_scale = 1.0f;
     g.gn_ws = nullptr; g.gn_cpg = 0; g.gn_part_nblk = 0; g.gn_part_base = 0;
-    g.act = 0; g.dy_pool = 0;
+    g.act = 0; g.dy_pool = 0; g.tq = nullptr; g.tq_mode = 0;
     g.ntap = ksize == 1 ? 1 : 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
     g.tapw = 0; g.dst_h = g.dst_w = 0; g.s2 = 0; g.phase_mode = 0;
     const int64_t m = (int64_t)n * g.h * g.w;

@@ -45,6 +45,14 @@ struct ConvGeom {
     int dy_pool;    // weight-gradient mx kernel: dy is given at HALF resolution (the gradient of a fused 2x2 average pool: every
                     // pooled pixel stands for its 2x2 block), dW is scaled by acc_scale
     int act;        // matrix/auxiliary-wave kernel: epilogue activation (0 none, 2 relu, 3 leaky relu 0.2), with acc_scale / out_gain
+    // matrix/auxiliary-wave kernel: DYNAMIC TILE QUEUE (vqk_set_tile_queue + tuning slot TILE_QUEUE).  tq = nullptr: the static
+    // share (tile j of block b = b + j * grid).  Otherwise tq[0..7] are the per-XCD counters and tq[8] the census of finished
+    // blocks (all zero on entry; the last block to finish leaves them zero again): the blocks of an XCD draw the tiles of the
+    // XCD's static sequence in order -- same tiles, same order, same L2 neighbourhoods, but a block that starts late (its CU was
+    // held by a collective's kernel or by a kernel of another stream) finds less work instead of a fixed share.
+    // tq_mode 1: a block's first tile is its static one (no start-up latency), 2: every tile comes from the queue.
+    int* tq;
+    int tq_mode;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {

@@ -21,7 +21,15 @@
 //                the staging tile: bias / residual add, optional 2x2 pooling, 16-byte stores of whole 256-byte pixel rows.
 //   One s_barrier per unit joins the two groups.  Each SIMD hosts one M and one X wave.
 //
-// LDS: 3 halo buffers (27 KiB) + the staging tile (256 pixels x 272 bytes) + 1 KiB of statistics partials = 150 KiB.
+// Tiles: static share (tile j of block b = b + j * grid in XCD-contiguous block order) or, with ConvGeom::tq, a DYNAMIC queue:
+// the blocks of an XCD draw the tiles of that XCD's static sequence from one atomic counter (same tiles, same order, same L2
+// neighbourhoods).  The first X wave fetches ahead -- the atomic of tile j+1 is issued four units before the tile's first
+// unit and published through an 8-entry LDS ring, so no wave ever waits for it -- and a block that starts late (its CU was
+// held by a collective's kernel or another stream's) finds less work instead of a fixed share.  Every block makes exactly ONE
+// fetch beyond the end of its XCD's sequence; the last block to do so (census word) zeroes the counters again.
+//
+// LDS: 3 halo buffers (27 KiB) + the staging tile (256 pixels x 272 bytes) + 1 KiB of statistics partials + the 64-byte
+// tile ring = 150 KiB.
 // Numerics: the convolution sum is rounded to bf16 ONCE more than in the stream kernel when a bias / residual / pooling
 // follows (the epilogue arithmetic runs on the parked bf16 values, in fp32).
 // ------------------------------------------------------------------------------------------------
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     constexpr int PIECES = (HROWS * 5 + 63) / 64;                // 1-KiB LDS-DMA pieces per halo
     constexpr int NBUF = S2 ? 2 : 3;                             // halo buffers (S2: a halo is 2.5x the bytes -- two fit)
     constexpr int BUF = PIECES * 1024, STG = NBUF * BUF, SPITCH = 272, SCR = STG + PIX * SPITCH;   // SCR: 1 KiB of statistics partials
+    constexpr int TQR = SCR + 1024;                              // 8-entry ring of tile ids (dynamic tile queue)
     constexpr int TWD = TAPW ? TAPW : NTAP == 9 ? 3 : NTAP == 4 ? 2 : 1;      // taps per window row
     constexpr int NI = PIX / 64, NJ = 2;                         // a matrix wave: NI x 32 pixels x 64 couts (PIX = 128: the half tile of the
                                                                  // 16x16 maps, twice as many blocks for a chip that their 256-pixel tiles leave half empty)
@@ -109,14 +118,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     const int total_tiles = g.n * tiles_y * tiles_x * g.tiles_n * (pmode == 1 ? 4 : 1);
     const int nch = g.cpt >> 2;                                  // 32-channel chunks per tile (and phase)
     const int nun = pmode == 2 ? 4 * nch : nch;                  // units per tile
-    const int vbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int my_tiles = (total_tiles - vbid + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int units = my_tiles * nun;
-    if (units <= 0) return;
+    // this block's XCD (block b runs on XCD b % 8) owns the virtual block ids [c0, c0 + cnt): xcd_remap, spelled out
+    const int grid = (int)gridDim.x, q8 = grid >> 3, r8 = grid & 7, xcd = (int)blockIdx.x & 7;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int vbid = c0 + ((int)blockIdx.x >> 3);
+    if (vbid >= total_tiles) return;
+    // k-th tile of the XCD's sequence (static share: block i of the XCD takes k = i, i + cnt, i + 2 cnt, ...)
+    auto tile_of = [&](int k) -> int { const int j = k / cnt; return c0 + (k - j * cnt) + j * grid; };
+    const int tqm = g.tq ? g.tq_mode : 0;                        // 0 static, 1 first tile static, 2 every tile from the queue
+    volatile VQK_LDS int* const ring = (volatile VQK_LDS int*)(smem + TQR);     // (explicit LDS pointer: a generic volatile one became flat_load + vmcnt(0))
+    // id of this block's j-th tile.  (readfirstlane: the ring holds ONE value per slot -- as a scalar it keeps every address
+    // derived from it wave-uniform; read as a vector value hipcc wrapped each weight load in a waterfall loop, +15 % kernel time)
+    auto next_id = [&](int j) -> int { return tqm ? __builtin_amdgcn_readfirstlane(ring[j & 7]) : vbid + j * grid; };
+    const bool pro_sync = tqm == 2 || (tqm && nun < 4);          // the ring's first entries are fetched before the first unit
 
     struct TilePos { int img, py0, px0, nt, ph; };
-    auto tile_pos = [&](int j) -> TilePos {
-        int t = vbid + j * (int)gridDim.x;
+    auto tile_pos = [&](int t) -> TilePos {
         TilePos tp;
         tp.nt = t % g.tiles_n; t /= g.tiles_n;
         tp.ph = 0;
@@ -157,8 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             const int a = ph >> 1, b = ph & 1;
             return pmode == 1 ? (a * HW2 + b) * RS : pmode == 2 ? ((1 - a) * HW2 + (1 - b)) * RS : 0;
         };
-        auto tile_nt = [&](int j) -> int {
-            const int t = vbid + j * (int)gridDim.x;
+        auto tile_nt = [&](int t) -> int {
             return (t % g.tiles_n) | (pmode == 1 ? ((t / g.tiles_n) & 3) << 16 : 0);
         };
         auto wload = [&](int soff) -> frag_t {
@@ -170,7 +187,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         f32x16 acc[NI][NJ];
         frag_t bw[RD][NJ];
         int wcur[NJ];
-        int cur_nt = tile_nt(0);
+        if (pro_sync) unit_barrier();                            // (joins the X waves' prologue: ring[0 ...] is published)
+        const int t_first = tqm == 2 ? __builtin_amdgcn_readfirstlane(ring[0]) : vbid;
+        if (t_first >= total_tiles) return;                      // queue mode 2, a late block: nothing left
+        int cur_nt = tile_nt(t_first);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) wcur[j] = unit_w(cur_nt, 0, j);
 #pragma unroll
@@ -179,12 +199,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             for (int j = 0; j < NJ; ++j) bw[d][j] = wload(wcur[j] + d * 1024);
         unit_barrier();                                          // the halo of unit 0 has landed
 
-        int tj = 0, c = 0, bi = 0;
-        for (int u = 0; u < units; ++u) {
-            int ntj = tj, nc = c + 1;
-            if (nc == nun) { nc = 0; ntj = tj + 1; }
-            if (u + 1 >= units) { ntj = tj; nc = c; }            // clamp: the weight prefetch stays unconditional
-            const int nxt_nt = (ntj == tj) ? cur_nt : tile_nt(ntj);
+        int tj = 0, c = 0, bi = 0, t_next = 0;
+        for (;;) {
+            // the id of the next tile is read one unit before it is needed (published two units earlier by the first X wave)
+            if (c == nun - 2) t_next = next_id(tj + 1);
+            const bool last_c = c == nun - 1, more = last_c && t_next < total_tiles;
+            int nc = c + 1, nxt_nt = cur_nt;
+            if (last_c) {
+                if (more) { nc = 0; nxt_nt = tile_nt(t_next); }
+                else nc = c;                                     // clamp: the weight prefetch stays unconditional
+            }
             int wnxt[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) wnxt[j] = unit_w(nxt_nt, nc, j);
@@ -268,7 +292,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                         }
             }
             unit_barrier();
-            cur_nt = nxt_nt; tj = ntj; c = nc;
+            if (last_c) { if (!more) break; ++tj; }
+            cur_nt = nxt_nt; c = nc;
             bi = bi == NBUF - 1 ? 0 : bi + 1;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) wcur[j] = wnxt[j];
@@ -510,18 +535,62 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         }
     };
 
-    // position of the unit whose halo is requested next (NBUF - 1 units ahead of the M waves)
-    int ltj = 0, lc = 0, lbuf = 0;
-    TilePos ltp = tile_pos(0);
-    auto advance = [&]() {
-        if (++lc == nun) { lc = 0; ++ltj; ltp = tile_pos(ltj < my_tiles ? ltj : my_tiles - 1); }
+    // ---- dynamic tile queue: the first X wave fetches, lane 0 holds the atomic's result until the next interval
+    int nissued = tqm == 2 ? 0 : 1, exhausted = 0, pend = 0, fv = 0;     // tiles fetched or static so far (wave-uniform)
+    const int qbase = tqm == 2 ? 0 : cnt;                        // mode 1: the XCD's first cnt tiles are the blocks' static ones
+    auto fetch_issue = [&]() {
+        if (lane == 0) fv = __hip_atomic_fetch_add(g.tq + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend = 1;
+    };
+    auto fetch_land = [&]() {
+        const int t = tile_of(__builtin_amdgcn_readfirstlane(fv) + qbase);
+        if (lane == 0) ring[nissued & 7] = t;
+        ++nissued; pend = 0;
+        if (t >= total_tiles) exhausted = 1;                     // the ONE fetch beyond the end: never fetch again
+    };
+    auto census = [&]() {                                        // the last block to finish zeroes the queue words again
+        if (tqm && xw == 0 && lane == 0) {
+            const int old = __hip_atomic_fetch_add(g.tq + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == grid - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) __hip_atomic_exchange(g.tq + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    if (tqm && xw == 0) {
+        // what the first intervals need before any fetch of the loop can land: tile 0 (mode 2) and, for tiles of fewer than
+        // four units, the tile of unit 3
+        const int need = 3 / nun;
+        while (nissued <= need && !exhausted) { fetch_issue(); fetch_land(); }
+    }
+    if (pro_sync) unit_barrier();
+    const int t_first = tqm == 2 ? __builtin_amdgcn_readfirstlane(ring[0]) : vbid;
+    if (t_first >= total_tiles) { census(); return; }            // queue mode 2, a late block: nothing left
+
+    // position of the unit whose halo is requested next (NBUF - 1 units ahead of the M waves).  A new tile's id is looked up
+    // right before its first halo is requested (lnew), one barrier after the interval that published it
+    int ltj = 0, lc = 0, lbuf = 0, lvalid = 1, lnew = 0;
+    TilePos ltp = tile_pos(t_first);
+    auto look = [&]() {
+        if (lnew) {
+            lnew = 0;
+            if (lvalid) {
+                const int t = next_id(ltj);
+                lvalid = t < total_tiles;
+                if (lvalid) ltp = tile_pos(t);
+            }
+        }
+    };
+    auto bump = [&]() {
+        if (++lc == nun) { lc = 0; ++ltj; lnew = 1; }
         lbuf = lbuf == NBUF - 1 ? 0 : lbuf + 1;
     };
-    issue_halo(ltp, lc, lbuf); advance();                        // unit 0
-    if constexpr (NBUF == 3) { issue_halo(ltp, lc, lbuf); advance(); }      // unit 1 (nch >= 2: it exists)
+    issue_halo(ltp, lc, lbuf); bump();                           // unit 0
+    if constexpr (NBUF == 3) { look(); if (lvalid) issue_halo(ltp, lc, lbuf); bump(); }     // unit 1
     int tj = 0, c = 0;
-    TilePos cur = tile_pos(0);
+    TilePos cur = tile_pos(t_first);
     OutPos done = out_pos(cur);
+    int fu = 4 % nun, ford = 4 / nun;                            // (u + 4) % nun, (u + 4) / nun: the tile of unit u + 4
     bool pending = false, flush = false;
     u32x4 rv[NR];
 #pragma unroll
@@ -529,31 +598,48 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unit_barrier();
 
-    for (int u = 0; u < units; ++u) {
+    for (;;) {
         // every vector-memory operation of the previous interval has completed: the halo of unit u+1 is in LDS (published
         // to the M waves by the barrier that ends this interval), the residual pieces are in registers
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tqm && xw == 0) {
+            // the fetch issued in the last interval has landed: into the ring (visible to the other waves after this interval's
+            // barrier); the tile of unit u + 4 is requested now -- two intervals before its first halo is
+            if (pend) fetch_land();
+            if (!exhausted && ford >= nissued) fetch_issue();
+        }
+        if (++fu == nun) { fu = 0; ++ford; }
         if constexpr (NBUF == 2) {
             // two halo buffers: the buffer of unit u+1 is the one unit u-1 was computed from -- free since the last barrier.
             // Requested first, it has this whole interval to land and is awaited before the barrier that publishes it
-            if (u + 1 < units) issue_halo(ltp, lc, lbuf);
-            advance();
+            look();
+            if (lvalid) issue_halo(ltp, lc, lbuf);
+            bump();
         }
         if (flush) { flush_stats(); flush = false; }
         if (pending && !((VQK_MXABL & 2) && g.n > 0)) { drain(done, rv); flush = g.gn_ws != nullptr; }   // tile parked during unit u-1
-        pending = (c == nun - 1);                                // unit u ends a tile: its residual is requested now,
+        const bool last_c = c == nun - 1;
+        int t_next = 0;
+        pending = last_c;                                        // unit u ends a tile: its residual is requested now,
         if (pending) {                                           // the tile itself is drained in the next interval
             done = out_pos(cur);
             if (res) load_res(done, rv);
+            t_next = next_id(tj + 1);
         }
         if constexpr (NBUF == 3) {
-            if (u + 2 < units && !((VQK_MXABL & 1) && g.n > 0)) issue_halo(ltp, lc, lbuf);      // unit u+2
-            advance();
+            look();
+            if (lvalid && !((VQK_MXABL & 1) && g.n > 0)) issue_halo(ltp, lc, lbuf);      // unit u+2
+            bump();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         unit_barrier();
-        if (++c == nun) { c = 0; ++tj; if (tj < my_tiles) cur = tile_pos(tj); }
+        if (last_c) {
+            if (t_next >= total_tiles) break;
+            c = 0; ++tj; cur = tile_pos(t_next);
+        } else {
+            ++c;
+        }
     }
     if (flush) flush_stats();
     if (pending) {
@@ -564,6 +650,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             flush_stats();
         }
     }
+    census();
 }
 
 }  // namespace
@@ -615,20 +702,32 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
     int cus = device_cus() - VQK_TUNE("COMM_CUS", 0);
     if (cus < 1) cus = 1;
     const dim3 grid((unsigned)(total < cus ? total : cus));
-    constexpr int lds5 = 3 * (((256 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
-    constexpr int lds4 = 3 * (((256 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
-    constexpr int lds4h = 3 * (((128 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
-    constexpr int lds5h = 3 * (((128 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
+    // dynamic tile queue (tuning slot TILE_QUEUE: 0 static share, 1 first tile static, 2 every tile from the queue) on the
+    // queue words of the calling thread's current stream (vqk_set_tile_queue); a grid of one tile per block has nothing to draw
+    const int tqm = VQK_TUNE("TILE_QUEUE", 0);
+    const DetState& tqs = tile_queue_state();
+    auto set_queue = [&](int tiles, int blocks) {
+        const bool on = tqm > 0 && tqs.ws != nullptr && tqs.bytes >= 64 && tiles > blocks && (g.cpt >> 2) >= 2;
+        g.tq = on ? reinterpret_cast<int*>(tqs.ws) : nullptr;
+        g.tq_mode = on ? (tqm >= 2 ? 2 : 1) : 0;
+    };
+    set_queue(total, (int)grid.x);
+    constexpr int TQB = 64;                                      // the kernel's tile ring
+    constexpr int lds5 = 3 * (((256 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024 + TQB;
+    constexpr int lds4 = 3 * (((256 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024 + TQB;
+    constexpr int lds4h = 3 * (((128 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024 + TQB;
+    constexpr int lds5h = 3 * (((128 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024 + TQB;
 #define MXL(K, L) return mx_launch<K>(grid, L, st, x, w, bias, res, y, g)
-    constexpr int lds4q = 3 * (((64 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 64 * 272 + 1024;
-    constexpr int lds5q = 3 * (((64 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 64 * 272 + 1024;
+    constexpr int lds4q = 3 * (((64 / 16 + 2) * 18 * 5 + 63) / 64) * 1024 + 64 * 272 + 1024 + TQB;
+    constexpr int lds5q = 3 * (((64 / 32 + 2) * 34 * 5 + 63) / 64) * 1024 + 64 * 272 + 1024 + TQB;
     if (g.s2) {
         // stride-2 3x3 conv: 128-pixel tiles, TWO halo buffers of four (TH+1) x (TW+1) parity sub-images
-        constexpr int lds5s = 2 * ((4 * (128 / 32 + 1) * 33 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
-        constexpr int lds4s = 2 * ((4 * (128 / 16 + 1) * 17 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024;
+        constexpr int lds5s = 2 * ((4 * (128 / 32 + 1) * 33 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024 + TQB;
+        constexpr int lds4s = 2 * ((4 * (128 / 16 + 1) * 17 * 5 + 63) / 64) * 1024 + 128 * 272 + 1024 + TQB;
         if (g.pool || g.ntap != 9 || (twlog == 4 ? (g.h % 8) : (g.h % 4)) != 0) return VQK_ERR_ARG;
         const int tot2 = g.n * (g.h / (128 >> twlog)) * (g.w >> twlog) * g.tiles_n;
         const dim3 grid2((unsigned)(tot2 < cus ? tot2 : cus));
+        set_queue(tot2, (int)grid2.x);
         if (twlog == 5) return mx_launch<conv3x3_mx_kernel<5, false, 9, 128, 0, true>>(grid2, lds5s, st, x, w, bias, res, y, g);
         return mx_launch<conv3x3_mx_kernel<4, false, 9, 128, 0, true>>(grid2, lds4s, st, x, w, bias, res, y, g);
     }
@@ -647,7 +746,7 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
         if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 4>), lds5); else MXL((conv3x3_mx_kernel<4, false, 4>), lds4);
     } else if (g.ntap == 1) {                                    // 1x1 conv: no halo, 2 phases per unit
         if (g.pool) return VQK_ERR_ARG;
-        constexpr int lds1 = 3 * ((256 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024;
+        constexpr int lds1 = 3 * ((256 * 5 + 63) / 64) * 1024 + 256 * 272 + 1024 + TQB;
         if (twlog == 5) MXL((conv3x3_mx_kernel<5, false, 1>), lds1); else MXL((conv3x3_mx_kernel<4, false, 1>), lds1);
     } else if (twlog == 5) {
         if (g.pool) MXL((conv3x3_mx_kernel<5, true, 9>), lds5); else MXL((conv3x3_mx_kernel<5, false, 9>), lds5);

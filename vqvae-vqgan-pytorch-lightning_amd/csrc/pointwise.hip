@@ -415,7 +415,9 @@ extern "C" int vqk_probe_stream_add(const float* src, float* dst, int64_t bytes,
     VQK_REQUIRE(src && dst, VQK_ERR_ARG);
     VQK_REQUIRE(bytes > 0 && (bytes % 16) == 0 && blocks > 0 && passes > 0 && sleep >= 0, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(src) && vqk_aligned16(dst), VQK_ERR_ALIGN);
-    hipLaunchKernelGGL(probe_stream_add_kernel, dim3((unsigned)blocks), dim3(256), 0, vqk_stream(stream), src, dst, bytes / 16, passes,
+    // 32 KiB of (unused) dynamic LDS per block, like a collective's kernel: a CU that hosts one of these blocks has no room
+    // left for a 150-KiB block of the persistent conv kernels -- the CU is HELD, not shared
+    hipLaunchKernelGGL(probe_stream_add_kernel, dim3((unsigned)blocks), dim3(256), 32768, vqk_stream(stream), src, dst, bytes / 16, passes,
                        sleep);
     VQK_CHECK_LAUNCH();
     return VQK_OK;

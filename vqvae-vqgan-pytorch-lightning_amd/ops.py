@@ -39,6 +39,7 @@ _DET_GEN = 0                           # every thread tracks what IT armed, agai
 _DET_WS_BYTES = 64 << 20
 _SCRATCH: dict = {}
 _SCRATCH_BYTES = 64 << 20
+_TILE_QUEUE: dict = {}               # (device, stream) -> int32 words of the conv kernels' dynamic tile queue (include/vqk.h)
 
 
 def _stream() -> int:
@@ -52,6 +53,10 @@ def _stream() -> int:
         if sc is None:                                           # no zero fill: every slice is written before it is summed
             sc = _SCRATCH[(dev, s)] = torch.empty(_SCRATCH_BYTES // 4, dtype=torch.float32, device=f'cuda:{dev}')
         _native.check(_native.lib().vqk_set_scratch(sc.data_ptr(), sc.numel() * 4), 'set_scratch')
+        tq = _TILE_QUEUE.get((dev, s))                           # tile-queue words of this stream (zero on entry, left zero)
+        if tq is None:
+            tq = _TILE_QUEUE[(dev, s)] = torch.zeros(64, dtype=torch.int32, device=f'cuda:{dev}')
+        _native.check(_native.lib().vqk_set_tile_queue(tq.data_ptr(), tq.numel() * 4), 'set_tile_queue')
         _DET_TLS.scratch = (dev, s)
     key = getattr(_DET_TLS, 'key', None)
     if DETERMINISTIC:
