@@ -87,6 +87,9 @@ def cpu_baseline(run: dict, image_size: int, batch: int, steps: int):
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / steps
     return dict(value=round(batch / t, 4), unit='images/sec', cores=cores, kind='port',
+                # B = 32, or a smaller batch with an explicit flag -- images/s of a CPU conv step is flat in the
+                # batch size at these sizes, so the figure stands for the B = 32 workload; a B = 32 step takes minutes here
+                extrapolated_from_batch=batch,
                 sample=f'{steps} timed steps (+1 warm-up) of the same train step at batch {batch}, fp32, '
                        f'torch-CPU oracle on {cores} threads; {t:.2f} s/step'), (params0, images, first)
 
@@ -227,6 +230,65 @@ def measure_traffic(kernel_sub: str, events_per_step: int, argv):
         return None, None
 
 
+# Reference box of the committed profile set (profiles/README.md lists every box of the round with these two figures): the
+# normalised step time is what THIS run's step would take on that box if the MFMA-bound share of the step scaled with the
+# calibration loop and the HBM-bound share with the copy (shares from profiles/round4_bench_kernel_stats.csv: conv kernels
+# 0.70 of the step's critical path, GroupNorm / elementwise / AdamW 0.25, launch gaps and the rest 0.05).
+CALIB_REF = dict(mfma_loop_tflops=None, hbm_copy_tbps=None)
+CALIB_SHARES = dict(mfma=0.70, hbm=0.25)
+
+
+def box_calibration(device, ms_per_step, seconds: float = 0.3) -> dict:
+    """what THIS box delivers on two fixed kernels of the library (csrc/calib.hip), ~0.3 s each: the matrix-wave instruction
+    mix of the role-split conv kernel on random bf16 operands, and a 1-GiB streaming copy.  Driver lines from different boxes
+    become comparable: the same library ran 4-5 % apart across the pool in round 4."""
+    native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
+    lib = native.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    w = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+    sink = torch.zeros(4, dtype=torch.float32, device=device)
+    native.check(lib.vqk_calib_fill(w.data_ptr(), w.numel(), st), 'calib_fill')
+    iters, blocks = 256, 256
+    flops = float(lib.vqk_calib_mfma_flops(iters, blocks))
+
+    def timed(launch, per_batch):
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        total_ms, n = 0.0, 0
+        t_host = time.perf_counter()
+        while time.perf_counter() - t_host < seconds:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(per_batch):
+                launch()
+            e1.record()
+            torch.cuda.synchronize()
+            total_ms += e0.elapsed_time(e1)
+            n += per_batch
+        return total_ms * 1e-3 / n, n
+
+    t_mfma, n_mfma = timed(lambda: native.check(lib.vqk_calib_mfma(w.data_ptr(), w.numel(), sink.data_ptr(), iters, blocks, st), 'calib_mfma'), 20)
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    native.check(lib.vqk_calib_fill(src.data_ptr(), nbytes, st), 'calib_fill')
+    t_copy, n_copy = timed(lambda: native.check(lib.vqk_calib_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), 'calib_copy'), 5)
+    del src, dst
+    out = dict(mfma_loop_tflops=round(flops / t_mfma / 1e12, 1), mfma_loop_launches=n_mfma,
+               hbm_copy_tbps=round(2.0 * nbytes / t_copy / 1e12, 3), hbm_copy_launches=n_copy, seconds_each=seconds,
+               kernels='csrc/calib.hip: matrix-wave instruction mix of conv3x3_mx_kernel on random bf16 operands (256 blocks x 4 waves); '
+                       '1-GiB streaming copy (read + write bytes)',
+               reference_box=dict(CALIB_REF), shares=dict(CALIB_SHARES))
+    if CALIB_REF['mfma_loop_tflops'] and CALIB_REF['hbm_copy_tbps']:
+        f = (CALIB_SHARES['mfma'] * out['mfma_loop_tflops'] / CALIB_REF['mfma_loop_tflops']
+             + CALIB_SHARES['hbm'] * out['hbm_copy_tbps'] / CALIB_REF['hbm_copy_tbps']
+             + (1.0 - CALIB_SHARES['mfma'] - CALIB_SHARES['hbm']))
+        out['ms_per_step_normalised'] = round(ms_per_step * f, 3)
+        out['box_speed_vs_reference'] = round(f, 4)
+    return out
+
+
 def _flush_c_stdio():
     try:
         import ctypes
@@ -272,6 +334,9 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel eagerly instead of replaying a hipGraph')
+    ap.add_argument('--allow-eager', action='store_true',
+                    help='multi-GPU runs: keep going (with "degraded" in the line) when the hipGraph capture fails; default: exit 3')
+    ap.add_argument('--no-calibration', action='store_true', help='skip the 0.6 s box calibration (box_calibration in the line)')
     ap.add_argument('--deterministic', action='store_true', help='deterministic mode (vqvae/train.py:130): ordered partial sums instead of atomics; reports its cost')
     ap.add_argument('--sustain-s', type=float, default=10.0,
                     help='after the K timed steps keep stepping for this many seconds and report the sustained ms/step '
@@ -318,10 +383,12 @@ def main():
     trainer = trainer_mod.MiniTrainer(num_training_batches=args.steps + args.warmup, deterministic=True if args.deterministic else None)
     trainer.attach(model)
     if os.environ.get('VQK_FORCE_DIST') == '1':
-        trainer.optimizers[0].force_collective = True
+        for o in trainer.optimizers:
+            o.force_collective = True
     model.on_train_start()
     g = torch.Generator().manual_seed(1234 + rank)
     images = torch.rand(args.batch, 3, args.image_size, args.image_size, generator=g).to(device)
+    native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
 
     def barrier():
         if world > 1 or dist.is_initialized():
@@ -330,14 +397,61 @@ def main():
 
     use_graph = not args.no_graph      # (VQ-GAN: three graphs -- AE half, discriminator half, discriminator half with R1)
     step_fn = trainer.train_batch
+    degraded = None
+    comm_ab = None
     if use_graph:
         try:
-            trainer.capture(model, images, warmup=max(1, min(3, args.warmup)))
+            # Data parallel: which form of the gradient all-reduce is faster HERE is measured, not assumed -- the three ranges
+            # reduced under the remaining backward (a collective's kernel holds CUs next to the persistent conv grids: those
+            # draw their tiles from a queue then, TILE_QUEUE) or north_star's literal single flat all-reduce after the backward.
+            # ~10 replayed steps each; the timed region runs in the faster form.  An explicit VQK_OVERLAP_ALLREDUCE /
+            # VQK_TILE_QUEUE in the environment pins the form instead.
+            pinned = 'VQK_OVERLAP_ALLREDUCE' in os.environ or 'VQK_TILE_QUEUE' in os.environ
+            if dist.is_initialized() and not args.gan and not pinned:
+                forms = [('overlap_queue', True, 2), ('overlap', True, 0), ('flat', False, 0)]
+                comm_ab, trainers = {}, {}
+                for name, overlap, tq in forms:
+                    native.check(native.lib().vqk_set_tuning(b'TILE_QUEUE', tq), 'set_tuning')
+                    t = trainer_mod.MiniTrainer(num_training_batches=args.steps + args.warmup, deterministic=True if args.deterministic else None)
+                    t.optimizers, t.overlap_allreduce, model.trainer = trainer.optimizers, overlap, t
+                    t.capture(model, images, warmup=1)
+                    for i in range(3):
+                        t.train_batch_graphed(model, images, i)
+                    barrier()
+                    ta = time.perf_counter()
+                    for i in range(10):
+                        t.train_batch_graphed(model, images, i)
+                    barrier()
+                    dt_ab = torch.tensor([(time.perf_counter() - ta) / 10], dtype=torch.float64, device=device)
+                    dist.all_reduce(dt_ab, op=dist.ReduceOp.MAX)
+                    comm_ab[name + '_ms'] = round(float(dt_ab.item()) * 1e3, 3)
+                    trainers[name] = (t, tq)
+                best = min(forms, key=lambda f: comm_ab[f[0] + '_ms'])[0]
+                comm_ab['chosen'] = best
+                trainer, tq = trainers[best]
+                model.trainer = trainer
+                native.check(native.lib().vqk_set_tuning(b'TILE_QUEUE', tq), 'set_tuning')     # (the eager event pass launches with it too)
+                del trainers
+            else:
+                trainer.capture(model, images, warmup=max(1, min(3, args.warmup)))
             step_fn = trainer.train_batch_graphed
-        except Exception as exc:               # never lose the run to a capture problem: fall back to eager launches
-            print(f'[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly', file=sys.stderr)
+        except Exception as exc:
+            # a capture problem must never produce a silent ~40 % slower "scaling curve": the line says so at top level, and a
+            # multi-GPU run stops with exit code 3 unless --allow-eager
+            degraded = f'eager launches (hipGraph capture failed: {type(exc).__name__}: {exc})'
+            import traceback
+            traceback.print_exc()
+            print(f'[bench] {degraded}', file=sys.stderr)
             torch.cuda.synchronize()
             use_graph = False
+            if world > 1 and not args.allow_eager:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                if rank == 0:
+                    print(json.dumps(dict(metric='images/sec/node (256x256 bs=32/GPU) VQ-VAE train step', value=None, n_gpus=world,
+                                          degraded=degraded, error='capture failed on a multi-GPU run (pass --allow-eager to time eager launches)')),
+                          flush=True)
+                raise SystemExit(3)
     for i in range(args.warmup):
         step_fn(model, images, i)
     barrier()
@@ -379,6 +493,14 @@ def main():
         ops.OVERLAP_WGRAD = overlap
         events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
 
+    calib = None
+    if rank == 0 and not args.no_calibration and os.environ.get('VQK_BENCH_CHILD') != '1':
+        try:
+            calib = box_calibration(device, elapsed / args.steps * 1e3)
+        except Exception as exc:
+            calib = dict(error=f'{type(exc).__name__}: {exc}')
+    if dist.is_initialized():
+        dist.barrier()
     comm = None
     if dist.is_initialized():
         # proof of what RCCL saw, and what the collectives cost on the critical path (same loop, collectives muted)
@@ -414,7 +536,9 @@ def main():
                     ms_per_step_with_collectives=round(float(tt[0]) * 1e3, 3), ms_per_step_collectives_muted=round(float(tt[1]) * 1e3, 3),
                     exposed_comm_ms=round(float(tt[0] - tt[1]) * 1e3, 3), probe_steps=probe,
                     overlap='gradient ranges all-reduced under the remaining backward (VQK_OVERLAP_ALLREDUCE=0: one flat all-reduce)'
-                            if trainer_mod.MiniTrainer.OVERLAP_ALLREDUCE else 'one flat all-reduce after the backward')
+                            if (trainer.overlap_allreduce and getattr(trainer, '_graph2', None) is not None) else 'one flat all-reduce after the backward')
+        if comm_ab is not None:
+            comm.update(comm_ab)                # overlap_queue_ms / overlap_ms / flat_ms of the ~10-step A/B, and which one the timed region ran
 
     roofline = None
     if events:
@@ -511,7 +635,9 @@ def main():
                                rccl_ranks=None if comm is None else comm['rccl_ranks'],
                                collectives_per_step=0 if comm is None else comm['collectives_per_step']),
                    roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel, sustained=sustained, comm=comm,
-                   bf16_vs_fp32_oracle=parity)
+                   bf16_vs_fp32_oracle=parity, box_calibration=calib)
+        if degraded is not None:
+            out['degraded'] = degraded
         if world == 1 and not args.no_other_configs:
             out['other_configs'] = other_configs()
         result_line = json.dumps(out)

@@ -300,6 +300,15 @@ int vqk_conv_set_block_caps(int stream_blocks, int wgrad_blocks);
  * dst[i] += src[i] over `bytes` (16-byte aligned, a multiple of 16) `passes` times, sleeping `sleep` x 64 cycles between
  * 4-KiB pieces, so that a chosen number of CUs stays occupied for a chosen time while the train step runs on another stream. */
 int vqk_probe_stream_add(const float* src, float* dst, int64_t bytes, int blocks, int passes, int sleep, void* stream);
+/* BOX CALIBRATION (bench.py `box_calibration`; csrc/calib.hip) -- not part of the train step.  vqk_calib_fill: pseudo-random bf16
+ * pairs of N(0,1)-like magnitude into w.  vqk_calib_mfma: `blocks` x 256 threads (one wave per SIMD) run `iters` x 18 phases of
+ * the role-split conv kernel's matrix-wave instruction mix (4 LDS fragment reads + 2 L2 weight fragments + 8 bf16 32x32x16 MFMAs)
+ * on the random operands of w (w_bytes: a power of two in [64 KiB, 1 GiB]); vqk_calib_mfma_flops = the multiply-add FLOPs of one
+ * such launch.  vqk_calib_copy: dst = src, 16 bytes per lane, streaming (bytes % 16 == 0): HBM read + write bandwidth. */
+int vqk_calib_fill(void* w, int64_t bytes, void* stream);
+int vqk_calib_mfma(const void* w, int64_t w_bytes, float* sink, int iters, int blocks, void* stream);
+int64_t vqk_calib_mfma_flops(int iters, int blocks);
+int vqk_calib_copy(const void* src, void* dst, int64_t bytes, void* stream);
 /* w [Cout][ks][ks][Cin] -> wt [Cin][ks][ks][Cout] with both taps flipped; src fp32, dst `dtype`. */
 int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, int ksize, void* stream);
 /* dw[Cout][ks][ks][Cin] (fp32) += sum_pix dy[pix][co] * x[pix (+) tap][ci].  dw must be pre-zeroed

@@ -246,7 +246,7 @@ def test_vqgan_shared_fake_pass_equals_two_passes(r1_every):
             m.on_train_batch_start(images, 0)
             res = m._gan_ae_half(images)
             g_ae = ae_opt.flat_g.detach().clone()
-            loss, d_loss, r1 = m._gan_disc_half(0)                     # step 0: with the R1 term when r1_every == 2
+            loss, d_loss, r1 = m._gan_disc_half(0, retain_graph=True)  # step 0: with the R1 term when r1_every == 2 (retain: the shared logits are inspected below)
             torch.cuda.synchronize()
             g_d = torch.cat([p.grad.detach().flatten().float() for p in m.criterion.discriminator.parameters()])
             assert (m.criterion.shared_fake_logits is not None) == share
@@ -483,8 +483,9 @@ def test_vqgan_disc_half_two_streams_equals_one_stream():
             m._gan_ae_half(images)
             used.clear()
             m._gan_disc_half(1)                                       # step 1: no R1
-            torch.cuda.synchronize()
             assert ('disc_real' in used) == side
+            # NO device synchronisation here: the gradients are read by work queued on the current stream right away, as the
+            # optimizer step would -- _gan_disc_half itself joins the real pass's stream (criterion.join_aux_streams)
             g = torch.cat([p.grad.detach().flatten().float() for p in m.criterion.discriminator.parameters()]).clone()
             grads.setdefault(side, []).append(g)
         ref = grads[False][0]

@@ -29,6 +29,9 @@ _PROTOS = {
     'vqk_vq_assign_f32': [P, P, P, P, L, I, I, I, P, P],
     'vqk_vq_assign_filtered_f32': [P, P, P, P, L, I, I, I, P, P, L, P],
     'vqk_probe_stream_add': [P, P, L, I, I, I, P],
+    'vqk_calib_fill': [P, L, P],
+    'vqk_calib_mfma': [P, L, P, I, I, P],
+    'vqk_calib_copy': [P, P, L, P],
     'vqk_vq_prepare_f32': [P, I, I, P, L, P],
     'vqk_vq_forward_f32': [P, P, P, L, L, I, I, I, P, P, P, P, P, P],
     'vqk_vq_backward_fused_f32': [P, P, P, P, I, L, I, I, F, F, P, P, P, P],
@@ -111,7 +114,7 @@ _PROTOS = {
 }
 _SPECIAL = {'vqk_set_tuning': (I, [c_char_p, I]), 'vqk_reset_tuning': (I, []), 'vqk_tuning_count': (I, []),
             'vqk_tuning_name': (c_char_p, [I]),
-            'vqk_conv_packed_elems': (c_int64, [I, I, I, I]), 'vqk_conv2d_wgrad_edge_ws_bytes': (c_int64, []), 'vqk_vq_filter_ws_bytes': (c_int64, [I, I]), 'vqk_status_str': (c_char_p, [I]), 'vqk_version': (I, []), 'vqk_arch': (c_char_p, [])}
+            'vqk_conv_packed_elems': (c_int64, [I, I, I, I]), 'vqk_calib_mfma_flops': (c_int64, [I, I]), 'vqk_conv2d_wgrad_edge_ws_bytes': (c_int64, []), 'vqk_vq_filter_ws_bytes': (c_int64, [I, I]), 'vqk_status_str': (c_char_p, [I]), 'vqk_version': (I, []), 'vqk_arch': (c_char_p, [])}
 EXPORTS = sorted(list(_PROTOS) + list(_SPECIAL))
 
 

@@ -212,11 +212,11 @@ class VQVAE(BaseVQVAE, _LightningBase):
         if share:
             # the discriminator half reuses THIS pass over the reconstruction (loss.SHARE_FAKE_PASS): its parameters stay in the
             # graph, the generator's backward skips their gradients (ops.no_param_grads) and keeps the saved activations
-            self.criterion.shared_fake_logits = None
+            self.criterion._share(None, None)
             res = self.criterion.forward_autoencoder(q_loss, target, recon_pad, self.current_epoch,
                                                      last_layer=self.decoder.conv_out.weight)
             with ops.no_param_grads():
-                res[0].backward(retain_graph=True)
+                res[0].backward(retain_graph=True)          # (the discriminator half backpropagates through the shared D(fake) pass)
         else:
             for p in disc_params:
                 p.requires_grad_(False)
@@ -227,11 +227,14 @@ class VQVAE(BaseVQVAE, _LightningBase):
                 for p in disc_params:
                     p.requires_grad_(True)
             self.manual_backward(res[0])
+        self.criterion.join_aux_streams()                   # LPIPS ran (and was differentiated) on its own stream
         self._gan_state = (target, recon_pad, q_loss, res)
         return res
 
-    def _gan_disc_half(self, step: int):
-        """second half: discriminator loss (+ R1 every r1_reg_every steps) and its backward; (loss, d_loss, r1_penalty)"""
+    def _gan_disc_half(self, step: int, retain_graph: bool = False):
+        """second half: discriminator loss (+ R1 every r1_reg_every steps) and its backward; (loss, d_loss, r1_penalty).
+        ``retain_graph``: only the graph-capturing trainer needs the generator half's autograd graph afterwards (it captures this
+        half twice on one generator half, with and without R1); an eager step releases it (MiniTrainer-less callers included)."""
         target, recon_pad, _, _ = self._gan_state
         _, disc_opt = self.optimizers()
         loss, d_loss, r1_penalty = self.criterion.forward_discriminator(target, recon_pad, self.current_epoch, step)
@@ -239,10 +242,18 @@ class VQVAE(BaseVQVAE, _LightningBase):
             disc_opt.zero_grad()
             if getattr(self.criterion, 'shared_fake_logits', None) is not None:
                 # the fake half of the loss hangs on the generator half's graph: only the discriminator's leaves are wanted
-                # (retain_graph: the graph-capturing trainer runs this half twice on one generator half -- with and without R1)
-                loss.backward(inputs=[p for p in self.criterion.discriminator.parameters() if p.requires_grad], retain_graph=True)
+                loss.backward(inputs=[p for p in self.criterion.discriminator.parameters() if p.requires_grad], retain_graph=retain_graph)
             else:
                 self.manual_backward(loss)
+            self.criterion.join_aux_streams()               # the real pass (forward + backward) ran on its own stream
+        if not retain_graph:
+            # nothing of the step's autograd graph outlives the step: the saved activations of the generator half (encoder, decoder,
+            # both VGG passes, the D(fake) pass) would otherwise stay allocated until the NEXT step's forward has allocated its own
+            # set -- twice the activation memory at the peak
+            self.criterion._share(None, None)
+            t, _, q, res = self._gan_state
+            self._gan_state = (None, None, q.detach(), tuple(v.detach() if torch.is_tensor(v) else v for v in res))
+            loss = loss.detach() if loss is not None else None
         return loss, d_loss, r1_penalty
 
     def _gan_log(self, res, q_loss, d_loss, r1_penalty):
@@ -267,7 +278,7 @@ class VQVAE(BaseVQVAE, _LightningBase):
             disc_opt.step()
         self._gan_log(res, self._gan_state[2], d_loss, r1_penalty)
         self.accumulate_usage(self.quantizer.last_hist)
-        return res[0]
+        return res[0].detach()
 
     def training_step(self, batch: Any, batch_index: int):
         if isinstance(self.criterion, VQLPIPSWithDiscriminator):

@@ -39,6 +39,10 @@ def discriminator_loss(logits_real: torch.Tensor, logits_fake: torch.Tensor, los
 
 
 class VQLPIPSWithDiscriminator(nn.Module):
+    shared_fake_logits = None                # (class defaults: a criterion assembled without __init__ has them too)
+    _shared_for = None
+    used_aux_streams = ()
+
     def __init__(self, image_size: int, l1_weight: float, l2_weight: float, perc_weight: float, adversarial_conf: dict):
         super().__init__()
         self.l1_weight, self.l2_weight, self.perceptual_weight = l1_weight, l2_weight, perc_weight
@@ -50,6 +54,24 @@ class VQLPIPSWithDiscriminator(nn.Module):
         self.use_adaptive_g_weight = adversarial_conf['use_adaptive']
         self.r1_regularization_cost = adversarial_conf['r1_reg_weight']
         self.r1_regularization_every = adversarial_conf['r1_reg_every']
+        self.shared_fake_logits = None       # D(fake) of the last generator half, kept for the discriminator half (SHARE_FAKE_PASS)
+        self._shared_for = None              # ... and the reconstruction tensor (weak reference) it was computed on
+        self.used_aux_streams = []           # side streams the last forward_* issued work on: the caller joins them after ITS backward
+
+    def _share(self, logits, reconstructions):
+        import weakref
+        self.shared_fake_logits = logits
+        self._shared_for = None if logits is None else weakref.ref(reconstructions)
+
+    def join_aux_streams(self) -> None:
+        """the current stream waits for every side stream the last forward used.  Autograd runs a node's backward on the stream
+        of its forward, and kernels that add weight / bias gradients straight into the optimizer's arena return None to autograd:
+        no AccumulateGrad node, so the engine's end-of-backward stream sync does not cover them -- the optimizer (current stream)
+        must not read the arena while a side stream's atomics are in flight.  One event wait per stream; legal under capture."""
+        cur = torch.cuda.current_stream()
+        for st in self.used_aux_streams:
+            cur.wait_stream(st)
+        self.used_aux_streams = []
 
     def calculate_adaptive_weight(self, nll_loss, g_loss, last_layer):
         """lambda = clamp(|d nll / d W_last| / (|d g / d W_last| + 1e-8), 0, 1e4) * g_weight   (loss.py:80-96)"""
@@ -64,12 +86,14 @@ class VQLPIPSWithDiscriminator(nn.Module):
         l1_loss, l2_loss = ops.ReconLossFn.apply(reconstructions, images, float(n * 3 * h * w))
         adversarial = current_epoch >= self.adversarial_start_epoch
         side = None
+        self.used_aux_streams = []
         if LPIPS_SIDE_STREAM and adversarial and reconstructions.is_cuda:
             # LPIPS (two VGG16 passes) and the discriminator pass over the reconstruction are independent until their gradients
             # meet at the reconstruction: LPIPS is issued on a second stream -- autograd runs its backward on that stream too --
             # so the under-filled small-map launches and the bandwidth-bound passes of one chain run next to the other's convs
             main, side = torch.cuda.current_stream(), ops.aux_stream(reconstructions.device, 'lpips')
             side.wait_stream(main)
+            self.used_aux_streams.append(side)
             with torch.cuda.stream(side):
                 p_loss = self.perceptual_loss(images, reconstructions)
         else:
@@ -80,7 +104,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
             main.wait_stream(side)
         nll_loss = l1_loss * self.l1_weight + l2_loss * self.l2_weight + p_loss * self.perceptual_weight
         if adversarial:
-            self.shared_fake_logits = logits_fake if (SHARE_FAKE_PASS and self.training) else None
+            self._share(logits_fake if (SHARE_FAKE_PASS and self.training) else None, reconstructions)
             g_loss = generator_loss(logits_fake, loss_type=self.adversarial_loss_type)
             if self.training and self.use_adaptive_g_weight:
                 g_weight = self.calculate_adaptive_weight(p_loss, g_loss, last_layer=last_layer)   # p_loss, as the reference
@@ -88,7 +112,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
                 g_weight = self.generator_weight
             loss = nll_loss + g_loss * g_weight + quantizer_loss
         else:
-            self.shared_fake_logits = None                   # (no discriminator pass in this step: nothing to share, nothing kept alive)
+            self._share(None, None)                          # (no discriminator pass in this step: nothing to share, nothing kept alive)
             g_loss = torch.zeros_like(nll_loss, requires_grad=False)
             g_weight = 0.
             loss = nll_loss + quantizer_loss
@@ -108,10 +132,16 @@ class VQLPIPSWithDiscriminator(nn.Module):
             compute_r1 = (self.training and current_step % self.r1_regularization_every == 0
                           and self.r1_regularization_cost is not None)
             images = images.detach().requires_grad_(compute_r1)
-            shared = getattr(self, 'shared_fake_logits', None) if SHARE_FAKE_PASS else None
-            if shared is not None and shared.shape[0] == reconstructions.shape[0]:
+            self.used_aux_streams = []
+            # the logits of the generator half are reused only for the VERY tensor they were computed on (object identity): any
+            # other reconstruction -- a caller following the reference loop with its own tensors -- takes the two-pass form, whose
+            # loss supports a plain loss.backward()
+            shared = self.shared_fake_logits if SHARE_FAKE_PASS else None
+            if shared is not None and not (self._shared_for is not None and self._shared_for() is reconstructions):
+                shared = None
+            if shared is not None:
                 # (the caller restricts the backward to the discriminator's parameters: the graph behind `shared` also leads
-                # into the decoder)
+                # into the decoder -- model.VQVAE._gan_disc_half)
                 logits_fake = shared
                 # Not in R1 steps: there the real pass is layer-by-layer and differentiated twice, so one parameter can receive a
                 # RETURNED gradient (autograd's read-modify-write accumulation) from one chain while the other chain's kernels add
@@ -123,6 +153,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
                     # (whose forward ran on the main stream in the generator half) -- two independent chains through the same weights
                     main, side = torch.cuda.current_stream(), ops.aux_stream(images.device, 'disc_real')
                     side.wait_stream(main)
+                    self.used_aux_streams.append(side)
                     with torch.cuda.stream(side):
                         logits_real = self.discriminator(images, double_backward=compute_r1)
                         r1_term = self.calculate_r1_regularization_term(logits_real, images, compute_r1)

@@ -24,7 +24,9 @@ def reduce_ema_stats(stats: torch.Tensor, local_batch: int, force_collective: bo
     on the rank-concatenated batch.  Host logic only (no kernel): callable on CPU tensors under gloo."""
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if world > 1 or (force_collective and dist.is_available() and dist.is_initialized()):
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        work = dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)     # async + wait: see optim.all_reduce_sum
+        if work is not None:
+            work.wait()
         EMA_COLLECTIVES[0] += 1
         EMA_COLLECTIVES[1] += stats.numel() * stats.element_size()
     return float(local_batch * world)

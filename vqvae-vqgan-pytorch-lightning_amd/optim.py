@@ -13,6 +13,19 @@ from . import _native
 _ALIGN = 64   # elements; keeps every tensor (fp32 and its bf16 shadow) 16-byte aligned inside the arena
 
 
+def all_reduce_sum(t: torch.Tensor) -> None:
+    """SUM all-reduce of ``t`` in place, ordered after the work queued on the current stream; the current stream waits for it.
+
+    Issued as an ASYNC collective + ``wait()`` (a stream-side wait, the host does not block): the process group then runs the
+    kernel on its own stream and records its completion events THERE.  A synchronous ``dist.all_reduce`` records them on the
+    CURRENT stream -- and when that stream is the one a hipGraph is captured on a moment later (MiniTrainer's settling steps run on
+    the capture stream), the group's watchdog thread polls an event 'last recorded in a capturing stream': hipErrorCapturedEvent,
+    the watchdog terminates the process (seen 1 run in 3 with the full-size VQ-GAN step, where a capture takes seconds)."""
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+    if work is not None:
+        work.wait()
+
+
 def _is_channels_last_param(p: torch.Tensor) -> bool:
     return p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
 
@@ -172,7 +185,7 @@ class FlatAdamW(torch.optim.Optimizer):
         """ONE collective per optimizer step (replaces DDP's bucketed reducer, vqvae/train.py:128)."""
         if self.collective_on():
             if not self.mute_collectives:
-                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+                all_reduce_sum(self.flat_g)
                 self._count(self.flat_g.numel())
             self.grad_scale = 1.0 / dist.get_world_size()
         else:

@@ -32,6 +32,16 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     return rank, local, world
 
 
+def _quiesce_collectives() -> None:
+    """before a hipGraph capture: every collective issued so far has completed on the device AND the process group's watchdog
+    thread (polls every 100 ms) has retired it -- the watchdog must not query RCCL events while this thread captures (HIP
+    rejects a query of an event whose stream is capturing: the watchdog would terminate the process)"""
+    torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+        import time
+        time.sleep(0.3)
+
+
 class MiniTrainer:
     def __init__(self, max_epochs: int = 1, num_training_batches: int | None = None, deterministic: bool | None = None):
         """``deterministic``: ``pl.Trainer(deterministic=True)`` of vqvae/train.py:130 -- ordered partial sums instead of atomics
@@ -42,6 +52,7 @@ class MiniTrainer:
         self.num_training_batches = num_training_batches
         self.optimizers = []
         self.global_step = 0
+        self.overlap_allreduce = self.OVERLAP_ALLREDUCE          # per trainer: bench.py times both forms on the same model
 
     def attach(self, model):
         model.trainer = self
@@ -78,7 +89,7 @@ class MiniTrainer:
     OVERLAP_ALLREDUCE = os.environ.get('VQK_OVERLAP_ALLREDUCE', '1') != '0'
 
     def _use_split(self, model, opt) -> bool:
-        return (self.OVERLAP_ALLREDUCE and opt.collective_on() and getattr(opt, 'front_numel', 0) > 0
+        return (self.overlap_allreduce and opt.collective_on() and getattr(opt, 'front_numel', 0) > 0
                 and hasattr(model, 'split_backward') and getattr(model, 'automatic_optimization', True))
 
     @staticmethod
@@ -171,7 +182,7 @@ class MiniTrainer:
             for i in range(warmup):
                 self._eager_step(model, self._static_in, i)
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        _quiesce_collectives()
         if snap is not None:
             self._restore(model, snap)
         # EMA quantizer: its statistics all-reduce must not sit inside the captured graph -- the update is deferred and
@@ -228,11 +239,17 @@ class MiniTrainer:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             ops._stream()
-            for i in range(max(warmup, 2)):               # both discriminator variants (with / without R1) run once
+            # both discriminator variants run once in the settling steps -- the R1 variant is the step with
+            # (epoch * batches + index) % r1_every == 0: the indices are chosen for it at ANY epoch (a re-capture at the start of
+            # the adversarial phase included), so no lazy pack / workspace allocation happens inside a capture
+            crit0 = model.criterion
+            every0 = crit0.r1_regularization_every if crit0.r1_regularization_cost is not None else 0
+            first = (-(model.current_epoch * self.num_training_batches)) % every0 if every0 else 0
+            for i in range(first, first + max(warmup, 2)):
                 model.on_train_batch_start(self._static_in, i)
                 model.training_step(self._static_in, i)
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        _quiesce_collectives()
         if snap is not None:
             self._restore(model, snap)
         crit = model.criterion
@@ -249,7 +266,7 @@ class MiniTrainer:
                     continue
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=g_ae.pool(), stream=side, capture_error_mode='thread_local'):
-                    out = model._gan_disc_half(step if every else 1)
+                    out = model._gan_disc_half(step if every else 1, retain_graph=True)
                 self._gan[key] = (g, out)
         finally:
             model.defer_usage_accumulation = False
