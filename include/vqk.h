@@ -324,6 +324,11 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
 int64_t vqk_conv2d_wgrad_edge_ws_bytes(void);
 int vqk_conv2d_wgrad_edge(int dtype, const void* x, const void* dy, float* dw, void* ws, int64_t ws_bytes, int n, int h,
                           int w, int cin, int cout, const void* zeros, void* stream);
+/* vqk_conv2d_wgrad_edge with the TRUE channel count of the thin side (thin_true in 1..8; 3 for the image / reconstruction): dw is
+ * the parameter's own unpadded gradient -- [128][3][3][thin_true] for (cin, cout) = (8, 128), [thin_true][3][3][128] for (128, 8) --
+ * the sums of the zero-padded channels are dropped.  thin_true = 8: vqk_conv2d_wgrad_edge. */
+int vqk_conv2d_wgrad_edge_true(int dtype, const void* x, const void* dy, float* dw, void* ws, int64_t ws_bytes, int n, int h,
+                               int w, int cin, int cout, int thin_true, const void* zeros, void* stream);
 /* The decoder's last conv (autoencoder.py:170): 3x3, stride 1, 'same', cin = 128 -> cout = 8 (the 3 image channels padded to
  * one 16-byte chunk), y = act(conv(x, w) + bias) with act 0 none / 1 tanh; bf16 in and out, h % 8 == 0, w % 32 == 0;
  * w: bf16 [8][3][3][128] (weight layout 0).  VQK_ERR_SHAPE when not served (nothing launched: callers use vqk_conv2d_fprop). */
@@ -331,6 +336,9 @@ int vqk_conv2d_thin_out(int dtype, const void* x, const void* w, const float* bi
                         int cout, int act, const void* zeros, void* stream);
 /* out[c] (+)= sum over rows of x[rows][c]  (bias gradients); out pre-zeroed. */
 int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream);
+/* vqk_colsum that writes only the first c_out <= c columns: `out` is the gradient of a bias whose layer carries zero-padded output
+ * channels (the decoder's 3-channel head on 8): the sums go straight into the parameter's own (unpadded) gradient. */
+int vqk_colsum_lead(int dtype, const void* x, int64_t rows, int c, int c_out, float* out, void* stream);
 /* elementwise fp32 -> dtype cast (weight shadow copies) */
 int vqk_cast(const float* src, void* dst, int dtype, int64_t n, void* stream);
 

@@ -33,8 +33,8 @@ def _grads(fuse, dtype, graphed=False):
         class Counting:
             def __getattr__(self, name):
                 fn = getattr(lib, name)
-                if name in ('vqk_colsum', 'vqk_gn_backward_colsum'):
-                    def wrapped(*a, _fn=fn, _k='colsum' if name == 'vqk_colsum' else 'fused'):
+                if name in ('vqk_colsum', 'vqk_colsum_lead', 'vqk_gn_backward_colsum'):
+                    def wrapped(*a, _fn=fn, _k='colsum' if name.startswith('vqk_colsum') else 'fused'):
                         calls[_k] += 1
                         return _fn(*a)
                     return wrapped

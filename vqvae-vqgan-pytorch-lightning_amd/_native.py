@@ -73,8 +73,10 @@ _PROTOS = {
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
     'vqk_conv2d_wgrad_pooled_dy': [I, P, P, P, I, I, I, I, I, F, P, P],
     'vqk_conv2d_wgrad_edge': [I, P, P, P, P, L, I, I, I, I, I, P, P],
+    'vqk_conv2d_wgrad_edge_true': [I, P, P, P, P, L, I, I, I, I, I, I, P, P],
     'vqk_conv2d_thin_out': [I, P, P, P, P, I, I, I, I, I, I, P, P],
     'vqk_colsum': [I, P, L, I, P, P],
+    'vqk_colsum_lead': [I, P, L, I, I, P, P],
     'vqk_cast': [P, P, I, L, P],
     'vqk_gn_stats': [I, P, I, L, I, I, F, P, P, P],
     'vqk_gn_apply': [I, P, P, P, P, P, I, L, I, I, I, P],

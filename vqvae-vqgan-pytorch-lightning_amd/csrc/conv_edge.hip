@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_thin_kernel(const bf16_r
 // dw[i] += sum over the blocks' partials in a FIXED order (deterministic): block = 16 outputs x 16 partial groups, every
 // thread sums its group's <= 16 partials (all loads independent: one round trip, not 64 dependent ones), the groups are
 // combined through LDS in group order
-__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int blocks) {
+// thin_true < 8 (the TRUE channel count of the thin side -- 3 for the image / reconstruction): dw is the parameter's own,
+// unpadded gradient ([128][9][thin_true] when thin_in, [thin_true][9][128] otherwise); the padded channels' sums are dropped
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int blocks,
+                                                                int thin_true, int thin_in) {
     __shared__ float part[16][17];
     const int o = threadIdx.x & 15, kg = threadIdx.x >> 4;
     const int i = (int)blockIdx.x * 16 + o;
@@ -178,7 +181,10 @@ __global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __r
         float t = 0.0f;
 #pragma unroll
         for (int g2 = 0; g2 < 16; ++g2) t += part[g2][threadIdx.x];
-        dw[i] += t;
+        const int i2 = (int)blockIdx.x * 16 + (int)threadIdx.x;
+        if (thin_true >= 8) dw[i2] += t;
+        else if (thin_in) { const int ci = i2 & 7; if (ci < thin_true) dw[(i2 >> 3) * thin_true + ci] += t; }     // i2 = (co * 9 + tap) * 8 + ci
+        else if (i2 < thin_true * 9 * EDGE_CW) dw[i2] += t;                                                      // i2 = (co * 9 + tap) * 128 + ci
     }
 }
 
@@ -318,7 +324,13 @@ int64_t vqk_conv2d_wgrad_edge_ws_bytes(void) { return (int64_t)256 * EDGE_OUT * 
 
 int vqk_conv2d_wgrad_edge(int dtype, const void* x, const void* dy, float* dw, void* ws, int64_t ws_bytes, int n, int h,
                           int w, int cin, int cout, const void* zeros, void* stream) {
+    return vqk_conv2d_wgrad_edge_true(dtype, x, dy, dw, ws, ws_bytes, n, h, w, cin, cout, 8, zeros, stream);
+}
+
+int vqk_conv2d_wgrad_edge_true(int dtype, const void* x, const void* dy, float* dw, void* ws, int64_t ws_bytes, int n, int h,
+                               int w, int cin, int cout, int thin_true, const void* zeros, void* stream) {
     VQK_REQUIRE(x && dy && dw && ws && zeros, VQK_ERR_ARG);
+    VQK_REQUIRE(thin_true >= 1 && thin_true <= 8, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(ws) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
     VQK_REQUIRE(dtype == VQK_BF16, VQK_ERR_DTYPE);
     VQK_REQUIRE(n > 0 && h > 0 && w > 0, VQK_ERR_SHAPE);
@@ -346,7 +358,7 @@ int vqk_conv2d_wgrad_edge(int dtype, const void* x, const void* dy, float* dw, v
     }
     VQK_CHECK_LAUNCH();
     static_assert(EDGE_OUT % 16 == 0, "reduce blocks own 16 outputs");
-    hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3(EDGE_OUT / 16), dim3(256), 0, st, (const float*)ws, dw, blocks);
+    hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3(EDGE_OUT / 16), dim3(256), 0, st, (const float*)ws, dw, blocks, thin_true, first ? 1 : 0);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

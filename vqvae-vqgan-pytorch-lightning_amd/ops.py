@@ -191,7 +191,46 @@ def pack_weights(w_mem_f32, dtype, cout, cin, ksize, transpose: bool, layout: in
 
 
 class _PackEntry:
-    __slots__ = ('wref', 'src', 'dst', 'desc', 'stamp', 'ready')
+    __slots__ = ('wref', 'src', 'dst', 'desc', 'stamp', 'ready', 'stage')
+
+
+class _PackStage:
+    """persistent fp32 image of a weight in the kernels' [O_pad][k][k][I_pad] order, for weights whose own memory is not that:
+    zero-padded channel counts (the 3-channel edge convs, the discriminator's fromrgb), torch-contiguous OIHW parameters (VGG16,
+    the StyleGAN2 layers), 2-D fully connected weights viewed as 1x1 convs, 1x1 weights placed at the centre tap of a 3x3
+    (``kind = 'centre3'``).  Refreshed by ONE strided copy when the master weight changes -- together with the packed operands,
+    i.e. after the optimizer step (:func:`repack_owned`), never inside the captured step.  (Before round 5 these weights were
+    zero-filled, copied and packed per conv CALL: 9 launches per headline step, 60 per VQ-GAN step.)"""
+    __slots__ = ('wref', 'buf', 'stamp', 'shape4', 'kind')
+
+    def refresh(self, weight, stamp) -> None:
+        if self.stamp == stamp:
+            return
+        o, i, k, _ = self.shape4
+        w4 = weight.detach().reshape(o, i, k, k)
+        with torch.no_grad():
+            if self.kind == 'centre3':
+                self.buf[:o, 1, 1, :i].copy_(w4.reshape(o, i))
+            else:
+                self.buf[:o, :, :, :i].copy_(w4.permute(0, 2, 3, 1))
+        self.stamp = stamp
+
+
+_PACK_STAGES: dict = {}         # (data_ptr, shape4, cin_pad, cout_pad, kind) -> _PackStage
+
+
+def _pack_stage(weight, shape4, cin_pad: int, cout_pad: int, kind: str) -> _PackStage:
+    key = (weight.data_ptr(), tuple(shape4), cin_pad, cout_pad, kind)
+    st = _PACK_STAGES.get(key)
+    if st is not None and st.wref() is not weight:
+        st = None
+    if st is None:
+        st = _PackStage()
+        k = 3 if kind == 'centre3' else shape4[2]
+        st.wref, st.shape4, st.kind, st.stamp = weakref.ref(weight), tuple(shape4), kind, None
+        st.buf = torch.zeros((cout_pad, k, k, cin_pad), dtype=torch.float32, device=weight.device)
+        _PACK_STAGES[key] = st
+    return st
 
 
 def _pack_written(entries) -> None:
@@ -217,7 +256,7 @@ def _pack_use(ent) -> torch.Tensor:
     return ent.dst
 
 
-_PACK_CACHE: dict = {}          # (data_ptr, o, i, k, transpose, layout, dtype) -> _PackEntry
+_PACK_CACHE: dict = {}          # (data_ptr, shape4, k, transpose, layout, dtype, cin_pad, cout_pad, kind) -> _PackEntry
 _PACK_BLOCKS = int(os.environ.get('VQK_PACK_BLOCKS', '128'))    # blocks per operand of the repack launch (32 -> 128: -0.05 ms/step, the 512x512x9 operands)
 _PACK_TABLE = None              # {tuple of keys: device int64 [n, 8]} descriptor tables of the repack launches
 
@@ -229,17 +268,19 @@ def _pack_stamp(weight):
     return (weight._version, owner.generation if owner is not None else -1)
 
 
-def packed_weight(weight, cin_pad: int, cout_pad: int, dtype, ksize: int, transpose: bool, layout: int) -> torch.Tensor:
-    """The conv operand of ``weight`` (logical [O,I,k,k]) in ``dtype`` / ``layout``, from a cache of persistent buffers
-    that is refreshed by ONE multi-tensor launch per optimizer step (:func:`repack_owned`) instead of one pack launch
-    per conv call.  Falls back to a per-call pack for zero-padded or non-channels_last weights."""
+def packed_weight(weight, cin_pad: int, cout_pad: int, dtype, ksize: int, transpose: bool, layout: int, shape4=None,
+                  kind: str = 'pad') -> torch.Tensor:
+    """The conv operand of ``weight`` (logical [O,I,k,k]; ``shape4``: that shape for a 2-D fully connected weight) in ``dtype`` /
+    ``layout``, from a cache of persistent buffers that is refreshed by ONE multi-tensor launch per optimizer step
+    (:func:`repack_owned`) instead of one pack launch per conv call.  ``kind = 'centre3'``: a 1x1 weight as the centre tap of a
+    3x3 operand (ksize = 3)."""
     w = weight.detach()
-    o, i = w.shape[0], w.shape[1]
-    if not (cin_pad == i and cout_pad == o and w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()):
-        return pack_weights(_weight_mem(weight, cin_pad, cout_pad), dtype, cout_pad, cin_pad, ksize, transpose, layout)
-    if layout == 0 and not transpose and dtype == torch.float32:
+    shape4 = tuple(shape4) if shape4 is not None else tuple(w.shape)
+    o, i = shape4[0], shape4[1]
+    direct = (kind == 'pad' and cin_pad == i and cout_pad == o and w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous())
+    if direct and layout == 0 and not transpose and dtype == torch.float32:
         return w.permute(0, 2, 3, 1).reshape(-1)
-    key = (w.data_ptr(), o, i, ksize, bool(transpose), layout, dtype)
+    key = (w.data_ptr(), shape4, ksize, bool(transpose), layout, dtype, cin_pad, cout_pad, kind)
     ent = _PACK_CACHE.get(key)
     stamp = _pack_stamp(weight)
     if ent is not None and ent.wref() is not weight:
@@ -247,16 +288,24 @@ def packed_weight(weight, cin_pad: int, cout_pad: int, dtype, ksize: int, transp
     if ent is not None and ent.stamp == stamp:
         return _pack_use(ent)
     if ent is None:
-        dc, di = (i, o) if transpose else (o, i)
+        dc, di = (cin_pad, cout_pad) if transpose else (cout_pad, cin_pad)
         ent = _PackEntry()
-        ent.wref, ent.src = weakref.ref(weight), w.permute(0, 2, 3, 1).reshape(-1)
-        ent.dst = torch.empty(_native.lib().vqk_conv_packed_elems(dc, di, ksize, layout), dtype=dtype, device=w.device)
-        ent.desc = [ent.src.data_ptr(), ent.dst.data_ptr(), dcode(dtype), o, i, ksize, int(transpose), layout]
+        ent.wref = weakref.ref(weight)
+        ent.stage = None if direct else _pack_stage(weight, shape4, cin_pad, cout_pad, kind)
+        ent.src = w.permute(0, 2, 3, 1).reshape(-1) if direct else ent.stage.buf.reshape(-1)
+        if layout == 0 and not transpose and dtype == torch.float32:
+            ent.dst = ent.src                            # the padded fp32 image IS the operand
+        else:
+            ent.dst = torch.empty(_native.lib().vqk_conv_packed_elems(dc, di, ksize, layout), dtype=dtype, device=w.device)
+        ent.desc = [ent.src.data_ptr(), ent.dst.data_ptr(), dcode(dtype), cout_pad, cin_pad, ksize, int(transpose), layout]
         ent.ready = None
         _PACK_CACHE[key] = ent
-    st = _native.lib().vqk_conv_pack_weights(ent.src.data_ptr(), ent.dst.data_ptr(), dcode(dtype), o, i, ksize,
-                                             int(transpose), layout, _stream())
-    _native.check(st, 'conv_pack_weights')
+    if ent.stage is not None:
+        ent.stage.refresh(weight, stamp)
+    if ent.dst is not ent.src:
+        st = _native.lib().vqk_conv_pack_weights(ent.src.data_ptr(), ent.dst.data_ptr(), dcode(dtype), cout_pad, cin_pad, ksize,
+                                                 int(transpose), layout, _stream())
+        _native.check(st, 'conv_pack_weights')
     ent.stamp = stamp
     _pack_written((ent,))
     return ent.dst
@@ -267,6 +316,7 @@ def repack_owned(owner=None) -> int:
     with one ``vqk_conv_pack_multi`` launch.  Called by ``FlatAdamW.step`` right after the AdamW kernel."""
     global _PACK_TABLE
     refresh_vq_prepared(owner)                           # the quantizer's prepared codebook follows the same rule
+    refresh_padded_vectors(owner)
     keys, dead = [], []
     for key, ent in _PACK_CACHE.items():
         weight = ent.wref()
@@ -279,21 +329,29 @@ def repack_owned(owner=None) -> int:
             keys.append(key)
     for key in dead:
         del _PACK_CACHE[key]
+    for key in [k for k, st in _PACK_STAGES.items() if st.wref() is None or st.wref().data_ptr() != k[0]]:
+        del _PACK_STAGES[key]
     if not keys:
         return 0
     keys = tuple(keys)
-    if _PACK_TABLE is None:
-        _PACK_TABLE = {}
-    # one device table per set of DESCRIPTORS (two optimizers alternate in the VQ-GAN step).  Keyed by the descriptors themselves:
-    # a later model may get the same parameter addresses (same keys) with other destination buffers
-    sig = tuple(tuple(int(v) for v in _PACK_CACHE[k].desc) for k in keys)
-    table = _PACK_TABLE.get(sig)
-    if table is None:
-        if len(_PACK_TABLE) >= 8:
-            _PACK_TABLE.clear()
-        dev = _PACK_CACHE[keys[0]].dst.device
-        table = _PACK_TABLE[sig] = torch.tensor([list(d) for d in sig], dtype=torch.int64).to(dev)
-    _native.check(_native.lib().vqk_conv_pack_multi(table.data_ptr(), len(keys), _PACK_BLOCKS, _stream()), 'conv_pack_multi')
+    for k in keys:                                       # the padded / re-ordered fp32 images first (one strided copy each)
+        ent = _PACK_CACHE[k]
+        if ent.stage is not None:
+            ent.stage.refresh(ent.wref(), _pack_stamp(ent.wref()))
+    pack_keys = tuple(k for k in keys if _PACK_CACHE[k].dst is not _PACK_CACHE[k].src)
+    if pack_keys:
+        if _PACK_TABLE is None:
+            _PACK_TABLE = {}
+        # one device table per set of DESCRIPTORS (two optimizers alternate in the VQ-GAN step).  Keyed by the descriptors themselves:
+        # a later model may get the same parameter addresses (same keys) with other destination buffers
+        sig = tuple(tuple(int(v) for v in _PACK_CACHE[k].desc) for k in pack_keys)
+        table = _PACK_TABLE.get(sig)
+        if table is None:
+            if len(_PACK_TABLE) >= 8:
+                _PACK_TABLE.clear()
+            dev = _PACK_CACHE[pack_keys[0]].dst.device
+            table = _PACK_TABLE[sig] = torch.tensor([list(d) for d in sig], dtype=torch.int64).to(dev)
+        _native.check(_native.lib().vqk_conv_pack_multi(table.data_ptr(), len(pack_keys), _PACK_BLOCKS, _stream()), 'conv_pack_multi')
     for k in keys:
         ent = _PACK_CACHE[k]
         ent.stamp = _pack_stamp(ent.wref())
@@ -301,9 +359,52 @@ def repack_owned(owner=None) -> int:
     return len(keys)
 
 
+class _PadVec:
+    __slots__ = ('wref', 'buf', 'stamp')
+
+
+_PAD_VECS: dict = {}            # (data_ptr, n_pad) -> _PadVec: a bias zero-padded to the kernels' channel count
+
+
+def padded_vector(vec, n_pad: int) -> torch.Tensor:
+    """fp32 copy of the 1-D parameter ``vec`` zero-padded to ``n_pad`` elements, persistent and refreshed like the packed
+    operands (a conv whose output channels are padded -- the decoder's 3-channel head -- zero-filled and copied its bias per call)"""
+    v = vec.detach()
+    if v.numel() == n_pad and v.dtype == torch.float32:
+        return v
+    key = (v.data_ptr(), n_pad)
+    ent = _PAD_VECS.get(key)
+    if ent is not None and ent.wref() is not vec:
+        ent = None
+    if ent is None:
+        ent = _PadVec()
+        ent.wref, ent.stamp = weakref.ref(vec), None
+        ent.buf = torch.zeros(n_pad, dtype=torch.float32, device=v.device)
+        _PAD_VECS[key] = ent
+    stamp = _pack_stamp(vec)
+    if ent.stamp != stamp:
+        with torch.no_grad():
+            ent.buf[:v.numel()].copy_(v)
+        ent.stamp = stamp
+    return ent.buf
+
+
+def refresh_padded_vectors(owner=None) -> None:
+    for key, ent in list(_PAD_VECS.items()):
+        vec = ent.wref()
+        if vec is None or vec.data_ptr() != key[0]:
+            del _PAD_VECS[key]
+        elif (owner is None and ent.stamp != _pack_stamp(vec)) or (owner is not None and getattr(vec, '_vqk_owner', None) is owner):
+            with torch.no_grad():
+                ent.buf[:vec.numel()].copy_(vec.detach())
+            ent.stamp = _pack_stamp(vec)
+
+
 def clear_pack_cache():
     global _PACK_TABLE
     _PACK_CACHE.clear()
+    _PACK_STAGES.clear()
+    _PAD_VECS.clear()
     _VQ_PREP.clear()
     _PACK_TABLE = None
 
@@ -519,25 +620,34 @@ def _edge_ws(device) -> torch.Tensor:
     return ws
 
 
-def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None) -> torch.Tensor:
+def edge_wgrad_served(x, dy, ksize: int, ups: bool) -> bool:
+    """the K = 72 weight-gradient kernel of the two edge convs (padded 3-channel image / reconstruction) serves this problem"""
+    n, cin, h, w = x.shape
+    return (_EDGE_WGRAD and x.dtype == torch.bfloat16 and ksize == 3 and not ups and (cin, dy.shape[1]) in ((8, 128), (128, 8))
+            and (h * w) % 128 == 0 and (w % 128 == 0 or 128 % w == 0))
+
+
+def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8) -> torch.Tensor:
     """dw as fp32 with memory [Cout][k][k][Cin] (logical [Cout,Cin,k,k] channels_last); ``out``: accumulate
-    into this (pre-existing) buffer instead of a fresh zeroed one."""
+    into this (pre-existing) buffer instead of a fresh zeroed one.  ``thin_true`` < 8 (edge convs only, with ``out``): ``out`` is
+    the parameter's own UNPADDED gradient (3 true channels on the thin side: vqk_conv2d_wgrad_edge_true)."""
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     dw = out if out is not None else \
         torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
     flops = 2.0 * n * dy.shape[2] * dy.shape[3] * cout * cin * ksize * ksize
-    if (_EDGE_WGRAD and x.dtype == torch.bfloat16 and ksize == 3 and not ups and (cin, cout) in ((8, 128), (128, 8))
-            and (h * w) % 128 == 0 and (w % 128 == 0 or 128 % w == 0)):
+    if edge_wgrad_served(x, dy, ksize, ups):
         # the two edge convs (padded 3-channel image / reconstruction): K = 72 GEMM, HBM-bound, workspace split-K
         ws = _edge_ws(x.device)
         nbytes = (x.numel() + dy.numel()) * 2
         st = _timed('conv3x3_wgrad_thin_kernel<bf16>' + (f' {cin}->{cout}@{h}x{w}' if _EVENT_SHAPES else ''), 0.0,
-                    lambda: _native.lib().vqk_conv2d_wgrad_edge(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
-                                                                ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout,
-                                                                zero_page(x.device).data_ptr(), _stream()), nbytes)
+                    lambda: _native.lib().vqk_conv2d_wgrad_edge_true(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
+                                                                     ws.data_ptr(), ws.numel() * 4, n, h, w, cin, cout, int(thin_true),
+                                                                     zero_page(x.device).data_ptr(), _stream()), nbytes)
         _native.check(st, 'conv2d_wgrad_edge')
         return dw
+    if thin_true != 8:
+        raise RuntimeError('vqk: an unpadded weight-gradient target needs the edge-conv kernel')
     mxw = (_WGMX_ON and x.dtype == torch.bfloat16 and ksize == 3 and cin % 64 == 0 and cout % 64 == 0
            and dy.shape[3] % 16 == 0 and dy.shape[2] % 8 == 0)
     kname = 'conv3x3_wgrad_mx_kernel<bf16>' if mxw else f'conv_wgrad_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>'
@@ -569,9 +679,11 @@ def raw_conv_wgrad_pooled_dy(x, dy_pooled, scale: float, out) -> bool:
     return True
 
 
-def raw_colsum(x2d_rows: int, c: int, x, out=None) -> torch.Tensor:
+def raw_colsum(x2d_rows: int, c: int, x, out=None, lead: int | None = None) -> torch.Tensor:
+    """``lead``: only the first ``lead`` columns are written (``out`` then has room for exactly those: the unpadded bias gradient)"""
     out = out if out is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
-    _native.check(_native.lib().vqk_colsum(dcode(x.dtype), x.data_ptr(), x2d_rows, c, out.data_ptr(), _stream()), 'colsum')
+    _native.check(_native.lib().vqk_colsum_lead(dcode(x.dtype), x.data_ptr(), x2d_rows, c, c if lead is None else lead, out.data_ptr(),
+                                                _stream()), 'colsum')
     return out
 
 
@@ -904,12 +1016,7 @@ class Conv2dFn(torch.autograd.Function):
         n_img, _, h_in, w_in = x.shape
         layout = weight_layout(dt, n_img, h_in, w_in, cin, cout_pad, k, ups, out_dtype)
         wq = packed_weight(weight, cin, cout_pad, dt, k, False, layout)
-        b32 = None
-        if bias is not None:
-            b32 = bias.detach()
-            if cout_pad != o:
-                b32 = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
-                b32[:o] = bias.detach()
+        b32 = padded_vector(bias, cout_pad) if bias is not None else None
         res = nhwc(residual) if residual is not None else None
         y = None
         phase = False
@@ -970,7 +1077,13 @@ class Conv2dFn(torch.autograd.Function):
         padded = cin != i or cout_pad != o
         if ctx.needs_input_grad[1]:
             tgt = None if padded else direct_grad(ctx.weight_ref)
-            dw = raw_conv_wgrad(x, dyc, k, ups, out=tgt)
+            thin = 8
+            if padded and edge_wgrad_served(x, dyc, k, ups) and (cin == i or cout_pad == o):
+                # the 3-channel edge convs (image in, reconstruction out): the kernel drops the zero-padded channels itself and adds
+                # the TRUE gradient to the arena -- no zero-filled padded temporary, no slice, no AccumulateGrad pass
+                tgt = direct_grad(ctx.weight_ref)
+                thin = (i if cin != i else o) if tgt is not None else 8
+            dw = raw_conv_wgrad(x, dyc, k, ups, out=tgt, thin_true=thin)
             if tgt is not None:
                 dw = None                                        # already accumulated in the flat arena
             elif padded:
@@ -979,8 +1092,8 @@ class Conv2dFn(torch.autograd.Function):
             _DB_DONE.discard(id(ctx.bias_ref))                   # the consumer's GroupNorm backward summed dy's columns already
         elif has_bias and ctx.needs_input_grad[2]:
             n, c, h, w = dyc.shape
-            tgt = None if padded else direct_grad(ctx.bias_ref)
-            db = raw_colsum(n * h * w, c, dyc, out=tgt)
+            tgt = direct_grad(ctx.bias_ref) if (cout_pad == c) else None     # (padded output channels: only the true ones are written)
+            db = raw_colsum(n * h * w, c, dyc, out=tgt, lead=o if tgt is not None else None)
             db = None if tgt is not None else db[:o]
         return dx, dw, db, dres, None, None, None, None
 
@@ -1462,10 +1575,10 @@ class VQLookupFn(torch.autograd.Function):
             _native.check(_native.lib().vqk_vq_gather_f32(flat.data_ptr(), cb.data_ptr(), idx.data_ptr(), n, k, d,
                                                           q32.data_ptr(), _p(qlo), sse.data_ptr(), hist.data_ptr(),
                                                           _stream()), 'vq_gather')
-        mse = sse / float(n * d)
-        loss = (mse + beta * mse) if codebook_loss else beta * mse
+        loss = sse * (((1.0 + beta) if codebook_loss else beta) / float(n * d))       # mse + beta * mse | beta * mse: one launch
         ctx.save_for_backward(z, cb, idx)
         ctx.cfg = (beta, codebook_loss, n, k, d)
+        ctx.cb_param = codebook
         ctx.mark_non_differentiable(idx, hist)
         q = qlo if qlo is not None else q32
         return q, idx.view(b, h * w), loss, hist
@@ -1475,7 +1588,11 @@ class VQLookupFn(torch.autograd.Function):
         z, cb, idx = ctx.saved_tensors
         beta, codebook_loss, n, k, d = ctx.cfg
         dz = torch.empty_like(z, memory_format=_CL)
-        de = torch.zeros_like(cb) if (codebook_loss and ctx.needs_input_grad[1]) else None
+        de = de_tgt = None
+        if codebook_loss and ctx.needs_input_grad[1]:
+            # the codebook gradient is accumulated (atomics / ordered adds) -- straight into the optimizer's arena when there is one
+            de_tgt = direct_grad(ctx.cb_param) if ctx.cb_param.is_contiguous() else None
+            de = de_tgt if de_tgt is not None else torch.zeros_like(cb)
         gs = dloss.to(torch.float32).contiguous() if dloss is not None else None
         dqc = nhwc(dq) if dq is not None else None
         scale = 2.0 / float(n * d)
@@ -1486,7 +1603,7 @@ class VQLookupFn(torch.autograd.Function):
                          beta * scale if gs is not None else 0.0,
                          scale if gs is not None else 0.0, _p(gs), dz.data_ptr(),
                          _p(de), _stream()), 'vq_backward')
-        return dz, de, None, None, None, None
+        return dz, (None if de_tgt is not None else de), None, None, None, None
 
 
 ENTROPY_FUSED_ROWS = os.environ.get('VQK_ENTROPY_FUSED_ROWS', '1') != '0'
@@ -1846,10 +1963,8 @@ def _conv_s2_fprop_raw(x, wq, bias, cout, h_out, w_out, act, acc_scale, out_gain
 
 
 def _packed_w4(weight, w4, cin, cout_pad, dt, k, transpose, layout):
-    """cached operand for 4-D conv parameters; 2-D (fully connected) weights viewed as 1x1 convs are packed per call"""
-    if weight.dim() == 4:
-        return packed_weight(weight, cin, cout_pad, dt, k, transpose, layout)
-    return pack_weights(_weight_mem(w4, cin, cout_pad), dt, cout_pad, cin, k, transpose, layout)
+    """cached operand of a conv parameter; ``w4``: its [O,I,k,k] view (2-D fully connected weights are 1x1 convs)"""
+    return packed_weight(weight, cin, cout_pad, dt, k, transpose, layout, shape4=tuple(w4.shape))
 
 
 class ConvActFn(torch.autograd.Function):
@@ -1880,19 +1995,12 @@ class ConvActFn(torch.autograd.Function):
         layout = weight_layout(dt, n, h, w, cin, cout_pad, k, False, out_dtype) if plain else (1 if s2 else 0)
         w4 = weight.reshape(o, i, k, k)
         wq = _packed_w4(weight, w4, cin, cout_pad, dt, k, False, layout)
-        b32 = None
-        if bias is not None:
-            b32 = bias.detach().to(torch.float32)
-            if cout_pad != o:
-                b32 = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
-                b32[:o] = bias.detach()
+        b32 = padded_vector(bias, cout_pad) if bias is not None else None
         if (k == 1 and plain and cin == 8 and dt == torch.bfloat16 and out_dtype == dt and w % 32 == 0 and cout_pad % 8 == 0):
             # a 1x1 conv on the padded 3-channel image (the discriminator's fromrgb, discriminator.py:198-199): the thin-input
             # 3x3 kernel with the weights at the centre tap (zero elsewhere) writes its 2*Cout bytes per pixel at memory speed;
             # the im2col kernel took 264 us for 8 -> 128 @256^2, bs 16
-            w3 = torch.zeros((cout_pad, 3, 3, 8), dtype=torch.float32, device=x.device)
-            w3[:o, 1, 1, :i] = weight.detach().reshape(o, i)
-            wq3 = pack_weights(w3.reshape(-1), dt, cout_pad, 8, 3, False, 0)
+            wq3 = packed_weight(weight, 8, cout_pad, dt, 3, False, 0, shape4=(o, i, 1, 1), kind='centre3')
             y = _conv_general_raw(x, wq3, b32, None, cout_pad, 3, 1, 1, 0, h_out, w_out, act, wgain, out_gain, out_dtype, 0)
         elif s2:
             y = _conv_s2_fprop_raw(x, wq, b32, cout_pad, h_out, w_out, act, wgain, out_gain)
