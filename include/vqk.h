@@ -336,9 +336,10 @@ int vqk_conv2d_thin_out(int dtype, const void* x, const void* w, const float* bi
                         int cout, int act, const void* zeros, void* stream);
 /* out[c] (+)= sum over rows of x[rows][c]  (bias gradients); out pre-zeroed. */
 int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream);
-/* vqk_colsum that writes only the first c_out <= c columns: `out` is the gradient of a bias whose layer carries zero-padded output
- * channels (the decoder's 3-channel head on 8): the sums go straight into the parameter's own (unpadded) gradient. */
-int vqk_colsum_lead(int dtype, const void* x, int64_t rows, int c, int c_out, float* out, void* stream);
+/* out[i] += scale * sum_rows x[row][i] for the first c_out <= c columns only: `out` is the gradient of a bias whose layer carries
+ * zero-padded output channels (the decoder's 3-channel head on 8) -- the sums go straight into the parameter's own (unpadded)
+ * gradient; `scale` undoes a gain folded into x (the StyleGAN2 layers' runtime weight gain). */
+int vqk_colsum_lead(int dtype, const void* x, int64_t rows, int c, int c_out, float scale, float* out, void* stream);
 /* elementwise fp32 -> dtype cast (weight shadow copies) */
 int vqk_cast(const float* src, void* dst, int dtype, int64_t n, void* stream);
 

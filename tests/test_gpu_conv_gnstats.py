@@ -105,7 +105,7 @@ def test_unclaimed_sums_do_not_leak_into_the_next_groupnorm():
         ops.FUSE_GN_STATS = True
         try:
             t = c1(x, next_gn=32)                 # sums of t are parked ... and never claimed
-            assert ops._PENDING_GN is not None
+            assert ops.pending_gn() is not None
             got = gn(up(t, next_gn=32), silu=True)
             t2 = c1(x, next_gn=32)                # parked again; the next consumer is a GroupNorm of ANOTHER tensor
             got2 = gn(ref.to(BF), silu=False)
@@ -117,7 +117,7 @@ def test_unclaimed_sums_do_not_leak_into_the_next_groupnorm():
     torch.cuda.synchronize()
     assert float((got.float() - ref.float()).norm() / ref.float().norm()) < 1e-3
     assert float((got2.float() - ref2.float()).norm() / ref2.float().norm()) < 1e-3
-    assert float(ops._gn_ws(x.device, 4 * 64 + 4).abs().max()) == 0.0 and ops._PENDING_GN is None
+    assert float(ops._gn_ws(x.device, 4 * 64 + 4).abs().max()) == 0.0 and ops.pending_gn() is None
 
 
 @pytest.mark.parametrize('cin,cout,h,ups,hr,pool', [(128, 128, 128, 0, 1, 0), (128, 256, 128, 0, 1, 1), (256, 256, 64, 0, 0, 0),

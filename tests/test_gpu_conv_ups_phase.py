@@ -60,7 +60,7 @@ def test_phase_form_gn_sums():
     gw, gb = torch.randn(c, device=DEV, generator=g), torch.randn(c, device=DEV, generator=g)
     w4 = ops.pack_weights(wmem, BF, c, c, 3, False, 2)
     y = ops.raw_conv_ups_phase(x, w4, bias, c, False, gn_groups=32)
-    assert y is not None and ops._PENDING_GN is not None
+    assert y is not None and ops.pending_gn() is not None
     a, st = ops.raw_gn_forward(y, gw, gb, 32, 1e-6, True)           # claims the sums
     a_ref, st_ref = ops.raw_gn_forward(y.clone(), gw, gb, 32, 1e-6, True)
     torch.cuda.synchronize()

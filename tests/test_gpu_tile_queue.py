@@ -17,7 +17,7 @@ DEV, BF, CL = 'cuda:0', torch.bfloat16, torch.channels_last
 def _queue_words():
     ops._stream()
     dev = torch.cuda.current_device()
-    return ops._TILE_QUEUE[(dev, torch.cuda.current_stream().cuda_stream)]
+    return ops._TILE_QUEUE[ops._wkey()]
 
 
 def _set_mode(m):
@@ -135,7 +135,7 @@ def test_queue_under_contention_and_in_graph_replay():
     with torch.cuda.stream(cap):
         ops._stream()
         ops.raw_conv_fprop(x, wq, None, None, 3, False, 0, BF, c, 1)
-        cap_words = ops._TILE_QUEUE[(torch.cuda.current_device(), cap.cuda_stream)]
+        cap_words = ops._TILE_QUEUE[ops._wkey()]
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=cap):

@@ -76,7 +76,7 @@ _PROTOS = {
     'vqk_conv2d_wgrad_edge_true': [I, P, P, P, P, L, I, I, I, I, I, I, P, P],
     'vqk_conv2d_thin_out': [I, P, P, P, P, I, I, I, I, I, I, P, P],
     'vqk_colsum': [I, P, L, I, P, P],
-    'vqk_colsum_lead': [I, P, L, I, I, P, P],
+    'vqk_colsum_lead': [I, P, L, I, I, F, P, P],
     'vqk_cast': [P, P, I, L, P],
     'vqk_gn_stats': [I, P, I, L, I, I, F, P, P, P],
     'vqk_gn_apply': [I, P, P, P, P, P, I, L, I, I, I, P],
@@ -192,6 +192,18 @@ def apply_env_tuning(cdll=None, environ=None) -> dict:
         check(cdll.vqk_set_tuning(name.encode(), val), f'set_tuning({name})')
         applied[name] = val
     return applied
+
+
+HOST_SWITCHES: dict = {}        # name -> (default, value in effect): every VQK_* switch of the HOST layer (ops.py), read once at import
+
+
+def switch(name: str, default: str) -> str:
+    """A/B switch of the host layer (``VQK_<NAME>`` in the environment, else ``default``).  The operators read their switches
+    through here -- one registry next to the library's tuning slots (``apply_env_tuning``), none scattered as ``os.environ`` reads
+    -- and ``HOST_SWITCHES`` lists what a process runs with."""
+    val = os.environ.get(name, default)
+    HOST_SWITCHES[name] = (default, val)
+    return val
 
 
 ERR_SHAPE = -1          # VQK_ERR_SHAPE (include/vqk.h)

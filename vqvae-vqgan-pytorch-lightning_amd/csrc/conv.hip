@@ -1974,7 +1974,7 @@ __global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__
 // over rows (the GroupNorm kernels' mapping); otherwise one column per thread.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t rows, int c, int64_t rows_per_block,
-                                                     float* __restrict__ out, int c_out) {
+                                                     float* __restrict__ out, int c_out, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sh = reinterpret_cast<float*>(smem);            // [c]
     for (int i = threadIdx.x; i < c; i += 256) sh[i] = 0.f;
@@ -2023,7 +2023,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < c_out; i += 256) atomicAdd(out + i, sh[i]);     // c_out <= c: the columns `out` has room for
+    for (int i = threadIdx.x; i < c_out; i += 256) atomicAdd(out + i, sh[i] * scale);     // c_out <= c: the columns `out` has room for
 }
 
 // deterministic column sums, round 4 (the first form -- one thread per column, 2-byte loads, one reducing block -- took 1.47 ms
@@ -2078,7 +2078,7 @@ __global__ __launch_bounds__(256) void colsum_det_scalar_kernel(const T* __restr
     }
 }
 __global__ __launch_bounds__(256) void colsum_det_reduce_kernel(const float* __restrict__ part, int blocks, int c, float* __restrict__ out,
-                                                                int c_out) {
+                                                                int c_out, float scale) {
     __shared__ float lane_sum[32][8];
     const int col = (int)blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
     float s = 0.f;
@@ -2090,7 +2090,7 @@ __global__ __launch_bounds__(256) void colsum_det_reduce_kernel(const float* __r
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 32; ++k) t += lane_sum[k][threadIdx.x];
-        out[col] += t;
+        out[col] += t * scale;
     }
 }
 
@@ -2838,10 +2838,10 @@ int vqk_conv2d_wgrad_general_scaled(int dtype, const void* x, const void* dy, fl
 }
 
 int vqk_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* stream) {
-    return vqk_colsum_lead(dtype, x, rows, c, c, out, stream);
+    return vqk_colsum_lead(dtype, x, rows, c, c, 1.0f, out, stream);
 }
 
-int vqk_colsum_lead(int dtype, const void* x, int64_t rows, int c, int c_out, float* out, void* stream) {
+int vqk_colsum_lead(int dtype, const void* x, int64_t rows, int c, int c_out, float scale, float* out, void* stream) {
     VQK_REQUIRE(x && out, VQK_ERR_ARG);
     VQK_REQUIRE(rows >= 0 && c > 0 && c <= 8192 && c_out > 0 && c_out <= c, VQK_ERR_SHAPE);
     VQK_REQUIRE(dtype == VQK_F32 || dtype == VQK_BF16, VQK_ERR_DTYPE);
@@ -2863,7 +2863,7 @@ int vqk_colsum_lead(int dtype, const void* x, int64_t rows, int c, int c_out, fl
             if (dtype == VQK_F32) hipLaunchKernelGGL(colsum_det_scalar_kernel<float>, dim3((unsigned)nb), dim3(256), 0, sd, (const float*)x, rows, c, rb, g_det_ws);
             else hipLaunchKernelGGL(colsum_det_scalar_kernel<bf16_raw>, dim3((unsigned)nb), dim3(256), 0, sd, (const bf16_raw*)x, rows, c, rb, g_det_ws);
         }
-        hipLaunchKernelGGL(colsum_det_reduce_kernel, dim3((unsigned)((c + 7) / 8)), dim3(256), 0, sd, (const float*)g_det_ws, (int)nb, c, out, c_out);
+        hipLaunchKernelGGL(colsum_det_reduce_kernel, dim3((unsigned)((c + 7) / 8)), dim3(256), 0, sd, (const float*)g_det_ws, (int)nb, c, out, c_out, scale);
         VQK_CHECK_LAUNCH();
         return VQK_OK;
     }
@@ -2876,11 +2876,11 @@ int vqk_colsum_lead(int dtype, const void* x, int64_t rows, int c, int c_out, fl
     const size_t lds = (size_t)c * 4;
     hipStream_t st = vqk_stream(stream);
     if (dtype == VQK_F32) {
-        if (vec) hipLaunchKernelGGL((colsum_kernel<float, true>), grid, dim3(256), lds, st, (const float*)x, rows, c, rpb, out, c_out);
-        else hipLaunchKernelGGL((colsum_kernel<float, false>), grid, dim3(256), lds, st, (const float*)x, rows, c, rpb, out, c_out);
+        if (vec) hipLaunchKernelGGL((colsum_kernel<float, true>), grid, dim3(256), lds, st, (const float*)x, rows, c, rpb, out, c_out, scale);
+        else hipLaunchKernelGGL((colsum_kernel<float, false>), grid, dim3(256), lds, st, (const float*)x, rows, c, rpb, out, c_out, scale);
     } else {
-        if (vec) hipLaunchKernelGGL((colsum_kernel<bf16_raw, true>), grid, dim3(256), lds, st, (const bf16_raw*)x, rows, c, rpb, out, c_out);
-        else hipLaunchKernelGGL((colsum_kernel<bf16_raw, false>), grid, dim3(256), lds, st, (const bf16_raw*)x, rows, c, rpb, out, c_out);
+        if (vec) hipLaunchKernelGGL((colsum_kernel<bf16_raw, true>), grid, dim3(256), lds, st, (const bf16_raw*)x, rows, c, rpb, out, c_out, scale);
+        else hipLaunchKernelGGL((colsum_kernel<bf16_raw, false>), grid, dim3(256), lds, st, (const bf16_raw*)x, rows, c, rpb, out, c_out, scale);
     }
     VQK_CHECK_LAUNCH();
     return VQK_OK;

@@ -30,14 +30,22 @@ class VGG16(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
 
+    def _zscore(self, c: int, device):
+        """per-channel (1 / std, -mean / std) zero-padded to the internal channel count: derived ONCE per (buffers, device) -- the
+        eight fill / copy / elementwise launches that built them ran in every VGG pass of every step"""
+        key = (c, device, self.mean._version, self.std._version, self.mean.data_ptr(), self.std.data_ptr())
+        if getattr(self, '_zs_key', None) != key:
+            scale = torch.zeros(c, dtype=torch.float32, device=device)
+            shift = torch.zeros(c, dtype=torch.float32, device=device)
+            scale[:3] = 1.0 / self.std.reshape(-1).to(device)
+            shift[:3] = -self.mean.reshape(-1).to(device) / self.std.reshape(-1).to(device)
+            self._zs_key, self._zs = key, (scale, shift)
+        return self._zs
+
     def forward(self, x):
         """-> the 5 tap activations (un-normalised; the tap kernel does the channel normalisation)"""
         x = _to_internal(x, self.compute_dtype)
-        c = x.shape[1]
-        scale = torch.zeros(c, dtype=torch.float32, device=x.device)
-        shift = torch.zeros(c, dtype=torch.float32, device=x.device)
-        scale[:3] = 1.0 / self.std.reshape(-1)
-        shift[:3] = -self.mean.reshape(-1) / self.std.reshape(-1)
+        scale, shift = self._zscore(x.shape[1], x.device)
         x = ops.ChannelAffineFn.apply(x, scale, shift)          # z-score; pad channels stay zero
         taps = []
         for e in _VGG16:
@@ -68,9 +76,6 @@ class LPIPS(nn.Module):
         with torch.no_grad():
             fx = self.net(x)
         fy = self.net(y)
-        total = None
-        for a, b, lin in zip(fx, fy, self.lin):
-            w = lin[1].weight.detach().reshape(-1).to(torch.float32).contiguous()
-            t = ops.LpipsTapFn.apply(a, b, w)                   # [B]
-            total = t if total is None else total + t
+        ws = [lin[1].weight.detach().reshape(-1).to(torch.float32).contiguous() for lin in self.lin]
+        total = ops.LpipsTapsFn.apply(len(ws), *fx, *fy, *ws)   # [B]: the five taps' terms, one accumulation buffer
         return total.mean()

@@ -39,7 +39,16 @@ _DET_GEN = 0                           # every thread tracks what IT armed, agai
 _DET_WS_BYTES = 64 << 20
 _SCRATCH: dict = {}
 _SCRATCH_BYTES = 64 << 20
-_TILE_QUEUE: dict = {}               # (device, stream) -> int32 words of the conv kernels' dynamic tile queue (include/vqk.h)
+_TILE_QUEUE: dict = {}               # _wkey() -> int32 words of the conv kernels' dynamic tile queue (include/vqk.h)
+
+
+def _wkey(device=None) -> tuple:
+    """key of every workspace a kernel WRITES: (device index, stream handle, host thread).  Per stream: launches on two streams may
+    run concurrently.  Per host thread: two Python threads that share a stream (the default one, typically) enqueue in an arbitrary
+    interleaving -- a producer's sums / split-K slices must not meet the other thread's between two launches
+    (tests/test_gpu_two_models.py)."""
+    dev = torch.cuda.current_device() if device is None else (device.index if device.index is not None else torch.cuda.current_device())
+    return (dev, torch.cuda.current_stream().cuda_stream, threading.get_ident())
 
 
 def _stream() -> int:
@@ -49,21 +58,23 @@ def _stream() -> int:
     s = torch.cuda.current_stream().cuda_stream
     dev = torch.cuda.current_device()                            # (the default stream's handle is 0 on every device)
     if getattr(_DET_TLS, 'scratch', None) != (dev, s):           # split-K scratch of this stream (private slices per split)
-        sc = _SCRATCH.get((dev, s))
+        wk = (dev, s, threading.get_ident())
+        sc = _SCRATCH.get(wk)
         if sc is None:                                           # no zero fill: every slice is written before it is summed
-            sc = _SCRATCH[(dev, s)] = torch.empty(_SCRATCH_BYTES // 4, dtype=torch.float32, device=f'cuda:{dev}')
+            sc = _SCRATCH[wk] = torch.empty(_SCRATCH_BYTES // 4, dtype=torch.float32, device=f'cuda:{dev}')
         _native.check(_native.lib().vqk_set_scratch(sc.data_ptr(), sc.numel() * 4), 'set_scratch')
-        tq = _TILE_QUEUE.get((dev, s))                           # tile-queue words of this stream (zero on entry, left zero)
+        tq = _TILE_QUEUE.get(wk)                                 # tile-queue words of this stream (zero on entry, left zero)
         if tq is None:
-            tq = _TILE_QUEUE[(dev, s)] = torch.zeros(64, dtype=torch.int32, device=f'cuda:{dev}')
+            tq = _TILE_QUEUE[wk] = torch.zeros(64, dtype=torch.int32, device=f'cuda:{dev}')
         _native.check(_native.lib().vqk_set_tile_queue(tq.data_ptr(), tq.numel() * 4), 'set_tile_queue')
         _DET_TLS.scratch = (dev, s)
     key = getattr(_DET_TLS, 'key', None)
     if DETERMINISTIC:
         if key != (_DET_GEN, dev, s):
-            ws = _DET_WS.get((dev, s))
+            wk = (dev, s, threading.get_ident())
+            ws = _DET_WS.get(wk)
             if ws is None:
-                ws = _DET_WS[(dev, s)] = torch.empty(_DET_WS_BYTES, dtype=torch.uint8, device=f'cuda:{dev}')
+                ws = _DET_WS[wk] = torch.empty(_DET_WS_BYTES, dtype=torch.uint8, device=f'cuda:{dev}')
             _native.check(_native.lib().vqk_set_deterministic(1, ws.data_ptr(), ws.numel()), 'set_deterministic')
             _DET_TLS.key = (_DET_GEN, dev, s)
     elif key is not None:
@@ -80,7 +91,7 @@ def set_deterministic(on: bool) -> None:
     DETERMINISTIC = bool(on)
     _DET_GEN += 1
     _DB_DONE.clear()
-    FUSE_GN_STATS = os.environ.get('VQK_FUSE_GN_STATS', '1') != '0'     # (deterministic mode: per-tile slots instead of atomics)
+    FUSE_GN_STATS = _native.switch('VQK_FUSE_GN_STATS', '1') != '0'     # (deterministic mode: per-tile slots instead of atomics)
     _GN_WS.clear(); _GN_PARTS.clear()
 
 
@@ -117,7 +128,7 @@ def empty_nhwc(n, c, h, w, dtype, device) -> torch.Tensor:
 KERNEL_EVENTS = None      # bench.py sets this to a list: (kernel, algorithmic FLOPs, algorithmic bytes, start, stop)
 
 
-_EVENT_SHAPES = os.environ.get('VQK_EVENT_SHAPES') == '1'     # tooling: one statistics line per (kernel, FLOP count)
+_EVENT_SHAPES = _native.switch('VQK_EVENT_SHAPES', '') == '1'     # tooling: one statistics line per (kernel, FLOP count)
 
 
 def _timed(name: str, flops: float, launch, nbytes: float = 0.0, launches: int = 1, exec_flops: float | None = None):
@@ -133,11 +144,11 @@ def _timed(name: str, flops: float, launch, nbytes: float = 0.0, launches: int =
     return st
 
 
-_MX_ON = os.environ.get('VQK_MX', '1') != '0'
-_THIN_OUT = os.environ.get('VQK_THIN_OUT', '1') != '0'
-_MX_MIN_TILES = int(os.environ.get('VQK_MX_MIN_TILES', '1'))
-_WGMX_ON = os.environ.get('VQK_WGMX', '1') != '0'
-_UPS_MERGE = os.environ.get('VQK_UPS_MERGE', '1') != '0'      # (the library's tuning slot of the same name: one launch per phase-form conv)
+_MX_ON = _native.switch('VQK_MX', '1') != '0'
+_THIN_OUT = _native.switch('VQK_THIN_OUT', '1') != '0'
+_MX_MIN_TILES = int(_native.switch('VQK_MX_MIN_TILES', '1'))
+_WGMX_ON = _native.switch('VQK_WGMX', '1') != '0'
+_UPS_MERGE = _native.switch('VQK_UPS_MERGE', '1') != '0'      # (the library's tuning slot of the same name: one launch per phase-form conv)
 
 
 def _fprop_kernel_name(dtype, wlayout: int, shape=None) -> str:
@@ -257,7 +268,8 @@ def _pack_use(ent) -> torch.Tensor:
 
 
 _PACK_CACHE: dict = {}          # (data_ptr, shape4, k, transpose, layout, dtype, cin_pad, cout_pad, kind) -> _PackEntry
-_PACK_BLOCKS = int(os.environ.get('VQK_PACK_BLOCKS', '128'))    # blocks per operand of the repack launch (32 -> 128: -0.05 ms/step, the 512x512x9 operands)
+_PACK_LOCK = threading.RLock()  # cache bookkeeping (the launches themselves are ordered by their streams)
+_PACK_BLOCKS = int(_native.switch('VQK_PACK_BLOCKS', '128'))    # blocks per operand of the repack launch (32 -> 128: -0.05 ms/step, the 512x512x9 operands)
 _PACK_TABLE = None              # {tuple of keys: device int64 [n, 8]} descriptor tables of the repack launches
 
 
@@ -281,6 +293,11 @@ def packed_weight(weight, cin_pad: int, cout_pad: int, dtype, ksize: int, transp
     if direct and layout == 0 and not transpose and dtype == torch.float32:
         return w.permute(0, 2, 3, 1).reshape(-1)
     key = (w.data_ptr(), shape4, ksize, bool(transpose), layout, dtype, cin_pad, cout_pad, kind)
+    with _PACK_LOCK:
+        return _packed_weight_locked(weight, w, key, direct, cin_pad, cout_pad, dtype, ksize, transpose, layout, shape4, kind)
+
+
+def _packed_weight_locked(weight, w, key, direct, cin_pad, cout_pad, dtype, ksize, transpose, layout, shape4, kind):
     ent = _PACK_CACHE.get(key)
     stamp = _pack_stamp(weight)
     if ent is not None and ent.wref() is not weight:
@@ -317,46 +334,42 @@ def repack_owned(owner=None) -> int:
     global _PACK_TABLE
     refresh_vq_prepared(owner)                           # the quantizer's prepared codebook follows the same rule
     refresh_padded_vectors(owner)
-    keys, dead = [], []
-    for key, ent in _PACK_CACHE.items():
-        weight = ent.wref()
-        if weight is None or weight.data_ptr() != key[0]:
-            dead.append(key)                             # parameter freed or re-pointed (e.g. into a flat arena)
-        elif owner is not None:
-            if getattr(weight, '_vqk_owner', None) is owner:
-                keys.append(key)
-        elif ent.stamp != _pack_stamp(weight):
-            keys.append(key)
-    for key in dead:
-        del _PACK_CACHE[key]
-    for key in [k for k, st in _PACK_STAGES.items() if st.wref() is None or st.wref().data_ptr() != k[0]]:
-        del _PACK_STAGES[key]
-    if not keys:
-        return 0
-    keys = tuple(keys)
-    for k in keys:                                       # the padded / re-ordered fp32 images first (one strided copy each)
-        ent = _PACK_CACHE[k]
-        if ent.stage is not None:
-            ent.stage.refresh(ent.wref(), _pack_stamp(ent.wref()))
-    pack_keys = tuple(k for k in keys if _PACK_CACHE[k].dst is not _PACK_CACHE[k].src)
-    if pack_keys:
-        if _PACK_TABLE is None:
-            _PACK_TABLE = {}
-        # one device table per set of DESCRIPTORS (two optimizers alternate in the VQ-GAN step).  Keyed by the descriptors themselves:
-        # a later model may get the same parameter addresses (same keys) with other destination buffers
-        sig = tuple(tuple(int(v) for v in _PACK_CACHE[k].desc) for k in pack_keys)
-        table = _PACK_TABLE.get(sig)
-        if table is None:
-            if len(_PACK_TABLE) >= 8:
-                _PACK_TABLE.clear()
-            dev = _PACK_CACHE[pack_keys[0]].dst.device
-            table = _PACK_TABLE[sig] = torch.tensor([list(d) for d in sig], dtype=torch.int64).to(dev)
-        _native.check(_native.lib().vqk_conv_pack_multi(table.data_ptr(), len(pack_keys), _PACK_BLOCKS, _stream()), 'conv_pack_multi')
-    for k in keys:
-        ent = _PACK_CACHE[k]
-        ent.stamp = _pack_stamp(ent.wref())
-    _pack_written([_PACK_CACHE[k] for k in keys])
-    return len(keys)
+    with _PACK_LOCK:                                     # (two models stepped from two host threads share the cache)
+        ents = []
+        for key, ent in list(_PACK_CACHE.items()):
+            weight = ent.wref()
+            if weight is None or weight.data_ptr() != key[0]:
+                _PACK_CACHE.pop(key, None)               # parameter freed or re-pointed (e.g. into a flat arena)
+            elif owner is not None:
+                if getattr(weight, '_vqk_owner', None) is owner:
+                    ents.append(ent)
+            elif ent.stamp != _pack_stamp(weight):
+                ents.append(ent)
+        for key, st in list(_PACK_STAGES.items()):
+            if st.wref() is None or st.wref().data_ptr() != key[0]:
+                _PACK_STAGES.pop(key, None)
+        if not ents:
+            return 0
+        for ent in ents:                                 # the padded / re-ordered fp32 images first (one strided copy each)
+            if ent.stage is not None:
+                ent.stage.refresh(ent.wref(), _pack_stamp(ent.wref()))
+        packs = [ent for ent in ents if ent.dst is not ent.src]
+        if packs:
+            if _PACK_TABLE is None:
+                _PACK_TABLE = {}
+            # one device table per set of DESCRIPTORS (two optimizers alternate in the VQ-GAN step).  Keyed by the descriptors
+            # themselves: a later model may get the same parameter addresses with other destination buffers
+            sig = tuple(tuple(int(v) for v in ent.desc) for ent in packs)
+            table = _PACK_TABLE.get(sig)
+            if table is None:
+                if len(_PACK_TABLE) >= 8:
+                    _PACK_TABLE.clear()
+                table = _PACK_TABLE[sig] = torch.tensor([list(d) for d in sig], dtype=torch.int64).to(packs[0].dst.device)
+            _native.check(_native.lib().vqk_conv_pack_multi(table.data_ptr(), len(packs), _PACK_BLOCKS, _stream()), 'conv_pack_multi')
+        for ent in ents:
+            ent.stamp = _pack_stamp(ent.wref())
+        _pack_written(ents)
+        return len(ents)
 
 
 class _PadVec:
@@ -470,8 +483,8 @@ def raw_conv_fprop_pooled(x, wq, bias, residual, ksize: int, ups: bool, cout: in
     return y
 
 
-FUSE_GN_STATS = os.environ.get('VQK_FUSE_GN_STATS', '1') != '0'
-if os.environ.get('VQK_DETERMINISTIC') == '1':          # same as set_deterministic(True), from the environment
+FUSE_GN_STATS = _native.switch('VQK_FUSE_GN_STATS', '1') != '0'
+if _native.switch('VQK_DETERMINISTIC', '') == '1':          # same as set_deterministic(True), from the environment
     DETERMINISTIC = True
 
 
@@ -486,7 +499,7 @@ def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: 
     ho, wo = (h * s // 2, w * s // 2) if pool else (h * s, w * s)
     if not FUSE_GN_STATS or x.dtype != torch.bfloat16 or ho * wo <= 1024:
         return None
-    if _PENDING_GN is not None:                                  # sums nobody claimed (the consumer was not a GroupNorm)
+    if _HANDOFF.gn is not None:                                  # sums nobody claimed (the consumer was not a GroupNorm)
         _claim_presummed(x, -1)
     y = empty_nhwc(n, cout, ho, wo, x.dtype, x.device)
     ws = _gn_sum_target(x.device, n, groups, h * s * w * s)
@@ -504,7 +517,7 @@ def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: 
     return y
 
 
-THIN_IN_GNSTATS = os.environ.get('VQK_THIN_IN_GNSTATS', '1') != '0'
+THIN_IN_GNSTATS = _native.switch('VQK_THIN_IN_GNSTATS', '1') != '0'
 
 
 def raw_conv_thin_in_gnstats(x, wq, bias, cout: int, groups: int):
@@ -514,7 +527,7 @@ def raw_conv_thin_in_gnstats(x, wq, bias, cout: int, groups: int):
     n, cin, h, w = x.shape
     if (not FUSE_GN_STATS or not THIN_IN_GNSTATS or DETERMINISTIC or x.dtype != torch.bfloat16 or cin != 8 or h * w <= 1024):
         return None
-    if _PENDING_GN is not None:
+    if _HANDOFF.gn is not None:
         _claim_presummed(x, -1)
     y = empty_nhwc(n, cout, h, w, x.dtype, x.device)
     ws = _gn_sum_target(x.device, n, groups, h * w)
@@ -529,7 +542,7 @@ def raw_conv_thin_in_gnstats(x, wq, bias, cout: int, groups: int):
     return y
 
 
-UPS_PHASE = int(os.environ.get('VQK_UPS_PHASE', '1'))      # 0 off, 1 forward + data gradient, 2 forward only
+UPS_PHASE = int(_native.switch('VQK_UPS_PHASE', '1'))      # 0 off, 1 forward + data gradient, 2 forward only
 
 
 def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int = 0):
@@ -547,7 +560,7 @@ def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int =
     y = empty_nhwc(n, cout, h if backward else 2 * h, w if backward else 2 * w, x.dtype, x.device)
     ws = None
     if gn_groups and not backward and FUSE_GN_STATS and 4 * h * w > 1024:
-        if _PENDING_GN is not None:
+        if _HANDOFF.gn is not None:
             _claim_presummed(x, -1)
         ws = _gn_sum_target(x.device, n, gn_groups, 4 * h * w)
     flops = 2.0 * n * 4 * h * w * cout * cin * 9                 # ALGORITHMIC: the 3x3 conv over the upsampled image
@@ -607,13 +620,14 @@ def direct_grad(param):
     return None
 
 
-_EDGE_WGRAD = os.environ.get('VQK_EDGE_WGRAD', '1') != '0'
+_EDGE_WGRAD = _native.switch('VQK_EDGE_WGRAD', '1') != '0'
 _EDGE_WS: dict = {}
 
 
 def _edge_ws(device) -> torch.Tensor:
     """split-K workspace of vqk_conv2d_wgrad_edge, one per (device, stream): plain stores + ordered reduce, no atomics"""
-    key = (device, _stream())
+    _stream()
+    key = _wkey(device)
     ws = _EDGE_WS.get(key)
     if ws is None:
         ws = _EDGE_WS[key] = torch.empty(_native.lib().vqk_conv2d_wgrad_edge_ws_bytes() // 4, dtype=torch.float32, device=device)
@@ -679,11 +693,12 @@ def raw_conv_wgrad_pooled_dy(x, dy_pooled, scale: float, out) -> bool:
     return True
 
 
-def raw_colsum(x2d_rows: int, c: int, x, out=None, lead: int | None = None) -> torch.Tensor:
-    """``lead``: only the first ``lead`` columns are written (``out`` then has room for exactly those: the unpadded bias gradient)"""
+def raw_colsum(x2d_rows: int, c: int, x, out=None, lead: int | None = None, scale: float = 1.0) -> torch.Tensor:
+    """out += scale * column sums; ``lead``: only the first ``lead`` columns are written (``out`` then has room for exactly those:
+    the unpadded bias gradient)"""
     out = out if out is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
-    _native.check(_native.lib().vqk_colsum_lead(dcode(x.dtype), x.data_ptr(), x2d_rows, c, c if lead is None else lead, out.data_ptr(),
-                                                _stream()), 'colsum')
+    _native.check(_native.lib().vqk_colsum_lead(dcode(x.dtype), x.data_ptr(), x2d_rows, c, c if lead is None else lead, float(scale),
+                                                out.data_ptr(), _stream()), 'colsum')
     return out
 
 
@@ -698,7 +713,7 @@ def raw_cast(src_f32, dtype) -> torch.Tensor:
 _GN_WS: dict = {}
 
 
-GN_CLUSTER_MAX_HW = int(os.environ.get('VQK_GN_CLUSTER_MAX_HW', '1024'))    # (mirrors the library's tuning slot: event bytes only)
+GN_CLUSTER_MAX_HW = int(_native.switch('VQK_GN_CLUSTER_MAX_HW', '1024'))    # (mirrors the library's tuning slot: event bytes only)
 
 
 def _gn_ws_doubles(n: int, c: int, groups: int) -> int:
@@ -723,7 +738,8 @@ _GN_PARTS: dict = {}
 def _gn_parts(device, n_doubles: int) -> torch.Tensor:
     """deterministic mode: the per-tile slots a conv's drain leaves its GroupNorm sums in (+ N*G*2 doubles of scratch in front for
     their ordered total): plain stores, every slot written before it is read -- no zero protocol"""
-    key = (device, _stream())
+    _stream()
+    key = _wkey(device)
     ws = _GN_PARTS.get(key)
     if ws is None or ws.numel() < n_doubles:
         ws = _GN_PARTS[key] = torch.empty(max(n_doubles, 1 << 20), dtype=torch.float64, device=device)
@@ -742,7 +758,8 @@ def _gn_sum_target(device, n: int, groups: int, conv_hw: int) -> torch.Tensor:
 def _gn_ws(device, n_doubles: int) -> torch.Tensor:
     """Persistent fp64 workspace of the GroupNorm kernels for the current stream (include/vqk.h: zero on entry, the
     consumer kernel leaves it zero again -> no memset launch per call)."""
-    key = (device, _stream())
+    _stream()
+    key = _wkey(device)
     ws = _GN_WS.get(key)
     if ws is None or ws.numel() < n_doubles:
         ws = torch.zeros(max(n_doubles, 8192), dtype=torch.float64, device=device)
@@ -754,28 +771,43 @@ def _gn_ws(device, n_doubles: int) -> torch.Tensor:
 # in the stream's workspace (vqk_conv2d_fprop_gnstats) and notes the tensor here; the next ``raw_gn_forward`` on exactly
 # that tensor claims them and skips its statistics pass.  Anything else arriving first finds the workspace dirty: it is
 # cleared and the note dropped (the unfused sequence runs), so a changed call order costs a memset, never a wrong result.
-_PENDING_GN = None
-_PENDING_GN_HW = [0]        # conv-resolution pixels per image of the noted tensor's producer (deterministic mode: slots = that / 256)
+#
+# The hand-off is a HANDLE owned by the producing host thread (``_HANDOFF``, thread-local): (weak reference to the produced tensor,
+# groups, workspace key, producer's conv resolution).  Producer and consumer run on one thread (a module's forward), the
+# workspace the sums sit in is that thread's (``_wkey``): two models stepped from two Python threads -- or interleaved on one --
+# cannot claim or clear each other's sums.
+class _Handoff(threading.local):
+    gn = None               # pending GroupNorm sums: (weakref(y), groups, workspace key, device, conv_hw)
+    db = None               # pending bias column sum: (weakref(y), bias parameter)
+    claimed_hw = 0          # conv resolution of the hand-off claimed last
+
+
+_HANDOFF = _Handoff()
+
+
+def pending_gn():
+    """the calling thread's pending GroupNorm hand-off (None: nothing pending) -- tests and tooling"""
+    return _HANDOFF.gn
 
 
 def _note_presummed(y, groups: int, conv_hw: int = 0) -> None:
     """the note is keyed by the tensor OBJECT (weak reference), not by its address: a freed tensor whose memory the caching
     allocator hands to another tensor of the same shape can never claim stale sums"""
-    global _PENDING_GN
-    _PENDING_GN = (weakref.ref(y), groups, _stream(), y.device)
-    _PENDING_GN_HW[0] = conv_hw if conv_hw else y.shape[2] * y.shape[3]
+    _stream()
+    _HANDOFF.gn = (weakref.ref(y), groups, _wkey(y.device), y.device, conv_hw if conv_hw else y.shape[2] * y.shape[3])
 
 
 def _claim_presummed(x, groups: int) -> bool:
-    global _PENDING_GN
-    p = _PENDING_GN
+    p = _HANDOFF.gn
     if p is None:
         return False
-    _PENDING_GN = None
-    ref, g, stream, device = p
+    _HANDOFF.gn = None
+    ref, g, wk, device, _hw = p
+    stream = wk[1]
+    _HANDOFF.claimed_hw = _hw
     if ref() is x and g == groups and stream == _stream():
         return True
-    ws = None if DETERMINISTIC else _GN_WS.get((device, stream))   # (deterministic mode: per-tile slots, nothing to clear)
+    ws = None if DETERMINISTIC else _GN_WS.get(wk)                  # (deterministic mode: per-tile slots, nothing to clear)
     if ws is not None:                         # only the workspace the unclaimed sums were left in -- never another stream's
         if stream == _stream():
             ws.zero_()
@@ -814,7 +846,7 @@ def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool
     nb = x.numel() * x.element_size()
     claimed = (not presummed) and _claim_presummed(x, groups)
     if claimed:
-        conv_hw = _PENDING_GN_HW[0]                               # (a pooled producer: 4x the pixels of x)
+        conv_hw = _HANDOFF.claimed_hw                              # (a pooled producer: 4x the pixels of x)
     presummed = presummed or claimed
     if presummed and DETERMINISTIC:
         nblk = (conv_hw or h * wd) // 256
@@ -877,9 +909,9 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
 # writes d(block input) = the conv's dy): Conv2dFn.forward notes (output tensor, bias parameter), ResBlockFn.forward claims the
 # note when that very tensor is its input, its backward hands the bias's arena gradient to the kernel and marks the bias as
 # done; Conv2dFn.backward then skips its column-sum pass over dy (185 us for the 537-MB gradient of the last Upsample conv).
-FUSE_BIAS_COLSUM = os.environ.get('VQK_FUSE_BIAS_COLSUM', '1') != '0'
-_PENDING_DB = None
-_DB_DONE: set = set()
+FUSE_BIAS_COLSUM = _native.switch('VQK_FUSE_BIAS_COLSUM', '1') != '0'
+_DB_DONE: set = set()         # ids of bias parameters whose gradient a GroupNorm backward already summed (autograd thread; keyed
+                              # by the parameter: two models never share an entry)
 
 
 def gn_colsum_ok(h: int, w: int) -> bool:
@@ -887,13 +919,11 @@ def gn_colsum_ok(h: int, w: int) -> bool:
 
 
 def _note_bias_colsum(y, bias) -> None:
-    global _PENDING_DB
-    _PENDING_DB = (weakref.ref(y), bias)
+    _HANDOFF.db = (weakref.ref(y), bias)
 
 
 def _claim_bias_colsum(x):
-    global _PENDING_DB
-    p, _PENDING_DB = _PENDING_DB, None
+    p, _HANDOFF.db = _HANDOFF.db, None
     if p is not None and p[0]() is x:
         return p[1]
     return None
@@ -1130,14 +1160,14 @@ class GroupNormSiLUFn(torch.autograd.Function):
         return dx, dw.view(wshape), db.view(bshape), None, None, None
 
 
-POOLED_BWD = os.environ.get('VQK_POOLED_BWD', '1') != '0'      # ResBlock + fused avg-pool: the backward keeps the gradient pooled
-OVERLAP_WGRAD = os.environ.get('VQK_OVERLAP_WGRAD', '1') == '1'
-OVERLAP_MODE = int(os.environ.get('VQK_OVERLAP_MODE', '3'))
-OVERLAP_WAIT_MIN_HW = int(os.environ.get('VQK_OVERLAP_WAIT_MIN_HW', '0'))   # maps below this many pixels: dgrad1 does not wait for wgrad2
-OVERLAP_STREAM_BLOCKS = int(os.environ.get('VQK_OVERLAP_STREAM_BLOCKS', '512'))
-OVERLAP_WGRAD_BLOCKS = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS', '320'))
-OVERLAP_WGRAD_BLOCKS_HI = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS_HI', '256'))   # the 256x256 levels: GroupNorm-bound in the backward -- the weight gradient on half the CUs (swept 192 / 224 / 256 / 288 / 320 / 448: -0.15 ms at 256)
-OVERLAP_WGRAD_BLOCKS_MID = int(os.environ.get('VQK_OVERLAP_WGRAD_BLOCKS_MID', str(OVERLAP_WGRAD_BLOCKS)))   # the 128x128 levels   # swept 192...512 with the 8x16-patch wgrad: flat 224...320
+POOLED_BWD = _native.switch('VQK_POOLED_BWD', '1') != '0'      # ResBlock + fused avg-pool: the backward keeps the gradient pooled
+OVERLAP_WGRAD = _native.switch('VQK_OVERLAP_WGRAD', '1') == '1'
+OVERLAP_MODE = int(_native.switch('VQK_OVERLAP_MODE', '3'))
+OVERLAP_WAIT_MIN_HW = int(_native.switch('VQK_OVERLAP_WAIT_MIN_HW', '0'))   # maps below this many pixels: dgrad1 does not wait for wgrad2
+OVERLAP_STREAM_BLOCKS = int(_native.switch('VQK_OVERLAP_STREAM_BLOCKS', '512'))
+OVERLAP_WGRAD_BLOCKS = int(_native.switch('VQK_OVERLAP_WGRAD_BLOCKS', '320'))
+OVERLAP_WGRAD_BLOCKS_HI = int(_native.switch('VQK_OVERLAP_WGRAD_BLOCKS_HI', '256'))   # the 256x256 levels: GroupNorm-bound in the backward -- the weight gradient on half the CUs (swept 192 / 224 / 256 / 288 / 320 / 448: -0.15 ms at 256)
+OVERLAP_WGRAD_BLOCKS_MID = int(_native.switch('VQK_OVERLAP_WGRAD_BLOCKS_MID', str(OVERLAP_WGRAD_BLOCKS)))   # the 128x128 levels   # swept 192...512 with the 8x16-patch wgrad: flat 224...320
 _SIDE_STREAMS: dict = {}
 
 
@@ -1166,7 +1196,7 @@ def aux_stream(device, tag: str) -> torch.cuda.Stream:
 # join variant tried: the kernel that reaches the chip first takes the CUs, the GroupNorm pass floods all 256 and the
 # weight gradient (one 512-thread, 120-KiB block per CU) only gets in as its blocks retire (wgrad 11.3 instead of 9.9 ms,
 # main queue waits 2.0 ms on it).  The weight gradient has to be launched first; the 10-us hops are the price.
-CHAIN_FIRST = os.environ.get('VQK_CHAIN_FIRST', '0') == '1'
+CHAIN_FIRST = _native.switch('VQK_CHAIN_FIRST', '0') == '1'
 
 
 def _fork_point(main):
@@ -1443,13 +1473,14 @@ class _MSE(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 # vector quantizer
 # ------------------------------------------------------------------------------------------------------
-VQ_FILTER = os.environ.get('VQK_VQ_FILTER', '1') != '0'
-VQ_FUSED = os.environ.get('VQK_VQ_FUSED', '1') != '0'      # one forward kernel + one backward kernel (0: the round-3 launch sequence)
+VQ_FILTER = _native.switch('VQK_VQ_FILTER', '1') != '0'
+VQ_FUSED = _native.switch('VQK_VQ_FUSED', '1') != '0'      # one forward kernel + one backward kernel (0: the round-3 launch sequence)
 _VQ_WS: dict = {}
 
 
 def _vq_filter_ws(device, k: int, d: int) -> torch.Tensor:
-    key = (device, _stream(), k, d)
+    _stream()
+    key = _wkey(device) + (k, d)
     ws = _VQ_WS.get(key)
     if ws is None:
         ws = _VQ_WS[key] = torch.empty(_native.lib().vqk_vq_filter_ws_bytes(k, d), dtype=torch.uint8, device=device)
@@ -1606,7 +1637,7 @@ class VQLookupFn(torch.autograd.Function):
         return dz, (None if de_tgt is not None else de), None, None, None, None
 
 
-ENTROPY_FUSED_ROWS = os.environ.get('VQK_ENTROPY_FUSED_ROWS', '1') != '0'
+ENTROPY_FUSED_ROWS = _native.switch('VQK_ENTROPY_FUSED_ROWS', '1') != '0'
 
 
 class EntropyVQFn(torch.autograd.Function):
@@ -2020,9 +2051,9 @@ class ConvActFn(torch.autograd.Function):
 
 
 def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None):
-    """ConvActFn's backward as a plain function (DiscBlockFn composes three of them).  ``make_t(scale, dbsum)``: the caller
-    produces t = scale * act'(y) * dy itself (fused into the pass that produces dy) and adds t's column sums to ``dbsum`` when that
-    is not None; ``dx_residual``: added to the data gradient in the conv kernel's epilogue."""
+    """ConvActFn's backward as a plain function (DiscBlockFn composes three of them).  ``make_t(scale, dbsum, db_scale)``: the caller
+    produces t = scale * act'(y) * dy itself (fused into the pass that produces dy) and adds db_scale * t's column sums to ``dbsum``
+    when that is not None; ``dx_residual``: added to the data gradient in the conv kernel's epilogue."""
     weight, bias = refs
     k, stride, pad, act, wgain, out_gain, o, i, cin, cout_pad, dt = cfg
     lib, st = _native.lib(), _stream()
@@ -2048,9 +2079,15 @@ def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None
             tgt_lin = direct_grad(weight)
     fold = float(wgain) if tgt is not None else 1.0
     if make_t is not None:
+        db_scale = 1.0
         if want_db:
-            dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
-        t = make_t(float(out_gain) * fold, dbsum)
+            if DIRECT_BIAS_GRAD and cout_pad == o and not torch.is_grad_enabled():
+                db_tgt = direct_grad(bias)               # the caller's column-sum pass adds (1 / fold) * colsum(t) to the arena
+            if db_tgt is not None:
+                dbsum, db_scale = db_tgt, 1.0 / fold
+            else:
+                dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
+        t = make_t(float(out_gain) * fold, dbsum, db_scale)
     elif act == 0 and dyn.dtype == dt:
         # linear layer (the discriminator's skip convs, its last fully connected layer): t = out_gain * dy is no pass over
         # the tensor -- the scalar rides in the data- / weight-gradient scale (and on the bias sum)
@@ -2308,6 +2345,43 @@ class LpipsTapFn(torch.autograd.Function):
         return None, dfy, None
 
 
+class LpipsTapsFn(torch.autograd.Function):
+    """sum over the feature taps of the per-image LPIPS contributions (lpips.py: the five taps' terms added up) as ONE node: the
+    tap kernels accumulate into one zero-filled [B] vector -- no fill and no add launch per tap; gradients to the ``fy`` only"""
+
+    @staticmethod
+    def forward(ctx, ntap: int, *args):
+        fxs, fys, lins = args[:ntap], args[ntap:2 * ntap], args[2 * ntap:3 * ntap]
+        _require_gpu(fxs[0])
+        fxs, fys = [nhwc(t) for t in fxs], [nhwc(t) for t in fys]
+        n = fxs[0].shape[0]
+        out = torch.zeros(n, dtype=torch.float32, device=fxs[0].device)
+        lib, st = _native.lib(), _stream()
+        for fx, fy, lin in zip(fxs, fys, lins):
+            _, c, h, w = fx.shape
+            _native.check(lib.vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
+                                            out.data_ptr(), 0, 1.0, 0, st), 'lpips_tap')
+        ctx.save_for_backward(*fxs, *fys, *lins)
+        ctx.ntap = ntap
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k = ctx.ntap
+        saved = ctx.saved_tensors
+        fxs, fys, lins = saved[:k], saved[k:2 * k], saved[2 * k:]
+        d = dout.contiguous().float()
+        lib, st = _native.lib(), _stream()
+        grads = []
+        for fx, fy, lin in zip(fxs, fys, lins):
+            n, c, h, w = fx.shape
+            dfy = torch.empty_like(fy, memory_format=_CL)
+            _native.check(lib.vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
+                                            0, d.data_ptr(), 1.0, dfy.data_ptr(), st), 'lpips_tap_backward')
+            grads.append(dfy)
+        return (None,) + (None,) * k + tuple(grads) + (None,) * k
+
+
 class MbstdFn(torch.autograd.Function):
     """minibatch-stddev feature appended as one extra channel (discriminator.py:277-293); output channels are
     padded with zeros to a whole 16-byte chunk"""
@@ -2378,9 +2452,9 @@ class AddFn(torch.autograd.Function):
         return dy, dy
 
 
-FUSE_DISC_BLOCK = os.environ.get('VQK_FUSE_DISC_BLOCK', '1') != '0'
-DIRECT_LINEAR_WGRAD = os.environ.get('VQK_DIRECT_LINEAR_WGRAD', '1') != '0'   # linear ConvActFn layers: scaled weight gradient straight into the arena
-DIRECT_BIAS_GRAD = os.environ.get('VQK_DIRECT_BIAS_GRAD', '1') != '0'    # ConvActFn: bias gradient straight into the optimizer's arena
+FUSE_DISC_BLOCK = _native.switch('VQK_FUSE_DISC_BLOCK', '1') != '0'
+DIRECT_LINEAR_WGRAD = _native.switch('VQK_DIRECT_LINEAR_WGRAD', '1') != '0'   # linear ConvActFn layers: scaled weight gradient straight into the arena
+DIRECT_BIAS_GRAD = _native.switch('VQK_DIRECT_BIAS_GRAD', '1') != '0'    # ConvActFn: bias gradient straight into the optimizer's arena
 
 
 def _conv_act_cfg(x, weight, k, stride, pad, act, wgain, out_gain):
@@ -2458,7 +2532,7 @@ class DiscBlockFn(torch.autograd.Function):
         pb = (fw - pad_blur[0] - 1, w - bw + pad_blur[0], fh - pad_blur[2] - 1, h - bh + pad_blur[2])
         act = cfg0[3]
 
-        def make_t(scale, dbsum):
+        def make_t(scale, dbsum, db_scale=1.0):
             t0 = torch.empty_like(y0, memory_format=_CL)
             st = _native.lib().vqk_upfirdn2d_act_backward(dcode(x.dtype), d_blur.data_ptr(), f.data_ptr(), y0.data_ptr(), t0.data_ptr(),
                                                           n, bh, bw, c, pb[0], pb[1], pb[2], pb[3], 1, float(scale), act, h, w,
@@ -2468,7 +2542,7 @@ class DiscBlockFn(torch.autograd.Function):
             else:                                        # shapes outside the fused kernel: blur^T, then the activation gradient
                 t0 = ActBwdFn.apply(UpfirdnNhwcFn.apply(d_blur, f, 1, 1, pb, True, 1.0), y0, act, float(scale), None)
             if dbsum is not None:
-                raw_colsum(n * h * w, c, t0, out=dbsum)
+                raw_colsum(n * h * w, c, t0, out=dbsum, scale=db_scale)
             return t0
 
         gx, dw0, db0 = _conv_act_backward(x, y0, (w0, b0), cfg0, (need[0], need[1], need[2]), None, make_t=make_t, dx_residual=u)
