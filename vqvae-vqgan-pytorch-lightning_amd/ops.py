@@ -2629,3 +2629,63 @@ class SumSqFn(torch.autograd.Function):
                                                           dout.to(torch.float32).contiguous().data_ptr(), 0, d.data_ptr(),
                                                           _stream()), 'sumsq_backward')
         return d
+
+
+# ------------------------------------------------------------------------------------------------------
+# tracing: named host ranges around every macro-op (VQK_TRACE=1)
+# ------------------------------------------------------------------------------------------------------
+# The reference names its custom ops for the profiler (stylegan2_discriminator/utils/misc.py:104-110: profiled_function ->
+# torch.autograd.profiler.record_function); here every autograd Function of this file gets a roctx range "vqk::<op>.forward /
+# .backward" (torch.cuda.nvtx = roctx on ROCm; visible to `rocprofv3 --marker-trace` and to torch.profiler) when VQK_TRACE=1.
+# Off by default: nothing is wrapped, no per-call cost.  The ranges are HOST ranges around the launches -- a replayed hipGraph
+# carries none (tools/trace_step.sh traces eager steps).
+TRACE = _native.switch('VQK_TRACE', '0') == '1'
+
+
+class trace_range:
+    """``with ops.trace_range('name'):`` -- a roctx range when tracing is on, nothing otherwise"""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if TRACE:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        if TRACE:
+            torch.cuda.nvtx.range_pop()
+
+
+def _ranged(name: str, fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        torch.cuda.nvtx.range_push(name)
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            torch.cuda.nvtx.range_pop()
+    return wrapped
+
+
+def install_tracing() -> int:
+    """wrap forward / backward of every autograd Function defined here in a named range; returns the number of ranges installed"""
+    n = 0
+    for cls_name, obj in list(globals().items()):
+        if isinstance(obj, type) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function:
+            label = cls_name.lstrip('_')
+            label = label[:-2] if label.endswith('Fn') else label
+            for meth in ('forward', 'backward'):
+                sm = obj.__dict__.get(meth)
+                if isinstance(sm, staticmethod) and not getattr(sm.__func__, '_vqk_ranged', False):
+                    w = _ranged(f'vqk::{label}.{meth}', sm.__func__)
+                    w._vqk_ranged = True
+                    setattr(obj, meth, staticmethod(w))
+                    n += 1
+    return n
+
+
+if TRACE:
+    install_tracing()

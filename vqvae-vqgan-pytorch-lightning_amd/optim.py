@@ -21,9 +21,11 @@ def all_reduce_sum(t: torch.Tensor) -> None:
     CURRENT stream -- and when that stream is the one a hipGraph is captured on a moment later (MiniTrainer's settling steps run on
     the capture stream), the group's watchdog thread polls an event 'last recorded in a capturing stream': hipErrorCapturedEvent,
     the watchdog terminates the process (seen 1 run in 3 with the full-size VQ-GAN step, where a capture takes seconds)."""
-    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
-    if work is not None:
-        work.wait()
+    from . import ops
+    with ops.trace_range('vqk::all_reduce_sum'):
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+        if work is not None:
+            work.wait()
 
 
 def _is_channels_last_param(p: torch.Tensor) -> bool:
@@ -218,15 +220,20 @@ class FlatAdamW(torch.optim.Optimizer):
         self.step_count += 1
         if not self.flat_p.is_cuda:
             raise RuntimeError('vqk: FlatAdamW.step runs on the GPU only (HIP kernel, no CPU fallback)')
-        st = _native.lib().vqk_adamw(self.flat_p.data_ptr(), self.flat_g.data_ptr(),
+        from . import ops
+        with ops.trace_range('vqk::FlatAdamW.step'):
+            st = self._launch_adamw(g0, b1, b2)
+        _native.check(st, 'adamw')
+        self.generation += 1
+        with ops.trace_range('vqk::repack_owned'):
+            ops.repack_owned(self)               # every cached conv operand of these weights, one launch
+        return loss
+
+    def _launch_adamw(self, g0, b1, b2):
+        return _native.lib().vqk_adamw(self.flat_p.data_ptr(), self.flat_g.data_ptr(),
                                      0 if self.flat_m is None else self.flat_m.data_ptr(), self.flat_v.data_ptr(),
                                      self.flat_p.numel(), self.seg_end.data_ptr(), self.seg_wd.data_ptr(),
                                      self.seg_end.numel(), float(g0['lr']), float(b1), float(b2), float(g0['eps']),
                                      self.step_count, float(self.grad_scale),
                                      0 if self.shadow is None else self.shadow.data_ptr(),
                                      torch.cuda.current_stream().cuda_stream)
-        _native.check(st, 'adamw')
-        self.generation += 1
-        from . import ops
-        ops.repack_owned(self)               # every cached conv operand of these weights, one launch
-        return loss
