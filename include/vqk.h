@@ -381,6 +381,12 @@ int vqk_gn_backward(int dtype, const void* x, const float* stats, const float* w
 int vqk_gn_backward_ws(int dtype, const void* x, const float* stats, const float* w, const float* b, const void* dy,
                        void* dx, float* dw, float* db, double* red, int64_t ws_doubles, int n, int h, int wd, int c, int groups,
                        int silu, int accumulate, const void* add, const void* add_pooled, float add_scale, void* stream);
+/* The cluster form waits for its <= 8 partner blocks inside the kernel (an ordinary launch, no cooperative groups).  Forward
+ * progress assumes that each XCD dispatches its share of a grid in block-index order (then the lowest waiting block's partners are
+ * always resident or done -- csrc/norm.hip); the wait is BOUNDED (~0.2 s): a block that gives up is counted and falls through with
+ * incomplete sums.  vqk_gn_cluster_timeouts reports the count (0 in a healthy run; synchronises the device).  A kernel killed
+ * mid-way leaves sums / tickets dirty: re-zero the workspace. */
+int vqk_gn_cluster_timeouts(int* count);
 /* vqk_gn_backward_ws (same-resolution addend) that also accumulates the per-channel sums of the dx it writes into
  * dx_colsum[C] (fp32): when x is the output of a conv with a bias, that is the conv's bias gradient -- no column-sum pass over
  * the gradient tensor.  Two-kernel form only; not in deterministic mode (VQK_ERR_ARG). */

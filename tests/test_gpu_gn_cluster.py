@@ -78,3 +78,12 @@ def test_cluster_backward_equals_two_kernel_form_and_fp64(dtype, n, c, h, mode):
         assert rel(a, t) < (1e-6 if dtype == torch.float32 else 3e-3), rel(a, t)      # two-kernel form (bf16: one output rounding)
         assert rel(a, a2) < 1e-6
         assert rel(a, r) < tol, rel(a, r)
+
+
+def test_cluster_wait_never_times_out():
+    """the in-kernel wait of the cluster form is bounded (csrc/norm.hip: GN_CL_SPIN_CAP); a healthy run never hits the bound"""
+    import ctypes
+    native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
+    cnt = ctypes.c_int(-1)
+    native.check(native.lib().vqk_gn_cluster_timeouts(ctypes.byref(cnt)), 'gn_cluster_timeouts')
+    assert cnt.value == 0

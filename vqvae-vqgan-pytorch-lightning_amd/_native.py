@@ -86,6 +86,7 @@ _PROTOS = {
     'vqk_gn_backward': [I, P, P, P, P, P, P, P, P, P, I, L, I, I, I, I, P, P],
     'vqk_gn_backward_pooled_add': [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, F, P],
     'vqk_gn_backward_ws': [I, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, I, P, P, F, P],
+    'vqk_gn_cluster_timeouts': [P],
     'vqk_gn_backward_colsum': [I, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, I, P, P, P],
     'vqk_pool2x2': [I, P, P, I, I, I, I, F, P],
     'vqk_unpool2x2': [I, P, P, I, I, I, I, F, P],

@@ -5,6 +5,10 @@
 // Thread mapping: a thread owns one 16-byte channel vector slot (fixed channels) and strides over pixels,
 // so per-channel affine terms / partial sums live in registers.
 #include "common.h"
+#ifndef GN_CL_SPIN_CAP
+#define GN_CL_SPIN_CAP (1u << 20)     // polls before a cluster block gives up waiting (x ~0.25 us each: ~0.2 s)
+#endif
+__device__ int g_gn_cluster_timeouts = 0;     // cluster blocks that gave up (gn_cluster_bwd_kernel); read by vqk_gn_cluster_timeouts
 #ifndef GN_CL_SLEEP
 #define GN_CL_SLEEP 8     // s_sleep argument (x 64 cycles) between two polls of a cluster's ticket
 #endif
@@ -806,7 +810,17 @@ __global__ __launch_bounds__(256) void gn_cluster_bwd_kernel(const T* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cl) __builtin_amdgcn_s_sleep(GN_CL_SLEEP);
+        // BOUNDED spin.  Forward progress rests on (a) every XCD dispatching its share of a grid in block-index order and (b) a
+        // cluster being <= 8 consecutive block ids: the lowest undispatched block's XCD then only holds blocks whose whole cluster
+        // is already dispatched, so they finish and free its slot (include/vqk.h: vqk_gn_backward_ws).  Should that ever not hold
+        // (a future dispatcher, a debugger pausing one die), the block gives up after ~0.2 s, counts the event in
+        // g_gn_cluster_timeouts (vqk_gn_cluster_timeouts) and falls through with whatever sums have arrived: a WRONG result that the
+        // host can detect, instead of a hung GPU.
+        unsigned spins = 0;
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cl) {
+            __builtin_amdgcn_s_sleep(GN_CL_SLEEP);
+            if (++spins >= GN_CL_SPIN_CAP) { atomicAdd(&g_gn_cluster_timeouts, 1); break; }
+        }
     }
     __syncthreads();
     if (threadIdx.x < SL) {
@@ -1161,6 +1175,16 @@ int vqk_gn_backward_pooled_add(int dtype, const void* x, const float* stats, con
     VQK_REQUIRE((int64_t)h * wd > 1024, VQK_ERR_SHAPE);       // the two-kernel path (the single-kernel small-map form has no pooled add)
     return gn_backward_impl(dtype, x, stats, w, b, dy, dx, dw, db, red, n, (int64_t)h * wd, c, groups, silu, 1, add_pooled, wd,
                             add_scale, stream);
+}
+
+/* diagnostic: number of cluster blocks of the single-kernel GroupNorm backward that gave up their bounded wait since the library
+ * was loaded (0 in every healthy run).  Synchronises the device. */
+int vqk_gn_cluster_timeouts(int* count) {
+    VQK_REQUIRE(count, VQK_ERR_ARG);
+    int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_gn_cluster_timeouts), sizeof(int), 0, hipMemcpyDeviceToHost) != hipSuccess) return VQK_ERR_LAUNCH;
+    *count = v;
+    return VQK_OK;
 }
 
 }  // extern "C"

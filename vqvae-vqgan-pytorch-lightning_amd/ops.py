@@ -1113,7 +1113,19 @@ class Conv2dFn(torch.autograd.Function):
                 # the TRUE gradient to the arena -- no zero-filled padded temporary, no slice, no AccumulateGrad pass
                 tgt = direct_grad(ctx.weight_ref)
                 thin = (i if cin != i else o) if tgt is not None else 8
-            dw = raw_conv_wgrad(x, dyc, k, ups, out=tgt, thin_true=thin)
+            if (tgt is not None and CONV_WGRAD_SIDE and OVERLAP_WGRAD and k == 3 and dt == torch.bfloat16 and thin == 8
+                    and dyc.shape[2] * dyc.shape[3] >= CONV_WGRAD_SIDE_MIN_HW and not DETERMINISTIC):
+                # a conv outside a ResBlock (the decoder's Upsample convs: 0.9 ms of weight gradients per step): the gradient goes
+                # to the arena and only the optimizer reads it -- issued on the side stream behind the data gradient; the next
+                # ResBlock's backward (or join_side_streams at the end of the backward) joins it
+                main, side = torch.cuda.current_stream(), _side_stream(x.device)
+                _side_after(side, _fork_point(main))
+                with torch.cuda.stream(side):
+                    raw_conv_wgrad(x, dyc, k, ups, out=tgt, thin_true=thin)
+                _SIDE_PENDING.add(x.device)
+                x.record_stream(side); dyc.record_stream(side)
+            else:
+                dw = raw_conv_wgrad(x, dyc, k, ups, out=tgt, thin_true=thin)
             if tgt is not None:
                 dw = None                                        # already accumulated in the flat arena
             elif padded:
@@ -1162,6 +1174,7 @@ class GroupNormSiLUFn(torch.autograd.Function):
 
 POOLED_BWD = _native.switch('VQK_POOLED_BWD', '1') != '0'      # ResBlock + fused avg-pool: the backward keeps the gradient pooled
 OVERLAP_WGRAD = _native.switch('VQK_OVERLAP_WGRAD', '1') == '1'
+SHORTCUT_WGRAD_SIDE = _native.switch('VQK_SHORTCUT_WGRAD_SIDE', '0') == '1'   # ResBlock shortcut: weight gradient on the side stream (measured +-0: 28.26 / 28.18 against 28.17 / 28.19 ms -- off)
 OVERLAP_MODE = int(_native.switch('VQK_OVERLAP_MODE', '3'))
 OVERLAP_WAIT_MIN_HW = int(_native.switch('VQK_OVERLAP_WAIT_MIN_HW', '0'))   # maps below this many pixels: dgrad1 does not wait for wgrad2
 OVERLAP_STREAM_BLOCKS = int(_native.switch('VQK_OVERLAP_STREAM_BLOCKS', '512'))
@@ -1197,6 +1210,19 @@ def aux_stream(device, tag: str) -> torch.cuda.Stream:
 # weight gradient (one 512-thread, 120-KiB block per CU) only gets in as its blocks retire (wgrad 11.3 instead of 9.9 ms,
 # main queue waits 2.0 ms on it).  The weight gradient has to be launched first; the 10-us hops are the price.
 CHAIN_FIRST = _native.switch('VQK_CHAIN_FIRST', '0') == '1'
+
+
+CONV_WGRAD_SIDE = _native.switch('VQK_CONV_WGRAD_SIDE', '0') == '1'
+CONV_WGRAD_SIDE_MIN_HW = int(_native.switch('VQK_CONV_WGRAD_SIDE_MIN_HW', '1024'))
+_SIDE_PENDING: set = set()      # devices whose side stream carries work no ResBlock backward has joined yet
+
+
+def join_side_streams() -> None:
+    """the current stream waits for side-stream work that was issued outside a ResBlock's backward (Conv2dFn's weight gradient):
+    called at the end of a backward, before the gradients are reduced / the optimizer steps"""
+    for dev in list(_SIDE_PENDING):
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+    _SIDE_PENDING.clear()
 
 
 def _fork_point(main):
@@ -1388,7 +1414,18 @@ class ResBlockFn(torch.autograd.Function):
                             raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
                 dskip, dwsc = dout, None
                 if scw is not None:
-                    dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
+                    tsc = direct_grad(scw) if SHORTCUT_WGRAD_SIDE else None
+                    if tsc is not None:
+                        # the 1x1 shortcut: its data gradient (the skip addend of the GroupNorm pass below) on the main stream, its
+                        # WEIGHT gradient -- needed by the optimizer only -- behind conv1's on the side stream, next to that pass
+                        # (it ran on the main stream before: 0.42 ms per step on the critical path, profiles/round4_step_timeline.txt)
+                        dskip, _ = conv_bwd(x, dout, scw, 1, cin, cout, need_dw=False)
+                        fork_sc = _fork_point(main)
+                        _side_after(side, fork_sc)
+                        with torch.cuda.stream(side):
+                            raw_conv_wgrad(x, dout, 1, False, out=tsc)
+                    else:
+                        dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
                 dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip, colsum_of=ctx.db_param)
                 if OVERLAP_MODE != 1 and CHAIN_FIRST:
                     _side_after(side, fork)

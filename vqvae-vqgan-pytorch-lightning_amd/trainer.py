@@ -76,6 +76,7 @@ class MiniTrainer:
         else:
             loss = model.training_step(batch, batch_index)
             loss.backward()
+            ops.join_side_streams()
             self._finish_deferred(model, opt)
             opt.all_reduce_grads()
         opt.step()
@@ -138,6 +139,7 @@ class MiniTrainer:
         works = []
         for k, (stage, (lo, hi)) in enumerate(zip(stages, self._ranges(opt, len(stages)))):
             stage()
+            ops.join_side_streams()
             if k == len(stages) - 1:
                 self._finish_deferred(model, opt)
             if hi > lo:
@@ -206,18 +208,22 @@ class MiniTrainer:
                     self._static_loss = model.training_step(self._static_in, 0)
                     stages = self._backward_halves(model)
                     stages[0]()
+                    ops.join_side_streams()
                 self._graph2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph2, pool=self._graph.pool(), stream=side, capture_error_mode='thread_local'):
                     stages[1]()
+                    ops.join_side_streams()
                 if len(stages) == 3:                      # the encoder's high-resolution head: the deep levels' range is reduced under it
                     self._graph3 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self._graph3, pool=self._graph.pool(), stream=side, capture_error_mode='thread_local'):
                         stages[2]()
+                        ops.join_side_streams()
             else:
                 with torch.cuda.graph(self._graph, stream=side, capture_error_mode='thread_local'):
                     opt.zero_grad()
                     self._static_loss = model.training_step(self._static_in, 0)
                     self._static_loss.backward()
+                    ops.join_side_streams()
         finally:
             model.defer_usage_accumulation = False
             model.split_backward = False
@@ -349,6 +355,7 @@ class MiniTrainer:
         else:
             loss = model.training_step(batch, batch_index)
             loss.backward()
+            ops.join_side_streams()
             self._finish_deferred(model, opt)
             opt.all_reduce_grads()
         opt.step()
