@@ -117,7 +117,13 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
 // ONLINE log-sum-exp per lane (running max m, s = sum exp(a - m), sa = sum exp(a - m) a; one rescale per 32-code tile), merged
 // over the row's eight partial states at the end: lse_i = m + log s, h_i = lse_i - sa / s, hsum += h_i -- the separate pass
 // over the [N][K] matrix (entropy_rows_kernel: 0.36 ms at N = 16,384, K = 8,192) disappears under the fp32 MFMAs.
-template <int ASSOC, bool WRITE_D, int DD, bool STATS = false>
+#ifndef VQK_ENT_CHAINS
+#define VQK_ENT_CHAINS 1      // accumulation chains of the Entropy quantizer's distance matrix (1: the canonical single chain).
+                              // 4 was MEASURED (round 5, tools/entropy_tol_probe.py): the codebook gradient at T = 0.01 moved from
+                              // 7.1e-3 to 1.4e-2 off the reference's fixture -- the chain length is not what separates the two fp32
+                              // results (the cancellation between -2 dd^T Z and 2 E colsum(dd) is: both sides carry it); 1 stays
+#endif
+template <int ASSOC, bool WRITE_D, int DD, bool STATS = false, int CH = 1>
 __global__ __launch_bounds__(256) void vq_assign_reg_kernel(const float* __restrict__ z, const float* __restrict__ e,
                                                             const float* __restrict__ z2, const float* __restrict__ e2,
                                                             int64_t n, int k, int64_t* __restrict__ idx,
@@ -167,23 +173,48 @@ __global__ __launch_bounds__(256) void vq_assign_reg_kernel(const float* __restr
             const int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             e2v[r] = e2[code < k ? code : k - 1];
         }
+        // CH accumulation chains over the 256 products of a distance.  CH = 1: ONE sequential chain -- the canonical order of
+        // oracle/vq_oracle.c (the plain assignment: indices bit-exact by construction).  CH = 4 (the Entropy quantizer's distance
+        // MATRIX): four chains of 32 MFMAs summed as (c0 + c1) + (c2 + c3) -- a chain's rounding error grows with its length, and at
+        // T = 0.01 the softmax multiplies the error of a distance by 100.  Measured: no closer to the reference's fixture (see
+        // VQK_ENT_CHAINS), so the shipped build keeps CH = 1 everywhere
         f32x16 acc = {0};
+        f32x16 accx[CH > 1 ? CH - 1 : 1];
+        if constexpr (CH > 1) {
+#pragma unroll
+            for (int q = 0; q < CH - 1; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accx[q][r] = 0.0f;
+        }
+        auto chain = [&](int i) -> f32x16& {                     // fragment i of NF -> its chain
+            if constexpr (CH > 1) { const int q = i / (NF / CH); return q == 0 ? acc : accx[q - 1]; }
+            else return acc;
+        };
 #pragma unroll
         for (int i = 0; i < HF; ++i) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][0], zr[i][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][1], zr[i][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][2], zr[i][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][3], zr[i][3], acc, 0, 0, 0);
+            f32x16& a_ = chain(i);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][0], zr[i][0], a_, 0, 0, 0);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][1], zr[i][1], a_, 0, 0, 0);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][2], zr[i][2], a_, 0, 0, 0);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][i][3], zr[i][3], a_, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < HF; ++i) ab[0][i] = *reinterpret_cast<const f32x4*>(en + 8 * i);
 #pragma unroll
         for (int i = 0; i < HF; ++i) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][0], zr[HF + i][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][1], zr[HF + i][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][2], zr[HF + i][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][3], zr[HF + i][3], acc, 0, 0, 0);
+            f32x16& a_ = chain(HF + i);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][0], zr[HF + i][0], a_, 0, 0, 0);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][1], zr[HF + i][1], a_, 0, 0, 0);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][2], zr[HF + i][2], a_, 0, 0, 0);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][i][3], zr[HF + i][3], a_, 0, 0, 0);
+        }
+        if constexpr (CH == 4) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = __fadd_rn(__fadd_rn(acc[r], accx[0][r]), __fadd_rn(accx[1][r], accx[2][r]));
+        } else if constexpr (CH == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = __fadd_rn(acc[r], accx[0][r]);
         }
         __builtin_amdgcn_sched_barrier(0);
         float av[16];
@@ -503,8 +534,8 @@ int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const 
     VQK_REQUIRE(lds <= 64 * 1024, VQK_ERR_SHAPE);
     const dim3 grid((unsigned)((n + 31) / 32));
     if (d == 256) {
-        if (assoc == 0) hipLaunchKernelGGL((vq_assign_reg_kernel<0, true, 256>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat);
-        else hipLaunchKernelGGL((vq_assign_reg_kernel<1, true, 256>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat);
+        if (assoc == 0) hipLaunchKernelGGL((vq_assign_reg_kernel<0, true, 256, false, VQK_ENT_CHAINS>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat);
+        else hipLaunchKernelGGL((vq_assign_reg_kernel<1, true, 256, false, VQK_ENT_CHAINS>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat);
         VQK_CHECK_LAUNCH();
         return VQK_OK;
     }
@@ -524,8 +555,8 @@ int vqk_vq_distances_stats_f32(const float* z, const float* e, const float* z2, 
     if (n == 0) return VQK_OK;
     const dim3 grid((unsigned)((n + 31) / 32));
     const float inv_t = 1.0f / temperature;
-    if (assoc == 0) hipLaunchKernelGGL((vq_assign_reg_kernel<0, true, 256, true>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat, inv_t, lse, hrow, hsum);
-    else hipLaunchKernelGGL((vq_assign_reg_kernel<1, true, 256, true>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat, inv_t, lse, hrow, hsum);
+    if (assoc == 0) hipLaunchKernelGGL((vq_assign_reg_kernel<0, true, 256, true, VQK_ENT_CHAINS>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat, inv_t, lse, hrow, hsum);
+    else hipLaunchKernelGGL((vq_assign_reg_kernel<1, true, 256, true, VQK_ENT_CHAINS>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat, inv_t, lse, hrow, hsum);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }
