@@ -232,8 +232,8 @@ def measure_traffic(kernel_sub: str, events_per_step: int, argv):
 
 # Reference box of the committed profile set (profiles/README.md lists every box of the round with these two figures): the
 # normalised step time is what THIS run's step would take on that box if the MFMA-bound share of the step scaled with the
-# calibration loop and the HBM-bound share with the copy (shares from profiles/round4_bench_kernel_stats.csv: conv kernels
-# 0.70 of the step's critical path, GroupNorm / elementwise / AdamW 0.25, launch gaps and the rest 0.05).
+# conv-kernel calibration (share from profiles/round4_bench_kernel_stats.csv: the conv kernels are 0.70 of the step's critical
+# path; GroupNorm / elementwise / AdamW 0.25 and the gaps 0.05 are taken as box-independent).
 CALIB_REF = dict(conv_kernel_tflops=1253.0, mfma_loop_tflops=1145.9, hbm_copy_tbps=5.12)       # the box of profiles/round5_bench.json
 CALIB_SHARES = dict(mfma=0.70, hbm=0.25)
 
@@ -294,10 +294,10 @@ def box_calibration(device, ms_per_step, seconds: float = 0.3) -> dict:
                        'that kernel on random bf16 operands, register / LDS / L2 resident (256 blocks x 4 waves); 1-GiB streaming copy '
                        '(read + write bytes)',
                reference_box=dict(CALIB_REF), shares=dict(CALIB_SHARES))
-    if CALIB_REF['conv_kernel_tflops'] and CALIB_REF['hbm_copy_tbps']:
-        f = (CALIB_SHARES['mfma'] * out['conv_kernel_tflops'] / CALIB_REF['conv_kernel_tflops']
-             + CALIB_SHARES['hbm'] * out['hbm_copy_tbps'] / CALIB_REF['hbm_copy_tbps']
-             + (1.0 - CALIB_SHARES['mfma'] - CALIB_SHARES['hbm']))
+    if CALIB_REF['conv_kernel_tflops']:
+        # only the conv-kernel figure enters: over the round's boxes it tracks the step (28.07 ms <-> 1252 TF, 28.39-28.49 <-> 1226-1228,
+        # normalised 27.95-28.08), the copy figure does not (4.89-5.21 TB/s on boxes whose steps agree) and is reported only
+        f = CALIB_SHARES['mfma'] * out['conv_kernel_tflops'] / CALIB_REF['conv_kernel_tflops'] + (1.0 - CALIB_SHARES['mfma'])
         out['ms_per_step_normalised'] = round(ms_per_step * f, 3)
         out['box_speed_vs_reference'] = round(f, 4)
     return out

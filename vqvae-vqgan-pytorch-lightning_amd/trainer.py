@@ -29,6 +29,12 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world > 1 and torch.cuda.is_available() and 'VQK_TILE_QUEUE' not in os.environ:
+        # data parallel: a collective's kernel may hold CUs next to the persistent conv grids -- those draw their tiles from a
+        # queue then (first tile static: no start-up latency; +0.1 ms per step without contention, -24 % kernel time with 16 CUs
+        # held: profiles/round5_comm_probe.txt).  bench.py times the forms itself and overrides this per form.
+        from . import _native
+        _native.check(_native.lib().vqk_set_tuning(b'TILE_QUEUE', 1), 'set_tuning(TILE_QUEUE)')
     return rank, local, world
 
 
