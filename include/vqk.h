@@ -209,6 +209,13 @@ int vqk_conv2d_general(int dtype, const void* x, const void* w, const float* bia
  * Cout % 64 == 0; VQK_ERR_SHAPE when not served (nothing launched: callers unpool and call vqk_conv2d_wgrad). */
 int vqk_conv2d_wgrad_pooled_dy(int dtype, const void* x, const void* dy_pooled, float* dw, int n, int h, int w, int cin,
                                int cout, float scale, const void* zeros, void* stream);
+/* Weight gradient of a nearest-x2 UPSAMPLE + 3x3 conv (vqvae/modules/autoencoder.py:102-105) in PHASE form (csrc/conv_wgmx.hip):
+ * x [n, h, w, cin] is the LOW-resolution input, dy [n, 2h, 2w, cout] the gradient of the conv's output;
+ * dw[Cout][3][3][Cin] += scale * the gradient, as four launches of a 2x2-window kernel (one per output phase: 4/9 of the
+ * multiply-adds of the tap form vqk_conv2d_wgrad(..., ups = 1)).  bf16, h % 8 == 0, w % 16 == 0, cin % 64 == 0, cout % 64 == 0;
+ * VQK_ERR_SHAPE when not served (deterministic mode included: nothing launched, callers use the tap form). */
+int vqk_conv2d_wgrad_ups_phase(int dtype, const void* x, const void* dy, float* dw, int n, int h, int w, int cin, int cout,
+                               float scale, const void* zeros, void* stream);
 int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
                              int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out,
                              const void* zeros, void* stream);

@@ -67,3 +67,34 @@ def test_phase_form_gn_sums():
     torch.testing.assert_close(st.view(-1, 2)[:, 0], st_ref.view(-1, 2)[:, 0], rtol=0, atol=2e-5)
     torch.testing.assert_close(st.view(-1, 2)[:, 1], st_ref.view(-1, 2)[:, 1], rtol=2e-5, atol=0)
     assert float(ops._gn_ws(x.device, n * 64 + n).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 128, 128, 16, 32), (4, 256, 256, 32, 32), (1, 64, 128, 24, 48), (3, 128, 64, 8, 16),
+                                             (2, 128, 128, 64, 64)])
+def test_phase_form_weight_gradient_matches_tap_form_and_torch(n, cin, cout, h, w):
+    """round 5: dW of nearest-x2 + 3x3 conv (autoencoder.py:102-105) as four 2x2-window launches on the low-resolution input
+    (vqk_conv2d_wgrad_ups_phase) against the tap form (the 3x3 kernel reading x through the upsample addressing) -- same bf16
+    operands, fp32 accumulation: only the summation order differs -- and against fp32 PyTorch on the same operands"""
+    g = torch.Generator(device=DEV).manual_seed(n + cin + cout + h)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).to(BF).contiguous(memory_format=CL)
+    dy = torch.randn(n, cout, 2 * h, 2 * w, device=DEV, generator=g).to(BF).contiguous(memory_format=CL)
+    saved = ops.UPS_PHASE_WGRAD
+    try:
+        ops.UPS_PHASE_WGRAD = True
+        a = ops.raw_conv_wgrad(x, dy, 3, True).float().clone()
+        ops.UPS_PHASE_WGRAD = False
+        b = ops.raw_conv_wgrad(x, dy, 3, True).float().clone()
+    finally:
+        ops.UPS_PHASE_WGRAD = saved
+    torch.cuda.synchronize()
+    assert a.shape == b.shape == (cout, cin, 3, 3)
+    assert float((a - b).norm() / b.norm()) < 2e-6
+    xu = torch.nn.functional.interpolate(x.float(), scale_factor=2, mode='nearest')
+    wref = torch.zeros(cout, cin, 3, 3, device=DEV, requires_grad=True)
+    torch.nn.functional.conv2d(xu, wref, padding=1).backward(dy.float())
+    assert float((a - wref.grad).norm() / wref.grad.norm()) < 2e-5
+    # accumulation into an existing buffer (the optimizer arena): dw += gradient
+    base = torch.randn(cout, 3, 3, cin, device=DEV, generator=g).permute(0, 3, 1, 2)
+    acc = base.clone()
+    ops.raw_conv_wgrad(x, dy, 3, True, out=acc)
+    assert float((acc - base - a).norm() / a.norm()) < 2e-6

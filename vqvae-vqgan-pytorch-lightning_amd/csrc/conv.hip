@@ -2725,7 +2725,8 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
             // above assumes: s* = sqrt(0.08 * pixels / tiles) under half the block cap
             const double coef = VQK_TUNE("WGMX_COEF_E4", 800) * 1e-4;          // (knob in units of 1e-4)
             const int comm = VQK_TUNE("COMM_CUS", 0);               // CUs left to a running collective (conv_mx.hip)
-            const int capm = cap / 2 - comm > tiles ? cap / 2 - comm : tiles;
+            const int nph = dy_pool == 6 ? 4 : 1;                   // all four phases of an upsample conv in one launch: 4 x the blocks
+            const int capm = (cap / 2 - comm) / nph > tiles ? (cap / 2 - comm) / nph : tiles;
             int sm = (int)(sqrt(coef * (double)g.m / tiles) + 0.5);
             if (sm > (capm + tiles - 1) / tiles) sm = (capm + tiles - 1) / tiles;
             if (sm > (total_patches + 3) / 4) sm = (total_patches + 3) / 4;          // >= 4 patches per block
@@ -2742,7 +2743,7 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
             if (sm < 2) part = nullptr;
             ConvGeom gm = g;
             gm.dy_pool = dy_pool; gm.acc_scale = dy_scale;
-            return vqkd::launch_conv3x3_wgrad_mx(x, dy, dw, zeros, gm, tiles, sm, ppm, vqk_stream(stream), part);
+            return vqkd::launch_conv3x3_wgrad_mx(x, dy, dw, zeros, gm, tiles, sm * nph, ppm, vqk_stream(stream), part);
         }
         if (dy_pool) return VQK_ERR_SHAPE;                      // half-resolution dy exists on the matrix/auxiliary-wave kernel only
         if (pw16 && (cin % 64) == 0 && (cout % 64) == 0 && !no_p16k) {
@@ -2823,6 +2824,21 @@ int vqk_conv2d_wgrad_pooled_dy(int dtype, const void* x, const void* dy_pooled, 
     const int wgmx = VQK_TUNE("WGMX", 1);
     VQK_REQUIRE(wgmx && g_force_variant != 0 && VQK_TUNE("WGRAD_BLOCKS", 0) == 0 && VQK_TUNE("WGRAD_NO_PW16", 0) == 0, VQK_ERR_SHAPE);
     return wgrad_general(dtype, x, dy_pooled, dw, n, h, w, cin, cout, 3, 1, 1, 0, h, w, zeros, stream, 1, scale);
+}
+
+int vqk_conv2d_wgrad_ups_phase(int dtype, const void* x, const void* dy, float* dw, int n, int h, int w, int cin, int cout,
+                                float scale, const void* zeros, void* stream) {
+    VQK_REQUIRE(dtype == VQK_BF16 && (h % 8) == 0 && (w % 16) == 0 && (cin % 64) == 0 && (cout % 64) == 0, VQK_ERR_SHAPE);
+    const int wgmx = VQK_TUNE("WGMX", 1);
+    VQK_REQUIRE(wgmx && g_force_variant != 0 && VQK_TUNE("WGRAD_BLOCKS", 0) == 0 && VQK_TUNE("WGRAD_NO_PW16", 0) == 0 && !g_det,
+                VQK_ERR_SHAPE);
+    if (VQK_TUNE("UPS_MERGE", 1))                                // the four output phases as ONE launch (phase = a dimension of the grid)
+        return wgrad_general(dtype, x, dy, dw, n, h, w, cin, cout, 3, 1, 1, 0, h, w, zeros, stream, 6, scale);
+    for (int ph = 0; ph < 4; ++ph) {                             // one launch per output phase (a, b) = (ph >> 1, ph & 1)
+        const int rc = wgrad_general(dtype, x, dy, dw, n, h, w, cin, cout, 3, 1, 1, 0, h, w, zeros, stream, 2 + ph, scale);
+        if (rc) return rc;
+    }
+    return VQK_OK;
 }
 
 int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,

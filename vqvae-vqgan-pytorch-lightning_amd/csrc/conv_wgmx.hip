@@ -14,6 +14,15 @@
 //                patch p is computed: THREE 40-KiB stages, one s_barrier per patch; the X waves wait with COUNTED vmcnt, so a patch's
 //                pieces have two whole intervals to land.
 // Same fragment reads and MFMA order per accumulator as conv3x3_wgrad_p16_kernel => bit-identical partial sums per block.
+//
+// NT = 4 (round 5): the weight gradient of a nearest-x2 UPSAMPLE conv in PHASE form.  Output pixel (2i+a, 2j+b) of the 3x3 conv
+// over the upsampled image reads low-resolution pixel (i + ((a+ky-1)>>1), j + ((b+kx-1)>>1)): per output phase (a, b) only a 2x2
+// window of low-resolution shifts occurs, so  dW[ky][kx] = sum over the four phases of G_ab[r(a,ky)][s(b,kx)],
+// G_ab[r][s] = sum_ij dy[2i+a][2j+b] x[i+r][j+s] -- sixteen low-resolution tap GEMMs over a quarter of the pixels each instead of
+// nine full-resolution ones: 4/9 of the multiply-adds, like the phase form of the forward / data gradient (conv_mx.hip).  One
+// launch per phase (g.dy_pool = 2 + 2a + b): x is the LOW-resolution input with the ordinary halo, the dy patch is gathered at
+// stride 2 from the full-resolution gradient by the LDS-DMA source addresses, four accumulators per wave, and the final atomic
+// pass adds G[ty][tx] to every tap (ky, kx) it stands for (1, 2 or 4 of them).
 // ------------------------------------------------------------------------------------------------
 #include "conv_geom.h"
 
@@ -43,6 +52,7 @@ __device__ __forceinline__ bf16x8_t tr_frag2(const char* p) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+template <int NT>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw* __restrict__ x,
                                                                   const bf16_raw* __restrict__ dy, float* __restrict__ dw,
                                                                   const char* __restrict__ zeros, ConvGeom g,
@@ -61,7 +71,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
     const int co0 = tco * 64, ci0 = tci * 64;
     const int pw = g.w >> 4, ph = g.h >> 3;
     const int total_patches = g.n * ph * pw;
-    const int p_begin = by * patches_per_split;
+    // NT = 4: g.dy_pool = 2 + phase (one phase per launch) or 6 (ALL FOUR phases in one launch: phase = by & 3, split = by >> 2 --
+    // a block still owns one phase, i.e. four accumulators, but the launch fills the chip with a quarter of the splits per phase:
+    // per-block prologue and atomic pass are amortised over 4x the patches of the one-phase-per-launch form)
+    const int phase = NT == 4 ? (g.dy_pool == 6 ? (by & 3) : g.dy_pool - 2) : 0;
+    const int split = (NT == 4 && g.dy_pool == 6) ? (by >> 2) : by;
+    const int p_begin = split * patches_per_split;
     const int p_end = min(total_patches, p_begin + patches_per_split);
     if (p_begin >= p_end) return;
     auto patch_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -69,11 +84,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
     if (wave < 4) {
         // ================================================================= M waves
         const int wi = wave >> 1, wj = wave & 1;
-        f32x16 acc[9];
+        f32x16 acc[NT];
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        const int ph_a = phase >> 1, ph_b = phase & 1;           // output phase (a, b)
         const int li = lane & 15, grp = (lane >> 4) & 1, kgrp = lane >> 5;
         const unsigned frag_lane = (unsigned)((li >> 2) * 64 + 32 * grp + 8 * (li & 3));
         const unsigned a_lane = (unsigned)(wi * DY_HALF) + frag_lane + (unsigned)(kgrp * 8 * 64);
@@ -83,6 +99,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
         for (int pch = p_begin; pch < p_end; ++pch) {
             const char* pa = smem + si * STAGE + a_lane;
             const char* pb = smem + si * STAGE + b_lane;
+            if constexpr (NT == 4) {
+                // 2x2 window of the phase: halo rows gk + a + {0, 1}, halo columns b + {0, 1}; slot gk % 2 holds halo row gk + a
+                bf16x8_t bw2[2][2], a2[2];
+                const char* pw = pb + (ph_a * HWD + ph_b) * 64;
+                a2[0] = tr_frag2(pa);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int tx = 0; tx < 2; ++tx) bw2[r][tx] = tr_frag2(pw + (r * HWD + tx) * 64);
+#pragma unroll
+                for (int gk = 0; gk < 8; ++gk) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[gk & 1], bw2[gk & 1][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[gk & 1], bw2[gk & 1][1], acc[1], 0, 0, 0);
+                    if (gk < 7) {
+                        a2[(gk + 1) & 1] = tr_frag2(pa + (gk + 1) * 16 * 64);
+#pragma unroll
+                        for (int tx = 0; tx < 2; ++tx) bw2[gk & 1][tx] = tr_frag2(pw + ((gk + 2) * HWD + tx) * 64);
+                    }
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[gk & 1], bw2[(gk + 1) & 1][0], acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[gk & 1], bw2[(gk + 1) & 1][1], acc[3], 0, 0, 0);
+                }
+            } else {
             bf16x8_t bwin[3][3], a[2];
             a[0] = tr_frag2(pa);
 #pragma unroll
@@ -117,11 +155,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
             patch_barrier();
             si = si == NST - 1 ? 0 : si + 1;
         }
         const int ci = ci0 + wj * 32 + (lane & 31);
         if ((VQK_WGMX_ABL & 2) && g.n > 0 && acc[0][0] != 12345.678f) return;      // timing-only: no atomic pass
+        if constexpr (NT == 4) {
+            // G[ty][tx] of phase (a, b) stands for the taps ky in {ty ? (a ? 2 : 1) : 0 .. ty ? 2 : (a ? 1 : 0)}, kx likewise
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ty = t >> 1, tx = t & 1;
+                const int ky0 = ty ? (ph_a ? 2 : 1) : 0, ky1 = ty ? 2 : (ph_a ? 1 : 0);
+                const int kx0 = tx ? (ph_b ? 2 : 1) : 0, kx1 = tx ? 2 : (ph_b ? 1 : 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+                    const float v = acc[t][r] * g.acc_scale;
+                    for (int ky = ky0; ky <= ky1; ++ky)
+                        for (int kx = kx0; kx <= kx1; ++kx)
+                            atomicAdd(dw + ((int64_t)co * 9 + ky * 3 + kx) * g.cin + ci, v);
+                }
+            }
+            return;
+        } else {
         if (part) {
             // deterministic mode: this block's partial tile goes to the workspace slot (split by, tile bx) with plain stores;
             // wgrad_mx_reduce_kernel adds the splits in index order
@@ -143,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
                 atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r] * g.acc_scale);
             }
         return;
+        }
     }
 
     // ===================================================================== X waves: the stage's forty LDS-DMA pieces
@@ -155,8 +213,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
 #pragma unroll
     for (int sl = 0; sl < NDY; ++sl) {
         const int q = xw + 4 * sl, half = q >> 3, prow = q & 7;
-        dyoff[sl] = g.dy_pool ? (unsigned)(((((prow >> 1) * (g.w >> 1) + (lrow >> 1)) * g.cout) + co0 + half * 32 + lch) * 2)
-                              : (unsigned)((((prow * g.w + lrow) * g.cout) + co0 + half * 32 + lch) * 2);
+        // dy_pool 1: dy at HALF resolution (every pooled pixel stands for its 2x2 block); >= 2 (NT = 4): dy at TWICE the resolution
+        // of the patch grid, one phase of it gathered at stride 2
+        dyoff[sl] = g.dy_pool == 1 ? (unsigned)(((((prow >> 1) * (g.w >> 1) + (lrow >> 1)) * g.cout) + co0 + half * 32 + lch) * 2)
+                  : g.dy_pool >= 2 ? (unsigned)(((((2 * prow) * (2 * g.w) + 2 * lrow) * g.cout) + co0 + half * 32 + lch) * 2)
+                                   : (unsigned)((((prow * g.w + lrow) * g.cout) + co0 + half * 32 + lch) * 2);
     }
 #pragma unroll
     for (int sl = 0; sl < NX; ++sl) {
@@ -173,7 +234,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
         pp.py0 = pyi * 8; pp.px0 = pxi * PWD;
         pp.interior = !g.ups && pp.py0 >= 1 && pp.py0 + 8 < g.h && pp.px0 >= 1 && pp.px0 + PWD < g.w;
         const int64_t pix = ((int64_t)pp.img * g.h + pp.py0) * g.w + pp.px0;
-        const int64_t dpix = g.dy_pool ? ((int64_t)pp.img * (g.h >> 1) + (pp.py0 >> 1)) * (g.w >> 1) + (pp.px0 >> 1) : pix;
+        const int64_t dpix = g.dy_pool == 1 ? ((int64_t)pp.img * (g.h >> 1) + (pp.py0 >> 1)) * (g.w >> 1) + (pp.px0 >> 1)
+                           : g.dy_pool >= 2 ? ((int64_t)pp.img * (2 * g.h) + 2 * pp.py0 + (phase >> 1)) * (2 * g.w) + 2 * pp.px0 + (phase & 1)
+                                            : pix;
         pp.bdy = reinterpret_cast<const char*>(dy + dpix * g.cout);
         pp.bx = reinterpret_cast<const char*>(x + (pix - g.w - 1) * g.cin);         // halo origin (py0 - 1, px0 - 1)
         return pp;
@@ -256,10 +319,19 @@ namespace vqkd {
 
 int launch_conv3x3_wgrad_mx(const void* x, const void* dy, float* dw, const void* zeros, const ConvGeom& g, int tiles,
                             int splits, int pps, hipStream_t st, float* part) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_wgrad_mx_kernel,
+    if (g.dy_pool >= 2) {                                         // one output phase of an upsample conv: the 2x2-window form
+        if (g.dy_pool > 6 || part || (g.dy_pool == 6 && (splits & 3))) return VQK_ERR_ARG;
+        static const hipError_t attr4 = hipFuncSetAttribute((const void*)conv3x3_wgrad_mx_kernel<4>,
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, VQK_WGMX_NST * 40960);
+        if (attr4 != hipSuccess) return VQK_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv3x3_wgrad_mx_kernel<4>, dim3((unsigned)tiles, (unsigned)splits), dim3(512), VQK_WGMX_NST * 40960, st,
+                           (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps, part);
+        return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
+    }
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_wgrad_mx_kernel<9>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, VQK_WGMX_NST * 40960);
     (void)attr;
-    hipLaunchKernelGGL(conv3x3_wgrad_mx_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(512), VQK_WGMX_NST * 40960, st,
+    hipLaunchKernelGGL(conv3x3_wgrad_mx_kernel<9>, dim3((unsigned)tiles, (unsigned)splits), dim3(512), VQK_WGMX_NST * 40960, st,
                        (const bf16_raw*)x, (const bf16_raw*)dy, dw, (const char*)zeros, g, pps, part);
     if (hipGetLastError() != hipSuccess) return VQK_ERR_LAUNCH;
     if (part) {

@@ -543,6 +543,7 @@ def raw_conv_thin_in_gnstats(x, wq, bias, cout: int, groups: int):
 
 
 UPS_PHASE = int(_native.switch('VQK_UPS_PHASE', '1'))      # 0 off, 1 forward + data gradient, 2 forward only
+UPS_PHASE_WGRAD = _native.switch('VQK_UPS_PHASE_WGRAD', '1') != '0'    # the upsample convs' WEIGHT gradient in phase form too (round 5)
 
 
 def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int = 0):
@@ -662,6 +663,17 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8) -
         return dw
     if thin_true != 8:
         raise RuntimeError('vqk: an unpadded weight-gradient target needs the edge-conv kernel')
+    if (ups and UPS_PHASE_WGRAD and _WGMX_ON and x.dtype == torch.bfloat16 and ksize == 3 and cin % 64 == 0 and cout % 64 == 0
+            and w % 16 == 0 and h % 8 == 0 and not DETERMINISTIC):
+        # the upsample conv's weight gradient in phase form: four 2x2-window launches on the LOW-resolution input, 4/9 of the
+        # multiply-adds (csrc/conv_wgmx.hip, NT = 4)
+        st = _timed('conv3x3_wgrad_mx_kernel<bf16>' + (f' {cin}->{cout}@{dy.shape[2]}x{dy.shape[3]} k{ksize} phase' if _EVENT_SHAPES else ''), flops,
+                    lambda: _native.lib().vqk_conv2d_wgrad_ups_phase(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w,
+                                                                     cin, cout, 1.0, zero_page(x.device).data_ptr(), _stream()),
+                    launches=4, exec_flops=flops * 4.0 / 9.0)
+        if st != _native.ERR_SHAPE:
+            _native.check(st, 'conv2d_wgrad_ups_phase')
+            return dw
     mxw = (_WGMX_ON and x.dtype == torch.bfloat16 and ksize == 3 and cin % 64 == 0 and cout % 64 == 0
            and dy.shape[3] % 16 == 0 and dy.shape[2] % 8 == 0)
     kname = 'conv3x3_wgrad_mx_kernel<bf16>' if mxw else f'conv_wgrad_kernel<{"f32" if x.dtype == torch.float32 else "bf16"}>'
