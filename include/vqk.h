@@ -194,6 +194,14 @@ int vqk_conv2d_thin_in_gnstats(int dtype, const void* x, const void* w, const fl
  * launched: callers use vqk_conv2d_fprop with ups = 1 / the pooled data gradient). */
 int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w,
                          int cin, int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream);
+/* Data gradient of a 3x3 conv that is FOLLOWED by a 2x2 average pool (the encoder's Downsample in a ResBlock's last conv,
+ * vqvae/modules/autoencoder.py:89-91), from the POOLED gradient, in phase form: dx [n, 2h, 2w, cout] = scale * (nearest-x2(dy_pooled)
+ * conv flip(W)^T) -- every full-resolution pixel of a 2x2 block sees the same pooled gradient, so phase (a, b) of dx reads a 2x2
+ * window of dy_pooled [n, h, w, cin] with pre-summed weights: 4/9 of the multiply-adds of the tap form (vqk_conv2d_general with the
+ * nearest-x2 addressing).  w4t = vqk_conv_pack_weights(..., transpose = 1, layout = 2) of the conv's weight (the operand of
+ * vqk_conv2d_ups_phase(backward = 1)); scale = the pool's 0.25.  Same shape rules as vqk_conv2d_ups_phase; VQK_ERR_SHAPE when not served. */
+int vqk_conv2d_pooled_dgrad_phase(int dtype, const void* dy_pooled, const void* w4t, void* dx, int n, int h, int w, int cin,
+                                  int cout, float scale, const void* zeros, void* stream);
 /* General form (im2col kernel when not plain): stride in {1,2}, explicit zero padding `pad`, explicit output size;
  * mode 0: x as is, 1: nearest x2 upsample of x, 2: x zero-stuffed x2 (the dgrad of a stride-2 conv, with flipped /
  * transposed weights and pad = ks-1-pad_fwd).  Epilogue: y = out_gain * act(acc * acc_scale + bias) + residual, act 0

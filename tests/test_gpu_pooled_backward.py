@@ -51,3 +51,25 @@ def test_pooled_gradient_path_matches_unpool_path(n, c, h, w):
     assert rel(g1, g0) < 6e-3, rel(g1, g0)
     for name, p in blk.named_parameters():
         assert rel(p.grad.float(), p.grad.float()) == 0.0 and float(p.grad.abs().max()) > 0, name
+
+
+@pytest.mark.parametrize('n,c,h', [(2, 128, 64), (3, 256, 32), (2, 128, 16)])
+def test_pooled_data_gradient_in_phase_form(n, c, h):
+    """round 5: the data gradient of conv2 + fused average pool from the pooled gradient as ONE forward-type phase launch
+    (vqk_conv2d_pooled_dgrad_phase: reversed phase blocks of the conv's phase-form data-gradient operand, 4/9 of the multiply-adds)
+    against fp32 PyTorch: d/dx of avg_pool2d(conv2d(x, W)) for the pooled cotangent"""
+    g = torch.Generator(device=DEV).manual_seed(n + c + h)
+    wgt = torch.nn.Parameter((torch.randn(c, c, 3, 3, device=DEV, generator=g) / (3 * c ** 0.5)).to(torch.bfloat16).float()
+                             .contiguous(memory_format=torch.channels_last))
+    dyp = torch.randn(n, c, h, h, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    got = ops.raw_conv_pooled_dgrad_phase(dyp, wgt, 0.25)
+    assert got is not None and got.shape == (n, c, 2 * h, 2 * h)
+    x = torch.zeros(n, c, 2 * h, 2 * h, device=DEV, requires_grad=True)
+    torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(x, wgt.detach().float(), padding=1), 2).backward(dyp.float())
+    err = float((got.float() - x.grad).norm() / x.grad.norm())
+    assert err < 6e-3, err                                      # bf16 output + weights pre-summed in fp32 and rounded once
+    # and against the tap form it replaces (same operands, bf16 output): agreement to the output rounding
+    lay = ops.weight_layout(torch.bfloat16, n, h, h, c, c, 3, True)
+    wt = ops.packed_weight(wgt, c, c, torch.bfloat16, 3, True, lay)
+    tap = ops._conv_general_raw(dyp, wt, None, None, c, 3, 1, 1, 1, 2 * h, 2 * h, 0, 0.25, 1.0, torch.bfloat16, lay)
+    assert float((got.float() - tap.float()).norm() / tap.float().norm()) < 8e-3

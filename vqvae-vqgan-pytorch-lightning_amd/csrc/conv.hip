@@ -2292,7 +2292,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.stride = 1; g.pad = ksize >> 1; g.zs = 0; g.vh = g.h; g.vw = g.w;
     g.acc_scale = 1.0f; g.out_gain = 1.0f; g.pool = 0; g.pool_scale = 1.0f;
     g.gn_ws = nullptr; g.gn_cpg = 0; g.gn_part_nblk = 0; g.gn_part_base = 0;
-    g.act = 0; g.dy_pool = 0; g.tq = nullptr; g.tq_mode = 0;
+    g.act = 0; g.dy_pool = 0; g.tq = nullptr; g.tq_mode = 0; g.phase_rev = 0;
     g.ntap = ksize == 1 ? 1 : 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
     g.tapw = 0; g.dst_h = g.dst_w = 0; g.s2 = 0; g.phase_mode = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
@@ -2451,8 +2451,27 @@ int vqk_conv2d_thin_in_gnstats(int dtype, const void* x, const void* w, const fl
     return VQK_OK;
 }
 
+static int ups_phase_impl(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w, int cin,
+                          int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream, int phase_rev,
+                          float acc_scale);
+
 int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w,
                          int cin, int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream) {
+    return ups_phase_impl(dtype, x, w4, bias, y, n, h, w, cin, cout, backward, gn_ws, groups, zeros, stream, 0, 1.0f);
+}
+
+int vqk_conv2d_pooled_dgrad_phase(int dtype, const void* dy_pooled, const void* w4t, void* dx, int n, int h, int w, int cin,
+                                  int cout, float scale, const void* zeros, void* stream) {
+    // dx [n, 2h, 2w, cout] = scale * (nearest-x2(dy_pooled) * flip(W)^T): forward-type phase launch on the pooled gradient with
+    // the conv's data-gradient operand, phase blocks reversed (conv_geom.h: phase_rev).  cin = channels of dy_pooled (the conv's
+    // output channels), cout = channels of dx (its input channels).  One launch (UPS_MERGE) only.
+    VQK_REQUIRE(VQK_TUNE("UPS_MERGE", 1) != 0, VQK_ERR_SHAPE);
+    return ups_phase_impl(dtype, dy_pooled, w4t, nullptr, dx, n, h, w, cin, cout, 0, nullptr, 0, zeros, stream, 1, scale);
+}
+
+static int ups_phase_impl(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w, int cin,
+                          int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream, int phase_rev,
+                          float acc_scale) {
     VQK_REQUIRE(x && w4 && y && zeros, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w4) && vqk_aligned16(y), VQK_ERR_ALIGN);
     VQK_REQUIRE(dtype == VQK_BF16, VQK_ERR_DTYPE);
@@ -2476,6 +2495,7 @@ int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* 
         if (!backward) {
             gp.phase_mode = 1;
             gp.dst_s = 2;
+            gp.phase_rev = phase_rev; gp.acc_scale = acc_scale;
             gp.gn_ws = gn_ws; gp.gn_cpg = gn_ws ? cout / groups : 0;
             if (gn_ws && g_det) { gp.gn_part_nblk = 4 * ((g.h * g.w) / 256); gp.gn_part_base = 0; }
         } else {

@@ -42,6 +42,11 @@ struct ConvGeom {
     int tapw, dst_h, dst_w, s2;
     int phase_mode; // ntap = 4, the four phases of an upsample conv in one launch: 1 forward (phase = a tile dimension), 2 data
                     // gradient (phase = a unit dimension: the tile accumulates all four in registers); weights: the four blocks of layout 2
+    int phase_rev;  // phase_mode 1 only: the weight block of output phase ph is block 3 - ph of the operand.  With the data-gradient
+                    // operand of a conv (layout 2, transpose: the pre-summed phase weights of W^T, taps mirrored) this makes the
+                    // forward-type phase launch compute  nearest-x2(dy) * flip(W)^T  = the data gradient of a conv FOLLOWED BY a
+                    // 2x2 average pool from the pooled gradient (vqk_conv2d_pooled_dgrad_phase): phase (a, b) of the mirrored
+                    // kernel is phase (1-a, 1-b) of the unmirrored one with its 2x2 window mirrored
     int dy_pool;    // weight-gradient mx kernel: dy is given at HALF resolution (the gradient of a fused 2x2 average pool: every
                     // pooled pixel stands for its 2x2 block), dW is scaled by acc_scale
     int act;        // matrix/auxiliary-wave kernel: epilogue activation (0 none, 2 relu, 3 leaky relu 0.2), with acc_scale / out_gain

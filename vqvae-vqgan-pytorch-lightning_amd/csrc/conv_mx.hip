@@ -168,7 +168,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         auto unit_ph = [&](int key, int c) -> int { return pmode == 2 ? c / nch : (key >> 16); };
         auto unit_w = [&](int key, int c, int j) -> int {
             const int ph = unit_ph(key, c), cc = pmode == 2 ? c - ph * nch : c;
-            return ph * phase_bytes + (((key & 0xffff) * 4 + wn * 2 + j) * nch + cc) * (NPH * 1024);
+            const int wph = (NTAP == 4 && g.phase_rev) ? 3 - ph : ph;      // (conv_geom.h: phase_rev -- the pooled data gradient)
+            return wph * phase_bytes + (((key & 0xffff) * 4 + wn * 2 + j) * nch + cc) * (NPH * 1024);
         };
         // window offset of a phase inside the halo: forward (a, b), data gradient (1 - a, 1 - b) (vqk_conv2d_ups_phase)
         auto phase_off = [&](int ph) -> int {

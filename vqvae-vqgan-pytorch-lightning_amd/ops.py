@@ -579,6 +579,35 @@ def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int =
     return y
 
 
+POOLED_DGRAD_PHASE = _native.switch('VQK_POOLED_DGRAD_PHASE', '1') != '0'
+
+
+def raw_conv_pooled_dgrad_phase(dy_pooled, weight, scale: float):
+    """data gradient of a 3x3 conv followed by a 2x2 average pool from the POOLED gradient, in phase form
+    (vqk_conv2d_pooled_dgrad_phase): dy_pooled [N, O, h, w] -> dx [N, I, 2h, 2w] = scale * (nearest-x2(dy_pooled) conv flip(W)^T),
+    4/9 of the multiply-adds of the tap form.  None when the kernel does not serve the problem (nothing launched)."""
+    _require_gpu(dy_pooled)
+    if not UPS_PHASE or dy_pooled.dtype != torch.bfloat16:
+        return None
+    o, i = weight.shape[0], weight.shape[1]
+    n, c, h, w = dy_pooled.shape
+    if c != o or i % 128 or o % 64:
+        return None
+    dx = empty_nhwc(n, i, 2 * h, 2 * w, dy_pooled.dtype, dy_pooled.device)
+    w4t = packed_weight(weight, i, o, dy_pooled.dtype, 3, True, 2)
+    flops = 2.0 * n * 4 * h * w * o * i * 9                      # ALGORITHMIC: the 3x3 data gradient at full resolution
+    nbytes = dy_pooled.numel() * 2 + dx.numel() * 2 + o * i * 9 * 2
+    st = _timed('conv3x3_mx_kernel<bf16>' + (f' {o}->{i}@{2 * h}x{2 * w} pooled-dgrad phase' if _EVENT_SHAPES else ''), flops,
+                lambda: _native.lib().vqk_conv2d_pooled_dgrad_phase(dcode(dy_pooled.dtype), dy_pooled.data_ptr(), w4t.data_ptr(),
+                                                                    dx.data_ptr(), n, h, w, o, i, float(scale),
+                                                                    zero_page(dy_pooled.device).data_ptr(), _stream()), nbytes,
+                exec_flops=flops * 4.0 / 9.0)
+    if st == _native.ERR_SHAPE:
+        return None
+    _native.check(st, 'conv2d_pooled_dgrad_phase')
+    return dx
+
+
 _DIRECT_GRAD = True
 
 
@@ -1326,7 +1355,9 @@ class ResBlockFn(torch.autograd.Function):
             try:
                 lay = weight_layout(dt, n, h // 2, w // 2, cout, cout, 3, True)
                 wt2 = packed_weight(c2w, cout, cout, dt, 3, True, lay)
-                d_a2 = _conv_general_raw(dout, wt2, None, None, cout, 3, 1, 1, 1, h, w, 0, 0.25, 1.0, dt, lay)
+                d_a2 = raw_conv_pooled_dgrad_phase(dout, c2w, 0.25) if POOLED_DGRAD_PHASE else None
+                if d_a2 is None:
+                    d_a2 = _conv_general_raw(dout, wt2, None, None, cout, 3, 1, 1, 1, h, w, 0, 0.25, 1.0, dt, lay)
                 fork = _fork_point(main)
                 if not CHAIN_FIRST:
                     _side_after(side, fork)
