@@ -202,6 +202,14 @@ int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* 
  * vqk_conv2d_ups_phase(backward = 1)); scale = the pool's 0.25.  Same shape rules as vqk_conv2d_ups_phase; VQK_ERR_SHAPE when not served. */
 int vqk_conv2d_pooled_dgrad_phase(int dtype, const void* dy_pooled, const void* w4t, void* dx, int n, int h, int w, int cin,
                                   int cout, float scale, const void* zeros, void* stream);
+/* FORWARD of a 3x3 conv followed by a 2x2 average pool, as the 4x4 stride-2 conv it is: y [n, h, w, cout] = scale * (sum over each
+ * 2x2 block of conv3x3(x, W)) + res_pooled, x [n, 2h, 2w, cin].  One data-gradient-type phase launch (the tile accumulates the four
+ * input phases in registers and is stored once) with the conv's FORWARD phase operand w4 = vqk_conv_pack_weights(..., transpose = 0,
+ * layout = 2), phase blocks reversed: 4/9 of the multiply-adds of the conv + pooling-drain form (vqk_conv2d_fprop_pooled).
+ * res_pooled (may be NULL): the POOLED residual, [n, h, w, cout]; gn_ws / groups as in vqk_conv2d_fprop_gnstats (sums of y).
+ * Same shape rules as vqk_conv2d_ups_phase; VQK_ERR_SHAPE when not served. */
+int vqk_conv2d_pooled_fprop_phase(int dtype, const void* x, const void* w4, const void* res_pooled, void* y, int n, int h, int w,
+                                  int cin, int cout, float scale, double* gn_ws, int groups, const void* zeros, void* stream);
 /* General form (im2col kernel when not plain): stride in {1,2}, explicit zero padding `pad`, explicit output size;
  * mode 0: x as is, 1: nearest x2 upsample of x, 2: x zero-stuffed x2 (the dgrad of a stride-2 conv, with flipped /
  * transposed weights and pad = ks-1-pad_fwd).  Epilogue: y = out_gain * act(acc * acc_scale + bias) + residual, act 0

@@ -73,3 +73,35 @@ def test_pooled_data_gradient_in_phase_form(n, c, h):
     wt = ops.packed_weight(wgt, c, c, torch.bfloat16, 3, True, lay)
     tap = ops._conv_general_raw(dyp, wt, None, None, c, 3, 1, 1, 1, 2 * h, 2 * h, 0, 0.25, 1.0, torch.bfloat16, lay)
     assert float((got.float() - tap.float()).norm() / tap.float().norm()) < 8e-3
+
+
+@pytest.mark.parametrize('n,c,h,res,gn', [(2, 128, 64, 1, 0), (3, 256, 32, 0, 0), (2, 128, 128, 1, 32), (2, 256, 64, 1, 32)])
+def test_pooled_forward_as_4x4_stride2_phase_launch(n, c, h, res, gn):
+    """round 5: avg_pool2d(conv2d(x, W) + skip) = the 4x4 stride-2 conv of x + pooled skip, as ONE data-gradient-type phase launch
+    with the conv's forward phase operand, phase blocks reversed (vqk_conv2d_pooled_fprop_phase) -- against fp32 PyTorch, against the
+    conv + pooling-drain kernel it replaces, and with the GroupNorm sums of the result left for the consumer"""
+    g = torch.Generator(device=DEV).manual_seed(n + c + h + res)
+    wgt = torch.nn.Parameter((torch.randn(c, c, 3, 3, device=DEV, generator=g) / (3 * c ** 0.5)).to(torch.bfloat16).float()
+                             .contiguous(memory_format=torch.channels_last))
+    x = torch.randn(n, c, h, h, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    skip = torch.randn(n, c, h, h, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    skip_p = ops.raw_pool(skip, 0.25) if res else None
+    got = ops.raw_conv_pooled_fprop_phase(x, wgt, skip_p, 0.25, gn)
+    assert got is not None and got.shape == (n, c, h // 2, h // 2)
+    want = torch.nn.functional.conv2d(x.float(), wgt.detach().float(), padding=1)
+    if res:
+        want = want + skip.float()
+    want = torch.nn.functional.avg_pool2d(want, 2)
+    assert float((got.float() - want).norm() / want.norm()) < 6e-3
+    wq = ops.packed_weight(wgt, c, c, torch.bfloat16, 3, False, 1)
+    old = ops.raw_conv_fprop_pooled(x, wq, None, skip, 3, False, c, 0.25)
+    assert float((got.float() - old.float()).norm() / old.float().norm()) < 8e-3
+    if gn and (h // 2) * (h // 2) > 1024:                       # (maps of <= 1024 pixels: the single-kernel GroupNorm, no hand-off)
+        # the sums left in the workspace are those of the STORED tensor: GroupNorm with them == GroupNorm with its own statistics pass
+        gw, gb = torch.randn(c, device=DEV, generator=g), torch.randn(c, device=DEV, generator=g)
+        assert ops.pending_gn() is not None
+        y1, st1 = ops.raw_gn_forward(got, gw, gb, gn, 1e-6, True)              # claims the hand-off
+        assert ops.pending_gn() is None
+        y2, st2 = ops.raw_gn_forward(got.clone(memory_format=torch.preserve_format), gw, gb, gn, 1e-6, True)
+        assert float((st1 - st2).abs().max() / st2.abs().max()) < 1e-4
+        assert float((y1.float() - y2.float()).norm() / y2.float().norm()) < 2e-3

@@ -55,6 +55,7 @@ _PROTOS = {
     'vqk_conv2d_fprop_gnstats': [I, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, I, P, P],
     'vqk_conv2d_ups_phase': [I, P, P, P, P, I, I, I, I, I, I, P, I, P, P],
     'vqk_conv2d_pooled_dgrad_phase': [I, P, P, P, I, I, I, I, I, F, P, P],
+    'vqk_conv2d_pooled_fprop_phase': [I, P, P, P, P, I, I, I, I, I, F, P, I, P, P],
     'vqk_conv2d_thin_in_gnstats': [I, P, P, P, P, I, I, I, I, P, I, P],
     'vqk_conv2d_s2_supported': [I, I, I, I, I, I, I],
     'vqk_conv2d_s2_fprop': [I, P, P, P, P, I, I, I, I, I, I, F, F, P, P],

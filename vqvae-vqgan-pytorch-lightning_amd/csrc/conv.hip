@@ -2453,7 +2453,7 @@ int vqk_conv2d_thin_in_gnstats(int dtype, const void* x, const void* w, const fl
 
 static int ups_phase_impl(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w, int cin,
                           int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream, int phase_rev,
-                          float acc_scale);
+                          float acc_scale, const void* res = nullptr);
 
 int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w,
                          int cin, int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream) {
@@ -2469,14 +2469,26 @@ int vqk_conv2d_pooled_dgrad_phase(int dtype, const void* dy_pooled, const void* 
     return ups_phase_impl(dtype, dy_pooled, w4t, nullptr, dx, n, h, w, cin, cout, 0, nullptr, 0, zeros, stream, 1, scale);
 }
 
+int vqk_conv2d_pooled_fprop_phase(int dtype, const void* x, const void* w4, const void* res_pooled, void* y, int n, int h, int w,
+                                  int cin, int cout, float scale, double* gn_ws, int groups, const void* zeros, void* stream) {
+    // y [n, h, w, cout] = scale * sum over each 2x2 block of conv3x3(x)  (+ res_pooled), x [n, 2h, 2w, cin]: a 4x4 stride-2 conv =
+    // the DATA-GRADIENT-type phase launch (phase = a unit dimension, the tile accumulates the four input phases in registers)
+    // with the conv's FORWARD phase operand, phase blocks reversed: scale * sum_{2x2} conv(x, W) == dgrad_ups(x; V = scale flip(W)^T)
+    // and the phase pack of V^T = flip(W) is the pack of W with phase (a, b) <-> (1-a, 1-b).
+    VQK_REQUIRE(VQK_TUNE("UPS_MERGE", 1) != 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(!gn_ws || (groups > 0 && cout % groups == 0 && (cout / groups) % 4 == 0), VQK_ERR_SHAPE);
+    return ups_phase_impl(dtype, x, w4, nullptr, y, n, h, w, cin, cout, 1, gn_ws, groups, zeros, stream, 1, scale, res_pooled);
+}
+
 static int ups_phase_impl(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w, int cin,
                           int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream, int phase_rev,
-                          float acc_scale) {
+                          float acc_scale, const void* res) {
     VQK_REQUIRE(x && w4 && y && zeros, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w4) && vqk_aligned16(y), VQK_ERR_ALIGN);
     VQK_REQUIRE(dtype == VQK_BF16, VQK_ERR_DTYPE);
     VQK_REQUIRE(backward == 0 || backward == 1, VQK_ERR_ARG);
-    VQK_REQUIRE(!gn_ws || (!backward && groups > 0 && cout % groups == 0 && (cout / groups) % 4 == 0), VQK_ERR_SHAPE);
+    VQK_REQUIRE(!gn_ws || ((!backward || phase_rev) && groups > 0 && cout % groups == 0 && (cout / groups) % 4 == 0), VQK_ERR_SHAPE);
+    VQK_REQUIRE(!res || (backward && phase_rev && vqk_aligned16(res)), VQK_ERR_ARG);
     ConvGeom g;
     const int rc = make_geom(g, dtype, n, h, w, cin, cout, 3, 0);            // tiles over the LOW-resolution h x w grid
     if (rc) return rc;
@@ -2502,8 +2514,11 @@ static int ups_phase_impl(int dtype, const void* x, const void* w4, const float*
             gp.phase_mode = 2;
             gp.src_s = 2;
             gp.h_in = 2 * h; gp.w_in = 2 * w;
+            gp.phase_rev = phase_rev; gp.acc_scale = acc_scale;              // (the pooled FORWARD: vqk_conv2d_pooled_fprop_phase)
+            gp.gn_ws = gn_ws; gp.gn_cpg = gn_ws ? cout / groups : 0;
+            if (gn_ws && g_det) { gp.gn_part_nblk = (g.h * g.w) / 256; gp.gn_part_base = 0; }
         }
-        return vqkd::launch_conv3x3_mx(x, w4, backward ? nullptr : bias, nullptr, y, zeros, gp, tw, st);
+        return vqkd::launch_conv3x3_mx(x, w4, backward ? nullptr : bias, res, y, zeros, gp, tw, st);
     }
     for (int ph = 0; ph < 4; ++ph) {
         const int a = ph >> 1, b = ph & 1;

@@ -608,6 +608,43 @@ def raw_conv_pooled_dgrad_phase(dy_pooled, weight, scale: float):
     return dx
 
 
+POOLED_FPROP_PHASE = _native.switch('VQK_POOLED_FPROP_PHASE', '1') != '0'
+POOLED_FPROP_MIN_HW = int(_native.switch('VQK_POOLED_FPROP_MIN_HW', '4096'))      # full-resolution pixels per image from which it is used
+
+
+def raw_conv_pooled_fprop_phase(x, weight, res_pooled, scale: float, gn_groups: int = 0):
+    """scale * sumpool2x2(conv3x3(x, W)) + res_pooled as ONE 4x4 stride-2 launch (vqk_conv2d_pooled_fprop_phase): x [N, I, 2h, 2w]
+    -> [N, O, h, w]; gn_groups: the GroupNorm sums of the result go to the stream's workspace.  None when not served."""
+    _require_gpu(x)
+    if not UPS_PHASE or x.dtype != torch.bfloat16:
+        return None
+    o, i = weight.shape[0], weight.shape[1]
+    n, c, hx, wx = x.shape
+    if c != i or o % 128 or i % 64 or hx % 2 or wx % 2:
+        return None
+    h, w = hx // 2, wx // 2
+    y = empty_nhwc(n, o, h, w, x.dtype, x.device)
+    ws = None
+    if gn_groups and FUSE_GN_STATS and h * w > 1024:
+        if _HANDOFF.gn is not None:
+            _claim_presummed(x, -1)
+        ws = _gn_sum_target(x.device, n, gn_groups, h * w)
+    w4 = packed_weight(weight, i, o, x.dtype, 3, False, 2)
+    flops = 2.0 * n * hx * wx * o * i * 9                        # ALGORITHMIC: the 3x3 conv at full resolution
+    nbytes = x.numel() * 2 + y.numel() * 2 * (2 if res_pooled is not None else 1) + o * i * 9 * 2
+    st = _timed('conv3x3_mx_kernel<bf16>' + (f' {i}->{o}@{hx}x{wx} pooled-fprop phase' if _EVENT_SHAPES else ''), flops,
+                lambda: _native.lib().vqk_conv2d_pooled_fprop_phase(dcode(x.dtype), x.data_ptr(), w4.data_ptr(), _p(res_pooled), y.data_ptr(),
+                                                                    n, h, w, i, o, float(scale), _p(ws), gn_groups,
+                                                                    zero_page(x.device).data_ptr(), _stream()), nbytes,
+                exec_flops=flops * 4.0 / 9.0)
+    if st == _native.ERR_SHAPE:
+        return None
+    _native.check(st, 'conv2d_pooled_fprop_phase')
+    if ws is not None:
+        _note_presummed(y, gn_groups, conv_hw=h * w)
+    return y
+
+
 _DIRECT_GRAD = True
 
 
@@ -1316,7 +1353,13 @@ class ResBlockFn(torch.autograd.Function):
         l2 = weight_layout(dt, n, h, w, cout, cout, 3, False)
         wq2 = packed_weight(c2w, cout, cout, dt, 3, False, l2)
         out = None
-        if next_gn and l2 == 1 and cout % 128 == 0:              # the sums for the GroupNorm that reads `out` next
+        if pool and POOLED_FPROP_PHASE and dt == torch.bfloat16 and l2 == 1 and cout % 128 == 0 and h * w >= POOLED_FPROP_MIN_HW:
+            # conv2 + the level's average pool as the 4x4 stride-2 conv it is (4/9 of the multiply-adds); the skip is pooled by its
+            # own memory-bound pass (the launch adds a residual at its OUTPUT resolution)
+            out = raw_conv_pooled_fprop_phase(a2, c2w, raw_pool(skip, 0.25), 0.25, next_gn)
+        if out is not None:
+            pass
+        elif next_gn and l2 == 1 and cout % 128 == 0:            # the sums for the GroupNorm that reads `out` next
             out = raw_conv_fprop_gnstats(a2, wq2, None, skip, False, cout, next_gn, pool=pool, pool_scale=0.25)
             if out is not None:
                 _note_presummed(out, next_gn, conv_hw=h * w)
