@@ -232,6 +232,12 @@ int vqk_conv2d_wgrad_pooled_dy(int dtype, const void* x, const void* dy_pooled, 
  * VQK_ERR_SHAPE when not served (deterministic mode included: nothing launched, callers use the tap form). */
 int vqk_conv2d_wgrad_ups_phase(int dtype, const void* x, const void* dy, float* dw, int n, int h, int w, int cin, int cout,
                                float scale, const void* zeros, void* stream);
+/* Weight gradient of a 3x3 conv FOLLOWED by a 2x2 average pool from the pooled gradient, in phase form (the mirror image of
+ * vqk_conv2d_wgrad_ups_phase: operands' roles swapped, csrc/conv_wgmx.hip): x [n, 2h, 2w, cin] the conv's input, dy_pooled
+ * [n, h, w, cout]; dw[Cout][3][3][Cin] += scale * wgrad(x, unpool(dy_pooled)) with 4/9 of the multiply-adds of
+ * vqk_conv2d_wgrad_pooled_dy.  Same shape rules; VQK_ERR_SHAPE when not served (deterministic mode included). */
+int vqk_conv2d_wgrad_pooled_dy_phase(int dtype, const void* x, const void* dy_pooled, float* dw, int n, int h, int w, int cin,
+                                     int cout, float scale, const void* zeros, void* stream);
 int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
                              int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out,
                              const void* zeros, void* stream);

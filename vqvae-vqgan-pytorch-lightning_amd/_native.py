@@ -75,6 +75,7 @@ _PROTOS = {
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
     'vqk_conv2d_wgrad_pooled_dy': [I, P, P, P, I, I, I, I, I, F, P, P],
     'vqk_conv2d_wgrad_ups_phase': [I, P, P, P, I, I, I, I, I, F, P, P],
+    'vqk_conv2d_wgrad_pooled_dy_phase': [I, P, P, P, I, I, I, I, I, F, P, P],
     'vqk_conv2d_wgrad_edge': [I, P, P, P, P, L, I, I, I, I, I, P, P],
     'vqk_conv2d_wgrad_edge_true': [I, P, P, P, P, L, I, I, I, I, I, I, P, P],
     'vqk_conv2d_thin_out': [I, P, P, P, P, I, I, I, I, I, I, P, P],

@@ -2760,7 +2760,7 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
             // above assumes: s* = sqrt(0.08 * pixels / tiles) under half the block cap
             const double coef = VQK_TUNE("WGMX_COEF_E4", 800) * 1e-4;          // (knob in units of 1e-4)
             const int comm = VQK_TUNE("COMM_CUS", 0);               // CUs left to a running collective (conv_mx.hip)
-            const int nph = dy_pool == 6 ? 4 : 1;                   // all four phases of an upsample conv in one launch: 4 x the blocks
+            const int nph = dy_pool >= 6 ? 4 : 1;                   // all four phases of an upsample conv in one launch: 4 x the blocks
             const int capm = (cap / 2 - comm) / nph > tiles ? (cap / 2 - comm) / nph : tiles;
             int sm = (int)(sqrt(coef * (double)g.m / tiles) + 0.5);
             if (sm > (capm + tiles - 1) / tiles) sm = (capm + tiles - 1) / tiles;
@@ -2874,6 +2874,18 @@ int vqk_conv2d_wgrad_ups_phase(int dtype, const void* x, const void* dy, float* 
         if (rc) return rc;
     }
     return VQK_OK;
+}
+
+int vqk_conv2d_wgrad_pooled_dy_phase(int dtype, const void* x, const void* dy_pooled, float* dw, int n, int h, int w, int cin,
+                                     int cout, float scale, const void* zeros, void* stream) {
+    // x [n, 2h, 2w, cin] (the conv's input), dy_pooled [n, h, w, cout]; dw[Cout][3][3][Cin] += scale * wgrad(x, unpool(dy_pooled)).
+    // The phase-form kernel with the operands' roles swapped (conv_wgmx.hip, dy_pool = 7): its "x" operand is dy_pooled (cout
+    // channels), its phase-gathered "dy" operand is x (cin channels); h, w: the POOLED grid.
+    VQK_REQUIRE(dtype == VQK_BF16 && (h % 8) == 0 && (w % 16) == 0 && (cin % 64) == 0 && (cout % 64) == 0, VQK_ERR_SHAPE);
+    const int wgmx = VQK_TUNE("WGMX", 1);
+    VQK_REQUIRE(wgmx && g_force_variant != 0 && VQK_TUNE("WGRAD_BLOCKS", 0) == 0 && VQK_TUNE("WGRAD_NO_PW16", 0) == 0 && !g_det &&
+                VQK_TUNE("UPS_MERGE", 1) != 0, VQK_ERR_SHAPE);
+    return wgrad_general(dtype, dy_pooled, x, dw, n, h, w, cout, cin, 3, 1, 1, 0, h, w, zeros, stream, 7, scale);
 }
 
 int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,

@@ -74,8 +74,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
     // NT = 4: g.dy_pool = 2 + phase (one phase per launch) or 6 (ALL FOUR phases in one launch: phase = by & 3, split = by >> 2 --
     // a block still owns one phase, i.e. four accumulators, but the launch fills the chip with a quarter of the splits per phase:
     // per-block prologue and atomic pass are amortised over 4x the patches of the one-phase-per-launch form)
-    const int phase = NT == 4 ? (g.dy_pool == 6 ? (by & 3) : g.dy_pool - 2) : 0;
-    const int split = (NT == 4 && g.dy_pool == 6) ? (by >> 2) : by;
+    // g.dy_pool = 7: as 6 with the operands' ROLES SWAPPED -- the weight gradient of a conv followed by a 2x2 average pool from the
+    // POOLED gradient: dW[ky][kx] = sum_YX dyp[Y>>1][X>>1] x[Y+ky-1][X+kx-1] re-indexed over the phases (a', b') of the FULL-resolution
+    // x: G'[r'][s'] = sum_ij x[2i+a'][2j+b'] dyp[i+r'][j+s'] over the same 2x2 windows.  The phase-gathered operand ("dy" of this
+    // kernel) is x, the windowed low-resolution operand ("x" of this kernel) is the pooled gradient; the tile comes out transposed
+    // (rows = the conv's input channels) and stands for the MIRRORED taps (2 - ky, 2 - kx): the final pass scatters accordingly.
+    const bool merged = NT == 4 && g.dy_pool >= 6, swapped = NT == 4 && g.dy_pool == 7;
+    const int phase = NT == 4 ? (merged ? (by & 3) : g.dy_pool - 2) : 0;
+    const int split = merged ? (by >> 2) : by;
     const int p_begin = split * patches_per_split;
     const int p_end = min(total_patches, p_begin + patches_per_split);
     if (p_begin >= p_end) return;
@@ -173,8 +179,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
                     const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
                     const float v = acc[t][r] * g.acc_scale;
                     for (int ky = ky0; ky <= ky1; ++ky)
-                        for (int kx = kx0; kx <= kx1; ++kx)
-                            atomicAdd(dw + ((int64_t)co * 9 + ky * 3 + kx) * g.cin + ci, v);
+                        for (int kx = kx0; kx <= kx1; ++kx) {
+                            if (swapped) atomicAdd(dw + ((int64_t)ci * 9 + (2 - ky) * 3 + (2 - kx)) * g.cout + co, v);
+                            else atomicAdd(dw + ((int64_t)co * 9 + ky * 3 + kx) * g.cin + ci, v);
+                        }
                 }
             }
             return;
@@ -320,7 +328,7 @@ namespace vqkd {
 int launch_conv3x3_wgrad_mx(const void* x, const void* dy, float* dw, const void* zeros, const ConvGeom& g, int tiles,
                             int splits, int pps, hipStream_t st, float* part) {
     if (g.dy_pool >= 2) {                                         // one output phase of an upsample conv: the 2x2-window form
-        if (g.dy_pool > 6 || part || (g.dy_pool == 6 && (splits & 3))) return VQK_ERR_ARG;
+        if (g.dy_pool > 7 || part || (g.dy_pool >= 6 && (splits & 3))) return VQK_ERR_ARG;
         static const hipError_t attr4 = hipFuncSetAttribute((const void*)conv3x3_wgrad_mx_kernel<4>,
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, VQK_WGMX_NST * 40960);
         if (attr4 != hipSuccess) return VQK_ERR_LAUNCH;

@@ -609,6 +609,7 @@ def raw_conv_pooled_dgrad_phase(dy_pooled, weight, scale: float):
 
 
 POOLED_FPROP_PHASE = _native.switch('VQK_POOLED_FPROP_PHASE', '1') != '0'
+POOLED_WGRAD_PHASE = _native.switch('VQK_POOLED_WGRAD_PHASE', '0') != '0'      # measured +-0 in the step (27.18 / 27.23 against 27.21 / 27.26 ms: these launches sit under the GroupNorm backward): off
 POOLED_FPROP_MIN_HW = int(_native.switch('VQK_POOLED_FPROP_MIN_HW', '4096'))      # full-resolution pixels per image from which it is used
 
 
@@ -761,6 +762,16 @@ def raw_conv_wgrad_pooled_dy(x, dy_pooled, scale: float, out) -> bool:
     if not (_WGMX_ON and x.dtype == torch.bfloat16 and cin % 64 == 0 and cout % 64 == 0 and w % 16 == 0 and h % 8 == 0):
         return False
     flops = 2.0 * n * h * w * cout * cin * 9
+    if POOLED_WGRAD_PHASE and not DETERMINISTIC and (h // 2) % 8 == 0 and (w // 2) % 16 == 0:
+        # phase form (operands' roles swapped, csrc/conv_wgmx.hip): 4/9 of the multiply-adds
+        st = _timed('conv3x3_wgrad_mx_kernel<bf16>' + (f' {cin}->{cout}@{h}x{w} pooled-dy phase' if _EVENT_SHAPES else ''), flops,
+                    lambda: _native.lib().vqk_conv2d_wgrad_pooled_dy_phase(dcode(x.dtype), x.data_ptr(), dy_pooled.data_ptr(), out.data_ptr(),
+                                                                           n, h // 2, w // 2, cin, cout, float(scale),
+                                                                           zero_page(x.device).data_ptr(), _stream()),
+                    exec_flops=flops * 4.0 / 9.0)
+        if st != _native.ERR_SHAPE:
+            _native.check(st, 'conv2d_wgrad_pooled_dy_phase')
+            return True
     st = _timed('conv3x3_wgrad_mx_kernel<bf16>' + (f' {cin}->{cout}@{h}x{w} pooled-dy' if _EVENT_SHAPES else ''), flops,
                 lambda: _native.lib().vqk_conv2d_wgrad_pooled_dy(dcode(x.dtype), x.data_ptr(), dy_pooled.data_ptr(), out.data_ptr(),
                                                                  n, h, w, cin, cout, float(scale),
