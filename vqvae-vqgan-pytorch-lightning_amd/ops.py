@@ -422,12 +422,13 @@ def clear_pack_cache():
     _PACK_TABLE = None
 
 
-def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_dtype, cout: int, wlayout: int = 0):
-    """x [N,Cin,H,W] nhwc; wq: packed weights (pack_weights) in x.dtype with layout ``wlayout``."""
+def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_dtype, cout: int, wlayout: int = 0, out=None):
+    """x [N,Cin,H,W] nhwc; wq: packed weights (pack_weights) in x.dtype with layout ``wlayout``.  ``out``: write here (a batch slice
+    of a larger nhwc tensor: the half-batch pipeline of ResBlockFn.backward)."""
     _require_gpu(x)
     n, cin, h, w = x.shape
     s = 2 if ups else 1
-    y = empty_nhwc(n, cout, h * s, w * s, out_dtype, x.device)
+    y = out if out is not None else empty_nhwc(n, cout, h * s, w * s, out_dtype, x.device)
     flops = 2.0 * n * h * s * w * s * cout * cin * ksize * ksize
     nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size() * (2 if residual is not None else 1)
               + cout * cin * ksize * ksize * x.element_size())
@@ -964,11 +965,11 @@ def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool
     return y, stats
 
 
-def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None, add=None, dx_colsum=None):
+def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None, add=None, dx_colsum=None, out=None):
     """``dx_colsum``: fp32 [C] buffer that also receives the per-channel sums of the dx written (the bias gradient of the conv
-    that produced x: vqk_gn_backward_colsum); the caller checks :func:`gn_colsum_ok` first"""
+    that produced x: vqk_gn_backward_colsum); the caller checks :func:`gn_colsum_ok` first.  ``out``: dx goes here (batch slice)."""
     n, c, h, wd = x.shape
-    dx = torch.empty_like(x, memory_format=_CL)
+    dx = out if out is not None else torch.empty_like(x, memory_format=_CL)
     dw = dw if dw is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     db = db if db is not None else torch.zeros(c, dtype=torch.float32, device=x.device)
     _claim_presummed(x, -1)                                      # (clears a stale note + workspace; never matches)
