@@ -12,7 +12,10 @@ from typing import Iterable
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _native, ops
+
+
+GAN_OPT_OVERLAP = _native.switch('VQK_GAN_OPT_OVERLAP', '1') != '0'     # VQ-GAN replay: the AE optimizer step beside the discriminator half
 
 
 def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
@@ -306,12 +309,25 @@ class MiniTrainer:
         ops.repack_owned(None)
         g_ae, res, q_loss = self._gan['ae']
         g_ae.replay()
-        ae_opt.all_reduce_grads()
-        ae_opt.step()
         step = model.current_epoch * self.num_training_batches + batch_index
         key = 'd_r1' if (self._gan_every and step % self._gan_every == 0) else 'd'
         g, (loss, d_loss, r1_penalty) = self._gan[key]
-        g.replay()
+        if GAN_OPT_OVERLAP and loss is not None:
+            # the autoencoder's all-reduce + AdamW + operand refresh beside the discriminator half: that graph reads the
+            # reconstruction the AE half left, the real batch and the discriminator -- nothing the AE optimizer writes (its
+            # backward stops at the discriminator's parameters, model.py::_gan_disc_half); model.py:251-264 has the same order of
+            # effects (opt_ae.step() before the discriminator loss, which sees x_rec.detach() of the OLD weights)
+            cur, osd = torch.cuda.current_stream(), ops.aux_stream(self._static_in.device, 'ae_opt')
+            osd.wait_stream(cur)
+            with torch.cuda.stream(osd):
+                ae_opt.all_reduce_grads()
+                ae_opt.step()
+            g.replay()
+            cur.wait_stream(osd)
+        else:
+            ae_opt.all_reduce_grads()
+            ae_opt.step()
+            g.replay()
         if loss is not None:
             disc_opt.all_reduce_grads()
             disc_opt.step()
