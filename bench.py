@@ -8,7 +8,9 @@
 A step = preprocess -> encoder -> quantizer -> decoder -> MSE -> backward -> one flat-gradient all-reduce
 -> AdamW, on a synthetic U(0,1) batch that is resident in HBM before the timed region.  Rank 0 prints ONE
 JSON line.  `roofline` is for the dominant kernel (the implicit-GEMM conv): algorithmic FLOPs of its launches
-(2*M*Cout*Cin*k*k each) over their HIP-event durations, recorded on the launch stream inside the timed region.
+(2*M*Cout*Cin*k*k each) over their HIP-event durations, recorded on the launch stream -- inside the timed region when the step
+is issued eagerly (--no-graph), in eager steps of the same shapes right after it when the timed region replays hipGraphs (events
+cannot be read back from inside a replayed graph; `roofline.event_pass` says which).
 `cpu_baseline` times the CPU oracle (oracle/vqvae_oracle.py, a PyTorch-CPU restatement: kind "port") on a
 bounded sample of the same workload, rank 0, N=1 only.
 """
