@@ -430,7 +430,18 @@ def main():
                     native.check(native.lib().vqk_set_tuning(b'TILE_QUEUE', tq), 'set_tuning')
                     t = trainer_mod.MiniTrainer(num_training_batches=args.steps + args.warmup, deterministic=True if args.deterministic else None)
                     t.optimizers, t.overlap_allreduce, model.trainer = trainer.optimizers, overlap, t
-                    t.capture(model, images, warmup=1)
+                    ok = 1
+                    try:
+                        t.capture(model, images, warmup=1)
+                    except Exception as exc:                 # this FORM could not be captured here: the others still can be timed
+                        ok = 0
+                        print(f'[bench] rank {rank}: form {name} not captured ({type(exc).__name__}: {exc})', file=sys.stderr)
+                        torch.cuda.synchronize()
+                    agree = torch.tensor([ok], dtype=torch.int32, device=device)
+                    dist.all_reduce(agree, op=dist.ReduceOp.MIN)          # every rank takes the same branch
+                    if int(agree.item()) == 0:
+                        comm_ab[name + '_ms'] = None
+                        continue
                     for i in range(3):
                         t.train_batch_graphed(model, images, i)
                     barrier()
@@ -442,7 +453,10 @@ def main():
                     dist.all_reduce(dt_ab, op=dist.ReduceOp.MAX)
                     comm_ab[name + '_ms'] = round(float(dt_ab.item()) * 1e3, 3)
                     trainers[name] = (t, tq)
-                best = min(forms, key=lambda f: comm_ab[f[0] + '_ms'])[0]
+                timed = [f for f in forms if comm_ab[f[0] + '_ms'] is not None]
+                if not timed:
+                    raise RuntimeError('none of the three reduction forms could be captured')
+                best = min(timed, key=lambda f: comm_ab[f[0] + '_ms'])[0]
                 comm_ab['chosen'] = best
                 trainer, tq = trainers[best]
                 model.trainer = trainer
