@@ -101,6 +101,11 @@ int vqk_entropy_forward_f32(const float* dmat, int64_t n, int k, float temperatu
 /* In place dmat <- dL_ent/dd (scaled by *gscale_dev): the cotangent that the two GEMMs turn into dz and dE. */
 int vqk_entropy_backward_f32(float* dmat, const float* lse, const float* hrow, const float* u, int64_t n, int k,
                              float temperature, float ratio, const float* gscale_dev, void* stream);
+/* The same cotangent as TWO bf16 matrices hi, lo [N][K] (hi = bf16(dd), lo = bf16(dd - hi); dmat is left untouched; K % 4 == 0):
+ * the operands of split-product GEMMs on the bf16 MFMA kernels (dd E ~ hi E_hi + hi E_lo + lo E_hi, relative error ~2^-16) where the
+ * reference multiplies in fp32 (vector_quantizers.py:296-356 differentiated; throughput mode only). */
+int vqk_entropy_backward_split_f32(const float* dmat, const float* lse, const float* hrow, const float* u, int64_t n, int k,
+                                   float temperature, float ratio, const float* gscale_dev, void* hi, void* lo, void* stream);
 /* ent_loss_type == 'argmax' (vector_quantizers.py:311-315): the targets are one_hot(argmax_k a) with the gradient of p
  * (straight-through).  idx = the assignment of vqk_vq_distances_f32 (argmax a == argmin d, first wins), hist = its code
  * histogram (vqk_vq_gather_f32).  Forward: lse / hrow as above, ssum += sum_i (lse_i - a_i[idx_i]), mbuf[k] scratch,

@@ -110,6 +110,35 @@ def test_config5_entropy_k8192(golden, tag, temp):
     close_norm(de[::64], g[f'{tag}.de_rows'], 5 * tol_de)
 
 
+@pytest.mark.parametrize('temp', [0.01, 0.05, 1.0])
+def test_config5_entropy_split_product_gemms_equal_the_fp32_gemms(temp):
+    """throughput mode (bf16 activations): the two GEMMs of the entropy cotangent run as bf16 split products
+    (dd = hi + lo, E = E_hi + E_lo: three of the four partial products, vqk_entropy_backward_split_f32) -- against the fp32-MFMA
+    GEMMs of the parity mode on the same inputs.  A product carries ~2^-16 relative error; dz is a plain sum of them, dE adds
+    the cancellation of -2 dd^T Z against 2 E colsum(dd) on top (both paths share it)"""
+    i = S.entropy_full_inputs(temp)
+    z = dev(i['z']).requires_grad_(True)
+    cb = dev(i['e']).requires_grad_(True)
+    res = {}
+    saved = ops.ENTROPY_SPLIT_GEMM
+    try:
+        for split in (True, False):
+            ops.ENTROPY_SPLIT_GEMM = split
+            q, idx, loss, hist = ops.EntropyVQFn.apply(z, cb, float(i['beta']), float(i['ratio']), temp, torch.bfloat16, 'softmax')
+            res[split] = torch.autograd.grad([loss], [z, cb]) + (idx, loss.detach())
+    finally:
+        ops.ENTROPY_SPLIT_GEMM = saved
+    assert torch.equal(res[True][2], res[False][2])                                    # the forward is the same kernel
+    assert abs(float(res[True][3]) - float(res[False][3])) <= 1e-6 * abs(float(res[False][3]))      # (row sums: fp32 atomics)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    # measured: T = 0.01 dz 7.6e-4, dE 6.4e-4; T = 0.05 dz 8.7e-5 -- the 2^-16 of a product times the cancellation in
+    # sum_k dd_ik e_k (the rows of dd sum to zero and the codes that carry the mass are neighbours: |e_k - z_i| << |e_k|); below the
+    # bf16 rounding (4e-3) every consumer of dz applies in this mode
+    tol = 2e-3 if temp < 0.05 else 3e-4
+    assert rel(res[True][0], res[False][0]) < tol, rel(res[True][0], res[False][0])
+    assert rel(res[True][1], res[False][1]) < tol, rel(res[True][1], res[False][1])
+
+
 def test_config5_entropy_keeps_no_n_by_k_tensor_between_forward_and_backward():
     """the forward reduces the [N][K] distance matrix to lse[N] / hrow[N] / u[K] and frees it; what stays
     allocated until the backward does not grow with N x K (round 3 saved the matrix: 134 MB here, 537 MB at BASELINE size)"""

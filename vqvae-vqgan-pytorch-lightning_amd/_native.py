@@ -40,6 +40,7 @@ _PROTOS = {
     'vqk_entropy_forward_presummed_f32': [P, L, I, F, P, P, P, P, P],
     'vqk_entropy_forward_f32': [P, L, I, F, P, P, P, P, P, P, P],
     'vqk_entropy_backward_f32': [P, P, P, P, L, I, F, F, P, P],
+    'vqk_entropy_backward_split_f32': [P, P, P, P, L, I, F, F, P, P, P, P],
     'vqk_entropy_argmax_forward_f32': [P, P, P, L, I, F, P, P, P, P, P, P, P, P],
     'vqk_entropy_argmax_backward_f32': [P, P, P, P, P, L, I, F, F, P, P],
     'vqk_row_scale_add_f32': [P, P, P, L, I, F, P],

@@ -96,6 +96,38 @@ __global__ __launch_bounds__(256) void entropy_dd_kernel(float* __restrict__ dma
     }
 }
 
+// the same cotangent written as TWO bf16 matrices hi + lo (hi = bf16(dd), lo = bf16(dd - hi): 16 significant bits, the bytes of the
+// fp32 matrix): the operands of the split-product GEMMs  dd E ~ hi E_hi + hi E_lo + lo E_hi  on the bf16 MFMA kernels (ops.py)
+__global__ __launch_bounds__(256) void entropy_dd_split_kernel(const float* __restrict__ dmat, const float* __restrict__ lse,
+                                                               const float* __restrict__ hrow, const float* __restrict__ u,
+                                                               int64_t n, int k, float inv_t, float coef, const float* __restrict__ gs,
+                                                               bf16_raw* __restrict__ hi, bf16_raw* __restrict__ lo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    if (gs) coef *= *gs;
+    const float* dr = dmat + row * k;
+    const float l = lse[row], h = hrow[row];
+    float ub = 0.f;
+    for (int c = lane; c < k; c += 64) ub = __fmaf_rn(__expf(-dr[c] * inv_t - l), u[c], ub);      // (same order as entropy_dd_kernel)
+    ub = wave_sum(ub);
+    unsigned* hr = reinterpret_cast<unsigned*>(hi + row * k);
+    unsigned* lr = reinterpret_cast<unsigned*>(lo + row * k);
+    for (int c = 2 * lane; c < k; c += 128) {                    // a lane owns two neighbouring codes: 4-byte stores (k % 4 == 0)
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float lp = -dr[c + e] * inv_t - l;
+            const float pr = __expf(lp);
+            v[e] = coef * pr * (-(lp + h) + (u[c + e] - ub));
+        }
+        const bf16_raw h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]);
+        const bf16_raw l0 = f32_to_bf16(v[0] - bf16_to_f32(h0)), l1 = f32_to_bf16(v[1] - bf16_to_f32(h1));
+        hr[c >> 1] = (unsigned)h0 | ((unsigned)h1 << 16);
+        lr[c >> 1] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+}
+
 // ---- ent_loss_type == 'argmax' (vector_quantizers.py:311-315): target = one_hot(argmax a) with the gradient of p.
 //   L = mean_i ( lse_i - a_i[c_i] ) + sum_k m_k log(m_k + 1e-5),  m_k = hist_k / N
 //   dL/da_ij = (1/N) [ p_ij ( -(log p_ij + h_i) + 1 + (u_j - ubar_i) ) - [j == c_i] ],  u from m as above
@@ -189,6 +221,17 @@ int vqk_entropy_backward_f32(float* dmat, const float* lse, const float* hrow, c
     const float coef = -ratio / ((float)n * temperature);
     hipLaunchKernelGGL(entropy_dd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, vqk_stream(stream), dmat, lse, hrow, u,
                        n, k, 1.0f / temperature, coef, gscale_dev);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}
+
+int vqk_entropy_backward_split_f32(const float* dmat, const float* lse, const float* hrow, const float* u, int64_t n, int k,
+                                   float temperature, float ratio, const float* gscale_dev, void* hi, void* lo, void* stream) {
+    VQK_REQUIRE(dmat && lse && hrow && u && hi && lo, VQK_ERR_ARG);
+    VQK_REQUIRE(n > 0 && k > 0 && (k & 3) == 0 && temperature > 0.f, VQK_ERR_SHAPE);
+    const float coef = -ratio / ((float)n * temperature);
+    hipLaunchKernelGGL(entropy_dd_split_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, vqk_stream(stream), dmat, lse, hrow, u,
+                       n, k, 1.0f / temperature, coef, gscale_dev, (bf16_raw*)hi, (bf16_raw*)lo);
     VQK_CHECK_LAUNCH();
     return VQK_OK;
 }

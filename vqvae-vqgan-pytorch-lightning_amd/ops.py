@@ -1775,6 +1775,9 @@ class VQLookupFn(torch.autograd.Function):
 ENTROPY_FUSED_ROWS = _native.switch('VQK_ENTROPY_FUSED_ROWS', '1') != '0'
 
 
+ENTROPY_SPLIT_GEMM = _native.switch('VQK_ENTROPY_SPLIT_GEMM', '1') != '0'     # bf16 compute mode: the entropy cotangent's two GEMMs as bf16 split products
+
+
 class EntropyVQFn(torch.autograd.Function):
     """Entropy-regularised lookup (vector_quantizers.py:290-356, ent_loss_type='softmax'):
     loss = beta*mse(q.detach(), z) + mse(q, z.detach()) + ratio*(mean_i H(p_i) - H(mean_i p_i)),  p = softmax(-d/T).
@@ -1843,6 +1846,8 @@ class EntropyVQFn(torch.autograd.Function):
         del dmat
         ctx.save_for_backward(z, cb, idx, lse, hrow, u, z2, e2)
         ctx.cfg = (beta, ratio, temperature, n, k, d, loss_type)
+        ctx.split_gemm = (ENTROPY_SPLIT_GEMM and out_dtype == torch.bfloat16 and loss_type == 'softmax' and k % 128 == 0
+                          and d % 128 == 0 and n % 128 == 0)
         ctx.mark_non_differentiable(idx, hist)
         return (qlo if qlo is not None else q32), idx.view(b, h * w), loss, hist
 
@@ -1869,6 +1874,35 @@ class EntropyVQFn(torch.autograd.Function):
         idx2 = torch.empty(n, dtype=torch.int64, device=z.device)
         _native.check(lib.vqk_vq_distances_f32(flat.data_ptr(), cb.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d, 1,
                                                idx2.data_ptr(), dmat.data_ptr(), st), 'vq_distances (backward recompute)')
+        if ctx.split_gemm:
+            # throughput mode: the cotangent as hi + lo bf16 matrices and the two GEMMs as split products on the bf16 MFMA kernels
+            #   dd E  ~ hi [E_hi | E_lo] + lo E_hi,     dd^T Z ~ hi^T [Z_hi | Z_lo] + lo^T Z_hi     (dropped: lo x lo, 2^-16 relative)
+            # -- 3x the multiply-adds at > 5x the rate of the fp32 MFMA kernels (0.70 ms per GEMM at N = 16,384, K = 8,192)
+            bf = dict(dtype=torch.bfloat16, device=z.device)
+            hi, lo = torch.empty((n, k), **bf), torch.empty((n, k), **bf)
+            _native.check(lib.vqk_entropy_backward_split_f32(dmat.data_ptr(), lse.data_ptr(), hrow.data_ptr(), u.data_ptr(), n, k,
+                                                             temperature, ratio, gs.data_ptr(), hi.data_ptr(), lo.data_ptr(), st),
+                          'entropy_backward_split')
+            del dmat
+
+            def split(t):
+                th = t.to(torch.bfloat16)
+                return th, (t - th.float()).to(torch.bfloat16)
+            e_hi, e_lo = split(cb)                                                      # [K][D]
+            z_hi, z_lo = split(flat)                                                    # [N][D]
+            img = lambda t: t.view(1, t.shape[0], 1, t.shape[1]).permute(0, 3, 1, 2)    # [rows][C] memory as a [1, C, rows, 1] nhwc image
+            w1 = torch.cat([e_hi.t(), e_lo.t()], 0).contiguous()                        # [2D][K]
+            g1 = raw_conv_fprop(img(hi), w1, None, None, 1, False, 0, torch.float32, 2 * d, 0).permute(0, 2, 3, 1).reshape(n, 2 * d)
+            g1b = raw_conv_fprop(img(lo), e_hi.t().contiguous(), None, None, 1, False, 0, torch.float32, d, 0).permute(0, 2, 3, 1).reshape(n, d)
+            dz.permute(0, 2, 3, 1).reshape(n, d).add_(g1[:, :d] + g1[:, d:] + g1b, alpha=-2.0)
+            zc = torch.cat([z_hi, z_lo], 1).contiguous()                                # [N][2D]
+            g2 = raw_conv_wgrad(img(zc), img(hi), 1, False).permute(0, 2, 3, 1).reshape(k, 2 * d)
+            g2b = raw_conv_wgrad(img(z_hi.contiguous()), img(lo), 1, False).permute(0, 2, 3, 1).reshape(k, d)
+            de.add_(g2[:, :d] + g2[:, d:] + g2b, alpha=-2.0)
+            cs = raw_colsum(n, k, hi)
+            raw_colsum(n, k, lo, out=cs)
+            _native.check(lib.vqk_row_scale_add_f32(de.data_ptr(), cb.data_ptr(), cs.data_ptr(), k, d, 2.0, st), 'row_scale_add')
+            return dz, de, None, None, None, None, None
         if loss_type == 'softmax':
             _native.check(lib.vqk_entropy_backward_f32(dmat.data_ptr(), lse.data_ptr(), hrow.data_ptr(), u.data_ptr(), n, k,
                                                        temperature, ratio, gs.data_ptr(), st), 'entropy_backward')
