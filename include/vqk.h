@@ -82,7 +82,10 @@ int vqk_vq_prepare_f32(const float* e, int k, int d, void* ws, int64_t ws_bytes,
 int vqk_vq_forward_f32(const float* z, const float* e, const void* ws, int64_t ws_bytes, int64_t n, int k, int d, int assoc,
                        int64_t* idx, float* q /* optional */, void* q_lo /* optional */, float* sse /* optional */,
                        int32_t* hist /* optional */, void* stream);
-/* Same search, additionally writing the full fp32 distance matrix dmat[N][K] (Entropy quantizer). */
+/* Same search, additionally writing the full fp32 distance matrix dmat[N][K] (Entropy quantizer).  d == 256, N % 128 == 0, K % 32 == 0
+ * and a stream scratch of >= 5 * parts * N * 4 bytes (vqk_set_scratch; parts <= 16): the code tiles go through LDS once per 128 rows
+ * (vq_assign_lds_kernel, blocks = N/128 x parts) and a second small launch folds the parts' (min, argmin) and log-sum-exp states;
+ * otherwise every wave streams the codebook itself.  Same distances and indices, bit for bit, either way. */
 int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const float* e2,
                          int64_t n, int k, int d, int assoc, int64_t* idx, float* dmat, void* stream);
 /* vqk_vq_distances_f32 (d == 256) that also leaves the softmax row statistics of a = -d / temperature: lse[N], hrow[N] (sample

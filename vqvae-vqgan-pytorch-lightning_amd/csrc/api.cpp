@@ -101,6 +101,7 @@ static TuneSlot g_tune[] = {
     {"MX_QUARTER", 0, 0},
     {"MX_S2", 0, 0},
     {"MX_S2_DGRAD_MIN", 0, 0},
+    {"VQ_LDS", 0, 0},
     {"UPS_MERGE", 0, 0},
     {"TILE_QUEUE", 0, 0}
 };

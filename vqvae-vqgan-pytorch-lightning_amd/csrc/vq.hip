@@ -302,6 +302,181 @@ __global__ __launch_bounds__(256) void vq_assign_reg_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Code tiles through LDS (round 5; the Entropy quantizer's distance matrix, K = 8192): block = 128 z rows (four waves, 32 rows each
+// in registers as above) x ONE part of the 32-code tiles (blockIdx.y of KS parts).  The four waves walk the SAME tiles: a tile is
+// fetched ONCE per block by LDS-DMA (one 1-KiB instruction per code row, 8 rows per wave; row pitch 1040 bytes: the lanes' 16-byte
+// fragment reads hit disjoint banks), double-buffered (65 KiB: two blocks per CU = two waves per SIMD), and every wave reads its
+// MFMA operands from it -- a quarter of the codebook traffic of the register-streaming kernel (where every wave pulls the whole
+// codebook through the vector-memory path, 4.3 GB per launch at N = 16,384, K = 8,192, with ONE wave per SIMD to hide it: 62 TF),
+// the operand fetch on the LDS latency.  Same MFMA sequence per (row, code) and the same comparisons => identical distances and
+// indices.  A block leaves its rows' partial (min, argmin) and online-softmax state per part in the stream's scratch
+// (vqk_set_scratch); vq_lds_merge_kernel folds the KS parts (lexicographic (distance, index): order-free; log-sum-exp merge).
+// ------------------------------------------------------------------------------------------------
+template <int ASSOC, bool WRITE_D, bool STATS>
+__global__ __launch_bounds__(256, 2) void vq_assign_lds_kernel(const float* __restrict__ z, const float* __restrict__ e,
+                                                               const float* __restrict__ z2, const float* __restrict__ e2,
+                                                               int64_t n, int k, float* __restrict__ dmat, float inv_t,
+                                                               float* __restrict__ part) {
+    constexpr int DD = 256, NF = DD / 8, PITCH = 1040, TILE = 32 * PITCH;      // bytes
+    extern __shared__ __attribute__((aligned(16))) char vsm[];                  // [2][32 rows][PITCH]
+    float m_run = -INFINITY, s_run = 0.0f, sa_run = 0.0f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int j = lane & 31, half = lane >> 5;
+    const float zz = z2[n0 + j];
+    f32x4 zr[NF];
+    {
+        const float* zp = z + (n0 + j) * DD + 4 * half;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) zr[i] = *reinterpret_cast<const f32x4*>(zp + 8 * i);
+    }
+    const int tiles_part = (k >> 5) / (int)gridDim.y;            // 32-code tiles per part (divides: the launcher's choice)
+    const int t_begin = (int)blockIdx.y * tiles_part, t_end = t_begin + tiles_part;
+    auto fetch = [&](int t, int b) {                             // this wave's 8 rows of tile t -> buffer b
+        const char* src = reinterpret_cast<const char*>(e + ((int64_t)t * 32 + wave * 8) * DD) + lane * 16;
+        char* dst = vsm + b * TILE + wave * 8 * PITCH;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            __builtin_amdgcn_global_load_lds((const VQK_GLB void*)(src + r * 1024), (VQK_LDS void*)(dst + r * PITCH), 16, 0, 0);
+    };
+    fetch(t_begin, 0);
+    float best = INFINITY;
+    int best_i = 0x7fffffff;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int b = (t - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's 8 rows of tile t have landed (and its older stores)
+        __syncthreads();                                         // ... the other waves' too; every wave is done with tile t-1
+        float e2v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e2v[r] = e2[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+        if (t + 1 < t_end) fetch(t + 1, b ^ 1);                  // into tile t-1's buffer, in flight under this tile's 128 MFMAs
+        const char* ap = vsm + b * TILE + j * PITCH + half * 16;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + i * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], zr[i][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], zr[i][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], zr[i][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], zr[i][3], acc, 0, 0, 0);
+        }
+        float av[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float ab2 = 2.0f * acc[r];
+            float dist;
+            if (ASSOC == 0) dist = __fsub_rn(__fadd_rn(zz, e2v[r]), ab2);
+            else            dist = __fadd_rn(__fsub_rn(zz, ab2), e2v[r]);
+            if (dist < best) { best = dist; best_i = code; }
+            if (WRITE_D) dmat[(n0 + j) * (int64_t)k + code] = dist;
+            av[r] = -dist * inv_t;
+        }
+        if (STATS) {
+            float tmax = av[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, av[r]);
+            const float mn = fmaxf(m_run, tmax);
+            const float sc = __expf(m_run - mn);                 // exp(-inf) = 0 on the first tile
+            float ts = 0.0f, tsa = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ex = __expf(av[r] - mn);
+                ts += ex;
+                tsa = __fmaf_rn(ex, av[r], tsa);
+            }
+            s_run = __fmaf_rn(s_run, sc, ts);
+            sa_run = __fmaf_rn(sa_run, sc, tsa);
+            m_run = mn;
+        }
+    }
+    if (STATS) {                                                 // the two half-waves of a row
+        const float om = __shfl_xor(m_run, 32, 64), os = __shfl_xor(s_run, 32, 64), osa = __shfl_xor(sa_run, 32, 64);
+        const float mn = fmaxf(m_run, om);
+        const float c0 = __expf(m_run - mn), c1 = __expf(om - mn);
+        s_run = s_run * c0 + os * c1;
+        sa_run = sa_run * c0 + osa * c1;
+        m_run = mn;
+    }
+    {
+        const float od = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(best_i, 32, 64);
+        if (od < best || (od == best && oi < best_i)) { best = od; best_i = oi; }
+    }
+    if (half == 0) {                                             // part[q][blockIdx.y][row], q = d, i, m, s, sa
+        const int64_t slot = (int64_t)blockIdx.y * n + n0 + j, plane = (int64_t)gridDim.y * n;
+        part[slot] = best;
+        reinterpret_cast<int*>(part)[plane + slot] = best_i;
+        if (STATS) { part[2 * plane + slot] = m_run; part[3 * plane + slot] = s_run; part[4 * plane + slot] = sa_run; }
+    }
+}
+
+// fold the KS partial states of every row: idx (lowest distance, then lowest index), lse / h of the row's softmax, hsum += h
+template <bool STATS>
+__global__ __launch_bounds__(256) void vq_lds_merge_kernel(const float* __restrict__ part, int64_t n, int ks, int64_t* __restrict__ idx,
+                                                           float* __restrict__ lse, float* __restrict__ hrow, float* __restrict__ hsum) {
+    __shared__ float hs[4];
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t plane = (int64_t)ks * n;
+    float h = 0.0f;
+    if (row < n) {
+        float bd = part[row]; int bi = reinterpret_cast<const int*>(part)[plane + row];
+        for (int p = 1; p < ks; ++p) {
+            const float od = part[(int64_t)p * n + row]; const int oi = reinterpret_cast<const int*>(part)[plane + (int64_t)p * n + row];
+            if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+        }
+        idx[row] = (bi == 0x7fffffff) ? 0 : (int64_t)bi;
+        if (STATS) {
+            float m = part[2 * plane + row], s_ = part[3 * plane + row], sa = part[4 * plane + row];
+            for (int p = 1; p < ks; ++p) {
+                const float om = part[2 * plane + (int64_t)p * n + row], os = part[3 * plane + (int64_t)p * n + row],
+                            osa = part[4 * plane + (int64_t)p * n + row];
+                const float mn = fmaxf(m, om);
+                const float c0 = __expf(m - mn), c1 = __expf(om - mn);
+                s_ = s_ * c0 + os * c1; sa = sa * c0 + osa * c1; m = mn;
+            }
+            const float l = m + __logf(s_);
+            h = l - sa / s_;
+            lse[row] = l;
+            hrow[row] = h;
+        }
+    }
+    if (STATS) {
+        h = wave_sum(h);
+        if ((threadIdx.x & 63) == 0) hs[threadIdx.x >> 6] = h;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(hsum, (hs[0] + hs[1]) + (hs[2] + hs[3]));
+    }
+}
+
+// the LDS form serves D = 256 with whole 128-row blocks and whole tiles, given the stream's scratch for the partial states;
+// everything else stays on the register-streaming kernel
+static int vq_lds_parts(int64_t n, int k, int d) {
+    if (!(d == 256 && n > 0 && (n % 128) == 0 && (k % 32) == 0 && VQK_TUNE("VQ_LDS", 1) != 0)) return 0;
+    const int tiles = k >> 5;
+    int ks = 1;
+    while ((n / 128) * ks < 512 && ks < 16 && tiles % (2 * ks) == 0 && tiles / (2 * ks) >= 8) ks *= 2;
+    const vqkd::DetState& sc = vqkd::scratch_state();
+    if (!sc.ws || sc.bytes < (int64_t)5 * ks * n * 4) return 0;
+    return ks;
+}
+template <int ASSOC, bool STATS>
+static int launch_vq_assign_lds(const float* z, const float* e, const float* z2, const float* e2, int64_t n, int k, int ks, int64_t* idx,
+                                float* dmat, float inv_t, float* lse, float* hrow, float* hsum, hipStream_t st) {
+    constexpr int lds = 2 * 32 * 1040;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)vq_assign_lds_kernel<ASSOC, true, STATS>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return VQK_ERR_LAUNCH;
+    float* part = vqkd::scratch_state().ws;
+    hipLaunchKernelGGL((vq_assign_lds_kernel<ASSOC, true, STATS>), dim3((unsigned)(n / 128), (unsigned)ks), dim3(256), lds, st, z, e, z2, e2,
+                       n, k, dmat, inv_t, part);
+    hipLaunchKernelGGL((vq_lds_merge_kernel<STATS>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)part, n, ks, idx, lse,
+                       hrow, hsum);
+    return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
 // q = e[idx]; sum (q-z)^2; histogram.  One wavefront per row, float4 per lane.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ z, const float* __restrict__ e,
@@ -533,6 +708,9 @@ int vqk_vq_distances_f32(const float* z, const float* e, const float* z2, const 
     const size_t lds = (size_t)32 * (d + 4) * 4 + 128 * 4 + 128 * 4;
     VQK_REQUIRE(lds <= 64 * 1024, VQK_ERR_SHAPE);
     const dim3 grid((unsigned)((n + 31) / 32));
+    if (const int ks = vq_lds_parts(n, k, d))
+        return assoc == 0 ? launch_vq_assign_lds<0, false>(z, e, z2, e2, n, k, ks, idx, dmat, 0.0f, nullptr, nullptr, nullptr, vqk_stream(stream))
+                          : launch_vq_assign_lds<1, false>(z, e, z2, e2, n, k, ks, idx, dmat, 0.0f, nullptr, nullptr, nullptr, vqk_stream(stream));
     if (d == 256) {
         if (assoc == 0) hipLaunchKernelGGL((vq_assign_reg_kernel<0, true, 256, false, VQK_ENT_CHAINS>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat);
         else hipLaunchKernelGGL((vq_assign_reg_kernel<1, true, 256, false, VQK_ENT_CHAINS>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat);
@@ -555,6 +733,9 @@ int vqk_vq_distances_stats_f32(const float* z, const float* e, const float* z2, 
     if (n == 0) return VQK_OK;
     const dim3 grid((unsigned)((n + 31) / 32));
     const float inv_t = 1.0f / temperature;
+    if (const int ks = vq_lds_parts(n, k, d))
+        return assoc == 0 ? launch_vq_assign_lds<0, true>(z, e, z2, e2, n, k, ks, idx, dmat, inv_t, lse, hrow, hsum, vqk_stream(stream))
+                          : launch_vq_assign_lds<1, true>(z, e, z2, e2, n, k, ks, idx, dmat, inv_t, lse, hrow, hsum, vqk_stream(stream));
     if (assoc == 0) hipLaunchKernelGGL((vq_assign_reg_kernel<0, true, 256, true, VQK_ENT_CHAINS>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat, inv_t, lse, hrow, hsum);
     else hipLaunchKernelGGL((vq_assign_reg_kernel<1, true, 256, true, VQK_ENT_CHAINS>), grid, dim3(256), 0, vqk_stream(stream), z, e, z2, e2, n, k, idx, dmat, inv_t, lse, hrow, hsum);
     VQK_CHECK_LAUNCH();
