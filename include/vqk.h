@@ -249,6 +249,16 @@ int vqk_conv2d_wgrad_pooled_dy_phase(int dtype, const void* x, const void* dy_po
 int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
                              int cout, int ksize, int stride, int pad, int mode, int h_out, int w_out,
                              const void* zeros, void* stream);
+/* Split-product mode (layout 5 above), weight gradient of a 3x3 conv (optionally behind a nearest-x2 upsample, ups = 1):
+ * vqk_split_pair_f32 turns an fp32 [rows][c] activation / gradient into its bf16 (hi | lo) PAIR tensor [rows][2c]
+ * (hi = bf16(v), lo = bf16(v - hi); c % 8 == 0); vqk_conv2d_wgrad_x3 takes x_pair [n][h_in][w_in][2 cin] and dy_pair
+ * [n][h][w][2 cout] and adds scale * (dy_hi^T x_hi + dy_hi^T x_lo + dy_lo^T x_hi) to dw fp32 [Cout][3][3][Cin]: three tile classes
+ * of ONE launch of the bf16 matrix/auxiliary-wave weight-gradient kernel (csrc/conv_wgmx.hip), folded by its atomic pass.
+ * cin % 64 == 0, cout % 64 == 0, h % 8 == 0, w % 16 == 0; VQK_ERR_SHAPE when not served (deterministic mode included:
+ * nothing launched, callers use the exact-fp32 vqk_conv2d_wgrad). */
+int vqk_split_pair_f32(const float* src, void* dst, int64_t rows, int c, void* stream);
+int vqk_conv2d_wgrad_x3(const void* x_pair, const void* dy_pair, float* dw, int n, int h_in, int w_in, int cin, int cout, int ups,
+                        float scale, const void* zeros, void* stream);
 /* the same with dW += scale * (the gradient): a layer whose backward carries a scalar gain (the discriminator's linear skip convs:
  * weight gain x output gain) accumulates straight into an optimizer's gradient arena -- no zeroed temporary, scale pass and add */
 int vqk_conv2d_wgrad_general_scaled(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin,
@@ -279,7 +289,12 @@ int vqk_conv2d_s2_dgrad(int dtype, const void* dy, const void* w3, const void* w
  * i.e. Cin/Cout swapped and both taps flipped).  2: the upsample-phase operand of vqk_conv2d_ups_phase (bf16, 3x3): four
  * phases (a, b) of fragment-major blocks with FOUR taps each, tap (r, s) of a phase = the sum of the 3x3 taps that fall
  * on the same low-resolution pixel (rows {0},{1,2} for a = 0 and {0,1},{2} for a = 1; columns alike); transpose = 1:
- * channels swapped and the 2x2 taps mirrored. */
+ * channels swapped and the 2x2 taps mirrored.  5: the SPLIT-PRODUCT operand (csrc/conv_x3.hip; dtype VQK_F32, 3x3, Cin % 32 == 0):
+ * layout 1 in bf16 with every fragment twice, hi = bf16(w) then lo = bf16(w - hi) -- [Cout/32][32-channel chunk][tap][k-substep]
+ * [hi | lo][lane][16 bytes], 4 bytes per weight like the fp32 operands.  vqk_conv2d_fprop(VQK_F32, ..., out VQK_F32, wlayout 5)
+ * then evaluates every product as x_hi w_hi + x_lo w_hi + x_hi w_lo on the bf16 matrix pipe with fp32 accumulation (the fp32
+ * activations are split on the fly; ~2^-17 relative per product): H % 8 == 0, W % 16 == 0 at the OUTPUT resolution, Cout % 4 == 0;
+ * callers choose it (vqk_conv_weight_layout never returns 5; layout 1 / dtype VQK_F32 stays the exact v_mfma_f32_32x32x2_f32 mode). */
 int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups);
 int64_t vqk_conv_packed_elems(int cout, int cin, int ksize, int layout);
 int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int cin, int ksize, int transpose,

@@ -1,0 +1,177 @@
+"""The split-product ("bf16x3") 3x3 convolution (csrc/conv_x3.hip, include/vqk.h layout 5): fp32 activations in / out, every
+product as x_hi w_hi + x_lo w_hi + x_hi w_lo on the bf16 matrix pipe.  Checked against the exact-fp32 kernel of the parity mode
+(v_mfma_f32_32x32x2_f32, itself pinned by the reference fixtures in tests/test_gpu_ops.py) and against an fp64 torch convolution:
+the error has to sit at the 2^-17-per-product level -- two orders below the plain bf16 mode, one above fp32 rounding."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ops = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.ops')
+native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
+DEV, F32, BF, CL = 'cuda:0', torch.float32, torch.bfloat16, torch.channels_last
+TOL = 3e-5          # relative to the largest output magnitude; the plain bf16 kernels sit at ~3e-3 on the same problems
+
+
+def _ref64(x, w_okki, bias, res, ups):
+    xd = x.double()
+    if ups:
+        xd = F.interpolate(xd, scale_factor=2, mode='nearest')
+    y = F.conv2d(xd, w_okki.permute(0, 3, 1, 2).double(), bias.double() if bias is not None else None, padding=1)
+    return y + res.double() if res is not None else y
+
+
+# n, cin, cout, h, w (input), ups, bias, residual
+CASES = [(2, 128, 128, 32, 32, 0, 0, 0), (2, 128, 128, 32, 32, 0, 1, 1), (1, 64, 256, 16, 48, 0, 0, 1), (2, 256, 128, 24, 32, 0, 1, 0),
+         (2, 128, 128, 16, 16, 1, 1, 0), (3, 512, 512, 16, 16, 0, 0, 1), (1, 96, 64, 8, 16, 0, 1, 1), (2, 32, 32, 8, 32, 0, 0, 0),
+         (5, 128, 256, 40, 16, 0, 0, 0), (2, 256, 512, 8, 16, 1, 0, 0)]
+
+
+@pytest.mark.parametrize('wl', [0, 1])
+@pytest.mark.parametrize('n,cin,cout,h,w,ups,hb,hr', CASES)
+def test_x3_fprop_matches_exact_fp32(n, cin, cout, h, w, ups, hb, hr, wl):
+    g = torch.Generator(device=DEV).manual_seed(cin + 3 * cout + h + 7 * ups + hb + 2 * hr)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    wt = torch.randn(cout, 3, 3, cin, device=DEV, generator=g) / (3 * cin ** 0.5)
+    s = 2 if ups else 1
+    bias = torch.randn(cout, device=DEV, generator=g) if hb else None
+    res = torch.randn(n, cout, h * s, w * s, device=DEV, generator=g).contiguous(memory_format=CL) if hr else None
+    assert ops.weight_layout(F32, n, h, w, cin, cout, 3, bool(ups), x3=True) == 5
+    assert ops.weight_layout(F32, n, h, w, cin, cout, 3, bool(ups), x3=False) in (0, 1)
+    w5 = ops.pack_weights(wt.reshape(-1), F32, cout, cin, 3, False, 5)
+    native.lib().vqk_set_tuning(b'X3_WL', wl)
+    try:
+        y3 = ops.raw_conv_fprop(x, w5, bias, res, 3, bool(ups), 0, F32, cout, 5)
+    finally:
+        native.lib().vqk_set_tuning(b'X3_WL', 1)
+    l1 = ops.weight_layout(F32, n, h, w, cin, cout, 3, bool(ups), x3=False)
+    y1 = ops.raw_conv_fprop(x, ops.pack_weights(wt.reshape(-1), F32, cout, cin, 3, False, l1), bias, res, 3, bool(ups), 0, F32, cout, l1)
+    ref = _ref64(x, wt, bias, res, ups)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    e3 = float((y3.double() - ref).abs().max()) / scale
+    e1 = float((y1.double() - ref).abs().max()) / scale
+    assert e1 < 5e-6, e1                                   # the exact-fp32 kernel: fp32 summation noise only
+    assert e3 < TOL, (e3, e1)
+    assert float((y3.double() - ref).norm() / ref.norm()) < 1e-5
+
+
+def test_x3_is_two_orders_better_than_bf16():
+    n, c, h, w = 2, 128, 32, 32
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, c, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    wt = torch.randn(c, 3, 3, c, device=DEV, generator=g) / (3 * c ** 0.5)
+    ref = _ref64(x, wt, None, None, 0)
+    y3 = ops.raw_conv_fprop(x, ops.pack_weights(wt.reshape(-1), F32, c, c, 3, False, 5), None, None, 3, False, 0, F32, c, 5)
+    lb = ops.weight_layout(BF, n, h, w, c, c, 3, False)
+    yb = ops.raw_conv_fprop(x.to(BF).contiguous(memory_format=CL), ops.pack_weights(wt.reshape(-1), BF, c, c, 3, False, lb), None, None,
+                            3, False, 0, BF, c, lb)
+    torch.cuda.synchronize()
+    e3 = float((y3.double() - ref).norm() / ref.norm())
+    eb = float((yb.double() - ref).norm() / ref.norm())
+    assert e3 * 100 < eb, (e3, eb)
+
+
+@pytest.mark.parametrize('act,acc_scale,out_gain,hb,hr,cout', [(2, 1.0, 1.0, 1, 0, 128), (3, 0.03, 1.41421356, 1, 1, 128), (0, 1.0, 1.0, 1, 1, 64),
+                                                                (1, 1.0, 1.0, 1, 0, 32)])
+def test_x3_general_epilogue(act, acc_scale, out_gain, hb, hr, cout):
+    """y = out_gain * act(acc * acc_scale + bias) + residual, and cout tiles that are not whole (64, 32 couts)"""
+    n, cin, h, w = 2, 64, 16, 32
+    g = torch.Generator(device=DEV).manual_seed(11 + act + cout)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    wt = torch.randn(cout, 3, 3, cin, device=DEV, generator=g) * (1.0 if acc_scale != 1.0 else 0.05)
+    bias = torch.randn(cout, device=DEV, generator=g) if hb else None
+    res = torch.randn(n, cout, h, w, device=DEV, generator=g).contiguous(memory_format=CL) if hr else None
+    y3 = ops._conv_general_raw(x, ops.pack_weights(wt.reshape(-1), F32, cout, cin, 3, False, 5), bias, res, cout, 3, 1, 1, 0, h, w, act,
+                               acc_scale, out_gain, F32, 5)
+    acc = F.conv2d(x.double(), wt.permute(0, 3, 1, 2).double(), None, padding=1) * acc_scale
+    if bias is not None:
+        acc = acc + bias.double()[None, :, None, None]
+    ref = {0: lambda t: t, 1: torch.tanh, 2: torch.relu, 3: lambda t: F.leaky_relu(t, 0.2)}[act](acc) * out_gain
+    if res is not None:
+        ref = ref + res.double()
+    torch.cuda.synchronize()
+    assert float((y3.double() - ref).abs().max()) / float(ref.abs().max()) < TOL
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 128, 256, 16, 32), (1, 256, 64, 8, 16)])
+def test_x3_dgrad_operand(n, cin, cout, h, w):
+    """transpose = 1 of layout 5: the data gradient = a conv of dy with the flipped, channel-swapped weights"""
+    g = torch.Generator(device=DEV).manual_seed(cin + cout)
+    dy = torch.randn(n, cout, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    wt = torch.randn(cout, 3, 3, cin, device=DEV, generator=g) / (3 * cout ** 0.5)
+    wtr = ops.pack_weights(wt.reshape(-1), F32, cout, cin, 3, True, 5)
+    dx = ops.raw_conv_fprop(dy, wtr, None, None, 3, False, 0, F32, cin, 5)
+    ref = F.conv_transpose2d(dy.double(), wt.permute(0, 3, 1, 2).double(), padding=1)
+    torch.cuda.synchronize()
+    assert float((dx.double() - ref).abs().max()) / float(ref.abs().max()) < TOL
+
+
+def test_split_pair_is_hi_lo():
+    g = torch.Generator(device=DEV).manual_seed(3)
+    t = (torch.randn(2, 64, 8, 16, device=DEV, generator=g) * torch.logspace(-6, 6, 64, device=DEV)[None, :, None, None]).contiguous(memory_format=CL)
+    p = ops.raw_split_pair(t)
+    torch.cuda.synchronize()
+    assert p.shape == (2, 128, 8, 16) and p.dtype == BF
+    hi, lo = p[:, :64], p[:, 64:]
+    assert torch.equal(hi, t.to(BF))                                           # round-to-nearest-even, like torch
+    assert torch.equal(lo, (t - hi.float()).to(BF))
+    rel = ((hi.double() + lo.double() - t.double()).abs() / t.double().abs()).max()
+    assert float(rel) < 2.0 ** -16
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,ups', [(2, 128, 128, 32, 32, 0), (3, 64, 256, 16, 48, 0), (2, 256, 64, 8, 16, 1), (4, 512, 512, 16, 16, 0)])
+def test_x3_wgrad_matches_fp64(n, cin, cout, h, w, ups):
+    g = torch.Generator(device=DEV).manual_seed(cin + 2 * cout + h + ups)
+    s = 2 if ups else 1
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    dy = torch.randn(n, cout, h * s, w * s, device=DEV, generator=g).contiguous(memory_format=CL)
+    pre = torch.randn(cout, 3, 3, cin, device=DEV, generator=g).permute(0, 3, 1, 2)    # dW ACCUMULATES into its target
+    dw = pre.clone(memory_format=torch.preserve_format)
+    assert dw.permute(0, 2, 3, 1).is_contiguous()
+    out = ops.raw_conv_wgrad(x, dy, 3, bool(ups), out=dw, x3=True)
+    assert out is dw
+    xd = x.double()
+    if ups:
+        xd = F.interpolate(xd, scale_factor=2, mode='nearest')
+    xd.requires_grad_(False)
+    wd = torch.zeros(cout, cin, 3, 3, device=DEV, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xd, wd, None, padding=1) * dy.double()).sum().backward()
+    ref = wd.grad + pre.double()
+    exact = ops.raw_conv_wgrad(x, dy, 3, bool(ups), out=pre.clone(memory_format=torch.preserve_format), x3=False)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((exact.double() - ref).abs().max()) / scale < 1e-5
+    assert float((dw.double() - ref).abs().max()) / scale < TOL
+    assert float((dw.double() - ref).norm() / ref.norm()) < 1e-5
+
+
+def test_x3_mode_runs_a_resblock_like_the_exact_mode():
+    """ops.set_conv_products: the autograd nodes carry the mode of their forward into their backward"""
+    n, c, h, w = 2, 128, 16, 32
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x0 = torch.randn(n, c, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    ps = [torch.randn(1, c, 1, 1, device=DEV, generator=g) * 0.1 + 1.0, torch.randn(1, c, 1, 1, device=DEV, generator=g) * 0.1,
+          (torch.randn(c, c, 3, 3, device=DEV, generator=g) / (3 * c ** 0.5)).contiguous(memory_format=CL),
+          torch.randn(1, c, 1, 1, device=DEV, generator=g) * 0.1 + 1.0, torch.randn(1, c, 1, 1, device=DEV, generator=g) * 0.1,
+          (torch.randn(c, c, 3, 3, device=DEV, generator=g) / (3 * c ** 0.5)).contiguous(memory_format=CL)]
+    dout = torch.randn(n, c, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    res = {}
+    for mode in ('fp32', 'bf16x3'):
+        ops.set_conv_products(mode)
+        try:
+            x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            p = [t.clone(memory_format=torch.preserve_format).requires_grad_(True) for t in ps]
+            y = ops.res_block(x, *p)
+            ops.set_conv_products('fp32')                 # the backward must not depend on the setting at backward time
+            y.backward(dout)
+            res[mode] = [y.detach(), x.grad] + [t.grad for t in p]
+        finally:
+            ops.set_conv_products('fp32')
+    torch.cuda.synchronize()
+    for a, b in zip(res['fp32'], res['bf16x3']):
+        assert float((a - b).abs().max()) / float(a.abs().max()) < 1e-4
+    assert not torch.equal(res['fp32'][0], res['bf16x3'][0])      # (it did take the other kernel)

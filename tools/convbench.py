@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-shape micro-benchmark of the conv kernels (fprop == dgrad kernel, wgrad) on the BASELINE layer shapes
-(bs=32).  Usage: python tools/convbench.py [bf16|f32] [iters]"""
+(bs=32).  Usage: python tools/convbench.py [bf16|f32|x3] [iters]   (x3: fp32 storage, split products on the bf16 pipe)"""
 import importlib
 import os
 import sys
@@ -36,6 +36,10 @@ def timeit(fn, iters):
 
 def main():
     dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
+    if len(sys.argv) > 1 and sys.argv[1] == 'x3':
+        ops.set_conv_products('bf16x3')
+        if os.environ.get('VQK_X3_WL'):
+            native.lib().vqk_set_tuning(b'X3_WL', int(os.environ['VQK_X3_WL']))
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     n = 32
     tot_f = tot_w = 0.0
@@ -62,7 +66,7 @@ def main():
         else:
             fn = lambda: ops.raw_conv_fprop(x, wq, None, None, k, bool(ups), 0, dt, cout, layout)
         tf = 1.0 if skip_f else timeit(fn, iters)
-        tw = 1.0 if skip_w else timeit(lambda: ops.raw_conv_wgrad(x, dy, k, bool(ups)), iters)
+        tw = 1.0 if skip_w else timeit(lambda: ops.raw_conv_wgrad(x, dy, k, bool(ups), x3=ops.X3), iters)
         tot_f += tf * cnt
         tot_w += tw * cnt
         print(f'{cin:4d}->{cout:4d} @{hw:3d}^2 k{k} ups{ups} x{cnt:<2d}          {fl / 1e9:8.1f} {tf * 1e6:9.1f} {fl / tf / 1e12:7.1f} '

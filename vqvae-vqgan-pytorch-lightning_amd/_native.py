@@ -76,6 +76,8 @@ _PROTOS = {
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
     'vqk_conv2d_wgrad_pooled_dy': [I, P, P, P, I, I, I, I, I, F, P, P],
     'vqk_conv2d_wgrad_ups_phase': [I, P, P, P, I, I, I, I, I, F, P, P],
+    'vqk_split_pair_f32': [P, P, L, I, P],
+    'vqk_conv2d_wgrad_x3': [P, P, P, I, I, I, I, I, I, F, P, P],
     'vqk_conv2d_wgrad_pooled_dy_phase': [I, P, P, P, I, I, I, I, I, F, P, P],
     'vqk_conv2d_wgrad_edge': [I, P, P, P, P, L, I, I, I, I, I, P, P],
     'vqk_conv2d_wgrad_edge_true': [I, P, P, P, P, L, I, I, I, I, I, I, P, P],

@@ -103,7 +103,8 @@ static TuneSlot g_tune[] = {
     {"MX_S2_DGRAD_MIN", 0, 0},
     {"VQ_LDS", 0, 0},
     {"UPS_MERGE", 0, 0},
-    {"TILE_QUEUE", 0, 0}
+    {"TILE_QUEUE", 0, 0},
+    {"X3_WL", 0, 0}
 };
 static constexpr int kTune = (int)(sizeof(g_tune) / sizeof(g_tune[0]));
 TuneSlot* tune_slot(const char* name) {

@@ -1955,18 +1955,66 @@ __device__ __forceinline__ void pack_any(const float* __restrict__ w, TD* __rest
     }
 }
 
+// layout 5 (split-product mode, conv_x3.hip): fragment-major like layout 1 in bf16, every fragment TWICE -- hi = bf16_rne(w),
+// lo = bf16_rne(w - hi): [cot][chunk of 32 channels][tap][ks][hi | lo][kg][co32][8].  The buffer has the byte size of the fp32
+// fragment-major operand (4 B per weight), which is how the fp32 descriptor / vqk_conv_packed_elems size it.
+__device__ __forceinline__ void pack_x3(const float* __restrict__ w, bf16_raw* __restrict__ out, int cout, int cin, int taps,
+                                        int transpose) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
+    const int cot_tiles = ((dcout + 127) / 128) * 4;
+    const int ncc = dcin / 32;
+    const int64_t total = (int64_t)cot_tiles * ncc * taps * 2 * 64;       // (hi, lo) pairs of 16-byte pieces
+    for (int64_t o = tid; o < total; o += nthr) {
+        int64_t r = o;
+        const int co32 = (int)(r & 31); r >>= 5;
+        const int kg = (int)(r & 1); r >>= 1;
+        const int ks = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % taps); r /= taps;
+        const int cc = (int)(r % ncc);
+        const int cot = (int)(r / ncc);
+        const int co = cot * 32 + co32;
+        const int ci = ((cc * 2 + ks) * 2 + kg) * 8;
+        float v[8], lo[8];
+        if (co >= dcout) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        } else if (!transpose) {
+            const float* src = w + ((int64_t)co * taps + tap) * cin + ci;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = src[e];
+        } else {
+            const float* src = w + ((int64_t)ci * taps + (taps - 1 - tap)) * cin + co;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = src[(int64_t)e * taps * cin];
+        }
+        const vqk_u32x4 hi = vqk_pack_bf16x8(v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lo[2 * q] = v[2 * q] - __uint_as_float(hi[q] << 16);
+            lo[2 * q + 1] = v[2 * q + 1] - __uint_as_float(hi[q] & 0xffff0000u);
+        }
+        const int64_t frag = (((int64_t)cot * ncc + cc) * taps + tap) * 2 + ks;          // (hi, lo) fragment pair index
+        bf16_raw* dst = out + (frag * 2 * 64 + kg * 32 + co32) * 8;
+        *reinterpret_cast<vqk_u32x4*>(dst) = hi;
+        *reinterpret_cast<vqk_u32x4*>(dst + 64 * 8) = vqk_pack_bf16x8(lo);
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restrict__ descs) {
     const int64_t* d = descs + (int64_t)blockIdx.y * 8;
     const float* src = reinterpret_cast<const float*>(d[0]);
     const int dtype = (int)d[2], cout = (int)d[3], cin = (int)d[4], ks = (int)d[5], tr = (int)d[6], lay = (int)d[7];
-    if (dtype == VQK_F32) pack_any<float>(src, reinterpret_cast<float*>(d[1]), cout, cin, ks * ks, tr, lay);
+    if (lay == 5) pack_x3(src, reinterpret_cast<bf16_raw*>(d[1]), cout, cin, ks * ks, tr);
+    else if (dtype == VQK_F32) pack_any<float>(src, reinterpret_cast<float*>(d[1]), cout, cin, ks * ks, tr, lay);
     else pack_any<bf16_raw>(src, reinterpret_cast<bf16_raw*>(d[1]), cout, cin, ks * ks, tr, lay);
 }
 
 // the same packing for ONE operand, descriptor by value (no device table: usable under stream capture)
 __global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__ src, void* __restrict__ dst, int dtype, int cout,
                                                        int cin, int ks, int tr, int lay) {
-    if (dtype == VQK_F32) pack_any<float>(src, reinterpret_cast<float*>(dst), cout, cin, ks * ks, tr, lay);
+    if (lay == 5) pack_x3(src, reinterpret_cast<bf16_raw*>(dst), cout, cin, ks * ks, tr);
+    else if (dtype == VQK_F32) pack_any<float>(src, reinterpret_cast<float*>(dst), cout, cin, ks * ks, tr, lay);
     else pack_any<bf16_raw>(src, reinterpret_cast<bf16_raw*>(dst), cout, cin, ks * ks, tr, lay);
 }
 
@@ -2295,6 +2343,7 @@ int make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int co
     g.act = 0; g.dy_pool = 0; g.tq = nullptr; g.tq_mode = 0; g.phase_rev = 0;
     g.ntap = ksize == 1 ? 1 : 9; g.tap_oy = g.tap_ox = 0; g.src_s = 1; g.src_a = g.src_b = 0; g.dst_s = 1; g.dst_a = g.dst_b = 0;
     g.tapw = 0; g.dst_h = g.dst_w = 0; g.s2 = 0; g.phase_mode = 0;
+    g.fold = 0;
     const int64_t m = (int64_t)n * g.h * g.w;
     if (m > 0x7fffffff - 256) return VQK_ERR_SHAPE;
     g.m = (int)m;
@@ -2324,7 +2373,7 @@ static int conv_general(int dtype, const void* x, const void* w, const float* bi
     VQK_REQUIRE(x && w && y && zeros, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
     VQK_REQUIRE(act >= 0 && act <= 3, VQK_ERR_ARG);
-    VQK_REQUIRE(wlayout == 0 || wlayout == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(wlayout == 0 || wlayout == 1 || wlayout == 5, VQK_ERR_ARG);
     VQK_REQUIRE(mode >= 0 && mode <= 2 && (stride == 1 || stride == 2) && pad >= 0, VQK_ERR_ARG);
     ConvGeom g;
     const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, mode ? 1 : 0);
@@ -2346,6 +2395,12 @@ static int conv_general(int dtype, const void* x, const void* w, const float* bi
     }
     g.acc_scale = acc_scale; g.out_gain = out_gain;
     hipStream_t st = vqk_stream(stream);
+    if (wlayout == 5) {
+        // split-product mode: fp32 activations, three bf16 products per multiply-add (conv_x3.hip)
+        VQK_REQUIRE(plain && dtype == VQK_F32 && out_dtype == VQK_F32 && ksize == 3, VQK_ERR_ARG);
+        VQK_REQUIRE(vqk_aligned16(y) && (!residual || vqk_aligned16(residual)), VQK_ERR_ALIGN);
+        return vqkd::launch_conv3x3_x3(x, w, bias, residual, y, zeros, g, act, g_stream_blocks, st);
+    }
     if (mode == 2 && stride == 1 && g_force_variant != 5) {
         // zero-stuffed input: one launch per output-parity class, each visiting only the taps that hit real samples
         const int saved = g_force_variant;
@@ -2680,6 +2735,10 @@ int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int ci
         const dim3 grid(vqk_grid_1d(total, 256));
         if (dtype == VQK_F32) hipLaunchKernelGGL(pack_frag_kernel<float>, grid, dim3(256), 0, st, w, (float*)out, cout, cin, taps, transpose, cot_tiles);
         else hipLaunchKernelGGL(pack_frag_kernel<bf16_raw>, grid, dim3(256), 0, st, w, (bf16_raw*)out, cout, cin, taps, transpose, cot_tiles);
+    } else if (layout == 5) {
+        const int dcin = transpose ? cout : cin;
+        VQK_REQUIRE(ksize == 3 && dtype == VQK_F32 && dcin % 32 == 0, VQK_ERR_SHAPE);
+        hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, out, dtype, cout, cin, ksize, transpose, layout);
     } else if (layout == 2 || layout == 3) {
         const int dcin = transpose ? cout : cin;
         VQK_REQUIRE(ksize == 3 && dtype == VQK_BF16 && dcin % 64 == 0 && (layout == 2 || transpose), VQK_ERR_SHAPE);
@@ -2712,7 +2771,7 @@ int vqk_conv_pack_dgrad(const float* w, void* wt, int dtype, int cout, int cin, 
 
 static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, int n, int h_in, int w_in, int cin, int cout,
                          int ksize, int stride, int pad, int mode, int h_out, int w_out, const void* zeros, void* stream,
-                         int dy_pool = 0, float dy_scale = 1.0f) {
+                         int dy_pool = 0, float dy_scale = 1.0f, int fold = 0) {
     VQK_REQUIRE(x && dy && dw && zeros, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy) && vqk_aligned16(zeros), VQK_ERR_ALIGN);
     VQK_REQUIRE(mode >= 0 && mode <= 1 && (stride == 1 || stride == 2) && pad >= 0, VQK_ERR_ARG);
@@ -2731,8 +2790,14 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
         VQK_REQUIRE(m < 0x7fffff00, VQK_ERR_SHAPE);
         g.m = (int)m;
     }
+    if (fold) {
+        // (hi | lo) pair operands of the split-product mode: only the matrix/auxiliary-wave kernel has the folded tile classes
+        VQK_REQUIRE(plain && dtype == VQK_BF16 && ksize == 3 && (g.h % 8) == 0 && (g.w % 16) == 0 && (cin % 128) == 0 && (cout % 128) == 0
+                    && !dy_pool && !g_det && g_force_variant != 0 && VQK_TUNE("WGMX", 1) && VQK_TUNE("WGRAD_BLOCKS", 0) == 0
+                    && VQK_TUNE("WGRAD_NO_PW16", 0) == 0, VQK_ERR_SHAPE);
+    }
     if (plain && dtype == VQK_BF16 && ksize == 3 && (g.h % 8) == 0 && (g.w % 8) == 0 && g_force_variant != 0) {
-        const int tiles = ((cout + 63) / 64) * ((cin + 63) / 64);
+        const int tiles = fold ? 3 * (cout / 128) * (cin / 128) : ((cout + 63) / 64) * ((cin + 63) / 64);
         const bool no_pw16 = VQK_TUNE("WGRAD_NO_PW16", 0) != 0;
         const bool pw16 = (g.w % 16) == 0 && !no_pw16;
         const int total_patches = g.n * (g.h / 8) * (g.w / (pw16 ? 16 : 8));
@@ -2777,10 +2842,10 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
             sm = (total_patches + ppm - 1) / ppm;
             if (sm < 2) part = nullptr;
             ConvGeom gm = g;
-            gm.dy_pool = dy_pool; gm.acc_scale = dy_scale;
+            gm.dy_pool = dy_pool; gm.acc_scale = dy_scale; gm.fold = fold;
             return vqkd::launch_conv3x3_wgrad_mx(x, dy, dw, zeros, gm, tiles, sm * nph, ppm, vqk_stream(stream), part);
         }
-        if (dy_pool) return VQK_ERR_SHAPE;                      // half-resolution dy exists on the matrix/auxiliary-wave kernel only
+        if (dy_pool || fold) return VQK_ERR_SHAPE;              // half-resolution dy / pair operands exist on the matrix/auxiliary-wave kernel only
         if (pw16 && (cin % 64) == 0 && (cout % 64) == 0 && !no_p16k) {
             static const hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_wgrad_p16_kernel,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 40960);
@@ -2851,6 +2916,15 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
     VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
     return wgrad_general(dtype, x, dy, dw, n, h_in, w_in, cin, cout, ksize, 1, ksize >> 1, ups, h_in << ups, w_in << ups,
                          zeros, stream);
+}
+
+int vqk_conv2d_wgrad_x3(const void* x_pair, const void* dy_pair, float* dw, int n, int h_in, int w_in, int cin, int cout, int ups,
+                        float scale, const void* zeros, void* stream) {
+    // x_pair [n, h_in, w_in, 2 cin], dy_pair [n, h, w, 2 cout] bf16 (vqk_split_pair_f32); dw fp32 [cout][3][3][cin] +=
+    VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
+    VQK_REQUIRE((cin % 64) == 0 && (cout % 64) == 0, VQK_ERR_SHAPE);
+    return wgrad_general(VQK_BF16, x_pair, dy_pair, dw, n, h_in, w_in, 2 * cin, 2 * cout, 3, 1, 1, ups, h_in << ups, w_in << ups,
+                         zeros, stream, 0, scale, 1);
 }
 
 int vqk_conv2d_wgrad_pooled_dy(int dtype, const void* x, const void* dy_pooled, float* dw, int n, int h, int w, int cin,

@@ -58,6 +58,10 @@ struct ConvGeom {
     // tq_mode 1: a block's first tile is its static one (no start-up latency), 2: every tile comes from the queue.
     int* tq;
     int tq_mode;
+    // weight-gradient mx kernel, split-product mode (conv_x3.hip): x and dy are (hi | lo) bf16 PAIR tensors, cin / cout are their
+    // pixel pitches (TWICE the true channel counts).  The grid carries three classes of 64 x 64 tiles -- dy_hi^T x_hi, dy_hi^T x_lo,
+    // dy_lo^T x_hi -- that the final atomic pass adds onto the same dW[cout / 2][9][cin / 2] tile.
+    int fold;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
@@ -82,6 +86,10 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
 // grid = tiles x splits blocks of 512 threads, `pps` 8x16-pixel patches per split
 // `part` (deterministic mode): workspace of splits * tiles * 64*9*64 floats -- the splits' partial tiles are stored there and
 // summed in split order by a second launch instead of being accumulated with fp32 atomics
+// split-product 3x3 conv (conv_x3.hip): fp32 in / out, three bf16 products per multiply-add; weights in layout 5
+int launch_conv3x3_x3(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
+                      const ConvGeom& g, int act, int blocks_cap, hipStream_t st);
+
 int launch_conv3x3_wgrad_mx(const void* x, const void* dy, float* dw, const void* zeros, const ConvGeom& g, int tiles,
                             int splits, int pps, hipStream_t st, float* part = nullptr);
 

@@ -64,11 +64,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_ci = g.cin >> 6;
+    // g.fold (split-product mode, conv_x3.hip): x / dy are (hi | lo) pair tensors with pixel pitches g.cin / g.cout = twice the TRUE
+    // channel counts; tile class 0 = dy_hi^T x_hi, 1 = dy_hi^T x_lo, 2 = dy_lo^T x_hi, all three added onto the same dW tile
+    const int cin_t = g.fold ? g.cin >> 1 : g.cin, cout_t = g.fold ? g.cout >> 1 : g.cout;
+    const int tiles_ci = cin_t >> 6;
     const int vb = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
-    const int bx = vb % (int)gridDim.x, by = vb / (int)gridDim.x;
+    const int bx0 = vb % (int)gridDim.x, by = vb / (int)gridDim.x;
+    const int tiles_pair = tiles_ci * (cout_t >> 6);
+    const int cls = g.fold ? bx0 / tiles_pair : 0;
+    const int bx = g.fold ? bx0 - cls * tiles_pair : bx0;
     const int tco = bx / tiles_ci, tci = bx - tco * tiles_ci;
-    const int co0 = tco * 64, ci0 = tci * 64;
+    const int co0 = tco * 64, ci0 = tci * 64;                    // dW tile (true channels)
+    const int co0m = co0 + (cls == 2 ? cout_t : 0), ci0m = ci0 + (cls == 1 ? cin_t : 0);      // operand channels in memory
     const int pw = g.w >> 4, ph = g.h >> 3;
     const int total_patches = g.n * ph * pw;
     // NT = 4: g.dy_pool = 2 + phase (one phase per launch) or 6 (ALL FOUR phases in one launch: phase = by & 3, split = by >> 2 --
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
-                atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r] * g.acc_scale);
+                atomicAdd(dw + ((int64_t)co * 9 + t) * cin_t + ci, acc[t][r] * g.acc_scale);
             }
         return;
         }
@@ -223,15 +230,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
         const int q = xw + 4 * sl, half = q >> 3, prow = q & 7;
         // dy_pool 1: dy at HALF resolution (every pooled pixel stands for its 2x2 block); >= 2 (NT = 4): dy at TWICE the resolution
         // of the patch grid, one phase of it gathered at stride 2
-        dyoff[sl] = g.dy_pool == 1 ? (unsigned)(((((prow >> 1) * (g.w >> 1) + (lrow >> 1)) * g.cout) + co0 + half * 32 + lch) * 2)
-                  : g.dy_pool >= 2 ? (unsigned)(((((2 * prow) * (2 * g.w) + 2 * lrow) * g.cout) + co0 + half * 32 + lch) * 2)
-                                   : (unsigned)((((prow * g.w + lrow) * g.cout) + co0 + half * 32 + lch) * 2);
+        dyoff[sl] = g.dy_pool == 1 ? (unsigned)(((((prow >> 1) * (g.w >> 1) + (lrow >> 1)) * g.cout) + co0m + half * 32 + lch) * 2)
+                  : g.dy_pool >= 2 ? (unsigned)(((((2 * prow) * (2 * g.w) + 2 * lrow) * g.cout) + co0m + half * 32 + lch) * 2)
+                                   : (unsigned)((((prow * g.w + lrow) * g.cout) + co0m + half * 32 + lch) * 2);
     }
 #pragma unroll
     for (int sl = 0; sl < NX; ++sl) {
         const int r = xw + 4 * sl, half = r / 12, row = min((r % 12) * 16 + lrow, HROWS - 1);
         const int hy = row / HWD, hx = row - hy * HWD;
-        xoff[sl] = (unsigned)((((hy * g.w_in + hx) * g.cin) + ci0 + half * 32 + lch) * 2);
+        xoff[sl] = (unsigned)((((hy * g.w_in + hx) * g.cin) + ci0m + half * 32 + lch) * 2);
     }
     struct PatchPos { int img, py0, px0; bool interior; const char* bdy; const char* bx; };
     auto decode = [&](int patch) -> PatchPos {
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mx_kernel(const bf16_raw
                 const int iy = pp.py0 + hy - 1, ix = pp.px0 + hx - 1;
                 const void* src = zeros;
                 if (iy >= 0 && iy < g.h && ix >= 0 && ix < g.w)
-                    src = x + (((int64_t)pp.img * g.h_in + (iy >> g.ups)) * g.w_in + (ix >> g.ups)) * g.cin + ci0 + half * 32 + lch;
+                    src = x + (((int64_t)pp.img * g.h_in + (iy >> g.ups)) * g.w_in + (ix >> g.ups)) * g.cin + ci0m + half * 32 + lch;
                 glds16(src, dst);
             }
         }
@@ -327,6 +334,7 @@ namespace vqkd {
 
 int launch_conv3x3_wgrad_mx(const void* x, const void* dy, float* dw, const void* zeros, const ConvGeom& g, int tiles,
                             int splits, int pps, hipStream_t st, float* part) {
+    if (g.fold && (g.dy_pool || part)) return VQK_ERR_ARG;        // split-product operands: plain 3x3 form, atomics only
     if (g.dy_pool >= 2) {                                         // one output phase of an upsample conv: the 2x2-window form
         if (g.dy_pool > 7 || part || (g.dy_pool >= 6 && (splits & 3))) return VQK_ERR_ARG;
         static const hipError_t attr4 = hipFuncSetAttribute((const void*)conv3x3_wgrad_mx_kernel<4>,

@@ -1,0 +1,373 @@
+// ------------------------------------------------------------------------------------------------
+// conv3x3_x3_kernel: the PARITY-GRADE 3x3 convolution on the bf16 matrix pipe -- fp32 activations in, fp32 out, every product
+// x*w evaluated as THREE bf16 products with fp32 accumulation ("split products"):
+//
+//      x = x_hi + x_lo,  w = w_hi + w_lo      (hi = bf16_rne(v), lo = bf16_rne(v - hi); |v - hi - lo| <= 2^-18 |v|)
+//      x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo      (dropped: x_lo*w_lo <= 2^-18 |x*w|)
+//
+// i.e. ~2^-17 relative per product against 2^-8 for the plain bf16 mode and 2^-24 for v_mfma_f32_32x32x2_f32 -- at 3/16 of the
+// fp32-MFMA cost per multiply-add.  Replaces the F.conv2d calls of vqvae/modules/autoencoder.py:57-60 (ResBlock), :102-105
+// (Upsample), :132 / :153 (conv_in / conv_out of the latent) in the fp32 compute mode; the exact-fp32 kernel
+// (conv.hip: conv3x3_halo_breg_kernel) stays as the reference mode (ops.set_conv_products('fp32')).
+//
+// Structure: the persistent software pipeline of conv3x3_stream_kernel (conv.hip), 128-pixel tiles (8x16), two 256-thread blocks
+// per CU.  A unit = (tile, 32-channel chunk).  While unit u runs out of LDS buffer u & 1, the fp32 halo of unit u + 1 is in flight
+// HBM -> registers; after the unit's MFMAs each lane SPLITS its four floats (2 x v_cvt_pk_bf16_f32, 4 subtractions, 2 more
+// conversions) and writes the hi and the lo bf16 PLANE of buffer (u + 1) & 1 (two ds_write_b64); one barrier per unit.  LDS rows are
+// 80 B per plane (64 B payload): the conflict-free `lane base + immediate` fragment addressing of the stream kernel, twice.
+// Weights: fragment-major hi/lo pairs (vqk_conv_pack_weights layout 5: [cot32][chunk32][tap][ks][hi|lo] x 1 KiB), streamed
+// L2 -> registers one tap ahead.  Per (tap, k-substep) and wave: NI x NJ x 3 MFMAs on NI x 2 pixel fragments + NJ x 2 weight
+// fragments.  fp32 epilogue straight from the accumulators (v_permlane32_swap pairs the half-wave runs: 32 B per lane).
+//
+// split_pair_kernel: fp32 [rows][C] -> bf16 [rows][2C] = (hi | lo): the operand form of the WEIGHT gradient in this mode
+// (conv_wgmx.hip, ConvGeom::fold): dW = dy_hi^T x_hi + dy_hi^T x_lo + dy_lo^T x_hi as three tile classes of ONE launch of the
+// bf16 matrix/auxiliary-wave weight-gradient kernel, folded onto the same dW tile by its final atomic pass.
+// ------------------------------------------------------------------------------------------------
+#include "conv_geom.h"
+#include <type_traits>
+
+namespace {
+
+using vqkd::ConvGeom;
+using vqkd::xcd_remap;
+using vqkd::pack_bf16x2;
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ float x3_act(float v, int act) {
+    if (act == 1) return tanhf(v);
+    if (act == 2) return fmaxf(v, 0.0f);
+    if (act == 3) return v > 0.0f ? v : 0.2f * v;
+    return v;
+}
+
+// WL 0: the four waves as 2 (pixels) x 2 (couts), wave tile 64 px x 64 couts; WL 1: 1 x 4, wave tile 128 px x 32 couts (half the
+// L2 -> register weight stream per MFMA, twice the LDS fragment reads)
+template <int TWLOG, int WL>
+__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restrict__ x, const bf16_raw* __restrict__ wp,
+                                                            const float* __restrict__ bias, const float* __restrict__ res,
+                                                            float* __restrict__ y, const char* __restrict__ zeros, ConvGeom g,
+                                                            int act) {
+    constexpr int PIX = 128, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr int RS = 80;                                       // padded LDS row stride per plane (64 B payload)
+    constexpr int HALO_INSTR = (HROWS + 7) / 8;                  // register pieces: 8 rows x 128 B (32 fp32 channels) per wave load
+    constexpr int PLANE = HALO_INSTR * 8 * RS, BUF = 2 * PLANE;  // hi plane, lo plane (whole pieces: the last piece's padding rows are written too)
+    constexpr int NSLOT = (HALO_INSTR + 3) / 4;
+    constexpr int NI = WL ? 4 : 2, NJ = WL ? 1 : 2;
+    constexpr int UNITW = 36 * 1024;                             // weight bytes of one (32-cout tile, chunk): 9 taps x 2 ks x (hi, lo)
+    typedef bf16x8_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = g.w >> TWLOG, tiles_y = g.h / TH;
+    const int total_tiles = g.n * tiles_y * tiles_x * g.tiles_n;
+    const int nch = g.cin >> 5;                                  // 32-channel chunks
+    const int vbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int my_tiles = (total_tiles - vbid + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int units = my_tiles * nch;
+    if (units <= 0) return;
+
+    const int wm = WL ? 0 : wave >> 1, wn = WL ? wave : wave & 1;
+    const int p = lane & 31, kg = lane >> 5;
+    auto pix_of = [&](int i, int& ty, int& tx) {                 // patch pixel of this lane in the wave's MFMA tile i
+        if (TWLOG == 5) { ty = wm * NI + i; tx = p; }
+        else { ty = wm * 2 * NI + 2 * i + (p >> 4); tx = p & 15; }
+    };
+    unsigned abase[NI];                                          // LDS byte offset of tile i's pixel, tap (0,0), ks 0, hi plane
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int ty, tx;
+        pix_of(i, ty, tx);
+        abase[i] = (unsigned)((ty * HW2 + tx) * RS + kg * 16);
+    }
+    int slot_hy[NSLOT], slot_hx[NSLOT];
+    unsigned slot_dst[NSLOT];
+    bool slot_ok[NSLOT];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+        const int q = wave + 4 * sl;
+        const int hr = q * 8 + (lane >> 3);
+        slot_ok[sl] = q < HALO_INSTR && hr < HROWS;
+        slot_hy[sl] = hr / HW2;
+        slot_hx[sl] = hr - slot_hy[sl] * HW2;
+        slot_dst[sl] = (unsigned)(hr * RS + (lane & 7) * 8);     // 4 bf16 = 8 B per lane and plane
+    }
+    const int lchan = (lane & 7) * 4;
+
+    struct TilePos { int img, py0, px0, nt; };
+    auto tile_pos = [&](int j) -> TilePos {
+        int t = vbid + j * (int)gridDim.x;
+        TilePos tp;
+        tp.nt = t % g.tiles_n; t /= g.tiles_n;
+        const int txi = t % tiles_x; t /= tiles_x;
+        const int tyi = t % tiles_y;
+        tp.img = t / tiles_y; tp.py0 = tyi * TH; tp.px0 = txi * TW;
+        return tp;
+    };
+    u32x4 hreg[NSLOT];
+    auto load_halo = [&](const TilePos& tp, int c) {
+        const float* ximg = x + (int64_t)tp.img * g.h_in * g.w_in * g.cin + c * 32 + lchan;
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int iy = tp.py0 + slot_hy[sl] - 1, ix = tp.px0 + slot_hx[sl] - 1;
+            const bool ok = slot_ok[sl] && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+            const float* src = ximg + ((int64_t)(iy >> g.ups) * g.w_in + (ix >> g.ups)) * g.cin;
+            const void* sp = ok ? (const void*)src : (const void*)zeros;      // select, not branch
+            hreg[sl] = *reinterpret_cast<const u32x4*>(sp);
+        }
+    };
+    // split the four floats of every slot into (hi, lo) bf16 and write both planes
+    auto store_halo = [&](char* buf) {
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            if (wave + 4 * sl >= HALO_INSTR) continue;
+            const float f0 = __uint_as_float(hreg[sl][0]), f1 = __uint_as_float(hreg[sl][1]);
+            const float f2 = __uint_as_float(hreg[sl][2]), f3 = __uint_as_float(hreg[sl][3]);
+            const unsigned h01 = pack_bf16x2(f0, f1), h23 = pack_bf16x2(f2, f3);
+            const float l0 = f0 - __uint_as_float(h01 << 16), l1 = f1 - __uint_as_float(h01 & 0xffff0000u);
+            const float l2 = f2 - __uint_as_float(h23 << 16), l3 = f3 - __uint_as_float(h23 & 0xffff0000u);
+            const u32x2 hi = {h01, h23}, lo = {pack_bf16x2(l0, l1), pack_bf16x2(l2, l3)};
+            *reinterpret_cast<u32x2*>(buf + slot_dst[sl]) = hi;
+            *reinterpret_cast<u32x2*>(buf + PLANE + slot_dst[sl]) = lo;
+        }
+    };
+    const unsigned lane16 = (unsigned)lane * 16;
+    const char* wroot = reinterpret_cast<const char*>(wp);
+    auto unit_w = [&](int nt, int c, int j) -> const char* {
+        const int cot = nt * 4 + (WL ? wn : wn * 2 + j);
+        return wroot + ((int64_t)cot * nch + c) * UNITW;
+    };
+
+    f32x16 acc[NI][NJ];
+
+    TilePos cur = tile_pos(0);
+    load_halo(cur, 0);
+    frag_t bw[NJ][2][2];                                         // [j][ks][hi / lo] of the current tap
+    const char* wcur[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wcur[j] = unit_w(cur.nt, 0, j);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) bw[j][ks][hl] = *reinterpret_cast<const frag_t*>(wcur[j] + (ks * 2 + hl) * 1024 + lane16);
+    store_halo(smem);
+    __syncthreads();
+
+    int tj = 0, c = 0;
+    for (int u = 0; u < units; ++u) {
+        const unsigned boff = (unsigned)((u & 1) * BUF);
+        int ntj = tj, nc = c + 1;
+        if (nc == nch) { nc = 0; ntj = tj + 1; }
+        const bool has_next = u + 1 < units;
+        if (!has_next) { ntj = tj; nc = c; }                     // clamp: loads stay unconditional
+        const TilePos nxt = (ntj == tj) ? cur : tile_pos(ntj);
+        load_halo(nxt, nc);                                      // in flight during this unit's MFMAs
+        const char* wnxt[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wnxt[j] = unit_w(nxt.nt, nc, j);
+        const char* lbase[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) lbase[i] = smem + boff + abase[i];
+
+        // pixel fragments (hi and lo plane) run one (tap, k-substep) phase ahead of the MFMAs that consume them
+        frag_t a[2][NI][2];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            a[0][i][0] = *reinterpret_cast<const frag_t*>(lbase[i]);
+            a[0][i][1] = *reinterpret_cast<const frag_t*>(lbase[i] + PLANE);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = ((tap / 3) * HW2 + (tap % 3)) * RS;        // compile-time after unrolling
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 0) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        a[1][i][0] = *reinterpret_cast<const frag_t*>(lbase[i] + toff + 32);
+                        a[1][i][1] = *reinterpret_cast<const frag_t*>(lbase[i] + PLANE + toff + 32);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NI, 0);
+                } else if (tap < 8) {
+                    const int toff1 = (((tap + 1) / 3) * HW2 + ((tap + 1) % 3)) * RS;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        a[0][i][0] = *reinterpret_cast<const frag_t*>(lbase[i] + toff1);
+                        a[0][i][1] = *reinterpret_cast<const frag_t*>(lbase[i] + PLANE + toff1);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NI, 0);
+                }
+                // three products; the dependent MFMAs on one accumulator are NI * NJ instructions apart
+                if (tap == 0 && ks == 0 && c == 0) {             // first MFMA of a tile starts from C = 0
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks][0], a[ks][i][0], zero, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks][0], a[ks][i][0], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks][0], a[ks][i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][ks][1], a[ks][i][0], acc[i][j], 0, 0, 0);
+                // rolling prefetch of the same slot for the next tap (next unit after tap 8)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl) {
+                        const char* src = (tap == 8) ? wnxt[j] + (ks * 2 + hl) * 1024 : wcur[j] + (((tap + 1) * 2 + ks) * 2 + hl) * 1024;
+                        bw[j][ks][hl] = *reinterpret_cast<const frag_t*>(src + lane16);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (c == nch - 1) {                                      // tile finished: fp32 epilogue from the accumulators
+            const int n0 = cur.nt * 128;
+            const int cwave = WL ? wn * 32 : wn * 64;            // first cout of this wave inside the 128-cout tile
+            const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
+            if (plain) {
+                // lanes l and l + 32 hold the two halves of every 8-cout run: one v_permlane32_swap per value pairs them up so
+                // that each lane owns 8 consecutive couts = 32 contiguous bytes
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    int ty, tx;
+                    pix_of(i, ty, tx);
+                    const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
+                    const int64_t o0 = pix * g.cout + n0 + cwave + 8 * kg;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int qp = 0; qp < 2; ++qp) {
+                            const int cw = j * 32 + 16 * qp;
+                            float v[8];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned lo = __float_as_uint(acc[i][j][8 * qp + e]);
+                                const unsigned hi = __float_as_uint(acc[i][j][8 * qp + 4 + e]);
+                                const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+                                v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+                            }
+                            if (bias) {
+                                const float* bp = bias + n0 + cwave + 8 * kg + cw;
+                                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                            }
+                            if (res) {
+                                const f32x4 r0 = *reinterpret_cast<const f32x4*>(res + o0 + cw);
+                                const f32x4 r1 = *reinterpret_cast<const f32x4*>(res + o0 + cw + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                            }
+                            const f32x4 s0 = {v[0], v[1], v[2], v[3]}, s1 = {v[4], v[5], v[6], v[7]};
+                            *reinterpret_cast<f32x4*>(y + o0 + cw) = s0;
+                            *reinterpret_cast<f32x4*>(y + o0 + cw + 4) = s1;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    int ty, tx;
+                    pix_of(i, ty, tx);
+                    const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int co = n0 + cwave + j * 32 + 8 * rq + 4 * kg;
+                            if (co < g.cout) {
+                                const int64_t o = pix * g.cout + co;
+                                f32x4 v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    v[e] = x3_act(acc[i][j][4 * rq + e] * g.acc_scale + (bias ? bias[co + e] : 0.0f), act) * g.out_gain;
+                                if (res) {
+                                    const f32x4 r = *reinterpret_cast<const f32x4*>(res + o);
+                                    v += r;
+                                }
+                                *reinterpret_cast<f32x4*>(y + o) = v;
+                            }
+                        }
+                }
+            }
+        }
+        if (has_next) store_halo(smem + ((u + 1) & 1) * BUF);
+        __syncthreads();
+        cur = nxt; tj = ntj; c = nc;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wcur[j] = wnxt[j];
+    }
+}
+
+// fp32 [rows][c] -> bf16 [rows][2c]: (hi | lo) per row; a thread owns 8 consecutive channels (two 16-byte loads, two 16-byte stores)
+__global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict__ src, bf16_raw* __restrict__ dst, int64_t rows, int c) {
+    const int c8 = c >> 3;
+    const int64_t total = rows * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c8;
+        const int k = (int)(i - r * c8) * 8;
+        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + r * c + k));
+        const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + r * c + k + 4));
+        const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        u32x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned h = pack_bf16x2(f[2 * q], f[2 * q + 1]);
+            hi[q] = h;
+            lo[q] = pack_bf16x2(f[2 * q] - __uint_as_float(h << 16), f[2 * q + 1] - __uint_as_float(h & 0xffff0000u));
+        }
+        *reinterpret_cast<u32x4*>(dst + r * 2 * c + k) = hi;
+        *reinterpret_cast<u32x4*>(dst + r * 2 * c + c + k) = lo;
+    }
+}
+
+}  // namespace
+
+namespace vqkd {
+
+// x fp32 [N, h_in, w_in, Cin], w: layout 5, y fp32 [N, h, w, Cout]; Cin % 32 == 0, h % 8 == 0, w % 16 == 0
+int launch_conv3x3_x3(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
+                      const ConvGeom& g, int act, int blocks_cap, hipStream_t st) {
+    if (g.ks != 3 || (g.cin & 31) || (g.h & 7) || (g.w & 15) || (g.cout & 3)) return VQK_ERR_SHAPE;
+    const int total = g.n * (g.h / 8) * (g.w / 16) * g.tiles_n;
+    const int cap = blocks_cap > 0 ? blocks_cap : 512;
+    const dim3 grid((unsigned)(total < cap ? total : cap));
+    constexpr int lds = 2 * 2 * 184 * 80;                        // two buffers x (hi, lo) planes of the 10x18 halo (23 pieces of 8 rows)
+    const int wl = VQK_TUNE("X3_WL", 1);
+    if (wl)
+        hipLaunchKernelGGL((conv3x3_x3_kernel<4, 1>), grid, dim3(256), lds, st, (const float*)x, (const bf16_raw*)w, bias,
+                           (const float*)res, (float*)y, (const char*)zeros, g, act);
+    else
+        hipLaunchKernelGGL((conv3x3_x3_kernel<4, 0>), grid, dim3(256), lds, st, (const float*)x, (const bf16_raw*)w, bias,
+                           (const float*)res, (float*)y, (const char*)zeros, g, act);
+    return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
+}
+
+}  // namespace vqkd
+
+extern "C" int vqk_split_pair_f32(const float* src, void* dst, int64_t rows, int c, void* stream) {
+    VQK_REQUIRE(src && dst, VQK_ERR_ARG);
+    VQK_REQUIRE(rows >= 0 && c > 0 && (c & 7) == 0, VQK_ERR_SHAPE);
+    VQK_REQUIRE(vqk_aligned16(src) && vqk_aligned16(dst), VQK_ERR_ALIGN);
+    if (rows == 0) return VQK_OK;
+    hipLaunchKernelGGL(split_pair_kernel, dim3((unsigned)vqk_grid_1d(rows * (c >> 3), 256, 256 * 16)), dim3(256), 0, vqk_stream(stream),
+                       src, (bf16_raw*)dst, rows, c);
+    VQK_CHECK_LAUNCH();
+    return VQK_OK;
+}

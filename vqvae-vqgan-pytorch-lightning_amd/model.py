@@ -26,7 +26,7 @@ from torch import nn
 
 from . import ops
 from .modules.abstract_modules.base_autoencoder import BaseVQVAE
-from .modules.autoencoder import Decoder, Encoder, GroupNorm, Conv2d, set_compute_dtype
+from .modules.autoencoder import Decoder, Encoder, GroupNorm, Conv2d, resolve_compute_dtype, set_compute_dtype
 from .modules.vector_quantizers import (EMAVectorQuantizer, EntropyVectorQuantizer, GumbelVectorQuantizer,
                                         VectorQuantizer)
 from .modules.loss import loss as loss_mod
@@ -123,7 +123,7 @@ class VQVAE(BaseVQVAE, _LightningBase):
 
         if init_cb:
             self.quantizer.init_codebook()
-        self.compute_dtype = compute_dtype
+        self.compute_dtype, self.conv_products = resolve_compute_dtype(compute_dtype)
         set_compute_dtype(self, compute_dtype)
 
     # ------------------------------------------------------------------ forward (model.py:151-161)

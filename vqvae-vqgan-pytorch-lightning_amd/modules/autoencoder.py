@@ -17,12 +17,27 @@ from torch import nn
 from .. import ops
 
 
-def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
+def resolve_compute_dtype(dtype):
+    """``torch.float32`` (exact fp32 products: the reference mode), ``torch.bfloat16`` (throughput mode) or the string ``'bf16x3'``:
+    fp32 storage and accumulation with every 3x3-conv product evaluated as three bf16 products on the bf16 matrix pipe
+    (``ops.set_conv_products``; parity-grade: ~2^-17 relative per product).  -> (storage dtype, conv products)"""
+    if dtype == 'bf16x3':
+        return torch.float32, 'bf16x3'
+    if dtype in ('fp32', 'float32'):
+        return torch.float32, 'fp32'
+    if dtype in ('bf16', 'bfloat16'):
+        return torch.bfloat16, 'fp32'
     if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError('compute dtype must be torch.float32 or torch.bfloat16')
+        raise ValueError("compute dtype must be torch.float32, torch.bfloat16 or 'bf16x3'")
+    return dtype, 'fp32'
+
+
+def set_compute_dtype(module: nn.Module, dtype) -> nn.Module:
+    dtype, products = resolve_compute_dtype(dtype)
     for m in module.modules():
         if hasattr(m, 'compute_dtype'):
             m.compute_dtype = dtype
+            m.conv_products = products
     return module
 
 
@@ -155,6 +170,7 @@ class Encoder(nn.Module):
     def forward(self, x, cut_after=None):
         """``cut_after``: index into ``self.blocks`` (``shallow_split()``): the autograd graph is cut behind that module and
         the pair (tensor before the cut, detached leaf after it) is left in ``self.last_cut``"""
+        ops.set_conv_products(getattr(self, 'conv_products', 'fp32'))
         x = _to_internal(x, self.compute_dtype)
         mods = list(self.blocks)
         i = 0
@@ -204,6 +220,7 @@ class Decoder(nn.Module):
 
     def forward_padded(self, x):
         """reconstruction with its zero pad channels ([N, 4 or 8, H, W], NHWC) -- what the fused loss reads"""
+        ops.set_conv_products(getattr(self, 'conv_products', 'fp32'))
         x = _to_internal(x, self.compute_dtype)
         x = self.conv_in(x)
         # a ResBlock / Upsample output is read next by a 32-group GroupNorm (the next block's norm1, finally self.norm)

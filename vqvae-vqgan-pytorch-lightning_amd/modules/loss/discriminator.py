@@ -181,6 +181,7 @@ class Discriminator(nn.Module):
         """halves: number of independent batches concatenated along dim 0 (only the minibatch-stddev layer couples samples);
         double_backward: this pass will be differentiated twice (R1, loss.py:98-112): layer-by-layer autograd nodes instead of
         the fused block nodes, whose backward is first-order only"""
+        ops.set_conv_products(getattr(self, 'conv_products', 'fp32'))
         img = _to_internal(img, self.compute_dtype)
         x = None
         for res in self.block_resolutions:

@@ -44,6 +44,7 @@ class VGG16(nn.Module):
 
     def forward(self, x):
         """-> the 5 tap activations (un-normalised; the tap kernel does the channel normalisation)"""
+        ops.set_conv_products(getattr(self, 'conv_products', 'fp32'))
         x = _to_internal(x, self.compute_dtype)
         scale, shift = self._zscore(x.shape[1], x.device)
         x = ops.ChannelAffineFn.apply(x, scale, shift)          # z-score; pad channels stay zero

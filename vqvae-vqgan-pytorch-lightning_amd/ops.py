@@ -83,6 +83,26 @@ def _stream() -> int:
     return s
 
 
+X3 = _native.switch('VQK_CONV_PRODUCTS', 'fp32') == 'bf16x3'
+
+
+def set_conv_products(mode: str) -> None:
+    """How the fp32 compute mode multiplies in the 3x3 convs: 'fp32' -- exact v_mfma_f32_32x32x2_f32 (the reference mode: what
+    the CPU oracle computes, bit for bit per product); 'bf16x3' -- every product as three bf16 products with fp32 accumulation
+    (csrc/conv_x3.hip: x_hi w_hi + x_lo w_hi + x_hi w_lo, ~2^-17 relative per product) on the bf16 matrix pipe, fp32 activation
+    storage, GroupNorm / quantizer / optimizer unchanged.  Read at FORWARD time (the autograd nodes carry it to their backward)."""
+    global X3
+    if mode not in ('fp32', 'bf16x3'):
+        raise ValueError("conv products: 'fp32' or 'bf16x3'")
+    X3 = mode == 'bf16x3'
+
+
+def x3_serves(dtype, out_dtype, h_out: int, w_out: int, cin: int, cout: int, ksize: int) -> bool:
+    """the split-product 3x3 kernel serves this problem (fp32 in / out, whole 32-channel chunks, 8x16-pixel tiles)"""
+    return (dtype == torch.float32 and out_dtype in (None, torch.float32) and ksize == 3 and cin % 32 == 0 and cout % 32 == 0
+            and h_out % 8 == 0 and w_out % 16 == 0)
+
+
 def set_deterministic(on: bool) -> None:
     """``pl.Trainer(deterministic=True)`` (vqvae/train.py:130) for the vqk kernels: ordered partial sums instead of atomics in
     arrival order (include/vqk.h: vqk_set_deterministic); the GroupNorm sums are no longer fused into the conv drains (those
@@ -161,6 +181,8 @@ def _fprop_kernel_name(dtype, wlayout: int, shape=None) -> str:
 
 
 def _fprop_kernel_name0(dtype, wlayout: int, shape=None) -> str:
+    if wlayout == 5:
+        return 'conv3x3_x3_kernel<f32 as 3 x bf16>'
     if wlayout == 1:
         if dtype != torch.bfloat16:
             return 'conv3x3_halo_breg_kernel<f32>'
@@ -174,11 +196,14 @@ def _fprop_kernel_name0(dtype, wlayout: int, shape=None) -> str:
 
 
 
-def weight_layout(dtype, n, h_in, w_in, cin, cout, ksize, ups, out_dtype=None) -> int:
-    """operand layout the fprop launcher wants for this problem (include/vqk.h: 0 = [O][kh][kw][I], 1 = fragment-major);
+def weight_layout(dtype, n, h_in, w_in, cin, cout, ksize, ups, out_dtype=None, x3=None) -> int:
+    """operand layout the fprop launcher wants for this problem (include/vqk.h: 0 = [O][kh][kw][I], 1 = fragment-major,
+    5 = fragment-major (hi | lo) bf16 pairs of the split-product mode; ``x3``: that mode on / off, None = the process setting);
     a 1x1 conv has a fragment-major form only on the bf16 -> bf16 matrix/auxiliary-wave kernel"""
     if ksize == 1 and (dtype != torch.bfloat16 or (out_dtype is not None and out_dtype != torch.bfloat16)):
         return 0
+    if (X3 if x3 is None else x3) and x3_serves(dtype, out_dtype, h_in << int(ups), w_in << int(ups), cin, cout, ksize):
+        return 5                                   # split products on the bf16 matrix pipe (csrc/conv_x3.hip)
     if (_THIN_OUT and ksize == 3 and not ups and dtype == torch.bfloat16 and out_dtype in (None, torch.bfloat16)
             and cin == 128 and cout == 8 and h_in % 8 == 0 and w_in % 32 == 0):
         return 0                                   # the decoder's last conv: plain weights for vqk_conv2d_thin_out
@@ -455,7 +480,8 @@ def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_d
                 lambda: _native.lib().vqk_conv2d_fprop(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias),
                                                        _p(residual), y.data_ptr(), dcode(out_dtype), n, h, w, cin,
                                                        cout, ksize, int(ups), act, wlayout,
-                                                       zero_page(x.device).data_ptr(), _stream()), nbytes)
+                                                       zero_page(x.device).data_ptr(), _stream()), nbytes,
+                exec_flops=3.0 * flops if wlayout == 5 else None)
     _native.check(st, 'conv2d_fprop')
     return y
 
@@ -710,7 +736,17 @@ def edge_wgrad_served(x, dy, ksize: int, ups: bool) -> bool:
             and (h * w) % 128 == 0 and (w % 128 == 0 or 128 % w == 0))
 
 
-def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8) -> torch.Tensor:
+def raw_split_pair(t) -> torch.Tensor:
+    """fp32 nhwc [N,C,H,W] -> bf16 nhwc [N,2C,H,W] = (hi | lo) per pixel (vqk_split_pair_f32): hi = bf16(v), lo = bf16(v - hi)"""
+    n, c, h, w = t.shape
+    out = empty_nhwc(n, 2 * c, h, w, torch.bfloat16, t.device)
+    st = _timed('split_pair_kernel (HBM)', 0.0,
+                lambda: _native.lib().vqk_split_pair_f32(t.data_ptr(), out.data_ptr(), n * h * w, c, _stream()), t.numel() * 8.0)
+    _native.check(st, 'split_pair')
+    return out
+
+
+def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8, x3: bool = False) -> torch.Tensor:
     """dw as fp32 with memory [Cout][k][k][Cin] (logical [Cout,Cin,k,k] channels_last); ``out``: accumulate
     into this (pre-existing) buffer instead of a fresh zeroed one.  ``thin_true`` < 8 (edge convs only, with ``out``): ``out`` is
     the parameter's own UNPADDED gradient (3 true channels on the thin side: vqk_conv2d_wgrad_edge_true)."""
@@ -731,6 +767,17 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8) -
         return dw
     if thin_true != 8:
         raise RuntimeError('vqk: an unpadded weight-gradient target needs the edge-conv kernel')
+    if (x3 and x.dtype == torch.float32 and dy.dtype == torch.float32 and ksize == 3 and cin % 64 == 0 and cout % 64 == 0
+            and dy.shape[3] % 16 == 0 and dy.shape[2] % 8 == 0 and not DETERMINISTIC and _WGMX_ON):
+        # split-product mode: both operands as (hi | lo) bf16 pair tensors, three tile classes of one launch of the bf16
+        # matrix/auxiliary-wave weight-gradient kernel folded onto dW (csrc/conv_wgmx.hip, ConvGeom::fold)
+        xp, dyp = raw_split_pair(x), raw_split_pair(dy)
+        st = _timed('conv3x3_wgrad_mx_kernel<f32 as 3 x bf16>' + (f' {cin}->{cout}@{dy.shape[2]}x{dy.shape[3]} k3' if _EVENT_SHAPES else ''), flops,
+                    lambda: _native.lib().vqk_conv2d_wgrad_x3(xp.data_ptr(), dyp.data_ptr(), dw.data_ptr(), n, h, w, cin, cout, int(ups),
+                                                              1.0, zero_page(x.device).data_ptr(), _stream()), exec_flops=3.0 * flops)
+        if st != _native.ERR_SHAPE:
+            _native.check(st, 'conv2d_wgrad_x3')
+            return dw
     if (ups and UPS_PHASE_WGRAD and _WGMX_ON and x.dtype == torch.bfloat16 and ksize == 3 and cin % 64 == 0 and cout % 64 == 0
             and w % 16 == 0 and h % 8 == 0 and not DETERMINISTIC):
         # the upsample conv's weight gradient in phase form: four 2x2-window launches on the LOW-resolution input, 4/9 of the
@@ -1161,6 +1208,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.bias_ref, ctx.weight_ref = bias, weight
         ctx.cfg = (k, ups, act, o, i, cin, cout_pad, bias is not None, residual is not None, dt)
         ctx.phase = phase
+        ctx.x3 = X3                                              # the backward multiplies the way the forward did
         if (bias is not None and act == 0 and cout_pad == o and out_dtype == dt and gn_colsum_ok(y.shape[2], y.shape[3])
                 and direct_grad(bias) is not None):
             _note_bias_colsum(y, bias)                           # a ResBlock reading y next computes db in its backward
@@ -1181,7 +1229,7 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             n_img, _, h_out, w_out = dyc.shape
-            layout = weight_layout(dt, n_img, h_out, w_out, cout_pad, cin, k, False)
+            layout = weight_layout(dt, n_img, h_out, w_out, cout_pad, cin, k, False, x3=ctx.x3)
             if ups and ctx.phase and UPS_PHASE == 1:             # data gradient in phase form: four 2x2-tap launches
                 dx = raw_conv_ups_phase(dyc, packed_weight(weight, cin, cout_pad, dt, k, True, 2), None, cin, True)
             if dx is not None:
@@ -1211,11 +1259,11 @@ class Conv2dFn(torch.autograd.Function):
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
                 _side_after(side, _fork_point(main))
                 with torch.cuda.stream(side):
-                    raw_conv_wgrad(x, dyc, k, ups, out=tgt, thin_true=thin)
+                    raw_conv_wgrad(x, dyc, k, ups, out=tgt, thin_true=thin, x3=ctx.x3)
                 _SIDE_PENDING.add(x.device)
                 x.record_stream(side); dyc.record_stream(side)
             else:
-                dw = raw_conv_wgrad(x, dyc, k, ups, out=tgt, thin_true=thin)
+                dw = raw_conv_wgrad(x, dyc, k, ups, out=tgt, thin_true=thin, x3=ctx.x3)
             if tgt is not None:
                 dw = None                                        # already accumulated in the flat arena
             elif padded:
@@ -1386,6 +1434,7 @@ class ResBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, st1, a1, r1, st2, a2, w1, b1, w2, b2)
         ctx.params = (n1w, n1b, c1w, n2w, n2b, c2w, scw)
         ctx.cfg = (groups, cin, cout, pool)
+        ctx.x3 = X3
         return out
 
     @staticmethod
@@ -1393,6 +1442,7 @@ class ResBlockFn(torch.autograd.Function):
         x, st1, a1, r1, st2, a2, w1, b1, w2, b2 = ctx.saved_tensors
         n1w, n1b, c1w, n2w, n2b, c2w, scw = ctx.params
         groups, cin, cout, pool = ctx.cfg
+        x3 = ctx.x3
         dt = x.dtype
         dout = nhwc(dout)
         n, _, h, w = x.shape
@@ -1433,12 +1483,12 @@ class ResBlockFn(torch.autograd.Function):
                 if not CHAIN_FIRST:
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
-                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1, x3=x3)
                 dx = raw_gn_backward_pooled_add(x, st1, w1, b1, d_a1, groups, True, tw1, tb1, dout, 0.25)
                 if CHAIN_FIRST:
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
-                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1, x3=x3)
                 main.wait_stream(side)
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)
@@ -1449,13 +1499,13 @@ class ResBlockFn(torch.autograd.Function):
         def conv_bwd(inp, dy, wparam, k, ci, co, need_dx=True, need_dw=True):
             dx = None
             if need_dx:
-                lay = weight_layout(dt, n, h, w, co, ci, k, False)
+                lay = weight_layout(dt, n, h, w, co, ci, k, False, x3=x3)
                 wt = packed_weight(wparam, ci, co, dt, k, True, lay)
                 dx = raw_conv_fprop(dy, wt, None, None, k, False, 0, dt, ci, lay)
             if not need_dw:
                 return dx, None
             tgt = direct_grad(wparam)
-            dw = raw_conv_wgrad(inp, dy, k, False, out=tgt)
+            dw = raw_conv_wgrad(inp, dy, k, False, out=tgt, x3=x3)
             return dx, (None if tgt is not None else dw)
 
         def gn_bwd(inp, st, wv, bv, dy, wparam, bparam, add=None, colsum_of=None):
@@ -1482,7 +1532,7 @@ class ResBlockFn(torch.autograd.Function):
                 if OVERLAP_MODE == 1:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        raw_conv_wgrad(a2, dout, 3, False, out=t2)
+                        raw_conv_wgrad(a2, dout, 3, False, out=t2, x3=x3)
                     d_a2, _ = conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)
                 else:                                    # wgrad starts behind the dgrad: it overlaps GroupNorm only
                     d_a2, _ = conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)
@@ -1490,16 +1540,16 @@ class ResBlockFn(torch.autograd.Function):
                     if not CHAIN_FIRST:
                         _side_after(side, fork)
                         with torch.cuda.stream(side):
-                            raw_conv_wgrad(a2, dout, 3, False, out=t2)
+                            raw_conv_wgrad(a2, dout, 3, False, out=t2, x3=x3)
                 d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
                 if OVERLAP_MODE != 1 and CHAIN_FIRST:
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
-                        raw_conv_wgrad(a2, dout, 3, False, out=t2)
+                        raw_conv_wgrad(a2, dout, 3, False, out=t2, x3=x3)
                 if OVERLAP_MODE == 1:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1, x3=x3)
                     d_a1, _ = conv_bwd(a1, d_r1, c1w, 3, cin, cout, need_dw=False)
                 else:
                     if OVERLAP_MODE == 3 and h * w >= OVERLAP_WAIT_MIN_HW:
@@ -1509,7 +1559,7 @@ class ResBlockFn(torch.autograd.Function):
                     if not CHAIN_FIRST:
                         _side_after(side, fork)
                         with torch.cuda.stream(side):
-                            raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                            raw_conv_wgrad(a1, d_r1, 3, False, out=t1, x3=x3)
                 dskip, dwsc = dout, None
                 if scw is not None:
                     tsc = direct_grad(scw) if SHORTCUT_WGRAD_SIDE else None
@@ -1521,14 +1571,14 @@ class ResBlockFn(torch.autograd.Function):
                         fork_sc = _fork_point(main)
                         _side_after(side, fork_sc)
                         with torch.cuda.stream(side):
-                            raw_conv_wgrad(x, dout, 1, False, out=tsc)
+                            raw_conv_wgrad(x, dout, 1, False, out=tsc, x3=x3)
                     else:
                         dskip, dwsc = conv_bwd(x, dout, scw, 1, cin, cout)
                 dx, dn1w, dn1b = gn_bwd(x, st1, w1, b1, d_a1, n1w, n1b, add=dskip, colsum_of=ctx.db_param)
                 if OVERLAP_MODE != 1 and CHAIN_FIRST:
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
-                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1)
+                        raw_conv_wgrad(a1, d_r1, 3, False, out=t1, x3=x3)
                 main.wait_stream(side)
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)
