@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 CONFIG_OF = {'standard': 'standard_vqvae.yaml', 'ema': 'ema_vqvae.yaml', 'entropy': 'entropy_vqvae.yaml',
              'gumbel': 'gumbel_vqgan.yaml'}
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0}     # MI355X_MICROARCH.md, dense (bf16x3: fp32 storage, three bf16 products per multiply-add -- priced against the bf16 pipe it runs on)
 HBM_PEAK_BPS = 8.0e12                                   # MI355X_MICROARCH.md: HBM3E peak (about 6.3e12 achievable)
 
 
@@ -105,7 +105,7 @@ def parity_cost(run: dict, image_size: int, oracle_step, device) -> dict:
     trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
     params0, images, r = oracle_step
     out = {}
-    for label, dt in (('bf16', torch.bfloat16), ('f32', torch.float32)):
+    for label, dt in (('bf16', torch.bfloat16), ('bf16x3', 'bf16x3'), ('f32', torch.float32)):
         m = model_mod.VQVAE(image_size, run['ae_conf'], run['q_conf'], None, run['t_conf'], compute_dtype=dt)
         m.load_state_dict(params0, strict=True)
         m = m.to(device).train()
@@ -139,6 +139,9 @@ OTHER_CONFIGS = {      # BASELINE.json configs[2..4], single-GPU part, at their 
     'standard_vqvae cb=1024 bs=32, deterministic mode': ['--deterministic'],
     # the mode in which north_star's parity statement holds bit for bit (fp32 storage, exact-fp32 MFMA): what parity costs
     'standard_vqvae cb=1024 bs=8, fp32 parity mode': ['--dtype', 'f32', '--batch', '8'],
+    # the parity-GRADE mode on the bf16 matrix pipe (fp32 storage, every conv product as three bf16 products, fp32 accumulation:
+    # indices / reconstructions / gradients within the fp32 tests' tolerances, tests/test_gpu_fullsize.py) at the headline batch
+    'standard_vqvae cb=1024 bs=32, bf16x3 parity-grade mode': ['--dtype', 'bf16x3', '--batch', '32'],
 }
 
 
@@ -341,7 +344,7 @@ def main():
     ap.add_argument('--config', type=str, default=None, help='example_confs-schema YAML (default: the one of --quantizer)')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--image-size', type=int, default=256)
-    ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
+    ap.add_argument('--dtype', choices=['bf16', 'f32', 'bf16x3'], default='bf16')
     ap.add_argument('--quantizer', choices=['standard', 'ema', 'entropy', 'gumbel'], default='standard')
     ap.add_argument('--gan', action='store_true', help='VQ-GAN criterion of gumbel_vqgan.yaml (LPIPS + StyleGAN2 discriminator, non-saturating, R1 every 16 steps)')
     ap.add_argument('--codebook', type=int, default=None, help='override quantizer.num_embeddings of the YAML')
@@ -382,7 +385,7 @@ def main():
                          f'pass --gpus {world} or launch --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else 'bf16x3' if args.dtype == 'bf16x3' else torch.float32
 
     torch.manual_seed(1234)                                   # identical replicas on every rank
     if args.gan:
@@ -393,8 +396,8 @@ def main():
                             compute_dtype=dtype).to(device)
     args.gan = run['use_adversarial']
     if args.gan:
-        model.criterion.discriminator.compute_dtype = dtype
-        model.criterion.perceptual_loss.net.compute_dtype = dtype
+        model.criterion.discriminator.compute_dtype = model.compute_dtype
+        model.criterion.perceptual_loss.net.compute_dtype = model.compute_dtype
     model.train()
     trainer = trainer_mod.MiniTrainer(num_training_batches=args.steps + args.warmup, deterministic=True if args.deterministic else None)
     trainer.attach(model)

@@ -248,13 +248,14 @@ def test_config4_discriminator_256_r1(golden, disc256):
         S.check_summary(gr, g['r1g.' + n], 'd256.r1g.' + n, 5e-3)
 
 
-def test_config1_standard_architecture_64(golden):
+@pytest.mark.parametrize('products', [torch.float32, 'bf16x3'])
+def test_config1_standard_architecture_64(golden, products):
     """standard_vqvae.yaml (channels 128, mult (1,2,2,4), 2 ResBlocks, K=1024, D=256) at 64x64, bs=8: indices, losses, all
     144 parameter gradients and the parameters after one AdamW step, against the reference modules' own results"""
     g, i = golden('full_config1'), S.config1_inputs()
     qc = dict(num_embeddings=1024, embedding_dim=256, reinit_every_n_epochs=None, type='standard',
               params=dict(commitment_cost=0.25))
-    m = model_mod.VQVAE(64, S.AE_FULL, qc, None, TC)
+    m = model_mod.VQVAE(64, S.AE_FULL, qc, None, TC, compute_dtype=products)
     S.fill_named(list(m.named_parameters()), i['seed'])
     with torch.no_grad():
         m.quantizer.codebook.weight.copy_(i['codebook'])
@@ -283,7 +284,7 @@ def test_config1_standard_architecture_64(golden):
         if k.startswith('p.'):
             # beta1 = 0: the first step moves every element by ~lr * sign(g); a sign flip where |g| ~ 1e-8 moves it 2 lr
             stepped_ok(named[k[2:]], g[k], 'c1.' + k)
-    print(f'config 1: worst gradient projection error {worst:.2e}')
+    print(f'config 1 ({products}): worst gradient projection error {worst:.2e}')
 
 
 @pytest.mark.parametrize('tag,adaptive,gw', [('fixed', False, 0.1), ('adaptive', True, 0.8)])

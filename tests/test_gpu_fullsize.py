@@ -131,7 +131,8 @@ def oracle_256():
     return params, images, r
 
 
-def test_full_architecture_256_vs_cpu_oracle(oracle_256):
+@pytest.mark.parametrize('products', [torch.float32, 'bf16x3'])
+def test_full_architecture_256_vs_cpu_oracle(oracle_256, products):
     """The north-star parity statement at the REAL architecture and resolution (config 2: channels 128, mult (1,2,2,4),
     2 ResBlocks per level, K=1024, D=256, 256x256), batch 2, fp32 parity mode, against the torch-CPU oracle on identical
     inputs and weights: reconstructions and loss within fp32 tolerance, every parameter gradient within 2e-3 relative,
@@ -139,7 +140,7 @@ def test_full_architecture_256_vs_cpu_oracle(oracle_256):
     the assignment kernel on the ORACLE's own latents bit-exact."""
     from oracle import vqvae_oracle as O
     params, images, r = oracle_256
-    m = model_mod.VQVAE(256, AE, QC, None, TC, compute_dtype=torch.float32)
+    m = model_mod.VQVAE(256, AE, QC, None, TC, compute_dtype=products)      # 'bf16x3': split products on the bf16 pipe, same tolerances
     m.load_state_dict(params, strict=True)
     m = m.to(DEV).train()
     tr = trainer_mod.MiniTrainer(num_training_batches=1)
@@ -175,7 +176,7 @@ def test_full_architecture_256_vs_cpu_oracle(oracle_256):
         checked += 1
         assert e < (2e-3 if len(mism) == 0 else 1e-1), (k, e)
     assert checked >= 100, checked
-    print(f'full-architecture parity: {len(mism)} of {len(idx_ref)} indices differ (near-ties), reconstruction rel err '
+    print(f'full-architecture parity ({products}): {len(mism)} of {len(idx_ref)} indices differ (near-ties), reconstruction rel err '
           f'{rec_err:.2e}, loss {loss.item():.6f} vs {r["loss"].item():.6f}, worst gradient rel err {worst:.2e} over {checked} tensors')
 
 

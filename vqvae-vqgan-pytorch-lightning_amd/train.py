@@ -89,7 +89,8 @@ def parse_args(argv=None):
     p.add_argument('--num_nodes', type=int, default=1)
     p.add_argument('--max_epochs', type=int, default=None, help='override training.max_epochs')
     p.add_argument('--batches_per_epoch', type=int, default=None, help='synthetic data: steps per epoch')
-    p.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
+    p.add_argument('--dtype', choices=['bf16', 'f32', 'bf16x3'], default='bf16',
+                   help="bf16: throughput mode; f32: exact fp32 products (the reference mode); bf16x3: fp32 storage, every conv product as three bf16 products (parity-grade)")
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     p.add_argument('--deterministic', action='store_true', help='Trainer(deterministic=True) of the reference (train.py:130): bit-reproducible gradients')
     p.add_argument('--optimizer_param_set', choices=['auto', 'all', 'reference'], default='auto',
@@ -148,7 +149,7 @@ def main(argv=None):
     device = torch.device('cuda', local)
     run = derive_run_config(get_model_conf(args.params_file), world, parse_overrides(args.set))
     torch.manual_seed(args.seed)                                     # pl.seed_everything: identical replicas
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else 'bf16x3' if args.dtype == 'bf16x3' else torch.float32
     kw = dict(image_size=run['image_size'], ae_conf=run['ae_conf'], q_conf=run['q_conf'], l_conf=run['l_conf'],
               t_conf=run['t_conf'], compute_dtype=dtype)
     param_set = args.optimizer_param_set
@@ -163,8 +164,8 @@ def main(argv=None):
         model = model_mod.VQVAE(init_cb=True, load_loss=True, **kw)
     model = model.to(device).train()
     if run['use_adversarial']:
-        model.criterion.discriminator.compute_dtype = dtype
-        model.criterion.perceptual_loss.net.compute_dtype = dtype
+        model.criterion.discriminator.compute_dtype = model.compute_dtype
+        model.criterion.perceptual_loss.net.compute_dtype = model.compute_dtype
     batches = _batches(args, run, device, rank, world)
     if not batches:
         raise SystemExit(f'train.py: the dataset holds fewer than one batch per rank '
