@@ -2185,6 +2185,19 @@ inline int halo_twlog(const ConvGeom& g) {
 template <typename T, typename TO>
 int launch_fprop(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                  const ConvGeom& g, int act, int wlayout, hipStream_t st) {
+    if constexpr (std::is_same<T, float>::value && std::is_same<TO, float>::value) {
+        // the edge convs in the fp32 modes (conv_thin_f32.hip): 4 channels on one side -- fp32 FMAs at memory speed instead of 7/8 padding
+        // on the matrix pipe
+        if (wlayout == 0 && g.ks == 3 && !g.ups && !g.zs && !g.sub && g.stride == 1 && g.pad == 1 && g.vh == g.h && g.vw == g.w &&
+            g_force_variant != 0) {
+            if (g.cout == 4 && (g.cin % 16) == 0 && (g.h % 8) == 0 && (g.w % 32) == 0)
+                return vqkd::launch_conv3x3_thin_out_f32((const float*)x, (const float*)w, bias, (const float*)res, (float*)y, g.n, g.h, g.w,
+                                                         g.cin, act, g.acc_scale, g.out_gain, st);
+            if (g.cin == 4 && (g.cout == 64 || g.cout == 128 || g.cout == 256) && !res && act == 0 && g.acc_scale == 1.0f &&
+                g.out_gain == 1.0f && g.w >= 2)
+                return vqkd::launch_conv3x3_thin_in_f32((const float*)x, (const float*)w, bias, (float*)y, g.n, g.h, g.w, g.cout, st);
+        }
+    }
     const int tw = halo_twlog(g);
     if (wlayout == 1 && sizeof(T) == 2 && g_force_variant != 3) {
         if (!tw) return VQK_ERR_SHAPE;
@@ -2699,6 +2712,8 @@ int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int co
     const int rc = make_geom(g, dtype, n, h_in, w_in, cin, cout, ksize, ups);
     if (rc) return rc;
     if (ksize == 1 && dtype != VQK_BF16) return 0;
+    if (dtype == VQK_F32 && cout == 4 && ksize == 3 && !ups && (cin % 16) == 0 && (g.h % 8) == 0 && (g.w % 32) == 0 && g_force_variant != 0)
+        return 0;                                                // the 3-channel head in the fp32 modes: conv_thin_f32.hip (plain weights)
     return (halo_twlog(g) && g_force_variant != 2) ? 1 : 0;
 }
 
@@ -2864,6 +2879,13 @@ static int wgrad_general(int dtype, const void* x, const void* dy, float* dw, in
         }
         VQK_CHECK_LAUNCH();
         return VQK_OK;
+    }
+    if (plain && dtype == VQK_F32 && ksize == 3 && mode == 0 && !g_det && !dy_pool && g_force_variant != 0 && (g.w % 4) == 0) {
+        // the edge convs' weight gradients in the fp32 modes (conv_thin_f32.hip)
+        if (cin == 4 && (cout == 64 || cout == 128 || cout == 256))
+            return vqkd::launch_conv3x3_wgrad_thin_f32(0, (const float*)dy, (const float*)x, dw, n, g.h, g.w, cout, dy_scale, vqk_stream(stream));
+        if (cout == 4 && (cin == 64 || cin == 128 || cin == 256))
+            return vqkd::launch_conv3x3_wgrad_thin_f32(1, (const float*)x, (const float*)dy, dw, n, g.h, g.w, cin, dy_scale, vqk_stream(stream));
     }
     const int kp = dtype == VQK_F32 ? 32 : 64;
     const int tiles = ((cout + 127) / 128) * ((cin + 127) / 128) * ksize * ksize;

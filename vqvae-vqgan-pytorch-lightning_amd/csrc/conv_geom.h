@@ -90,6 +90,13 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
 int launch_conv3x3_x3(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                       const ConvGeom& g, int act, int blocks_cap, hipStream_t st);
 
+// exact-fp32 kernels of the two edge convs (conv_thin_f32.hip): one side of the GEMM is the 4-channel (padded 3-channel) tensor
+int launch_conv3x3_thin_out_f32(const float* x, const float* w, const float* bias, const float* res, float* y, int n, int h, int wd,
+                                int cin, int act, float acc_scale, float out_gain, hipStream_t st);
+int launch_conv3x3_thin_in_f32(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cout, hipStream_t st);
+int launch_conv3x3_wgrad_thin_f32(int mode, const float* wide, const float* thin, float* dw, int n, int h, int w, int cw, float scale,
+                                  hipStream_t st);
+
 int launch_conv3x3_wgrad_mx(const void* x, const void* dy, float* dw, const void* zeros, const ConvGeom& g, int tiles,
                             int splits, int pps, hipStream_t st, float* part = nullptr);
 
