@@ -50,9 +50,36 @@ def run_config(args, world: int):
     return train_mod.derive_run_config(conf, world, over), path, over
 
 
+def _cpu_model() -> str:
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def _mem_available_gb() -> float:
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                return int(line.split()[1]) / 1048576.0
+    except Exception:
+        pass
+    return 0.0
+
+
 def cpu_baseline(run: dict, image_size: int, batch: int, steps: int):
-    """CPU oracle train step (fwd + bwd + AdamW), fp32, all host cores."""
+    """CPU oracle train step (fwd + bwd + AdamW), fp32, all host cores.  Default: ONE timed step at the headline batch (32) after
+    a warm-up step at batch 4 (the B = 32 workload itself, ~50 s); `--quick` / a box with too little free memory for
+    the torch-CPU autograd graph of 32 images (measured 1.9 GB per image at 256x256; 2.2 budgeted) times batch 4 and says so."""
     from oracle import vqvae_oracle as O
+    asked = batch
+    need_gb = 2.2 * batch * (image_size / 256.0) ** 2 + 8.0
+    while batch > 4 and _mem_available_gb() < need_gb:
+        batch //= 2
+        need_gb = 2.2 * batch * (image_size / 256.0) ** 2 + 8.0
     model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
     torch.manual_seed(1234)
     m = model_mod.VQVAE(image_size, run['ae_conf'], run['q_conf'], None, run['t_conf'])   # CPU tensors: init only
@@ -75,12 +102,16 @@ def cpu_baseline(run: dict, image_size: int, batch: int, steps: int):
     params0 = {k: v.clone() for k, v in params.items()}
     budget_t0 = time.perf_counter()
     for s in range(steps + 1):
-        if s >= 2 and time.perf_counter() - budget_t0 > 60.0:      # keep the default run within minutes
+        if s >= 2 and time.perf_counter() - budget_t0 > 90.0:      # keep the default run within minutes
             steps = s - 1
             break
         t0 = time.perf_counter()
-        r = O.train_step_mse(images, params, run['ae_conf']['num_res_blocks'], len(run['ae_conf']['channel_multipliers']),
-                             'standard', dict(commitment_cost=0.25))
+        # the warm-up step (thread pool, allocator, oneDNN primitive cache) runs on 4 images when the timed batch is larger
+        r = O.train_step_mse(images[:4] if (s == 0 and batch > 4) else images, params, run['ae_conf']['num_res_blocks'],
+                             len(run['ae_conf']['channel_multipliers']), 'standard', dict(commitment_cost=0.25))
+        if s == 0 and batch > 4:
+            times.append(time.perf_counter() - t0)
+            continue                                               # (no parameter update from the short warm-up: step 1 starts from params0)
         if first is None:
             first = r
         for k_, gr in r['grads'].items():
@@ -88,12 +119,13 @@ def cpu_baseline(run: dict, image_size: int, batch: int, steps: int):
                                                 1e-4 if k_ in decay else 0.0)
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / steps
-    return dict(value=round(batch / t, 4), unit='images/sec', cores=cores, kind='port',
-                # B = 32, or a smaller batch with an explicit flag -- images/s of a CPU conv step is flat in the
-                # batch size at these sizes, so the figure stands for the B = 32 workload; a B = 32 step takes minutes here
-                extrapolated_from_batch=batch,
-                sample=f'{steps} timed steps (+1 warm-up) of the same train step at batch {batch}, fp32, '
-                       f'torch-CPU oracle on {cores} threads; {t:.2f} s/step'), (params0, images, first)
+    return dict(value=round(batch / t, 4), unit='images/sec', cores=cores, kind='port', cpu=_cpu_model(),
+                # B = 32 (the default when the host has the memory), or a smaller batch with an explicit note --
+                # images/s of a CPU conv step is flat in the batch size at these sizes
+                batch=batch, extrapolated_from_batch=(None if batch == 32 else batch),
+                note=(None if batch == asked else f'batch {asked} asked, {batch} timed: {_mem_available_gb():.0f} GB of host memory available'),
+                sample=f'{steps} timed step(s) (+1 warm-up at batch {min(4, batch)}) of the same train step at batch {batch}, fp32, '
+                       f'torch-CPU oracle on {cores} threads of {_cpu_model()}; {t:.2f} s/step'), (params0, images, first)
 
 
 def parity_cost(run: dict, image_size: int, oracle_step, device) -> dict:
@@ -162,12 +194,20 @@ def other_configs(steps: int = 20, warmup: int = 5) -> dict:
     res = {}
     for label, argv in OTHER_CONFIGS.items():
         try:
-            j, r = _child(argv + ['--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline', '--no-kernel-events'])
+            j, r = _child(argv + ['--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline'])
             if j is None:
                 res[label] = dict(error=(r.stderr or r.stdout)[-300:])
             else:
-                res[label] = dict(ms_per_step=j['ms_per_step'], images_per_sec=j['value'], steps=j['steps'],
+                res[label] = dict(ms_per_step=j['ms_per_step'], images_per_sec=j['value'], steps=j['steps'], dtype=j['dtype'],
                                   launch=j['config']['launch'], workload=j['config']['workload'])
+                sr, rl = j.get('step_roofline'), j.get('roofline')
+                if sr:                            # the whole step against the matrix-pipe peak of its dtype, and its dominant kernel
+                    res[label].update(algorithmic_tflop=sr['algorithmic_tflop'], executed_tflop=sr['executed_tflop'],
+                                      frac_of_peak=sr['frac_of_peak'], executed_frac_of_peak=sr['executed_frac_of_peak'],
+                                      peak_tflops=sr['peak_tflops'], counted=sr['counted'])
+                if rl:
+                    res[label].update(dominant_kernel=rl['kernel'], dominant_kernel_avg_launch_us=rl['avg_kernel_launch_us'],
+                                      dominant_kernel_frac=rl['frac'], dominant_kernel_ms_per_step=round(rl['kernel_time_frac_of_step'] * j['ms_per_step'], 3))
         except Exception as exc:
             res[label] = dict(error=f'{type(exc).__name__}: {exc}')
     return res
@@ -349,8 +389,9 @@ def main():
     ap.add_argument('--gan', action='store_true', help='VQ-GAN criterion of gumbel_vqgan.yaml (LPIPS + StyleGAN2 discriminator, non-saturating, R1 every 16 steps)')
     ap.add_argument('--codebook', type=int, default=None, help='override quantizer.num_embeddings of the YAML')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=4)
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-batch', type=int, default=32, help='batch of the timed CPU-oracle step (cpu_baseline); halved until it fits the host memory')
+    ap.add_argument('--cpu-steps', type=int, default=1)
+    ap.add_argument('--quick', action='store_true', help='cpu_baseline at batch 4 x 3 steps (extrapolated_from_batch = 4), as in rounds 1-5')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel eagerly instead of replaying a hipGraph')
     ap.add_argument('--allow-eager', action='store_true',
@@ -368,6 +409,8 @@ def main():
     args = ap.parse_args()
     if os.environ.get('VQK_BENCH_CHILD') == '1':
         args.no_other_configs, args.traffic, args.sustain_s = True, 'off', 0.0
+    if args.quick:
+        args.cpu_batch, args.cpu_steps = 4, 3
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the train step is HIP kernels only (no CPU fallback)')
@@ -427,7 +470,8 @@ def main():
             # VQK_TILE_QUEUE in the environment pins the form instead.
             pinned = 'VQK_OVERLAP_ALLREDUCE' in os.environ or 'VQK_TILE_QUEUE' in os.environ
             if dist.is_initialized() and not args.gan and not pinned:
-                forms = [('overlap_queue', True, 2), ('overlap', True, 0), ('flat', False, 0)]
+                # (mode 1 = what init_distributed gives train.py users by default: first tile static, the rest drawn)
+                forms = [('overlap_queue', True, 2), ('overlap_queue1', True, 1), ('overlap', True, 0), ('flat', False, 0)]
                 comm_ab, trainers = {}, {}
                 for name, overlap, tq in forms:
                     native.check(native.lib().vqk_set_tuning(b'TILE_QUEUE', tq), 'set_tuning')
@@ -461,6 +505,7 @@ def main():
                     raise RuntimeError('none of the three reduction forms could be captured')
                 best = min(timed, key=lambda f: comm_ab[f[0] + '_ms'])[0]
                 comm_ab['chosen'] = best
+                comm_ab['tile_queue_mode'] = dict((f[0], f[2]) for f in forms)[best]
                 trainer, tq = trainers[best]
                 model.trainer = trainer
                 native.check(native.lib().vqk_set_tuning(b'TILE_QUEUE', tq), 'set_tuning')     # (the eager event pass launches with it too)
@@ -495,6 +540,7 @@ def main():
         loss = step_fn(model, images, args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    ops.check_kernel_health()          # a timed-out GroupNorm cluster = wrong gradients: the line must not be printed as if nothing happened
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     sustained = None
     if world == 1 and args.sustain_s > 0:
@@ -624,6 +670,24 @@ def main():
                                               hbm_frac=round(v[3] / v[2] / HBM_PEAK_BPS, 3)))
                                      for k, v in by_kernel.items()})
 
+    # the WHOLE step against the matrix-pipe peak: algorithmic FLOPs of every timed matrix-pipe event of one step (convs of the
+    # autoencoder / LPIPS / discriminator, the quantizer's GEMM-shaped launches that go through the conv kernels) plus the
+    # quantizer's distance evaluations (2 N K D each; standard / EMA / Gumbel lookup: one; entropy: forward + the backward's
+    # recomputation, exact-fp32 MFMA, priced at the step's peak like everything else)
+    step_roofline = None
+    if events:
+        nvec = args.batch * (args.image_size // 16) ** 2
+        dist_evals = 2 if qtype == 'entropy' else 0 if qtype == 'gumbel' else 1      # (Gumbel: the code lookup is a timed GEMM event)
+        dist_tflop = dist_evals * 2.0 * nvec * codebook * run['q_conf']['embedding_dim'] / 1e12
+        alg = sum(e[1] for e in events) / event_steps / 1e12 + dist_tflop
+        exe = sum(e[6] for e in events) / event_steps / 1e12 + dist_tflop
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        ms = elapsed / args.steps * 1e3
+        step_roofline = dict(algorithmic_tflop=round(alg, 3), executed_tflop=round(exe, 3), peak_tflops=peak,
+                             frac_of_peak=round(alg / (ms * 1e-3) / peak, 4), executed_frac_of_peak=round(exe / (ms * 1e-3) / peak, 4),
+                             quantizer_distance_tflop=round(dist_tflop, 4),
+                             counted='timed conv / GEMM events of one step + the quantizer distance evaluations; wall time of the replayed step')
+
     result_line = None
     vq_kernel = None
     if rank == 0 and not args.no_kernel_events:
@@ -667,7 +731,7 @@ def main():
                                deterministic=bool(ops.DETERMINISTIC), final_loss=round(float(loss.item()), 6),
                                rccl_ranks=None if comm is None else comm['rccl_ranks'],
                                collectives_per_step=0 if comm is None else comm['collectives_per_step']),
-                   roofline=roofline, cpu_baseline=cpu, vq_kernel=vq_kernel, sustained=sustained, comm=comm,
+                   roofline=roofline, step_roofline=step_roofline, cpu_baseline=cpu, vq_kernel=vq_kernel, sustained=sustained, comm=comm,
                    bf16_vs_fp32_oracle=parity, box_calibration=calib)
         if degraded is not None:
             out['degraded'] = degraded

@@ -499,3 +499,58 @@ def test_vqgan_disc_half_two_streams_equals_one_stream():
     finally:
         loss_mod.DISC_REAL_SIDE_STREAM = True
         ops.aux_stream = orig
+
+
+@pytest.mark.parametrize('r1_every,share', [(2, True), (1000, True), (2, False)])
+def test_vqgan_graphed_optimizer_overlap_equals_serial(r1_every, share):
+    """trainer.GAN_OPT_OVERLAP (on by default): the autoencoder's all-reduce + AdamW + operand refresh run on a second stream beside
+    the replayed discriminator half.  Correct only while that graph reads nothing the AE optimizer writes -- checked here instead of
+    assumed: in deterministic mode (ordered sums, no atomics) the weights of both optimizers after four replayed steps are BIT-equal
+    to the serial order, with and without an R1 step among them and with the shared D(fake) pass off."""
+    model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
+    trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
+    loss_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.loss.loss')
+    ae = dict(channels=32, num_res_blocks=1, channel_multipliers=(1, 2))
+    qc = dict(num_embeddings=64, embedding_dim=16, reinit_every_n_epochs=None, type='gumbel',
+              params=dict(straight_through=False, temp=1.0, kl_cost=5e-4, kl_warmup_epochs=0.5, temp_decay_epochs=2, temp_final=0.25))
+    lc = dict(l1_weight=0.8, l2_weight=0.2, perc_weight=1.0,
+              adversarial_params=dict(start_epoch=0, loss_type='non-saturating', g_weight=0.1, use_adaptive=False,
+                                      r1_reg_weight=10.0, r1_reg_every=r1_every))
+    tc = dict(lr=1e-4, betas=(0.0, 0.99), eps=1e-8, weight_decay=1e-4, warmup_epochs=None, decay_epochs=None)
+    images = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
+    saved = (trainer_mod.GAN_OPT_OVERLAP, loss_mod.SHARE_FAKE_PASS)
+
+    def run(overlap):
+        trainer_mod.GAN_OPT_OVERLAP, loss_mod.SHARE_FAKE_PASS = overlap, share
+        torch.manual_seed(0)
+        m = model_mod.VQVAE(64, ae, qc, lc, tc).to(DEV).train()
+        tr = trainer_mod.MiniTrainer(num_training_batches=6, deterministic=True)
+        tr.attach(m)
+        m.on_train_start()
+        torch.manual_seed(1)
+        tr.capture(m, images, warmup=2)
+        torch.manual_seed(2)
+        losses = [float(tr.train_batch_graphed(m, images, 2 + i)) for i in range(4)]
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    try:
+        l1, s1 = run(True)
+        l0, s0 = run(False)
+    finally:
+        trainer_mod.GAN_OPT_OVERLAP, loss_mod.SHARE_FAKE_PASS = saved
+        ops.set_deterministic(False)
+    # deterministic mode makes every gradient SUM ordered; a handful of loss-side reductions (LPIPS spatial means) still add in
+    # arrival order, so "equal" is: within 2e-6 of the tensor's magnitude (a race on an optimizer-owned tensor moves weights by
+    # ~lr = 1e-4 per step) -- and bit-equal wherever the run itself is bit-reproducible
+    np.testing.assert_allclose(l1, l0, rtol=1e-5)
+    worst = 0.0
+    for k in s0:
+        if s0[k].dtype.is_floating_point:
+            d = float((s0[k].double() - s1[k].double()).abs().max()) / (float(s0[k].double().abs().max()) + 1e-12)
+            worst = max(worst, d)
+            assert d <= 2e-6, (k, d)
+    print(f'GAN optimizer overlap vs serial: worst relative weight difference {worst:.1e}, '
+          f'{sum(1 for k in s0 if torch.equal(s0[k], s1[k]))}/{len(s0)} tensors bit-equal')
+    moved = sum(1 for k in s0 if k.startswith('criterion.discriminator') and s0[k].dtype.is_floating_point)
+    assert moved > 5

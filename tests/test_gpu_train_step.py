@@ -81,7 +81,7 @@ def test_train_step_fp32_golden(golden, qtype, products):
         tol = dict(rtol=1e-5, atol=1e-7) if products == torch.float32 else dict(rtol=1e-4, atol=5e-6)
         np.testing.assert_allclose(m.quantizer.ema_weight.cpu().numpy(), g['after.ema_weight'], **tol)
         np.testing.assert_allclose(m.quantizer.codebook.weight.detach().cpu().numpy(), g['after.codebook.weight'],
-                                   rtol=1e-4, atol=1e-6)
+                                   rtol=1e-4, atol=1e-6 if products == torch.float32 else 2e-5)      # (= ema_weight / count: same inheritance)
     if qtype == 'standard':                       # one AdamW step with the reference's two groups
         opt.step()
         decay = {n for n, _ in m.optimizer_groups()[0]}

@@ -103,6 +103,19 @@ def x3_serves(dtype, out_dtype, h_out: int, w_out: int, cin: int, cout: int, ksi
             and h_out % 8 == 0 and w_out % 16 == 0)
 
 
+def check_kernel_health() -> None:
+    """Raise if a kernel of the run reported that it gave up on a cross-block rendezvous (the cluster GroupNorm backward's bounded
+    spin, csrc/norm.hip: a block that times out continues with INCOMPLETE sums -- a wrong gradient, not a hang).  Synchronises the
+    device: called where a run synchronises anyway (end of an epoch, before a checkpoint is written, end of the benchmark's timed
+    region), never inside a step."""
+    import ctypes
+    cnt = ctypes.c_int(0)
+    _native.check(_native.lib().vqk_gn_cluster_timeouts(ctypes.byref(cnt)), 'gn_cluster_timeouts')
+    if cnt.value:
+        raise RuntimeError(f'vqk: {cnt.value} GroupNorm cluster block(s) timed out waiting for their partners: the gradients of this run '
+                           'are not trustworthy (set the tuning slot GN_CLUSTER_MAX_HW to 0 for the two-kernel passes)')
+
+
 def set_deterministic(on: bool) -> None:
     """``pl.Trainer(deterministic=True)`` (vqvae/train.py:130) for the vqk kernels: ordered partial sums instead of atomics in
     arrival order (include/vqk.h: vqk_set_deterministic); the GroupNorm sums are no longer fused into the conv drains (those

@@ -198,6 +198,7 @@ def main(argv=None):
         for i, batch in enumerate(batches):
             loss = step(model, batch, i)
         model.on_train_epoch_end()
+        importlib.import_module(PKG + '.ops').check_kernel_health()       # a kernel that gave up on a rendezvous = untrustworthy gradients: stop
         if rank == 0:
             print(f'[epoch {epoch}] loss {float(loss):.6f}', flush=True)
         if args.save_path and (epoch + 1) % args.save_every_n_epochs == 0:

@@ -423,6 +423,7 @@ class MiniTrainer:
         'lr_schedulers' and the version stamp are absent: ``Trainer.fit(ckpt_path=...)`` of real Lightning needs those).
         Rank 0 writes (temporary file + rename), every rank waits."""
         import torch.distributed as dist
+        ops.check_kernel_health()                       # never persist weights stepped on a corrupted gradient
         distributed = dist.is_available() and dist.is_initialized()
         if not distributed or dist.get_rank() == 0:
             sd = {k: v.detach().clone(memory_format=torch.contiguous_format).cpu() for k, v in model.state_dict().items()}
@@ -474,5 +475,6 @@ class MiniTrainer:
             for i, batch in enumerate(batches):
                 loss = self.train_batch(model, batch, i)
             model.on_train_epoch_end()
+            ops.check_kernel_health()                   # (the epoch end synchronises for the code-usage statistics anyway)
         model.on_train_end()
         return loss
