@@ -399,3 +399,101 @@ def test_rccl_two_ranks_equal_big_batch():
         p.join(600)
         assert p.exitcode == 0
     assert out.get() == 'ok'
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Two RANKS through the HIP path on ONE GPU.  RCCL refuses two ranks on one device, gloo does not: both
+# ranks open cuda:0, every product collective (ranged gradient all-reduces between the three captured graphs, the EMA statistics
+# all-reduce behind the replay, the two optimizers' reductions of the VQ-GAN step) goes through gloo on CUDA tensors.  This is
+# the rank-divergent control flow around hipGraph replay that world-1 runs (forced RCCL) and CPU gloo runs cannot show:
+# capture on two ranks at once, the tile queue armed (init_distributed, world > 1), async collective + wait between replays.
+# Yardstick: the data-parallel run on two half batches follows the single-process run on the concatenated batch.
+# ------------------------------------------------------------------------------------------------------------------------
+def _env_one_gpu(rank, world, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', VQK_SPLIT_ENCODER_FRACTION='0.5')
+
+
+def _graphed_run(kind, images, steps, world):
+    """``steps`` replayed train steps of a small model on ``images`` (this rank's batch) -> (losses, weights, collectives issued)"""
+    model_mod = importlib.import_module(PKG + '.model')
+    trainer_mod = importlib.import_module(PKG + '.trainer')
+    torch.manual_seed(0)
+    if kind == 'gan':
+        m = model_mod.VQVAE(64, AE, GAN_STD_Q, GAN_L, dict(TC, lr=TRAJ_LR))
+    else:
+        m = model_mod.VQVAE(32, AE, _qc(kind), None, dict(TC, lr=TRAJ_LR))
+    with torch.no_grad():
+        m.quantizer.codebook.weight.mul_(32.0)
+    m = m.to('cuda:0').train()
+    tr = trainer_mod.MiniTrainer(num_training_batches=100)
+    opts = tr.attach(m)
+    m.on_train_start()
+    tr.capture(m, images, warmup=2, preserve_state=True)          # the settling steps do not train: both runs start from the same weights
+    n0 = sum(o.collectives_issued for o in opts)
+    losses = [float(tr.train_batch_graphed(m, images, i).detach()) for i in range(steps)]
+    torch.cuda.synchronize()
+    graphs = sum(1 for g in (tr._graph, getattr(tr, '_graph2', None), getattr(tr, '_graph3', None)) if g is not None)
+    return losses, {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}, \
+        (sum(o.collectives_issued for o in opts) - n0, graphs)
+
+
+def _one_gpu_images(kind):
+    g = torch.Generator().manual_seed(31)
+    size = 64 if kind == 'gan' else 32
+    return [torch.rand(4, 3, size, size, generator=g) for _ in range(2)]
+
+
+def _gloo_one_gpu_worker(rank, port, kind, steps, out):
+    _env_one_gpu(rank, 2, port)
+    trainer_mod = importlib.import_module(PKG + '.trainer')
+    r, local, world = trainer_mod.init_distributed('gloo')
+    assert dist.is_initialized() and dist.get_backend() == 'gloo' and world == 2 and local == 0
+    torch.cuda.set_device(0)
+    parts = _one_gpu_images(kind)
+    losses, state, (ncoll, graphs) = _graphed_run(kind, parts[rank].to('cuda:0'), steps, 2)
+    dist.barrier()
+    out.put((rank, losses, {k: v.numpy() for k, v in state.items()}, ncoll, graphs))     # by value: the child exits before the parent reads
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['standard', 'ema', 'gan'])
+def test_two_ranks_on_one_gpu_gloo_graph_replay_equals_big_batch(kind):
+    steps = 3
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = {'standard': 29651, 'ema': 29652, 'gan': 29653}[kind]
+    procs = [ctx.Process(target=_gloo_one_gpu_worker, args=(r, port, kind, steps, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, losses, state, ncoll, graphs = out.get()
+        got[rank] = (losses, {k: torch.from_numpy(v) for k, v in state.items()}, ncoll, graphs)
+    for p in procs:
+        p.join(600)                                                # no deadlock between capture, replay and the collectives
+        assert p.exitcode == 0
+    # the same step on the concatenated batch, one process, no process group (VQ-GAN: interleaved, so that the minibatch-stddev
+    # groups of the big batch are the ranks' batches)
+    parts = _one_gpu_images(kind)
+    big = _interleave(parts) if kind == 'gan' else torch.cat(parts, 0)
+    l_big, s_big, _ = _graphed_run(kind, big.to('cuda:0'), steps, 1)
+    (l0, s0, n0, g0), (l1, s1, n1, g1) = got[0], got[1]
+    # data parallel: three captured graphs and three ranged all-reduces per step (+ the EMA statistics); VQ-GAN: two optimizers
+    per_step = {'standard': 3, 'ema': 3, 'gan': 2}[kind]
+    assert n0 == n1 == per_step * steps, (n0, n1)
+    assert g0 == g1 == (3 if kind != 'gan' else g0)
+    # both ranks hold the same weights, and they are the big-batch run's (beta1 = 0: a step is ~lr * sign(g); a sign flip of a
+    # ~1e-9 gradient element moves that weight by 2 lr -- the yardstick of test_rccl_collectives_world1_graph_replay)
+    bad = total = 0
+    for k in s_big:
+        if not s_big[k].dtype.is_floating_point:
+            continue
+        assert torch.equal(s0[k], s1[k]), k                        # identical replicas: same reduced gradients, same update
+        assert (s0[k] - s_big[k]).abs().max().item() <= steps * 2.1 * TRAJ_LR + 1e-5 * s_big[k].abs().max().item(), k
+        bad += (~torch.isclose(s0[k], s_big[k], rtol=2e-3, atol=1e-5)).sum().item()
+        total += s_big[k].numel()
+    assert bad <= 0.02 * total, (kind, bad, total)
+    if kind != 'gan':
+        np.testing.assert_allclose(0.5 * (np.array(l0) + np.array(l1)), l_big, rtol=2e-3)

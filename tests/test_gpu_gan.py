@@ -505,8 +505,10 @@ def test_vqgan_disc_half_two_streams_equals_one_stream():
 def test_vqgan_graphed_optimizer_overlap_equals_serial(r1_every, share):
     """trainer.GAN_OPT_OVERLAP (on by default): the autoencoder's all-reduce + AdamW + operand refresh run on a second stream beside
     the replayed discriminator half.  Correct only while that graph reads nothing the AE optimizer writes -- checked here instead of
-    assumed: in deterministic mode (ordered sums, no atomics) the weights of both optimizers after four replayed steps are BIT-equal
-    to the serial order, with and without an R1 step among them and with the shared D(fake) pass off."""
+    assumed, with and without an R1 step among the four replayed steps and with the shared D(fake) pass off: the weights of both
+    optimizers match the serial order bit for bit when the run itself is bit-reproducible, and otherwise (measured: the VQ-GAN step
+    is not, even in deterministic mode -- 51 of 135 tensors bit-equal between two serial runs, 3e-4 = 3 lr apart) deviate from it
+    no more than two serial runs deviate from each other."""
     model_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.model')
     trainer_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.trainer')
     loss_mod = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd.modules.loss.loss')
@@ -530,27 +532,35 @@ def test_vqgan_graphed_optimizer_overlap_equals_serial(r1_every, share):
         torch.manual_seed(1)
         tr.capture(m, images, warmup=2)
         torch.manual_seed(2)
-        losses = [float(tr.train_batch_graphed(m, images, 2 + i)) for i in range(4)]
+        losses = [float(tr.train_batch_graphed(m, images, 2 + i).detach()) for i in range(4)]
         torch.cuda.synchronize()
         return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}
 
     try:
-        l1, s1 = run(True)
         l0, s0 = run(False)
+        l0b, s0b = run(False)
+        l1, s1 = run(True)
     finally:
         trainer_mod.GAN_OPT_OVERLAP, loss_mod.SHARE_FAKE_PASS = saved
         ops.set_deterministic(False)
-    # deterministic mode makes every gradient SUM ordered; a handful of loss-side reductions (LPIPS spatial means) still add in
-    # arrival order, so "equal" is: within 2e-6 of the tensor's magnitude (a race on an optimizer-owned tensor moves weights by
-    # ~lr = 1e-4 per step) -- and bit-equal wherever the run itself is bit-reproducible
-    np.testing.assert_allclose(l1, l0, rtol=1e-5)
-    worst = 0.0
-    for k in s0:
-        if s0[k].dtype.is_floating_point:
-            d = float((s0[k].double() - s1[k].double()).abs().max()) / (float(s0[k].double().abs().max()) + 1e-12)
-            worst = max(worst, d)
-            assert d <= 2e-6, (k, d)
-    print(f'GAN optimizer overlap vs serial: worst relative weight difference {worst:.1e}, '
-          f'{sum(1 for k in s0 if torch.equal(s0[k], s1[k]))}/{len(s0)} tensors bit-equal')
+
+    def dev(a, b):
+        worst, nbit = 0.0, 0
+        for k in a:
+            if a[k].dtype.is_floating_point:
+                worst = max(worst, float((a[k].double() - b[k].double()).abs().max()))
+            nbit += int(torch.equal(a[k], b[k]))
+        return worst, nbit
+    base, nb = dev(s0, s0b)
+    got, ng = dev(s0, s1)
+    print(f'GAN optimizer overlap: serial vs serial {base:.2e} ({nb}/{len(s0)} tensors bit-equal), overlap vs serial {got:.2e} ({ng}/{len(s0)})')
+    if nb == len(s0):
+        # the run is bit-reproducible in deterministic mode: the overlapped order has to be, too
+        assert ng == len(s0) and l1 == l0, [k for k in s0 if not torch.equal(s0[k], s1[k])][:5]
+    else:
+        # (beta1 = 0: a step is ~lr * sign(g); where a reduction still adds in arrival order a ~1e-9 gradient element flips its
+        # sign run to run and moves that weight by 2 lr) -- the overlapped order may not deviate more than two serial runs do
+        assert got <= max(2.0 * base, 4 * 2.1 * 1e-4), (got, base)
+        np.testing.assert_allclose(l1, l0, rtol=max(1e-4, 10 * max(abs(a - b) / abs(b) for a, b in zip(l0b, l0))))
     moved = sum(1 for k in s0 if k.startswith('criterion.discriminator') and s0[k].dtype.is_floating_point)
     assert moved > 5
