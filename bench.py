@@ -213,27 +213,34 @@ def other_configs(steps: int = 20, warmup: int = 5) -> dict:
     return res
 
 
+GN_FAMILIES = {      # bench event name -> kernel symbols behind it (csrc/norm.hip)
+    'group_norm_fwd (HBM)': ('gn_stats_kernel', 'gn_apply_fin_kernel', 'gn_apply_kernel', 'gn_small_fwd_kernel'),
+    'group_norm_bwd (HBM)': ('gn_bwd_reduce_kernel', 'gn_bwd_apply_kernel', 'gn_small_bwd_kernel', 'gn_cluster_bwd_kernel',
+                             'gn_bwd_finish_kernel'),
+}
+
+
 def measure_traffic(kernel_sub: str, events_per_step: int, argv):
-    """HBM bytes per bench event of the dominant kernel, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE --
-    separate passes, counters only, as MI355X_MICROARCH.md prescribes) over a 2-step eager run of this same command;
-    bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB units; gfx950 tallies wide coalesced reads at half).  (None, None) when
-    rocprofv3 is absent or a pass fails."""
+    """HBM bytes per bench event of the dominant kernel -- and per STEP of the GroupNorm kernel families -- measured now: two
+    rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- separate passes, counters only, as MI355X_MICROARCH.md prescribes) over a
+    2-step eager run of this same command; bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB units; gfx950 tallies wide coalesced reads
+    at half).  (None, None, {}) when rocprofv3 is absent or a pass fails."""
     import shutil
     import sqlite3
     import tempfile
     prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
     if prof is None:
-        return None, None
+        return None, None, {}
     keep = []
     skip = {'--steps', '--warmup', '--sustain-s', '--traffic', '--cpu-batch', '--cpu-steps'}
     it = iter(argv)
     for a in it:
         if a in skip:
             next(it, None)
-        elif a not in ('--no-graph', '--no-cpu-baseline', '--no-kernel-events', '--no-other-configs'):
+        elif a not in ('--no-graph', '--no-cpu-baseline', '--no-kernel-events', '--no-other-configs', '--quick'):
             keep.append(a)
     steps = 2
-    total = {}
+    total, fam = {}, {k: {} for k in GN_FAMILIES}
     try:
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
             d = tempfile.mkdtemp(prefix=f'vqk_pmc_{ctr}_', dir='/tmp')
@@ -249,30 +256,40 @@ def measure_traffic(kernel_sub: str, events_per_step: int, argv):
                     os.environ['TMPDIR'] = env_tmp
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith('.db')]
             if not dbs:
-                return None, None
+                return None, None, {}
             db = sqlite3.connect(dbs[0])
             tables = [r_[0] for r_ in db.execute("select name from sqlite_master where type='table'")]
             t = lambda pfx: next(x for x in tables if x.startswith(pfx))
             kd, ks, pe, pi = t('rocpd_kernel_dispatch'), t('rocpd_info_kernel_symbol'), t('rocpd_pmc_event'), t('rocpd_info_pmc')
             cols = [r_[1] for r_ in db.execute(f'pragma table_info({ks})')]
             name_col = 'display_name' if 'display_name' in cols else 'kernel_name'
-            q = (f'select sum(e.value), count(*) from {pe} e join {pi} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id '
-                 f"join {ks} s on d.kernel_id = s.id where p.name = '{ctr}' and s.{name_col} like '%{kernel_sub}%' "
-                 f"and s.{name_col} not like '%, 1, 256>%'")          # (the NTAP = 1 instantiations are the 1x1 convs: their own line)
+            base = (f'select sum(e.value), count(*) from {pe} e join {pi} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id '
+                    f"join {ks} s on d.kernel_id = s.id where p.name = '{ctr}' and ")
+            q = base + (f"s.{name_col} like '%{kernel_sub}%' "
+                        f"and s.{name_col} not like '%, 1, 256>%'")          # (the NTAP = 1 instantiations are the 1x1 convs: their own line)
             tot, n = db.execute(q).fetchone()
+            for fname, syms in GN_FAMILIES.items():
+                cond = ' or '.join(f"s.{name_col} like '%{sym}%'" for sym in syms)
+                ft, fn = db.execute(base + f'({cond})').fetchone()
+                fam[fname][ctr] = (float(ft or 0.0), int(fn or 0))
             db.close()
             shutil.rmtree(d, ignore_errors=True)
             if not n:
-                return None, None
+                return None, None, {}
             total[ctr] = (float(tot), int(n))
         # (warmup 1 + 2 timed) eager steps were traced: every step launches the same kernels
         traced_steps = steps + 1
         kib = (2.0 * total['FETCH_SIZE'][0] + total['WRITE_SIZE'][0]) / traced_steps / events_per_step
+        fam_bytes = {k: dict(hbm_bytes_per_step=int((2.0 * v['FETCH_SIZE'][0] + v['WRITE_SIZE'][0]) / traced_steps * 1024),
+                             fetch_bytes_per_step=int(2.0 * v['FETCH_SIZE'][0] / traced_steps * 1024),
+                             write_bytes_per_step=int(v['WRITE_SIZE'][0] / traced_steps * 1024),
+                             kernel_launches_per_step=v['FETCH_SIZE'][1] // traced_steps)
+                     for k, v in fam.items() if v.get('FETCH_SIZE', (0, 0))[1]}
         return int(kib * 1024), (f'measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over {traced_steps} '
-                                 f'eager steps, {total["FETCH_SIZE"][1]} kernel launches; 2*FETCH_SIZE + WRITE_SIZE per bench event')
+                                 f'eager steps, {total["FETCH_SIZE"][1]} kernel launches; 2*FETCH_SIZE + WRITE_SIZE per bench event'), fam_bytes
     except Exception as exc:
         print(f'[bench] traffic pass failed ({type(exc).__name__}: {exc})', file=sys.stderr)
-        return None, None
+        return None, None, {}
 
 
 # Reference box of the committed profile set (profiles/README.md lists every box of the round with these two figures): the
@@ -631,9 +648,9 @@ def main():
             rec[4] += nlaunch
             rec[5] += xflops
         name, (count, flops, secs, nbytes, klaunches, xflops) = max(((k, v) for k, v in by_kernel.items() if v[1] > 0), key=lambda kv: kv[1][2])
-        traffic, traffic_source = None, None
+        traffic, traffic_source, fam_traffic = None, None, {}
         if rank == 0 and world == 1 and args.traffic == 'auto':
-            traffic, traffic_source = measure_traffic(name.split('<')[0], count // event_steps, sys.argv[1:])
+            traffic, traffic_source, fam_traffic = measure_traffic(name.split('<')[0], count // event_steps, sys.argv[1:])
         if traffic is None:
             try:                               # HBM bytes per launch from the committed rocprofv3 --pmc passes
                 for tag in ('round3', 'round2', 'round1'):
@@ -669,6 +686,17 @@ def main():
                                               algorithmic_tbps=round(v[3] / v[2] / 1e12, 2),
                                               hbm_frac=round(v[3] / v[2] / HBM_PEAK_BPS, 3)))
                                      for k, v in by_kernel.items()})
+        # measured HBM bytes of the GroupNorm passes against their algorithmic bytes: > 1.1 would be wasted re-reads
+        for k, fb in fam_traffic.items():
+            if k in roofline['all_kernels'] and k in by_kernel and by_kernel[k][3] > 0:
+                alg = by_kernel[k][3] / event_steps
+                roofline['all_kernels'][k].update(measured_hbm_bytes_per_step=fb['hbm_bytes_per_step'],
+                                                  algorithmic_bytes_per_step=int(alg),
+                                                  traffic_over_algorithmic=round(fb['hbm_bytes_per_step'] / alg, 3),
+                                                  measured_tbps=round(fb['hbm_bytes_per_step'] / (by_kernel[k][2] / event_steps) / 1e12, 2),
+                                                  traffic_source='rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE of this run (2*FETCH + WRITE, eager steps)')
+        if fam_traffic:
+            roofline['gn_traffic'] = fam_traffic
 
     # the WHOLE step against the matrix-pipe peak: algorithmic FLOPs of every timed matrix-pipe event of one step (convs of the
     # autoencoder / LPIPS / discriminator, the quantizer's GEMM-shaped launches that go through the conv kernels) plus the
