@@ -256,7 +256,12 @@ int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw
  * of ONE launch of the bf16 matrix/auxiliary-wave weight-gradient kernel (csrc/conv_wgmx.hip), folded by its atomic pass.
  * cin % 64 == 0, cout % 64 == 0, h % 8 == 0, w % 16 == 0; VQK_ERR_SHAPE when not served (deterministic mode included:
  * nothing launched, callers use the exact-fp32 vqk_conv2d_wgrad). */
+/* vqk_conv2d_wgrad_x3_f32: the same gradient straight from the fp32 tensors x [n][h_in][w_in][cin], dy [n][h][w][cout] -- both are
+ * split in registers on their way into LDS and all three products come from one staged patch (csrc/conv_x3.hip:
+ * conv3x3_wgrad_x3_kernel; no pair tensors, no split passes).  cin % 64 == 0, cout % 64 == 0, h % 8 == 0, w % 8 == 0. */
 int vqk_split_pair_f32(const float* src, void* dst, int64_t rows, int c, void* stream);
+int vqk_conv2d_wgrad_x3_f32(const float* x, const float* dy, float* dw, int n, int h_in, int w_in, int cin, int cout, int ups,
+                            float scale, void* stream);
 int vqk_conv2d_wgrad_x3(const void* x_pair, const void* dy_pair, float* dw, int n, int h_in, int w_in, int cin, int cout, int ups,
                         float scale, const void* zeros, void* stream);
 /* the same with dW += scale * (the gradient): a layer whose backward carries a scalar gain (the discriminator's linear skip convs:

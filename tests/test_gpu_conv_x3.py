@@ -123,8 +123,13 @@ def test_split_pair_is_hi_lo():
     assert float(rel) < 2.0 ** -16
 
 
-@pytest.mark.parametrize('n,cin,cout,h,w,ups', [(2, 128, 128, 32, 32, 0), (3, 64, 256, 16, 48, 0), (2, 256, 64, 8, 16, 1), (4, 512, 512, 16, 16, 0)])
-def test_x3_wgrad_matches_fp64(n, cin, cout, h, w, ups):
+@pytest.mark.parametrize('fold', [False, True])
+@pytest.mark.parametrize('n,cin,cout,h,w,ups', [(2, 128, 128, 32, 32, 0), (3, 64, 256, 16, 48, 0), (2, 256, 64, 8, 16, 1), (4, 512, 512, 16, 16, 0),
+                                                (5, 128, 64, 24, 16, 0), (1, 64, 64, 8, 8, 1)])
+def test_x3_wgrad_matches_fp64(n, cin, cout, h, w, ups, fold, monkeypatch):
+    """fold = False: conv3x3_wgrad_x3_kernel (both operands split in registers, three products per staged fragment pair);
+    True: the pair-tensor form (vqk_split_pair_f32 twice + the folded bf16 role-split kernel)"""
+    monkeypatch.setattr(ops, 'X3_WGRAD_FOLD', fold)
     g = torch.Generator(device=DEV).manual_seed(cin + 2 * cout + h + ups)
     s = 2 if ups else 1
     x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)

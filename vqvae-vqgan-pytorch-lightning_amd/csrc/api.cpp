@@ -104,7 +104,9 @@ static TuneSlot g_tune[] = {
     {"VQ_LDS", 0, 0},
     {"UPS_MERGE", 0, 0},
     {"TILE_QUEUE", 0, 0},
-    {"X3_WL", 0, 0}
+    {"X3_WL", 0, 0},
+    {"X3_WGRAD_COEF_E4", 0, 0},
+    {"X3_WGRAD_FOLD", 0, 0}
 };
 static constexpr int kTune = (int)(sizeof(g_tune) / sizeof(g_tune[0]));
 TuneSlot* tune_slot(const char* name) {

@@ -2940,6 +2940,20 @@ int vqk_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw, int n,
                          zeros, stream);
 }
 
+int vqk_conv2d_wgrad_x3_f32(const float* x, const float* dy, float* dw, int n, int h_in, int w_in, int cin, int cout, int ups,
+                            float scale, void* stream) {
+    // split-product weight gradient straight from the fp32 tensors (csrc/conv_x3.hip: conv3x3_wgrad_x3_kernel)
+    VQK_REQUIRE(x && dy && dw, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy), VQK_ERR_ALIGN);
+    VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
+    ConvGeom g;
+    const int rc = make_geom(g, VQK_F32, n, h_in, w_in, cin, cout, 3, ups);
+    if (rc) return rc;
+    VQK_REQUIRE(!g_det && g_force_variant != 0, VQK_ERR_SHAPE);      // atomics only: deterministic mode keeps the exact-fp32 kernel
+    g.acc_scale = scale;
+    return vqkd::launch_conv3x3_wgrad_x3(x, dy, dw, g, g_wgrad_blocks, vqk_stream(stream));
+}
+
 int vqk_conv2d_wgrad_x3(const void* x_pair, const void* dy_pair, float* dw, int n, int h_in, int w_in, int cin, int cout, int ups,
                         float scale, const void* zeros, void* stream) {
     // x_pair [n, h_in, w_in, 2 cin], dy_pair [n, h, w, 2 cout] bf16 (vqk_split_pair_f32); dw fp32 [cout][3][3][cin] +=

@@ -89,6 +89,8 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
 // split-product 3x3 conv (conv_x3.hip): fp32 in / out, three bf16 products per multiply-add; weights in layout 5
 int launch_conv3x3_x3(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                       const ConvGeom& g, int act, int blocks_cap, hipStream_t st);
+// ... and its weight gradient straight from the fp32 tensors (no pair tensors): fp32 atomics into dw
+int launch_conv3x3_wgrad_x3(const void* x, const void* dy, float* dw, const ConvGeom& g, int blocks_cap, hipStream_t st);
 
 // exact-fp32 kernels of the two edge convs (conv_thin_f32.hip): one side of the GEMM is the 4-channel (padded 3-channel) tensor
 int launch_conv3x3_thin_out_f32(const float* x, const float* w, const float* bias, const float* res, float* y, int n, int h, int wd,

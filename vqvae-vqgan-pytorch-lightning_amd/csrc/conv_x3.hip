@@ -25,6 +25,7 @@
 // ------------------------------------------------------------------------------------------------
 #include "conv_geom.h"
 #include <type_traits>
+#include <math.h>
 
 namespace {
 
@@ -315,6 +316,135 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3x3_wgrad_x3_kernel: the weight gradient of the split-product mode WITHOUT pair tensors -- fp32 x and fp32 dy are loaded into
+// registers (16 B = 4 channels of one pixel per lane and slot), split into (hi, lo) bf16 there and written to the hi / lo planes of
+// ONE 44-KiB LDS stage; the matrix loop forms all three products from the staged data (3 MFMAs per fragment pair instead of three
+// passes over three pair tensors: 3x the arithmetic intensity of the bf16 kernel per staged byte, no split passes, no folded tile
+// classes).  Geometry of conv3x3_wgrad_halo_kernel<false> (conv.hip): block = 64 co x 64 ci x 9 taps over a range of 8x8-pixel
+// patches, wave (i, j) owns the 32 x 32 tile of all taps (144 accumulators), fragments by ds_read_b64_tr_b16 from [rows][64 B] half
+// tiles.  Pipeline: the loads of patch p + 1 are in flight during the MFMAs of patch p; store phase and matrix phase are separated
+// by two barriers, and the second resident block of the CU (2 x 44 KiB) computes while this one converts.
+// dW[co][tap][ci] += scale * sum_pix dy[pix][co] * x[pix (+) tap][ci]   (autoencoder.py:57-60, :102-105, :132, :153)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8_t x3_tr_frag2(const char* p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VQK_LDS s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VQK_LDS s16x4*)(p + 256));      // rows +4
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ dw, ConvGeom g, int patches_per_split) {
+    constexpr int PWD = 8, PIX = 64, HWD = 10, HROWS = 100, X_ROWS = 112;
+    constexpr int DY_HALF = PIX * 64, X_HALF = X_ROWS * 64;      // bytes per 32-channel half tile (bf16)
+    constexpr int PLANE = 2 * DY_HALF + 2 * X_HALF;              // 22528: one of (hi, lo)
+    constexpr int DY_UNITS = PIX * 16, UNITS = DY_UNITS + HROWS * 16, NSLOT = (UNITS + 255) / 256;      // 16-byte fp32 units: 2624 -> 11 slots
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_ci = g.cin >> 6;
+    const int vb = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int bx = vb % (int)gridDim.x, by = vb / (int)gridDim.x;
+    const int tco = bx / tiles_ci, tci = bx - tco * tiles_ci;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int pw = g.w >> 3, ph = g.h >> 3;
+    const int total_patches = g.n * ph * pw;
+    const int p_begin = by * patches_per_split;
+    const int p_end = min(total_patches, p_begin + patches_per_split);
+    if (p_begin >= p_end) return;
+
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // per-lane slots: unit u = tid + 256 * sl.  Slots 0..3 are dy (1024 units = 64 pixels x 16 four-channel groups): pixel row
+    // (tid >> 4) + 16 sl; slots 4..10 the x halo: halo row (tid >> 4) + 16 (sl - 4) < 100.  Channels 4 * (tid & 15) in every slot.
+    // Everything is affine in sl: two per-thread constants instead of per-slot register arrays (the 144 accumulators leave no room).
+    static_assert(NSLOT == 11 && DY_UNITS == 1024, "slot split");
+    const int c4 = tid & 15, trow = tid >> 4;
+    const int ch = c4 * 4;
+    const unsigned dst0 = (unsigned)((c4 >> 3) * DY_HALF + trow * 64 + (c4 & 7) * 8);                  // + sl * 1024
+    const unsigned dst1 = (unsigned)(2 * DY_HALF + (c4 >> 3) * X_HALF + trow * 64 + (c4 & 7) * 8);     // + (sl - 4) * 1024
+    u32x4 stage[NSLOT];
+    auto load_patch = [&](int patch) {
+        const int img = patch / (ph * pw), rem = patch - img * (ph * pw);
+        const int pyi = rem / pw, pxi = rem - pyi * pw;
+        const int py0 = pyi * 8, px0 = pxi * PWD;
+        const float* dyp = dy + (((int64_t)img * g.h + py0 + (trow >> 3)) * g.w + px0 + (trow & 7)) * g.cout + co0 + ch;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)                           // patch rows (trow >> 3) + 2 sl
+            stage[sl] = *reinterpret_cast<const u32x4*>(dyp + (int64_t)(2 * sl) * g.w * g.cout);
+        const float* ximg = x + (int64_t)img * g.h_in * g.w_in * g.cin + ci0 + ch;
+#pragma unroll
+        for (int sl = 4; sl < NSLOT; ++sl) {
+            const int row = trow + 16 * (sl - 4);
+            const int hy = row / HWD, hx = row - hy * HWD;
+            const int iy = py0 + hy - 1, ix = px0 + hx - 1;
+            const bool ok = row < HROWS && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+            const int cy = ok ? iy >> g.ups : 0, cx = ok ? ix >> g.ups : 0;            // clamped address: the load stays unconditional
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)cy * g.w_in + cx) * g.cin);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            stage[sl] = ok ? v : z;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            if (sl == NSLOT - 1 && trow >= HROWS - 16 * (NSLOT - 5)) continue;       // halo rows 100..111 do not exist
+            const float f0 = __uint_as_float(stage[sl][0]), f1 = __uint_as_float(stage[sl][1]);
+            const float f2 = __uint_as_float(stage[sl][2]), f3 = __uint_as_float(stage[sl][3]);
+            const unsigned h01 = pack_bf16x2(f0, f1), h23 = pack_bf16x2(f2, f3);
+            const float l0 = f0 - __uint_as_float(h01 << 16), l1 = f1 - __uint_as_float(h01 & 0xffff0000u);
+            const float l2 = f2 - __uint_as_float(h23 << 16), l3 = f3 - __uint_as_float(h23 & 0xffff0000u);
+            const u32x2 hi = {h01, h23}, lo = {pack_bf16x2(l0, l1), pack_bf16x2(l2, l3)};
+            const unsigned d = sl < 4 ? dst0 + sl * 1024 : dst1 + (sl - 4) * 1024;
+            *reinterpret_cast<u32x2*>(smem + d) = hi;
+            *reinterpret_cast<u32x2*>(smem + PLANE + d) = lo;
+        }
+    };
+
+    const int li = lane & 15, grp = (lane >> 4) & 1, kgrp = lane >> 5;
+    const unsigned frag_lane = (unsigned)((li >> 2) * 64 + 32 * grp + 8 * (li & 3));
+    const unsigned a_lane = (unsigned)(wi * DY_HALF) + frag_lane + (unsigned)(kgrp * 8 * 64);
+    // k-group 1 = pixels 8..15 of the MFMA's 16 = the next patch row: + HWD halo rows
+    const unsigned b_lane = (unsigned)(2 * DY_HALF + wj * X_HALF) + frag_lane + (unsigned)(kgrp * HWD * 64);
+    const char* pa = smem + a_lane;
+    const char* pb = smem + b_lane;
+
+    load_patch(p_begin);
+    for (int pch = p_begin; pch < p_end; ++pch) {
+        store_patch();                                           // (waits for the loads of this patch)
+        __syncthreads();
+        if (pch + 1 < p_end) load_patch(pch + 1);                // in flight during the MFMAs below
+#pragma unroll
+        for (int gk = 0; gk < PIX / 16; ++gk) {                  // 16 pixels = patch rows 2 gk, 2 gk + 1
+            const bf16x8_t ah = x3_tr_frag2(pa + gk * 16 * 64), al = x3_tr_frag2(pa + PLANE + gk * 16 * 64);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int off = ((2 * gk + t / 3) * HWD + (t % 3)) * 64;
+                const bf16x8_t bh = x3_tr_frag2(pb + off), bl = x3_tr_frag2(pb + PLANE + off);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                         // everyone left the stage before it is rewritten
+    }
+    const int ci = ci0 + wj * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+            atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r] * g.acc_scale);
+        }
+}
+
 // fp32 [rows][c] -> bf16 [rows][2c]: (hi | lo) per row; a thread owns 8 consecutive channels (two 16-byte loads, two 16-byte stores)
 __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict__ src, bf16_raw* __restrict__ dst, int64_t rows, int c) {
     const int c8 = c >> 3;
@@ -359,6 +489,29 @@ int launch_conv3x3_x3(const void* x, const void* w, const float* bias, const voi
     return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
 }
 
+}  // namespace vqkd
+
+namespace vqkd {
+// x fp32 [n][h_in][w_in][cin], dy fp32 [n][h][w][cout], dw fp32 [cout][3][3][cin] +=; cin % 64 == 0, cout % 64 == 0, h % 8 == 0, w % 8 == 0
+int launch_conv3x3_wgrad_x3(const void* x, const void* dy, float* dw, const ConvGeom& g, int blocks_cap, hipStream_t st) {
+    if ((g.cin & 63) || (g.cout & 63) || (g.h & 7) || (g.w & 7) || g.ks != 3) return VQK_ERR_SHAPE;
+    const int tiles = (g.cout >> 6) * (g.cin >> 6);
+    const int total_patches = g.n * (g.h >> 3) * (g.w >> 3);
+    // split-K over pixel patches: the cost model of the bf16 kernels (conv.hip::wgrad_general) with a third of their atomic passes
+    // per multiply-add -- s* = sqrt(c * pixels / tiles) under the block cap (two blocks per CU)
+    const int cap = blocks_cap > 0 ? blocks_cap : 512;
+    const double coef = VQK_TUNE("X3_WGRAD_COEF_E4", 3200) * 1e-4;
+    int splits = (int)(sqrt(coef * (double)g.m / tiles) + 0.5);
+    if (splits > (cap + tiles - 1) / tiles) splits = (cap + tiles - 1) / tiles;
+    if (splits > (total_patches + 3) / 4) splits = (total_patches + 3) / 4;          // >= 256 pixels per block
+    if (splits < 1) splits = 1;
+    const int pps = (total_patches + splits - 1) / splits;
+    splits = (total_patches + pps - 1) / pps;
+    constexpr int lds = 2 * 22528;
+    hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, (const float*)x,
+                       (const float*)dy, dw, g, pps);
+    return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
+}
 }  // namespace vqkd
 
 extern "C" int vqk_split_pair_f32(const float* src, void* dst, int64_t rows, int c, void* stream) {

@@ -84,6 +84,7 @@ def _stream() -> int:
 
 
 X3 = _native.switch('VQK_CONV_PRODUCTS', 'fp32') == 'bf16x3'
+X3_WGRAD_FOLD = _native.switch('VQK_X3_WGRAD_FOLD', '0') == '1'     # A/B: the pair-tensor form (two split passes + the folded bf16 role-split kernel) instead of conv3x3_wgrad_x3_kernel
 
 
 def set_conv_products(mode: str) -> None:
@@ -780,6 +781,16 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8, x
         return dw
     if thin_true != 8:
         raise RuntimeError('vqk: an unpadded weight-gradient target needs the edge-conv kernel')
+    if (x3 and not X3_WGRAD_FOLD and x.dtype == torch.float32 and dy.dtype == torch.float32 and ksize == 3 and cin % 64 == 0
+            and cout % 64 == 0 and dy.shape[3] % 8 == 0 and dy.shape[2] % 8 == 0 and not DETERMINISTIC):
+        # split-product mode: both fp32 operands split in registers on their way into LDS, three products per staged fragment pair
+        # (csrc/conv_x3.hip: conv3x3_wgrad_x3_kernel)
+        st = _timed('conv3x3_wgrad_x3_kernel<f32 as 3 x bf16>' + (f' {cin}->{cout}@{dy.shape[2]}x{dy.shape[3]} k3' if _EVENT_SHAPES else ''), flops,
+                    lambda: _native.lib().vqk_conv2d_wgrad_x3_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, cin, cout, int(ups),
+                                                                  1.0, _stream()), exec_flops=3.0 * flops)
+        if st != _native.ERR_SHAPE:
+            _native.check(st, 'conv2d_wgrad_x3_f32')
+            return dw
     if (x3 and x.dtype == torch.float32 and dy.dtype == torch.float32 and ksize == 3 and cin % 64 == 0 and cout % 64 == 0
             and dy.shape[3] % 16 == 0 and dy.shape[2] % 8 == 0 and not DETERMINISTIC and _WGMX_ON):
         # split-product mode: both operands as (hi | lo) bf16 pair tensors, three tile classes of one launch of the bf16
