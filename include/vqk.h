@@ -338,6 +338,21 @@ int vqk_set_scratch(void* ws, int64_t ws_bytes);
  * functions of the tile index only).  VQK_ERR_WORKSPACE below 64 bytes, VQK_ERR_ALIGN unless 16-byte aligned.
  * A kernel that is KILLED mid-way leaves the words dirty: re-zero them before the next launch. */
 int vqk_set_tile_queue(void* ws, int64_t ws_bytes);
+/* WORKSPACE CONTEXTS (round 6): the three workspaces above as fields of an object instead of three thread-local pointers.
+ * A context is plain host memory (no device allocation, no stream): create one per (device, stream, host thread) that launches,
+ * give it its workspaces ONCE, and name it before a batch of launches -- vqk_ctx_make_current is one pointer store, the only
+ * thread-local state left on this path (the analogue of hipSetDevice).  ctx = NULL in a vqk_ctx_set_* call addresses the calling
+ * thread's current context, which is what vqk_set_scratch / vqk_set_tile_queue / vqk_set_deterministic do: they are wrappers.
+ * vqk_ctx_make_current(NULL) returns to the thread's own default context.  Two models stepped from two host threads, or one
+ * thread alternating between two streams, hold one context each (ops.py::_stream).  A context must not be destroyed while a
+ * thread still has it current (the destroying thread's own current pointer is reset). */
+typedef struct vqk_ctx vqk_ctx;
+int vqk_ctx_create(vqk_ctx** ctx);
+int vqk_ctx_destroy(vqk_ctx* ctx);
+int vqk_ctx_make_current(vqk_ctx* ctx);
+int vqk_ctx_set_scratch(vqk_ctx* ctx, void* ws, int64_t ws_bytes);
+int vqk_ctx_set_tile_queue(vqk_ctx* ctx, void* ws, int64_t ws_bytes);
+int vqk_ctx_set_deterministic(vqk_ctx* ctx, int on, void* ws, int64_t ws_bytes);
 /* Tuning slots: the launch heuristics that tools/ sweep (formerly read-once environment variables).  name = one of
  * vqk_tuning_name(0 .. vqk_tuning_count() - 1): MX, MX_1X1, TW16, STREAM_BLOCKS, MX_MIN_TILES, FPROP_SPLITK, SK_BLOCKS, SK_MINSTEPS, SK_MAXMB, UPS_PHASE, WGRAD_BLOCKS, WGMX, WGRAD_GEN_BLOCKS, WGRAD_NO_PW16, WGRAD_NO_P16K, MX_HALF, MX_HALF_HW, UPFIRDN_TILE, GN_BLOCKS_REDUCE, GN_BLOCKS_APPLY, GN_NT_MB, GN_NO_SMALL, WGMX_COEF_E4, GN_CLUSTER_MAX_HW, COMM_CUS, MX_QUARTER, MX_S2, MX_S2_DGRAD_MIN, UPS_MERGE, TILE_QUEUE.
  * A set slot overrides the built-in default at the next launch; vqk_reset_tuning returns every slot to its default.

@@ -145,7 +145,7 @@ def test_graph_captured_on_one_thread_replays_identically_from_another():
 
     def thread_b():
         torch.cuda.set_device(0)
-        assert getattr(ops._DET_TLS, 'key', None) is None            # this thread never armed the deterministic mode
+        assert getattr(ops._DET_TLS, 'ctx', None) is None            # this thread never armed a workspace context, deterministic or not
         box['opt'].flat_g.fill_(float('nan'))                        # the graph's own zero_grad must clear this
         box['tr']._graph.replay()
         torch.cuda.synchronize()

@@ -85,7 +85,7 @@ def test_scratch_and_deterministic_setters_validate():
     assert lib.vqk_set_deterministic(1, buf.data_ptr() + 8, 1024) == ALIGN
     assert lib.vqk_set_deterministic(0, 0, 0) == OK
     assert lib.vqk_set_scratch(0, 0) == OK
-    ops._DET_TLS.scratch = None                                   # this thread re-arms its scratch on the next op
+    ops.rearm_workspaces()                                        # (the setters above addressed this thread's current context)
 
 
 def test_round4_quantizer_entry_points_validate_before_launching():
@@ -156,7 +156,7 @@ def test_round4_groupnorm_and_tuning_entry_points_validate():
         assert cl() == ARG                                            # arrival-order atomics: refused in deterministic mode
     finally:
         assert lib.vqk_set_deterministic(0, 0, 0) == OK
-        ops._DET_TLS.key = None
+        ops.rearm_workspaces()
     torch.cuda.synchronize()
     assert float(dx.float().abs().sum()) == 0.0 and float(cs.abs().sum()) == 0.0
     assert bw() == OK and cl() == OK

@@ -72,6 +72,12 @@ _PROTOS = {
     'vqk_set_deterministic': [I, P, L],
     'vqk_set_scratch': [P, L],
     'vqk_set_tile_queue': [P, L],
+    'vqk_ctx_create': [P],
+    'vqk_ctx_destroy': [P],
+    'vqk_ctx_make_current': [P],
+    'vqk_ctx_set_scratch': [P, P, L],
+    'vqk_ctx_set_tile_queue': [P, P, L],
+    'vqk_ctx_set_deterministic': [P, I, P, L],
     'vqk_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'vqk_conv2d_wgrad': [I, P, P, P, I, I, I, I, I, I, I, P, P],
     'vqk_conv2d_wgrad_pooled_dy': [I, P, P, P, I, I, I, I, I, F, P, P],

@@ -1,5 +1,6 @@
 // Status strings / version of the vqk C-ABI (include/vqk.h).
 #include <stdint.h>
+#include <new>
 #include "common.h"
 
 extern "C" {
@@ -22,51 +23,82 @@ const char* vqk_arch(void) { return "gfx950"; }
 
 }  // extern "C"
 
-// deterministic mode: see include/vqk.h
+// Workspace contexts (include/vqk.h: vqk_ctx_*): the three caller-owned workspaces a launch may need -- split-K scratch, tile-queue
+// words, deterministic-mode slices -- travel together in a context object.  A host thread has ONE current context (its own default
+// context until vqk_ctx_make_current names another); the launchers read it through det_state() / scratch_state() /
+// tile_queue_state().  The rounds-1-5 setters below are thin wrappers over the thread's current context.
+struct vqk_ctx {
+    vqkd::DetState det, scratch, tq;
+};
 namespace vqkd {
-DetState& det_state() {
-    static thread_local DetState st = {0, nullptr, 0};
-    return st;
+static vqk_ctx& default_ctx() {
+    static thread_local vqk_ctx c = {{0, nullptr, 0}, {0, nullptr, 0}, {0, nullptr, 0}};
+    return c;
 }
-DetState& scratch_state() {
-    static thread_local DetState st = {0, nullptr, 0};
-    return st;
+static vqk_ctx*& current_ctx() {
+    static thread_local vqk_ctx* cur = nullptr;
+    return cur;
 }
-DetState& tile_queue_state() {
-    static thread_local DetState st = {0, nullptr, 0};
-    return st;
+static vqk_ctx& ctx() {
+    vqk_ctx* c = current_ctx();
+    return c ? *c : default_ctx();
 }
+DetState& det_state() { return ctx().det; }
+DetState& scratch_state() { return ctx().scratch; }
+DetState& tile_queue_state() { return ctx().tq; }
 }  // namespace vqkd
 
-extern "C" int vqk_set_tile_queue(void* ws, int64_t ws_bytes) {
+extern "C" int vqk_ctx_create(vqk_ctx** out) {
+    if (!out) return VQK_ERR_ARG;
+    *out = new (std::nothrow) vqk_ctx{{0, nullptr, 0}, {0, nullptr, 0}, {0, nullptr, 0}};
+    return *out ? VQK_OK : VQK_ERR_WORKSPACE;
+}
+
+extern "C" int vqk_ctx_destroy(vqk_ctx* c) {
+    if (c && vqkd::current_ctx() == c) vqkd::current_ctx() = nullptr;      // (other threads must not hold it current any more: caller's contract)
+    delete c;
+    return VQK_OK;
+}
+
+extern "C" int vqk_ctx_make_current(vqk_ctx* c) {
+    vqkd::current_ctx() = c;                                     // NULL: back to the calling thread's default context
+    return VQK_OK;
+}
+
+extern "C" int vqk_ctx_set_tile_queue(vqk_ctx* c, void* ws, int64_t ws_bytes) {
     if (ws && ws_bytes < 64) return VQK_ERR_WORKSPACE;           // eight per-XCD counters + the census word
     if (ws && (reinterpret_cast<uintptr_t>(ws) & 15)) return VQK_ERR_ALIGN;
-    vqkd::DetState& d = vqkd::tile_queue_state();
+    vqkd::DetState& d = c ? c->tq : vqkd::ctx().tq;
     d.on = ws ? 1 : 0;
     d.ws = reinterpret_cast<float*>(ws);
     d.bytes = ws ? ws_bytes : 0;
     return VQK_OK;
 }
 
-extern "C" int vqk_set_scratch(void* ws, int64_t ws_bytes) {
+extern "C" int vqk_ctx_set_scratch(vqk_ctx* c, void* ws, int64_t ws_bytes) {
     if (ws && ws_bytes < 0) return VQK_ERR_ARG;
     if (ws && (reinterpret_cast<uintptr_t>(ws) & 15)) return VQK_ERR_ALIGN;       // the split slices are written with 16-byte stores
-    vqkd::DetState& d = vqkd::scratch_state();
+    vqkd::DetState& d = c ? c->scratch : vqkd::ctx().scratch;
     d.on = ws ? 1 : 0;
     d.ws = reinterpret_cast<float*>(ws);
     d.bytes = ws ? ws_bytes : 0;
     return VQK_OK;
 }
 
-extern "C" int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes) {
+extern "C" int vqk_ctx_set_deterministic(vqk_ctx* c, int on, void* ws, int64_t ws_bytes) {
     if (on && ws && ws_bytes < 0) return VQK_ERR_ARG;
     if (on && ws && (reinterpret_cast<uintptr_t>(ws) & 15)) return VQK_ERR_ALIGN;
-    vqkd::DetState& d = vqkd::det_state();
+    vqkd::DetState& d = c ? c->det : vqkd::ctx().det;
     d.on = on ? 1 : 0;
     d.ws = (on && ws) ? reinterpret_cast<float*>(ws) : nullptr;
     d.bytes = (on && ws) ? ws_bytes : 0;
     return VQK_OK;
 }
+
+// the setters of rounds 1-5: the calling thread's CURRENT context
+extern "C" int vqk_set_tile_queue(void* ws, int64_t ws_bytes) { return vqk_ctx_set_tile_queue(nullptr, ws, ws_bytes); }
+extern "C" int vqk_set_scratch(void* ws, int64_t ws_bytes) { return vqk_ctx_set_scratch(nullptr, ws, ws_bytes); }
+extern "C" int vqk_set_deterministic(int on, void* ws, int64_t ws_bytes) { return vqk_ctx_set_deterministic(nullptr, on, ws, ws_bytes); }
 
 // ---------------------------------------------------------------- tuning slots (include/vqk.h: vqk_set_tuning)
 #include <string.h>

@@ -216,7 +216,7 @@ class VQVAE(BaseVQVAE, _LightningBase):
             res = self.criterion.forward_autoencoder(q_loss, target, recon_pad, self.current_epoch,
                                                      last_layer=self.decoder.conv_out.weight)
             with ops.no_param_grads():
-                res[0].backward(retain_graph=True)          # (the discriminator half backpropagates through the shared D(fake) pass)
+                ops.backward(res[0], retain_graph=True)     # (the discriminator half backpropagates through the shared D(fake) pass)
         else:
             for p in disc_params:
                 p.requires_grad_(False)

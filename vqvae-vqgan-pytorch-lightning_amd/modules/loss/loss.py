@@ -76,8 +76,8 @@ class VQLPIPSWithDiscriminator(nn.Module):
     def calculate_adaptive_weight(self, nll_loss, g_loss, last_layer):
         """lambda = clamp(|d nll / d W_last| / (|d g / d W_last| + 1e-8), 0, 1e4) * g_weight   (loss.py:80-96)"""
         with ops.no_direct_grad(), ops.no_param_grads():     # (only d/d last_layer is asked for: no discriminator weight gradients)
-            nll_grads = torch.autograd.grad(nll_loss, last_layer, retain_graph=True)[0].detach()
-            g_grads = torch.autograd.grad(g_loss, last_layer, retain_graph=True)[0].detach()
+            nll_grads = ops.autograd_grad(nll_loss, last_layer, retain_graph=True)[0].detach()
+            g_grads = ops.autograd_grad(g_loss, last_layer, retain_graph=True)[0].detach()
         w = torch.norm(nll_grads, p=2) / (torch.norm(g_grads, p=2) + 1e-8)
         return torch.clamp(w, 0.0, 1e4).detach() * self.generator_weight
 

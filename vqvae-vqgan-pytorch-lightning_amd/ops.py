@@ -51,36 +51,68 @@ def _wkey(device=None) -> tuple:
     return (dev, torch.cuda.current_stream().cuda_stream, threading.get_ident())
 
 
+class _WsCtx:
+    """one ``vqk_ctx`` (include/vqk.h) = the workspaces of ONE (device, stream, host thread): split-K scratch, tile-queue words and --
+    armed lazily, when deterministic mode is on -- the ordered-sum slices.  Created once, named with ONE call when the thread's
+    current (device, stream) changes (rounds 1-5 re-armed three thread-local pointers instead)."""
+    __slots__ = ('handle', 'scratch', 'tq', 'det', 'det_gen')
+
+    def __init__(self, dev: int):
+        import ctypes
+        lib = _native.lib()
+        h = ctypes.c_void_p()
+        _native.check(lib.vqk_ctx_create(ctypes.byref(h)), 'ctx_create')
+        self.handle = h.value
+        self.scratch = torch.empty(_SCRATCH_BYTES // 4, dtype=torch.float32, device=f'cuda:{dev}')      # no zero fill: every slice is written before it is summed
+        self.tq = torch.zeros(64, dtype=torch.int32, device=f'cuda:{dev}')                              # zero on entry, left zero by the kernels
+        _native.check(lib.vqk_ctx_set_scratch(self.handle, self.scratch.data_ptr(), self.scratch.numel() * 4), 'ctx_set_scratch')
+        _native.check(lib.vqk_ctx_set_tile_queue(self.handle, self.tq.data_ptr(), self.tq.numel() * 4), 'ctx_set_tile_queue')
+        self.det, self.det_gen = None, -1
+
+
+_WS_CTX: dict = {}                   # _wkey() -> _WsCtx
+
+
 def _stream() -> int:
-    """handle of the current stream (every launcher passes it to the C-ABI).  In deterministic mode this is also where the
-    library's per-thread workspace follows the stream (partial sums of two concurrent streams must not share a buffer), and
-    where a thread that was armed before the mode was switched off disarms itself."""
+    """handle of the current stream (every launcher passes it to the C-ABI) -- and the point where the library's workspace context
+    follows the calling thread's (device, stream): partial sums of two concurrent streams, or of two host threads that share a
+    stream, must not share a buffer.  Deterministic mode arms / disarms the context's ordered-sum workspace here."""
     s = torch.cuda.current_stream().cuda_stream
     dev = torch.cuda.current_device()                            # (the default stream's handle is 0 on every device)
-    if getattr(_DET_TLS, 'scratch', None) != (dev, s):           # split-K scratch of this stream (private slices per split)
+    cur = getattr(_DET_TLS, 'ctx', None)
+    if cur is None or cur[0] != (dev, s):
         wk = (dev, s, threading.get_ident())
-        sc = _SCRATCH.get(wk)
-        if sc is None:                                           # no zero fill: every slice is written before it is summed
-            sc = _SCRATCH[wk] = torch.empty(_SCRATCH_BYTES // 4, dtype=torch.float32, device=f'cuda:{dev}')
-        _native.check(_native.lib().vqk_set_scratch(sc.data_ptr(), sc.numel() * 4), 'set_scratch')
-        tq = _TILE_QUEUE.get(wk)                                 # tile-queue words of this stream (zero on entry, left zero)
-        if tq is None:
-            tq = _TILE_QUEUE[wk] = torch.zeros(64, dtype=torch.int32, device=f'cuda:{dev}')
-        _native.check(_native.lib().vqk_set_tile_queue(tq.data_ptr(), tq.numel() * 4), 'set_tile_queue')
-        _DET_TLS.scratch = (dev, s)
-    key = getattr(_DET_TLS, 'key', None)
+        ctx = _WS_CTX.get(wk)
+        if ctx is None:
+            ctx = _WS_CTX[wk] = _WsCtx(dev)
+            _SCRATCH[wk], _TILE_QUEUE[wk] = ctx.scratch, ctx.tq                  # (names the tests and tools read)
+        _native.check(_native.lib().vqk_ctx_make_current(ctx.handle), 'ctx_make_current')
+        _DET_TLS.ctx = cur = ((dev, s), ctx)
+    ctx = cur[1]
     if DETERMINISTIC:
-        if key != (_DET_GEN, dev, s):
-            wk = (dev, s, threading.get_ident())
-            ws = _DET_WS.get(wk)
-            if ws is None:
-                ws = _DET_WS[wk] = torch.empty(_DET_WS_BYTES, dtype=torch.uint8, device=f'cuda:{dev}')
-            _native.check(_native.lib().vqk_set_deterministic(1, ws.data_ptr(), ws.numel()), 'set_deterministic')
-            _DET_TLS.key = (_DET_GEN, dev, s)
-    elif key is not None:
-        _native.check(_native.lib().vqk_set_deterministic(0, 0, 0), 'set_deterministic')
-        _DET_TLS.key = None
+        if ctx.det_gen != _DET_GEN:
+            if ctx.det is None:
+                ctx.det = torch.empty(_DET_WS_BYTES, dtype=torch.uint8, device=f'cuda:{dev}')
+                _DET_WS[(dev, s, threading.get_ident())] = ctx.det
+            _native.check(_native.lib().vqk_ctx_set_deterministic(ctx.handle, 1, ctx.det.data_ptr(), ctx.det.numel()), 'ctx_set_deterministic')
+            ctx.det_gen = _DET_GEN
+    elif ctx.det_gen != -1:
+        _native.check(_native.lib().vqk_ctx_set_deterministic(ctx.handle, 0, 0, 0), 'ctx_set_deterministic')
+        ctx.det_gen = -1
     return s
+
+
+def rearm_workspaces() -> None:
+    """after a caller went around this module and changed the calling thread's CURRENT context through the C-ABI setters
+    (vqk_set_scratch / vqk_set_tile_queue / vqk_set_deterministic -- tests do): put this thread's context back in order"""
+    cur = getattr(_DET_TLS, 'ctx', None)
+    if cur is not None:
+        ctx, lib = cur[1], _native.lib()
+        _native.check(lib.vqk_ctx_set_scratch(ctx.handle, ctx.scratch.data_ptr(), ctx.scratch.numel() * 4), 'ctx_set_scratch')
+        _native.check(lib.vqk_ctx_set_tile_queue(ctx.handle, ctx.tq.data_ptr(), ctx.tq.numel() * 4), 'ctx_set_tile_queue')
+        _native.check(lib.vqk_ctx_set_deterministic(ctx.handle, 0, 0, 0), 'ctx_set_deterministic')
+        ctx.det_gen = -1
+    _DET_TLS.ctx = None
 
 
 X3 = _native.switch('VQK_CONV_PRODUCTS', 'fp32') == 'bf16x3'
@@ -687,44 +719,104 @@ def raw_conv_pooled_fprop_phase(x, weight, res_pooled, scale: float, gn_groups: 
     return y
 
 
-_DIRECT_GRAD = True
+# ---- gradient modes of ONE backward call (no process-wide flag) -------------------------------------------------------------
+# `no_direct_grad` / `no_param_grads` describe a particular backward()/autograd.grad() call.  The custom Functions' backward methods
+# run on the autograd engine's device thread, not on the caller's -- so the mode travels with the GRAPH TASK: the caller's
+# contexts push onto a thread-local stack, `ops.backward` / `ops.autograd_grad` tag the graph task they start (a hook on the root
+# runs first thing inside it and files the caller's mode under torch._C._current_graph_task_id()), and `_grad_modes()` inside a
+# node's backward looks its own task up.  Two models stepping on two host threads -- two VQ-GAN steps included -- cannot see each
+# other's modes (tests/test_gpu_two_models.py); rounds 1-5 kept these as module globals with save / restore.
+_MODE_TLS = threading.local()
+_TASK_MODES: dict = {}            # graph task id -> (direct_grad, param_grads)
+_DEFAULT_MODES = (True, True)
 
 
-class no_direct_grad:
-    """context: gradients are RETURNED through autograd instead of being accumulated into the flat arena
-    (needed by ``torch.autograd.grad`` calls such as the adaptive generator weight, loss.py:80-96)"""
+def _mode_stack() -> list:
+    st = getattr(_MODE_TLS, 'stack', None)
+    if st is None:
+        st = _MODE_TLS.stack = []
+    return st
+
+
+def _grad_modes() -> tuple:
+    """(direct_grad, param_grads) of the backward call this code runs under"""
+    tid = torch._C._current_graph_task_id()
+    if tid != -1:
+        m = _TASK_MODES.get(tid)
+        if m is not None:
+            return m
+    st = getattr(_MODE_TLS, 'stack', None)          # (a backward executed on the calling thread itself; plain forward code)
+    return st[-1] if st else _DEFAULT_MODES
+
+
+class _mode_ctx:
+    _index, _value = 0, False
 
     def __enter__(self):
-        global _DIRECT_GRAD
-        self._prev, _DIRECT_GRAD = _DIRECT_GRAD, False
+        st = _mode_stack()
+        cur = list(st[-1] if st else _DEFAULT_MODES)
+        cur[self._index] = self._value
+        st.append(tuple(cur))
 
     def __exit__(self, *exc):
-        global _DIRECT_GRAD
-        _DIRECT_GRAD = self._prev
+        _mode_stack().pop()
 
 
-_PARAM_GRADS = True
+class no_direct_grad(_mode_ctx):
+    """context around ``ops.autograd_grad`` / ``ops.backward``: gradients are RETURNED through autograd instead of being accumulated
+    into the flat arena (the adaptive generator weight asks for d loss / d last_layer, loss.py:80-96)"""
+    _index, _value = 0, False
 
 
-class no_param_grads:
-    """context: ConvActFn's backward computes the DATA gradient only (the weight / bias gradients are neither computed nor
-    returned).  The generator loss backpropagates through the discriminator for the sake of the decoder alone (the reference
-    zeroes the discriminator gradients of that pass before its discriminator step, model.py:258); with the fake pass shared
-    between the two halves of the step the discriminator's parameters must keep requires_grad, so freezing them is no option."""
+class no_param_grads(_mode_ctx):
+    """context around ``ops.backward`` / ``ops.autograd_grad``: ConvActFn's backward computes the DATA gradient only.  The generator
+    loss backpropagates through the discriminator for the sake of the decoder alone (the reference zeroes the discriminator
+    gradients of that pass before its discriminator step, model.py:258); with the fake pass shared between the two halves of the
+    step the discriminator's parameters must keep requires_grad, so freezing them is no option."""
+    _index, _value = 1, False
 
-    def __enter__(self):
-        global _PARAM_GRADS
-        self._prev, _PARAM_GRADS = _PARAM_GRADS, False
 
-    def __exit__(self, *exc):
-        global _PARAM_GRADS
-        _PARAM_GRADS = self._prev
+def _tagged(roots, run):
+    """run() -- a backward()/autograd.grad() over ``roots`` -- with the calling thread's gradient modes attached to its graph task"""
+    st = getattr(_MODE_TLS, 'stack', None)
+    mode = st[-1] if st else _DEFAULT_MODES
+    if mode == _DEFAULT_MODES:
+        return run()
+    seen, hooks = [], []
+
+    def tag(grad):
+        tid = torch._C._current_graph_task_id()
+        if tid != -1 and tid not in seen:
+            _TASK_MODES[tid] = mode
+            seen.append(tid)
+        return None
+    for r in roots:
+        if torch.is_tensor(r) and r.requires_grad:
+            hooks.append(r.register_hook(tag))
+    try:
+        return run()
+    finally:
+        for h in hooks:
+            h.remove()
+        for tid in seen:
+            _TASK_MODES.pop(tid, None)
+
+
+def backward(tensor, *args, **kwargs):
+    """``tensor.backward(...)`` under the calling thread's ``no_direct_grad`` / ``no_param_grads`` contexts"""
+    return _tagged((tensor,), lambda: tensor.backward(*args, **kwargs))
+
+
+def autograd_grad(outputs, inputs, *args, **kwargs):
+    """``torch.autograd.grad(...)`` under the calling thread's gradient-mode contexts"""
+    roots = outputs if isinstance(outputs, (tuple, list)) else (outputs,)
+    return _tagged(roots, lambda: torch.autograd.grad(outputs, inputs, *args, **kwargs))
 
 
 def direct_grad(param):
     """The flat-arena gradient view of ``param`` when the HIP kernels may accumulate straight into it
     (FlatAdamW marks its parameters; the arena is zeroed once per step by ``zero_grad``), else None."""
-    if _DIRECT_GRAD and getattr(param, '_vqk_direct_grad', False) and param.grad is not None:
+    if _grad_modes()[0] and getattr(param, '_vqk_direct_grad', False) and param.grad is not None:
         return param.grad
     return None
 
@@ -2302,8 +2394,9 @@ def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None
     lib, st = _native.lib(), _stream()
     # t and dx are built from differentiable Functions so that R1 (autograd.grad(..., create_graph=True) through
     # this backward, loss.py:98-112) can differentiate them again; in an ordinary backward they record nothing.
-    want_db = bias is not None and needs[2] and _PARAM_GRADS
-    want_dw = needs[1] and _PARAM_GRADS
+    param_grads = _grad_modes()[1]
+    want_db = bias is not None and needs[2] and param_grads
+    want_dw = needs[1] and param_grads
     dyn = nhwc(dy) if dy is not None else None
     dy_dtype = dyn.dtype if dyn is not None else dt
     dbsum = db_tgt = None
