@@ -439,7 +439,13 @@ def main():
     if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
         # the capture's settling steps run on the capture stream, the eager event pass on the default stream: intended
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-    rank, local, world = trainer_mod.init_distributed('nccl')
+    # VQK_BENCH_ONE_GPU=1 (dry run of the multi-rank path on a 1-GPU box: `torchrun --nproc-per-node 2 bench.py --gpus 2` with every
+    # rank on cuda:0 over gloo -- RCCL refuses two ranks per device): capture on several ranks at once, the form A/B, the barriers and
+    # the MAX-over-ranks timing run as they will on a real node; the number it prints is NOT a scaling figure and says so
+    one_gpu = os.environ.get('VQK_BENCH_ONE_GPU') == '1'
+    if one_gpu:
+        os.environ['LOCAL_RANK'] = '0'
+    rank, local, world = trainer_mod.init_distributed('gloo' if one_gpu else 'nccl')
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (the launcher started {world} ranks); '
                          f'pass --gpus {world} or launch --nproc-per-node {args.gpus}')
@@ -763,6 +769,8 @@ def main():
                    bf16_vs_fp32_oracle=parity, box_calibration=calib)
         if degraded is not None:
             out['degraded'] = degraded
+        if one_gpu and world > 1:
+            out['degraded'] = f'dry run: {world} ranks share ONE GPU over gloo (VQK_BENCH_ONE_GPU=1) -- control flow only, not a scaling figure'
         if world == 1 and not args.no_other_configs:
             out['other_configs'] = other_configs()
         result_line = json.dumps(out)

@@ -852,6 +852,9 @@ def raw_split_pair(t) -> torch.Tensor:
     return out
 
 
+_ABL_SKIP_SMALL_WGRAD = int(_native.switch('VQK_ABL_SKIP_SMALL_WGRAD', '0'))      # TIMING-ONLY ablation (tools/ab_env_multi.sh): 3x3 weight gradients on maps of <= this many pixels are not launched -- is their time hidden under the GroupNorm backward?
+
+
 def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8, x3: bool = False) -> torch.Tensor:
     """dw as fp32 with memory [Cout][k][k][Cin] (logical [Cout,Cin,k,k] channels_last); ``out``: accumulate
     into this (pre-existing) buffer instead of a fresh zeroed one.  ``thin_true`` < 8 (edge convs only, with ``out``): ``out`` is
@@ -861,6 +864,8 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8, x
     dw = out if out is not None else \
         torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
     flops = 2.0 * n * dy.shape[2] * dy.shape[3] * cout * cin * ksize * ksize
+    if _ABL_SKIP_SMALL_WGRAD and ksize == 3 and out is not None and dy.shape[2] * dy.shape[3] <= _ABL_SKIP_SMALL_WGRAD:
+        return dw                                                # (wrong gradients: a timing experiment, never a training run)
     if edge_wgrad_served(x, dy, ksize, ups):
         # the two edge convs (padded 3-channel image / reconstruction): K = 72 GEMM, HBM-bound, workspace split-K
         ws = _edge_ws(x.device)
@@ -1430,10 +1435,12 @@ POOLED_BWD = _native.switch('VQK_POOLED_BWD', '1') != '0'      # ResBlock + fuse
 OVERLAP_WGRAD = _native.switch('VQK_OVERLAP_WGRAD', '1') == '1'
 SHORTCUT_WGRAD_SIDE = _native.switch('VQK_SHORTCUT_WGRAD_SIDE', '0') == '1'   # ResBlock shortcut: weight gradient on the side stream (measured +-0: 28.26 / 28.18 against 28.17 / 28.19 ms -- off)
 OVERLAP_MODE = int(_native.switch('VQK_OVERLAP_MODE', '3'))
+WGRAD_NOJOIN_HW = int(_native.switch('VQK_WGRAD_NOJOIN_HW', '0'))      # ResBlocks on maps of <= this many pixels: weight gradients joined at the END of the backward
 OVERLAP_WAIT_MIN_HW = int(_native.switch('VQK_OVERLAP_WAIT_MIN_HW', '0'))   # maps below this many pixels: dgrad1 does not wait for wgrad2
 OVERLAP_STREAM_BLOCKS = int(_native.switch('VQK_OVERLAP_STREAM_BLOCKS', '512'))
 OVERLAP_WGRAD_BLOCKS = int(_native.switch('VQK_OVERLAP_WGRAD_BLOCKS', '320'))
 OVERLAP_WGRAD_BLOCKS_HI = int(_native.switch('VQK_OVERLAP_WGRAD_BLOCKS_HI', '256'))   # the 256x256 levels: GroupNorm-bound in the backward -- the weight gradient on half the CUs (swept 192 / 224 / 256 / 288 / 320 / 448: -0.15 ms at 256)
+OVERLAP_WGRAD_BLOCKS_LO = int(_native.switch('VQK_OVERLAP_WGRAD_BLOCKS_LO', str(OVERLAP_WGRAD_BLOCKS)))     # maps of <= 32x32: the GroupNorm backward beside the weight gradient is ONE short kernel
 OVERLAP_WGRAD_BLOCKS_MID = int(_native.switch('VQK_OVERLAP_WGRAD_BLOCKS_MID', str(OVERLAP_WGRAD_BLOCKS)))   # the 128x128 levels   # swept 192...512 with the 8x16-patch wgrad: flat 224...320
 _SIDE_STREAMS: dict = {}
 
@@ -1491,6 +1498,8 @@ def _side_after(side, fork) -> None:
 
 def _wgrad_cap(hw: int) -> int:
     """grid cap of the weight-gradient kernel next to the GroupNorm backward, per resolution level"""
+    if hw <= 1024:
+        return OVERLAP_WGRAD_BLOCKS_LO
     return OVERLAP_WGRAD_BLOCKS_HI if hw >= 65536 else OVERLAP_WGRAD_BLOCKS_MID if hw >= 16384 else OVERLAP_WGRAD_BLOCKS
 
 
@@ -1695,7 +1704,16 @@ class ResBlockFn(torch.autograd.Function):
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
                         raw_conv_wgrad(a1, d_r1, 3, False, out=t1, x3=x3)
-                main.wait_stream(side)
+                if h * w <= WGRAD_NOJOIN_HW:
+                    # small maps: the block's GroupNorm backward is ONE short kernel, the weight gradients outlast it (measured: not
+                    # launching them at all on <= 32^2 maps saves 1.23 ms of a 27.8-ms step, profiles/round6_small_wgrad_ab.txt) --
+                    # they are joined at the end of the backward (join_side_streams) instead of at the end of the block and run
+                    # beside the next blocks' kernels, which leave CUs free on these maps
+                    _SIDE_PENDING.add(x.device)
+                    for t in (a1, a2, dout, d_r1):
+                        t.record_stream(side)
+                else:
+                    main.wait_stream(side)
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)
             return dx, dn1w, dn1b, None, dn2w, dn2b, None, dwsc, None, None, None, None
