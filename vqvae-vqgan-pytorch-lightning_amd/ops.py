@@ -1790,1199 +1790,16 @@ class _MSE(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------------
-# vector quantizer
+# switches of the operator families that live in _ops_vq.py / _ops_gan.py (kept HERE: tests and tools flip them as `ops.X = ...`)
 # ------------------------------------------------------------------------------------------------------
 VQ_FILTER = _native.switch('VQK_VQ_FILTER', '1') != '0'
 VQ_FUSED = _native.switch('VQK_VQ_FUSED', '1') != '0'      # one forward kernel + one backward kernel (0: the round-3 launch sequence)
-_VQ_WS: dict = {}
-
-
-def _vq_filter_ws(device, k: int, d: int) -> torch.Tensor:
-    _stream()
-    key = _wkey(device) + (k, d)
-    ws = _VQ_WS.get(key)
-    if ws is None:
-        ws = _VQ_WS[key] = torch.empty(_native.lib().vqk_vq_filter_ws_bytes(k, d), dtype=torch.uint8, device=device)
-    return ws
-
-
-class _VQPrep:
-    __slots__ = ('wref', 'ws', 'stamp', 'k', 'd')
-
-
-_VQ_PREP: dict = {}             # data_ptr of the codebook -> _VQPrep: what vqk_vq_prepare_f32 derived from it
-
-
-def _vq_prepare_now(ent, cb) -> None:
-    _native.check(_native.lib().vqk_vq_prepare_f32(cb.data_ptr(), ent.k, ent.d, ent.ws.data_ptr(), ent.ws.numel(), _stream()),
-                  'vq_prepare')
-
-
-def vq_prepared(codebook) -> torch.Tensor | None:
-    """Workspace of the filtered assignment for ``codebook`` (a Parameter / tensor [K, 256] fp32, contiguous): the bf16
-    fragment-major copy, |e|^2, the filter margins and max |e|^2 -- everything that depends on the codebook only.  Built
-    when the codebook CHANGES, not per step: the entry is stamped like the packed conv operands (in-place version +
-    generation of the owning FlatAdamW), refreshed by :func:`repack_owned` right after the AdamW kernel and by
-    :func:`ema_apply` after the EMA update, so a captured step holds no prepare launch.  None: shape not served."""
-    k, d = codebook.shape
-    if not (VQ_FILTER and VQ_FUSED and d == 256 and k % 32 == 0 and codebook.dtype == torch.float32 and codebook.is_contiguous()):
-        return None
-    cb = codebook.detach()
-    ent = _VQ_PREP.get(cb.data_ptr())
-    if ent is not None and (ent.wref() is not codebook or ent.k != k):
-        ent = None
-    stamp = _pack_stamp(codebook)
-    if ent is None:
-        ent = _VQPrep()
-        ent.wref, ent.k, ent.d, ent.stamp = weakref.ref(codebook), k, d, None
-        ent.ws = torch.empty(_native.lib().vqk_vq_filter_ws_bytes(k, d), dtype=torch.uint8, device=cb.device)
-        _VQ_PREP[cb.data_ptr()] = ent
-    if ent.stamp != stamp:
-        _vq_prepare_now(ent, cb)
-        ent.stamp = stamp
-    return ent.ws
-
-
-def refresh_vq_prepared(owner=None, data_ptr: int | None = None) -> int:
-    """re-derive the prepared workspaces whose codebook belongs to ``owner`` (a FlatAdamW that just stepped), lives at
-    ``data_ptr`` (the EMA update wrote it through the C-ABI: no version bump), or -- both None -- is stale"""
-    n = 0
-    for ptr, ent in list(_VQ_PREP.items()):
-        cbp = ent.wref()
-        if cbp is None or cbp.data_ptr() != ptr:
-            del _VQ_PREP[ptr]
-            continue
-        if data_ptr is not None:
-            hit = ptr == data_ptr
-        elif owner is not None:
-            hit = getattr(cbp, '_vqk_owner', None) is owner
-        else:
-            hit = ent.stamp != _pack_stamp(cbp)
-        if hit:
-            _vq_prepare_now(ent, cbp.detach())
-            ent.stamp = _pack_stamp(cbp)
-            n += 1
-    return n
-
-
-def vq_assign(flat_z: torch.Tensor, codebook: torch.Tensor, assoc: int) -> torch.Tensor:
-    """flat_z [N,D] fp32, codebook [K,D] fp32 -> idx [N] int64 (bit-exact vs oracle/vq_oracle.c)."""
-    _require_gpu(flat_z)
-    n, d = flat_z.shape
-    k = codebook.shape[0]
-    lib = _native.lib()
-    z2 = torch.empty(n, dtype=torch.float32, device=flat_z.device)
-    e2 = torch.empty(k, dtype=torch.float32, device=flat_z.device)
-    idx = torch.empty(n, dtype=torch.int64, device=flat_z.device)
-    s = _stream()
-    _native.check(lib.vqk_row_sqnorm_f32(flat_z.data_ptr(), n, d, z2.data_ptr(), s), 'row_sqnorm(z)')
-    _native.check(lib.vqk_row_sqnorm_f32(codebook.data_ptr(), k, d, e2.data_ptr(), s), 'row_sqnorm(e)')
-    if VQ_FILTER and d == 256 and k % 32 == 0:
-        # bf16 candidate filter + exact fp32 re-rank: the same indices, bit for bit (csrc/vq_filter.hip)
-        ws = _vq_filter_ws(flat_z.device, k, d)
-        st = lib.vqk_vq_assign_filtered_f32(flat_z.data_ptr(), codebook.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d,
-                                            assoc, idx.data_ptr(), ws.data_ptr(), ws.numel(), s)
-        if st != _native.ERR_SHAPE:
-            _native.check(st, 'vq_assign_filtered')
-            return idx
-    _native.check(lib.vqk_vq_assign_f32(flat_z.data_ptr(), codebook.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d,
-                                        assoc, idx.data_ptr(), s), 'vq_assign')
-    return idx
-
-
-class VQLookupFn(torch.autograd.Function):
-    """Nearest-codeword lookup with straight-through gradient and the (q-z)^2 losses.
-
-    Standard (vector_quantizers.py:23-61): loss = mse(q, z.detach()) + beta * mse(q.detach(), z), grads to z and E.
-    EMA      (vector_quantizers.py:128-180): loss = beta * mse(q.detach(), z), codebook has no grad.
-    Returns (q [B,D,H,W] in out_dtype, idx [B, H*W] int64, loss 0-dim fp32, hist int32 [K])."""
-
-    @staticmethod
-    def forward(ctx, z, codebook, beta: float, codebook_loss: bool, assoc: int, out_dtype):
-        _require_gpu(z)
-        z = nhwc(z.to(torch.float32))
-        b, d, h, w = z.shape
-        n = b * h * w
-        # EMA rewrites the codebook in place right after the lookup: backward must see the pre-update rows
-        cb = codebook.detach().contiguous() if codebook_loss else codebook.detach().clone()
-        k = cb.shape[0]
-        flat = z.permute(0, 2, 3, 1).reshape(n, d)           # a view: NHWC memory is already [N][D]
-        qlo = empty_nhwc(b, d, h, w, torch.bfloat16, z.device) if out_dtype == torch.bfloat16 else None
-        zbuf = torch.zeros(k + 1, dtype=torch.int32, device=z.device)            # histogram | loss sum: one fill launch
-        hist, sse = zbuf[:k], zbuf[k:].view(torch.float32).view(())
-        ws = vq_prepared(codebook) if codebook.is_contiguous() else None
-        if ws is not None:
-            # ONE kernel: |z|^2, bf16 filter + exact re-rank, gather, sum (q - z)^2, histogram (csrc/vq_filter.hip); the
-            # fp32 copy of q is only written when it is the output
-            q32 = empty_nhwc(b, d, h, w, torch.float32, z.device) if qlo is None else None
-            idx = torch.empty(n, dtype=torch.int64, device=z.device)
-            _native.check(_native.lib().vqk_vq_forward_f32(flat.data_ptr(), codebook.detach().data_ptr(), ws.data_ptr(), ws.numel(),
-                                                           n, k, d, assoc, idx.data_ptr(), _p(q32), _p(qlo), sse.data_ptr(),
-                                                           hist.data_ptr(), _stream()), 'vq_forward')
-        else:
-            idx = vq_assign(flat, cb, assoc)
-            q32 = empty_nhwc(b, d, h, w, torch.float32, z.device)
-            _native.check(_native.lib().vqk_vq_gather_f32(flat.data_ptr(), cb.data_ptr(), idx.data_ptr(), n, k, d,
-                                                          q32.data_ptr(), _p(qlo), sse.data_ptr(), hist.data_ptr(),
-                                                          _stream()), 'vq_gather')
-        loss = sse * (((1.0 + beta) if codebook_loss else beta) / float(n * d))       # mse + beta * mse | beta * mse: one launch
-        ctx.save_for_backward(z, cb, idx)
-        ctx.cfg = (beta, codebook_loss, n, k, d)
-        ctx.cb_param = codebook
-        ctx.mark_non_differentiable(idx, hist)
-        q = qlo if qlo is not None else q32
-        return q, idx.view(b, h * w), loss, hist
-
-    @staticmethod
-    def backward(ctx, dq, _didx, dloss, _dhist):
-        z, cb, idx = ctx.saved_tensors
-        beta, codebook_loss, n, k, d = ctx.cfg
-        dz = torch.empty_like(z, memory_format=_CL)
-        de = de_tgt = None
-        if codebook_loss and ctx.needs_input_grad[1]:
-            # the codebook gradient is accumulated (atomics / ordered adds) -- straight into the optimizer's arena when there is one
-            de_tgt = direct_grad(ctx.cb_param) if ctx.cb_param.is_contiguous() else None
-            de = de_tgt if de_tgt is not None else torch.zeros_like(cb)
-        gs = dloss.to(torch.float32).contiguous() if dloss is not None else None
-        dqc = nhwc(dq) if dq is not None else None
-        scale = 2.0 / float(n * d)
-        fused = VQ_FUSED and d == 256 and not DETERMINISTIC       # (deterministic mode: the ordered two-kernel form)
-        fn = _native.lib().vqk_vq_backward_fused_f32 if fused else _native.lib().vqk_vq_backward_f32
-        _native.check(fn(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), _p(dqc),
-                         dcode(dqc.dtype) if dqc is not None else F32, n, k, d,
-                         beta * scale if gs is not None else 0.0,
-                         scale if gs is not None else 0.0, _p(gs), dz.data_ptr(),
-                         _p(de), _stream()), 'vq_backward')
-        return dz, (None if de_tgt is not None else de), None, None, None, None
-
-
 ENTROPY_FUSED_ROWS = _native.switch('VQK_ENTROPY_FUSED_ROWS', '1') != '0'
-
-
 ENTROPY_SPLIT_GEMM = _native.switch('VQK_ENTROPY_SPLIT_GEMM', '1') != '0'     # bf16 compute mode: the entropy cotangent's two GEMMs as bf16 split products
-
-
-class EntropyVQFn(torch.autograd.Function):
-    """Entropy-regularised lookup (vector_quantizers.py:290-356, ent_loss_type='softmax'):
-    loss = beta*mse(q.detach(), z) + mse(q, z.detach()) + ratio*(mean_i H(p_i) - H(mean_i p_i)),  p = softmax(-d/T).
-    The fp32 distance matrix is a TRANSIENT of each direction (N*K*4 bytes: 0.5 GB at N=16384, K=8192): the forward
-    reduces it to lse[N], hrow[N], u[K] and frees it, the backward recomputes it once (same kernel, same bits) and
-    overwrites it in place by its cotangent; dz / dE come from two fp32-MFMA GEMMs that reuse the 1x1 conv kernels.
-    Returns (q, idx [B,HW], loss, hist)."""
-
-    @staticmethod
-    def forward(ctx, z, codebook, beta: float, ratio: float, temperature: float, out_dtype, loss_type: str = 'softmax'):
-        _require_gpu(z)
-        if loss_type not in ('softmax', 'argmax'):
-            raise ValueError('Entropy loss {} not supported'.format(loss_type))      # vector_quantizers.py:317, at forward
-        z = nhwc(z.to(torch.float32))
-        b, d, h, w = z.shape
-        n = b * h * w
-        cb = codebook.detach().contiguous()
-        k = cb.shape[0]
-        if k % 4:
-            raise RuntimeError('vqk: entropy quantizer needs num_embeddings % 4 == 0')
-        flat = z.permute(0, 2, 3, 1).reshape(n, d)
-        lib, st, dev = _native.lib(), _stream(), z.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        z2, e2 = torch.empty(n, **f32), torch.empty(k, **f32)
-        idx = torch.empty(n, dtype=torch.int64, device=dev)
-        dmat = torch.empty((n, k), **f32)
-        _native.check(lib.vqk_row_sqnorm_f32(flat.data_ptr(), n, d, z2.data_ptr(), st), 'row_sqnorm(z)')
-        _native.check(lib.vqk_row_sqnorm_f32(cb.data_ptr(), k, d, e2.data_ptr(), st), 'row_sqnorm(e)')
-        scal = torch.zeros(3, **f32)                           # sse, hsum, avg_term
-        lse, hrow = torch.empty(n, **f32), torch.empty(n, **f32)
-        fused_rows = loss_type == 'softmax' and d == 256 and ENTROPY_FUSED_ROWS
-        if fused_rows:                                         # the row statistics ride under the distance MFMAs (csrc/vq.hip)
-            _native.check(lib.vqk_vq_distances_stats_f32(flat.data_ptr(), cb.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d, 1,
-                                                         idx.data_ptr(), dmat.data_ptr(), temperature, lse.data_ptr(),
-                                                         hrow.data_ptr(), scal[1:2].data_ptr(), st), 'vq_distances_stats')
-        else:
-            _native.check(lib.vqk_vq_distances_f32(flat.data_ptr(), cb.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d, 1,
-                                                   idx.data_ptr(), dmat.data_ptr(), st), 'vq_distances')
-        q32 = empty_nhwc(b, d, h, w, torch.float32, dev)
-        qlo = empty_nhwc(b, d, h, w, torch.bfloat16, dev) if out_dtype == torch.bfloat16 else None
-        hist = torch.zeros(k, dtype=torch.int32, device=dev)
-        _native.check(lib.vqk_vq_gather_f32(flat.data_ptr(), cb.data_ptr(), idx.data_ptr(), n, k, d, q32.data_ptr(),
-                                            _p(qlo), scal[0:1].data_ptr(), hist.data_ptr(), st), 'vq_gather')
-        psum, u = torch.zeros(k, **f32), torch.empty(k, **f32)
-        if fused_rows:
-            _native.check(lib.vqk_entropy_forward_presummed_f32(dmat.data_ptr(), n, k, temperature, lse.data_ptr(), psum.data_ptr(),
-                                                                u.data_ptr(), scal[2:3].data_ptr(), st), 'entropy_forward_presummed')
-            ent = scal[1] / float(n) + scal[2]
-        elif loss_type == 'softmax':
-            _native.check(lib.vqk_entropy_forward_f32(dmat.data_ptr(), n, k, temperature, lse.data_ptr(), hrow.data_ptr(),
-                                                      scal[1:2].data_ptr(), psum.data_ptr(), u.data_ptr(),
-                                                      scal[2:3].data_ptr(), st), 'entropy_forward')
-            ent = scal[1] / float(n) + scal[2]
-        else:                                                  # one-hot targets: sample term from the assigned code only
-            s2 = torch.zeros(2, **f32)                         # row-entropy sum (unused by the loss), sample-term sum
-            _native.check(lib.vqk_entropy_argmax_forward_f32(dmat.data_ptr(), idx.data_ptr(), hist.data_ptr(), n, k,
-                                                             temperature, lse.data_ptr(), hrow.data_ptr(),
-                                                             s2[0:1].data_ptr(), s2[1:2].data_ptr(), psum.data_ptr(),
-                                                             u.data_ptr(), scal[2:3].data_ptr(), st), 'entropy_argmax_forward')
-            ent = s2[1] / float(n) + scal[2]
-        mse = scal[0] / float(n * d)
-        loss = beta * mse + mse + ent * ratio
-        # Nothing of size N x K survives the forward: the backward recomputes the distance matrix ONCE (the same kernel, the same
-        # bits) into a transient buffer; what is kept is z, the codebook, idx and the row / column statistics lse[N], hrow[N], u[K]
-        # (round 3 saved dmat: 537 MB at N = 16,384, K = 8,192, growing with N x K)
-        del dmat
-        ctx.save_for_backward(z, cb, idx, lse, hrow, u, z2, e2)
-        ctx.cfg = (beta, ratio, temperature, n, k, d, loss_type)
-        ctx.split_gemm = (ENTROPY_SPLIT_GEMM and out_dtype == torch.bfloat16 and loss_type == 'softmax' and k % 128 == 0
-                          and d % 128 == 0 and n % 128 == 0)
-        ctx.mark_non_differentiable(idx, hist)
-        return (qlo if qlo is not None else q32), idx.view(b, h * w), loss, hist
-
-    @staticmethod
-    def backward(ctx, dq, _didx, dloss, _dhist):
-        z, cb, idx, lse, hrow, u, z2, e2 = ctx.saved_tensors
-        beta, ratio, temperature, n, k, d, loss_type = ctx.cfg
-        lib, st = _native.lib(), _stream()
-        flat = z.permute(0, 2, 3, 1).reshape(n, d)
-        gs = dloss.to(torch.float32).contiguous() if dloss is not None else None
-        dqc = nhwc(dq) if dq is not None else None
-        scale = 2.0 / float(n * d) if gs is not None else 0.0
-        dz = torch.empty_like(z, memory_format=_CL)
-        de = torch.zeros_like(cb)
-        fused = VQ_FUSED and d == 256 and not DETERMINISTIC       # one kernel (csrc/vq_filter.hip); K = 8192: 41 against 235 us
-        fn = lib.vqk_vq_backward_fused_f32 if fused else lib.vqk_vq_backward_f32
-        _native.check(fn(z.data_ptr(), cb.data_ptr(), idx.data_ptr(), _p(dqc),
-                         dcode(dqc.dtype) if dqc is not None else F32, n, k, d, beta * scale, scale,
-                         _p(gs), dz.data_ptr(), de.data_ptr(), st), 'vq_backward')
-        if gs is None:
-            return dz, de, None, None, None, None, None
-        # the distance matrix again (transient), then dmat <- dL_ent/dd  (rows sum to zero)
-        dmat = torch.empty((n, k), dtype=torch.float32, device=z.device)
-        idx2 = torch.empty(n, dtype=torch.int64, device=z.device)
-        _native.check(lib.vqk_vq_distances_f32(flat.data_ptr(), cb.data_ptr(), z2.data_ptr(), e2.data_ptr(), n, k, d, 1,
-                                               idx2.data_ptr(), dmat.data_ptr(), st), 'vq_distances (backward recompute)')
-        if ctx.split_gemm:
-            # throughput mode: the cotangent as hi + lo bf16 matrices and the two GEMMs as split products on the bf16 MFMA kernels
-            #   dd E  ~ hi [E_hi | E_lo] + lo E_hi,     dd^T Z ~ hi^T [Z_hi | Z_lo] + lo^T Z_hi     (dropped: lo x lo, 2^-16 relative)
-            # -- 3x the multiply-adds at > 5x the rate of the fp32 MFMA kernels (0.70 ms per GEMM at N = 16,384, K = 8,192)
-            bf = dict(dtype=torch.bfloat16, device=z.device)
-            hi, lo = torch.empty((n, k), **bf), torch.empty((n, k), **bf)
-            _native.check(lib.vqk_entropy_backward_split_f32(dmat.data_ptr(), lse.data_ptr(), hrow.data_ptr(), u.data_ptr(), n, k,
-                                                             temperature, ratio, gs.data_ptr(), hi.data_ptr(), lo.data_ptr(), st),
-                          'entropy_backward_split')
-            del dmat
-
-            def split(t):
-                th = t.to(torch.bfloat16)
-                return th, (t - th.float()).to(torch.bfloat16)
-            e_hi, e_lo = split(cb)                                                      # [K][D]
-            z_hi, z_lo = split(flat)                                                    # [N][D]
-            img = lambda t: t.view(1, t.shape[0], 1, t.shape[1]).permute(0, 3, 1, 2)    # [rows][C] memory as a [1, C, rows, 1] nhwc image
-            w1 = torch.cat([e_hi.t(), e_lo.t()], 0).contiguous()                        # [2D][K]
-            g1 = raw_conv_fprop(img(hi), w1, None, None, 1, False, 0, torch.float32, 2 * d, 0).permute(0, 2, 3, 1).reshape(n, 2 * d)
-            g1b = raw_conv_fprop(img(lo), e_hi.t().contiguous(), None, None, 1, False, 0, torch.float32, d, 0).permute(0, 2, 3, 1).reshape(n, d)
-            dz.permute(0, 2, 3, 1).reshape(n, d).add_(g1[:, :d] + g1[:, d:] + g1b, alpha=-2.0)
-            zc = torch.cat([z_hi, z_lo], 1).contiguous()                                # [N][2D]
-            g2 = raw_conv_wgrad(img(zc), img(hi), 1, False).permute(0, 2, 3, 1).reshape(k, 2 * d)
-            g2b = raw_conv_wgrad(img(z_hi.contiguous()), img(lo), 1, False).permute(0, 2, 3, 1).reshape(k, d)
-            de.add_(g2[:, :d] + g2[:, d:] + g2b, alpha=-2.0)
-            cs = raw_colsum(n, k, hi)
-            raw_colsum(n, k, lo, out=cs)
-            _native.check(lib.vqk_row_scale_add_f32(de.data_ptr(), cb.data_ptr(), cs.data_ptr(), k, d, 2.0, st), 'row_scale_add')
-            return dz, de, None, None, None, None, None
-        if loss_type == 'softmax':
-            _native.check(lib.vqk_entropy_backward_f32(dmat.data_ptr(), lse.data_ptr(), hrow.data_ptr(), u.data_ptr(), n, k,
-                                                       temperature, ratio, gs.data_ptr(), st), 'entropy_backward')
-        else:
-            _native.check(lib.vqk_entropy_argmax_backward_f32(dmat.data_ptr(), idx.data_ptr(), lse.data_ptr(), hrow.data_ptr(),
-                                                              u.data_ptr(), n, k, temperature, ratio, gs.data_ptr(), st),
-                          'entropy_argmax_backward')
-        dd = dmat.view(1, n, 1, k).permute(0, 3, 1, 2)            # [1, K, N, 1] logical, [N][K] memory (NHWC)
-        # dz += -2 dd @ E      (1x1 conv: pixels = rows of dd, Cin = K, Cout = D, weight [D][K] = E^T)
-        et = cb.t().contiguous()
-        g1 = raw_conv_fprop(dd, et, None, None, 1, False, 0, torch.float32, d, 0)        # [1, D, N, 1] -> memory [N][D]
-        _native.check(lib.vqk_axpby(F32, g1.data_ptr(), dz.data_ptr(), dz.data_ptr(), -2.0, 1.0, n * d, st), 'axpby')
-        # dE += -2 dd^T @ Z + 2 E * colsum(dd)   (1x1 wgrad: contraction over the N rows)
-        zimg = flat.view(1, n, 1, d).permute(0, 3, 1, 2)
-        g2 = raw_conv_wgrad(zimg, dd, 1, False)                                           # memory [K][D]
-        g2 = g2.permute(0, 2, 3, 1).reshape(k, d)
-        _native.check(lib.vqk_axpby(F32, g2.data_ptr(), de.data_ptr(), de.data_ptr(), -2.0, 1.0, k * d, st), 'axpby')
-        cs = raw_colsum(n, k, dmat)
-        _native.check(lib.vqk_row_scale_add_f32(de.data_ptr(), cb.data_ptr(), cs.data_ptr(), k, d, 2.0, st), 'row_scale_add')
-        return dz, de, None, None, None, None, None
-
-
-class GumbelVQFn(torch.autograd.Function):
-    """Gumbel-softmax quantization of logits [B,K,H,W] (vector_quantizers.py:233-243): y = softmax((logits+g)/tau),
-    q = y @ E, kl = kl_cost * mean_i sum_n qy log(qy K + 1e-10).  The Exp(1) noise is an INPUT (drawn with torch's
-    RNG by the module, or injected for parity).  Both GEMMs (y@E, dq@E^T) and dE = y^T@dq run on the 1x1 conv
-    kernels.  Returns (q [B,D,H,W], idx [B,H,W], kl, hist)."""
-
-    @staticmethod
-    def forward(ctx, logits, codebook, noise, tau: float, kl_cost: float, hard: bool, out_dtype, sched=None):
-        """``sched``: optional device tensor [tau, kl_cost] that overrides the two scalars inside the kernels (graph replay)"""
-        _require_gpu(logits)
-        logits = nhwc(logits.to(torch.float32))
-        noise = nhwc(noise.to(torch.float32))
-        b, k, h, w = logits.shape
-        n = b * h * w
-        cb = codebook.detach().contiguous()
-        d = cb.shape[1]
-        dt = out_dtype
-        lib, st, dev = _native.lib(), _stream(), logits.device
-        y = torch.empty(n * k, dtype=dt, device=dev).view(1, n, 1, k).permute(0, 3, 1, 2)
-        idx = torch.empty(n, dtype=torch.int64, device=dev)
-        klsum = torch.zeros((), dtype=torch.float32, device=dev)
-        hist = torch.zeros(k, dtype=torch.int32, device=dev)
-        _native.check(lib.vqk_gumbel_forward(dcode(dt), logits.data_ptr(), noise.data_ptr(), n, k, tau, int(hard),
-                                             y.data_ptr(), idx.data_ptr(), klsum.data_ptr(), hist.data_ptr(), _p(sched), st),
-                      'gumbel_forward')
-        et = pack_weights(cb.t().contiguous().reshape(-1), dt, d, k, 1, False, 0)                # [D][K]
-        q = raw_conv_fprop(y, et, None, None, 1, False, 0, dt, d, 0)                              # [1,D,N,1] == [N][D]
-        q = q.permute(0, 2, 3, 1).reshape(b, h, w, d).permute(0, 3, 1, 2)                         # [B,D,H,W] nhwc view
-        ctx.save_for_backward(logits, noise, cb, y)
-        ctx.cfg = (tau, kl_cost, n, k, d, dt, (b, h, w))
-        ctx.sched = sched
-        ctx.mark_non_differentiable(idx, hist)
-        kl = klsum * (kl_cost / float(n)) if sched is None else klsum * sched[1] / float(n)
-        return q, idx.view(b, h, w), kl, hist
-
-    @staticmethod
-    def backward(ctx, dq, _didx, dkl, _dhist):
-        logits, noise, cb, y = ctx.saved_tensors
-        tau, kl_cost, n, k, d, dt, (b, h, w) = ctx.cfg
-        lib, st = _native.lib(), _stream()
-        dqc = nhwc(dq.to(dt)) if dq is not None else torch.zeros((b, d, h, w), dtype=dt, device=logits.device).contiguous(memory_format=_CL)
-        dq_img = dqc.permute(0, 2, 3, 1).reshape(1, n, 1, d).permute(0, 3, 1, 2)                  # [1,D,N,1], memory [N][D]
-        e_w = pack_weights(cb.reshape(-1), dt, k, d, 1, False, 0)                                 # [K][D]
-        dyv = raw_conv_fprop(dq_img, e_w, None, None, 1, False, 0, dt, k, 0)                      # [N][K]
-        gs = dkl.to(torch.float32).contiguous() if dkl is not None else None
-        dlogits = torch.empty_like(logits, memory_format=_CL)
-        _native.check(lib.vqk_gumbel_backward(dcode(dt), logits.data_ptr(), noise.data_ptr(), dyv.data_ptr(), n, k, tau,
-                                              kl_cost if gs is not None else 0.0, _p(gs), dlogits.data_ptr(),
-                                              _p(ctx.sched) if gs is not None else 0, st),
-                      'gumbel_backward')
-        de = None
-        if ctx.needs_input_grad[1]:
-            de = raw_conv_wgrad(dq_img, y, 1, False).permute(0, 2, 3, 1).reshape(k, d)            # y^T @ dq
-        return dlogits, de, None, None, None, None, None, None
-
-
-def ema_stats(flat_z, idx, k: int, out=None) -> torch.Tensor:
-    """packed [counts(K) | dw(K*D)] of this rank's batch (vector_quantizers.py:159-163); ``out``: a persistent buffer
-    (zeroed here) so that a captured graph always writes the same memory"""
-    n, d = flat_z.shape
-    buf = out if out is not None else torch.empty(k + k * d, dtype=torch.float32, device=flat_z.device)
-    buf.zero_()
-    fn = _native.lib().vqk_ema_stats_fused_f32 if (VQ_FUSED and d == 256) else _native.lib().vqk_ema_stats_f32
-    _native.check(fn(flat_z.data_ptr(), idx.data_ptr(), n, k, d, buf.data_ptr(), buf[k:].data_ptr(), _stream()), 'ema_stats')
-    return buf
-
-
-def ema_apply(buf, ema_count, ema_weight, codebook, decay: float, eps: float, batch: float) -> None:
-    """EMA update in place from the (all-reduced) packed statistics (vector_quantizers.py:164-169)"""
-    k, d = codebook.shape
-    _native.check(_native.lib().vqk_ema_update_f32(ema_count.data_ptr(), ema_weight.data_ptr(), codebook.data_ptr(),
-                                                   buf.data_ptr(), buf[k:].data_ptr(), k, d, decay, eps, batch, _stream()),
-                  'ema_update')
-    refresh_vq_prepared(data_ptr=codebook.data_ptr())      # written through the C-ABI: no version bump to notice
-
-
-# ------------------------------------------------------------------------------------------------------
-# StyleGAN2 plugin ops (same call surface as the reference's python wrappers)
-# ------------------------------------------------------------------------------------------------------
-_ACT_IDX = {'linear': 1, 'lrelu': 3}
-
-
-def _bias_act_raw(x, b, yref, dy, grad, dim, act, alpha, gain, clamp):
-    x = x.contiguous()
-    y = torch.empty_like(x)
-    inner = 1
-    for s in x.shape[dim + 1:]:
-        inner *= s
-    st = _native.lib().vqk_bias_act(x.data_ptr(), _p(b), 0, _p(yref), _p(dy), y.data_ptr(), x.numel(), inner,
-                                    x.shape[dim] if b is not None else 1, grad, _ACT_IDX[act], alpha, gain, clamp,
-                                    _stream())
-    _native.check(st, 'bias_act')
-    return y
-
-
-class BiasActFn(torch.autograd.Function):
-    """bias_act.py:129-210 (lrelu / linear, first-order; second order re-applies the same mask)."""
-
-    @staticmethod
-    def forward(ctx, x, b, dim, act, alpha, gain, clamp):
-        _require_gpu(x)
-        y = _bias_act_raw(x, b, None, None, 0, dim, act, alpha, gain, clamp)
-        ctx.save_for_backward(y)
-        ctx.cfg = (dim, act, alpha, gain, clamp, b is not None, x.shape)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        (y,) = ctx.saved_tensors
-        dim, act, alpha, gain, clamp, has_b, shape = ctx.cfg
-        dx = BiasActGradFn.apply(dy.contiguous(), y, dim, act, alpha, gain, clamp)
-        db = None
-        if has_b:
-            db = dx.sum([i for i in range(dx.ndim) if i != dim])
-        return dx, db, None, None, None, None, None
-
-
-class BiasActGradFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, dy, y, dim, act, alpha, gain, clamp):
-        dx = _bias_act_raw(dy, None, y, None, 1, dim, act, alpha, gain, clamp) if act != 'linear' or gain != 1 or clamp >= 0 \
-            else dy
-        ctx.save_for_backward(y)
-        ctx.cfg = (dim, act, alpha, gain, clamp)
-        return dx
-
-    @staticmethod
-    def backward(ctx, d_dx):
-        (y,) = ctx.saved_tensors
-        dim, act, alpha, gain, clamp = ctx.cfg
-        return BiasActGradFn.apply(d_dx.contiguous(), y, dim, act, alpha, gain, clamp), None, None, None, None, None, None
-
-
-def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None):
-    """Same signature and defaults as the reference's ``bias_act`` (bias_act.py:55-89)."""
-    defaults = {'linear': (0.0, 1.0), 'lrelu': (0.2, 2.0 ** 0.5)}
-    if act not in defaults:
-        raise RuntimeError(f'vqk: bias_act activation {act!r} is not on the discriminator path')
-    alpha = float(defaults[act][0] if alpha is None else alpha)
-    gain = float(defaults[act][1] if gain is None else gain)
-    clamp = float(-1 if clamp is None else clamp)
-    return BiasActFn.apply(x, b, dim, act, alpha, gain, clamp)
-
-
-def _upfirdn2d_raw(x, f, up, down, pad, flip, gain):
-    x = x.contiguous()
-    n, c, h, w = x.shape
-    fh, fw = f.shape
-    upx, upy = up
-    downx, downy = down
-    px0, px1, py0, py1 = pad
-    ow = (w * upx + px0 + px1 - fw + downx) // downx
-    oh = (h * upy + py0 + py1 - fh + downy) // downy
-    y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
-    st = _native.lib().vqk_upfirdn2d(x.data_ptr(), f.contiguous().data_ptr(), y.data_ptr(), n, c, h, w, fh, fw, upx, upy,
-                                     downx, downy, px0, px1, py0, py1, int(flip), gain, oh, ow, _stream())
-    _native.check(st, 'upfirdn2d')
-    return y
-
-
-class Upfirdn2dFn(torch.autograd.Function):
-    """upfirdn2d.py:214-268: linear op, backward = the same op with up<->down, flipped filter."""
-
-    @staticmethod
-    def forward(ctx, x, f, up, down, pad, flip, gain):
-        _require_gpu(x)
-        ctx.save_for_backward(f)
-        ctx.cfg = (up, down, pad, flip, gain, x.shape)
-        return _upfirdn2d_raw(x, f, up, down, pad, flip, gain)
-
-    @staticmethod
-    def backward(ctx, dy):
-        (f,) = ctx.saved_tensors
-        up, down, pad, flip, gain, xs = ctx.cfg
-        fh, fw = f.shape
-        _, _, ih, iw = xs
-        _, _, oh, ow = dy.shape
-        p = (fw - pad[0] - 1, iw * up[0] - ow * down[0] + pad[0] - up[0] + 1,
-             fh - pad[2] - 1, ih * up[1] - oh * down[1] + pad[2] - up[1] + 1)
-        return Upfirdn2dFn.apply(dy, f, down, up, p, not flip, gain), None, None, None, None, None, None
-
-
-def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
-    """Same signature as the reference's ``upfirdn2d`` (upfirdn2d.py:120-164); 2-D filters only."""
-    up = (up, up) if isinstance(up, int) else tuple(up)
-    down = (down, down) if isinstance(down, int) else tuple(down)
-    if isinstance(padding, int):
-        padding = (padding,) * 4
-    padding = tuple(padding)
-    if len(padding) == 2:
-        padding = (padding[0], padding[0], padding[1], padding[1])
-    if f.ndim != 2:
-        raise RuntimeError('vqk: upfirdn2d expects a 2-D FIR filter')
-    return Upfirdn2dFn.apply(x, f.to(torch.float32), up, down, padding, bool(flip_filter), float(gain))
-
-
-# ------------------------------------------------------------------------------------------------------
-# VQ-GAN loss path: general conv + activation, NHWC resampling, pooling, LPIPS tap, minibatch-stddev, losses
-# ------------------------------------------------------------------------------------------------------
 ACT_CODE = {'linear': 0, 'tanh': 1, 'relu': 2, 'lrelu': 3}
-
-
-def _conv_general_raw(x, wq, bias, residual, cout, k, stride, pad, mode, h_out, w_out, act, acc_scale, out_gain, out_dtype,
-                      wlayout=0):
-    n, cin, h, w = x.shape
-    y = empty_nhwc(n, cout, h_out, w_out, out_dtype, x.device)
-    flops = 2.0 * n * h_out * w_out * cout * cin * k * k
-    st = _timed(_fprop_kernel_name(x.dtype, wlayout, (n, h_out, w_out, cin, cout, act, out_dtype) if stride == 1 and mode != 2 else None), flops,
-                lambda: _native.lib().vqk_conv2d_general(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias), _p(residual),
-                                                         y.data_ptr(), dcode(out_dtype), n, h, w, cin, cout, k, stride, pad,
-                                                         mode, h_out, w_out, act, float(acc_scale), float(out_gain), wlayout,
-                                                         zero_page(x.device).data_ptr(), _stream()))
-    _native.check(st, 'conv2d_general')
-    return y
-
-
-def _s2_served(dt, out_dtype, n, h, w, h_out, w_out, cin, cout, k, stride, pad, backward: bool) -> bool:
-    """the stride-2 3x3 conv without padding on a (2 h_out + 1) x (2 w_out + 1) input (the discriminator's down-sampling conv
-    after its blur, discriminator.py:95 / conv2d_resample.py:119-122) has a matrix/auxiliary-wave form (vqk_conv2d_s2_*)"""
-    if not (k == 3 and stride == 2 and pad == 0 and dt == torch.bfloat16 and out_dtype == torch.bfloat16
-            and h == 2 * h_out + 1 and w == 2 * w_out + 1):
-        return False
-    return bool(_native.lib().vqk_conv2d_s2_supported(dcode(dt), n, h_out, w_out, cin, cout, int(backward)))
-
-
-def _conv_s2_fprop_raw(x, wq, bias, cout, h_out, w_out, act, acc_scale, out_gain):
-    n, cin, h, w = x.shape
-    y = empty_nhwc(n, cout, h_out, w_out, x.dtype, x.device)
-    flops = 2.0 * n * h_out * w_out * cout * cin * 9
-    st = _timed('conv3x3_mx_kernel<bf16> (stride 2)', flops,
-                lambda: _native.lib().vqk_conv2d_s2_fprop(dcode(x.dtype), x.data_ptr(), wq.data_ptr(), _p(bias), y.data_ptr(), n,
-                                                          h_out, w_out, cin, cout, act, float(acc_scale), float(out_gain),
-                                                          zero_page(x.device).data_ptr(), _stream()))
-    _native.check(st, 'conv2d_s2_fprop')
-    return y
-
-
-def _packed_w4(weight, w4, cin, cout_pad, dt, k, transpose, layout):
-    """cached operand of a conv parameter; ``w4``: its [O,I,k,k] view (2-D fully connected weights are 1x1 convs)"""
-    return packed_weight(weight, cin, cout_pad, dt, k, transpose, layout, shape4=tuple(w4.shape))
-
-
-class ConvActFn(torch.autograd.Function):
-    """y = out_gain * act(conv(x, W) * wgain + bias), stride in {1,2}, explicit zero padding.
-
-    The StyleGAN2 ``Conv2dLayer`` / ``FullyConnectedLayer`` arithmetic (discriminator.py:104-120, :164-173: runtime
-    weight gain 1/sqrt(fan_in), fused bias + activation + gain = the reference's ``bias_act`` plugin) and the VGG16
-    conv+bias+ReLU of LPIPS, all in the conv kernel's epilogue.  Backward: t = out_gain * act'(y) * dy (``bias_act``
-    grad=1), db = colsum(t), dx = wgain * dgrad(t) (zero-stuffed gather for stride 2), dW = wgain * wgrad(x, t)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, k: int, stride: int, pad: int, act: int, wgain: float, out_gain: float, out_dtype):
-        _require_gpu(x)
-        x = nhwc(x)
-        dt = x.dtype
-        out_dtype = out_dtype or dt
-        o, i = weight.shape[0], weight.shape[1]
-        cin = x.shape[1]
-        e = max(epc(dt), epc(out_dtype))
-        cout_pad = -(-o // e) * e
-        if cin < i or cin % epc(dt):
-            raise RuntimeError(f'vqk: conv input has {cin} channels, weight expects {i}')
-        n, _, h, w = x.shape
-        h_out = (h + 2 * pad - k) // stride + 1
-        w_out = (w + 2 * pad - k) // stride + 1
-        plain = stride == 1 and pad == k // 2
-        s2 = _s2_served(dt, out_dtype, n, h, w, h_out, w_out, cin, cout_pad, k, stride, pad, False)
-        layout = weight_layout(dt, n, h, w, cin, cout_pad, k, False, out_dtype) if plain else (1 if s2 else 0)
-        w4 = weight.reshape(o, i, k, k)
-        wq = _packed_w4(weight, w4, cin, cout_pad, dt, k, False, layout)
-        b32 = padded_vector(bias, cout_pad) if bias is not None else None
-        if (k == 1 and plain and cin == 8 and dt == torch.bfloat16 and out_dtype == dt and w % 32 == 0 and cout_pad % 8 == 0):
-            # a 1x1 conv on the padded 3-channel image (the discriminator's fromrgb, discriminator.py:198-199): the thin-input
-            # 3x3 kernel with the weights at the centre tap (zero elsewhere) writes its 2*Cout bytes per pixel at memory speed;
-            # the im2col kernel took 264 us for 8 -> 128 @256^2, bs 16
-            wq3 = packed_weight(weight, 8, cout_pad, dt, 3, False, 0, shape4=(o, i, 1, 1), kind='centre3')
-            y = _conv_general_raw(x, wq3, b32, None, cout_pad, 3, 1, 1, 0, h_out, w_out, act, wgain, out_gain, out_dtype, 0)
-        elif s2:
-            y = _conv_s2_fprop_raw(x, wq, b32, cout_pad, h_out, w_out, act, wgain, out_gain)
-        else:
-            y = _conv_general_raw(x, wq, b32, None, cout_pad, k, stride, pad, 0, h_out, w_out, act, wgain, out_gain, out_dtype,
-                                  layout)
-        ctx.save_for_backward(x, y)
-        ctx.refs = (weight, bias)
-        ctx.cfg = (k, stride, pad, act, wgain, out_gain, o, i, cin, cout_pad, dt)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, y = ctx.saved_tensors
-        dx, dw, db = _conv_act_backward(x, y, ctx.refs, ctx.cfg, ctx.needs_input_grad, dy)
-        return dx, dw, db, None, None, None, None, None, None, None
-
-
-def _conv_act_backward(x, y, refs, cfg, needs, dy, make_t=None, dx_residual=None):
-    """ConvActFn's backward as a plain function (DiscBlockFn composes three of them).  ``make_t(scale, dbsum, db_scale)``: the caller
-    produces t = scale * act'(y) * dy itself (fused into the pass that produces dy) and adds db_scale * t's column sums to ``dbsum``
-    when that is not None; ``dx_residual``: added to the data gradient in the conv kernel's epilogue."""
-    weight, bias = refs
-    k, stride, pad, act, wgain, out_gain, o, i, cin, cout_pad, dt = cfg
-    lib, st = _native.lib(), _stream()
-    # t and dx are built from differentiable Functions so that R1 (autograd.grad(..., create_graph=True) through
-    # this backward, loss.py:98-112) can differentiate them again; in an ordinary backward they record nothing.
-    param_grads = _grad_modes()[1]
-    want_db = bias is not None and needs[2] and param_grads
-    want_dw = needs[1] and param_grads
-    dyn = nhwc(dy) if dy is not None else None
-    dy_dtype = dyn.dtype if dyn is not None else dt
-    dbsum = db_tgt = None
-    gscale = 1.0
-    # weight gradient straight into the optimizer's flat gradient arena (unpadded layers of a FlatAdamW-owned module): the
-    # 1/sqrt(fan_in) weight gain then rides in t (t' = wgain * t: dx = dgrad(t', W), dW += wgrad(x, t'), db = colsum(t') / wgain)
-    # -- no zero-filled temporary, no scale pass, no accumulate pass per parameter
-    tgt = tgt_lin = None
-    if (want_dw and dy_dtype == dt and cout_pad == o and cin == i and wgain > 0.0
-            and not torch.is_grad_enabled()):            # (a create_graph pass -- R1's inner autograd.grad -- must not touch .grad)
-        if act != 0:
-            tgt = direct_grad(weight)
-        elif make_t is None and DIRECT_LINEAR_WGRAD:
-            # linear layer (skip convs, the last fully connected layer): t = dy is no pass, the gains ride in the weight-gradient
-            # kernel's own scale (vqk_conv2d_wgrad_general_scaled) -- also straight into the arena
-            tgt_lin = direct_grad(weight)
-    fold = float(wgain) if tgt is not None else 1.0
-    if make_t is not None:
-        db_scale = 1.0
-        if want_db:
-            if DIRECT_BIAS_GRAD and cout_pad == o and not torch.is_grad_enabled():
-                db_tgt = direct_grad(bias)               # the caller's column-sum pass adds (1 / fold) * colsum(t) to the arena
-            if db_tgt is not None:
-                dbsum, db_scale = db_tgt, 1.0 / fold
-            else:
-                dbsum = torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
-        t = make_t(float(out_gain) * fold, dbsum, db_scale)
-    elif act == 0 and dyn.dtype == dt:
-        # linear layer (the discriminator's skip convs, its last fully connected layer): t = out_gain * dy is no pass over
-        # the tensor -- the scalar rides in the data- / weight-gradient scale (and on the bias sum)
-        t, gscale = dyn, float(out_gain)
-    else:
-        if want_db and dyn.dtype == dt:                  # the bias gradient rides in the act-backward pass
-            vec = 4 if dt == torch.float32 else 8
-            if DIRECT_BIAS_GRAD and cout_pad == o and cout_pad % vec == 0 and cout_pad // vec <= 256 and not torch.is_grad_enabled():
-                db_tgt = direct_grad(bias)               # ... straight into the optimizer's arena (no zero fill, scale, add)
-            dbsum = db_tgt if db_tgt is not None else torch.zeros(cout_pad, dtype=torch.float32, device=x.device)
-        t = ActBwdFn.apply(dyn, y, act, float(out_gain) * fold, dbsum, 1.0 / fold if db_tgt is not None else 1.0)
-    tc = t if t.dtype == dt else nhwc(t.to(dt))
-    n, _, h, w = x.shape
-    _, _, h_out, w_out = tc.shape
-    dx = dw = db = None
-    if needs[0]:
-        dx = ConvDgradFn.apply(tc, weight, k, stride, pad, 1.0 if tgt is not None else float(wgain) * gscale, cin, cout_pad, h, w,
-                               dx_residual)
-    if tgt is not None:
-        _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tc.detach().data_ptr(), tgt.data_ptr(), n, h, w, cin,
-                                                   cout_pad, k, stride, pad, 0, h_out, w_out,
-                                                   zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
-    elif tgt_lin is not None:
-        _native.check(lib.vqk_conv2d_wgrad_general_scaled(dcode(dt), x.data_ptr(), tc.detach().data_ptr(), tgt_lin.data_ptr(), n, h, w,
-                                                          cin, cout_pad, k, stride, pad, 0, h_out, w_out, float(wgain) * gscale,
-                                                          zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
-    elif want_dw:
-        tcd = tc.detach()
-        dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=x.device)
-        _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), x.data_ptr(), tcd.data_ptr(), dwp.data_ptr(), n, h, w, cin,
-                                                   cout_pad, k, stride, pad, 0, h_out, w_out,
-                                                   zero_page(x.device).data_ptr(), st), 'conv2d_wgrad_general')
-        if wgain * gscale != 1.0:
-            _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain) * gscale, 0.0, dwp.numel(), st), 'axpby')
-        dw = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
-    if want_db and db_tgt is None:
-        fused = dbsum is not None and (make_t is not None or (cout_pad % (4 if dt == torch.float32 else 8) == 0
-                                                               and cout_pad // (4 if dt == torch.float32 else 8) <= 256))
-        db = (dbsum if fused else raw_colsum(n * h_out * w_out, cout_pad, tc.detach()))[:o]
-        if gscale != 1.0 or fold != 1.0:
-            db = db * (gscale / fold)
-    return dx, dw, db
-
-
-class ActBwdFn(torch.autograd.Function):
-    """t = scale * act'(y) * dy -- linear in dy for the piecewise-linear / saved-output activations used here, so
-    its own backward is the same op (bias_act.py:197-198: lrelu / relu have no second-order term)"""
-
-    @staticmethod
-    def forward(ctx, dy, y, act: int, scale: float, colsum=None, colsum_scale: float = 1.0):
-        """colsum: fp32 [C] buffer that ALSO receives colsum_scale * the column sums of the result (the conv's bias gradient) -- one pass"""
-        t = torch.empty_like(dy, memory_format=_CL)
-        n, c, h, w = dy.shape
-        v = 4 if dy.dtype == torch.float32 else 8
-        if colsum is not None and c % v == 0 and c // v <= 256:
-            _native.check(_native.lib().vqk_act_backward_colsum_scaled(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(),
-                                                                       n * h * w, c, act, scale, float(colsum_scale),
-                                                                       colsum.data_ptr(), _stream()), 'act_backward_colsum')
-            ctx.fused_colsum = True
-        else:
-            _native.check(_native.lib().vqk_act_backward(dcode(dy.dtype), dy.data_ptr(), y.data_ptr(), t.data_ptr(), dy.numel(),
-                                                         act, scale, _stream()), 'act_backward')
-            ctx.fused_colsum = False
-        ctx.save_for_backward(y)
-        ctx.cfg = (act, scale)
-        if act == 1:
-            ctx.set_materialize_grads(False)
-        return t
-
-    @staticmethod
-    def backward(ctx, v):
-        (y,) = ctx.saved_tensors
-        act, scale = ctx.cfg
-        if act == 1:
-            raise NotImplementedError('second-order tanh epilogue is not on any path')
-        return ActBwdFn.apply(nhwc(v), y, act, scale), None, None, None, None, None
-
-
-class ConvDgradFn(torch.autograd.Function):
-    """dx = wgain * dgrad(t, W): bilinear in (t, W).  Differentiating it (R1) gives a FORWARD conv of the incoming
-    cotangent and a wgrad with the cotangent in the role of the layer input."""
-
-    @staticmethod
-    def forward(ctx, t, weight, k: int, stride: int, pad: int, wgain: float, cin: int, cout_pad: int, h: int, w: int,
-                residual=None):
-        """residual (a constant of the differentiation: DiscBlockFn's other branch gradient) is added in the kernel's epilogue"""
-        dt = t.dtype
-        o, i = weight.shape[0], weight.shape[1]
-        w4 = weight.detach().reshape(o, i, k, k)
-        n, _, h_out, w_out = t.shape
-        if stride == 1 and pad == k // 2:
-            layout = weight_layout(dt, n, h_out, w_out, cout_pad, cin, k, False)
-            wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, layout)
-            dx = _conv_general_raw(t, wt, None, residual, cin, k, 1, k // 2, 0, h, w, 0, wgain, 1.0, dt, layout)
-            residual = None
-        elif _s2_served(dt, dt, n, h, w, h_out, w_out, cin, cout_pad, k, stride, pad, True):
-            wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 0)
-            w3 = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 3)
-            dx = empty_nhwc(n, cin, h, w, dt, t.device)
-            st = _timed('conv3x3_mx_kernel<bf16> (stride-2 dgrad phases)', 2.0 * n * h_out * w_out * cout_pad * cin * 9,
-                        lambda: _native.lib().vqk_conv2d_s2_dgrad(dcode(dt), t.data_ptr(), w3.data_ptr(), wt.data_ptr(), dx.data_ptr(),
-                                                                  n, h_out, w_out, cin, cout_pad, float(wgain),
-                                                                  zero_page(t.device).data_ptr(), _stream()))
-            _native.check(st, 'conv2d_s2_dgrad')
-        else:
-            wt = _packed_w4(weight, w4, cin, cout_pad, dt, k, True, 0)
-            dx = _conv_general_raw(t, wt, None, None, cin, k, 1, k - 1 - pad, 2 if stride == 2 else 0, h, w, 0, wgain, 1.0,
-                                   dt, 0)
-        if residual is not None:                         # (the strided / padded forms have no residual operand)
-            dx = AddFn.apply(dx, residual)
-        ctx.save_for_backward(t)
-        ctx.refs = (weight,)
-        ctx.cfg = (k, stride, pad, wgain, cin, cout_pad, o, i)
-        return dx
-
-    @staticmethod
-    def backward(ctx, v):
-        (t,) = ctx.saved_tensors
-        (weight,) = ctx.refs
-        k, stride, pad, wgain, cin, cout_pad, o, i = ctx.cfg
-        v = nhwc(v)
-        dt = t.dtype
-        n, _, h, w = v.shape
-        _, _, h_out, w_out = t.shape
-        w4 = weight.detach().reshape(o, i, k, k)
-        lib, st = _native.lib(), _stream()
-        d_t = d_w = None
-        if ctx.needs_input_grad[0] and _s2_served(dt, dt, n, h, w, h_out, w_out, cin, cout_pad, k, stride, pad, False):
-            d_t = _conv_s2_fprop_raw(v, _packed_w4(weight, w4, cin, cout_pad, dt, k, False, 1), None, cout_pad, h_out, w_out, 0,
-                                     wgain, 1.0)
-        elif ctx.needs_input_grad[0]:
-            wq = _packed_w4(weight, w4, cin, cout_pad, dt, k, False, 0)
-            d_t = _conv_general_raw(v, wq, None, None, cout_pad, k, stride, pad, 0, h_out, w_out, 0, wgain, 1.0, dt, 0)
-        if ctx.needs_input_grad[1]:
-            dwp = torch.zeros((cout_pad, k, k, cin), dtype=torch.float32, device=v.device)
-            _native.check(lib.vqk_conv2d_wgrad_general(dcode(dt), v.data_ptr(), t.data_ptr(), dwp.data_ptr(), n, h, w, cin,
-                                                       cout_pad, k, stride, pad, 0, h_out, w_out,
-                                                       zero_page(v.device).data_ptr(), st), 'conv2d_wgrad_general')
-            if wgain != 1.0:
-                _native.check(lib.vqk_axpby(F32, dwp.data_ptr(), 0, dwp.data_ptr(), float(wgain), 0.0, dwp.numel(), st), 'axpby')
-            d_w = dwp.permute(0, 3, 1, 2)[:o, :i].reshape(weight.shape)
-        return d_t, d_w, None, None, None, None, None, None, None, None, None
-
-
-def conv_act(x, weight, bias=None, k=3, stride=1, pad=None, act='linear', wgain=1.0, out_gain=1.0, out_dtype=None):
-    return ConvActFn.apply(x, weight, bias, k, stride, k // 2 if pad is None else pad, ACT_CODE[act], float(wgain),
-                           float(out_gain), out_dtype)
-
-
-class UpfirdnNhwcFn(torch.autograd.Function):
-    """upfirdn2d on NHWC activations (same op, same padding algebra, same backward rule as upfirdn2d.py:214-268)."""
-
-    @staticmethod
-    def forward(ctx, x, f, up, down, pad, flip, gain):
-        _require_gpu(x)
-        x = nhwc(x)
-        n, c, h, w = x.shape
-        fh, fw = f.shape
-        ow = (w * up + pad[0] + pad[1] - fw + down) // down
-        oh = (h * up + pad[2] + pad[3] - fh + down) // down
-        y = empty_nhwc(n, c, oh, ow, x.dtype, x.device)
-        st = _native.lib().vqk_upfirdn2d_nhwc(dcode(x.dtype), x.data_ptr(), f.data_ptr(), y.data_ptr(), n, h, w, c, fh, fw,
-                                              up, up, down, down, pad[0], pad[1], pad[2], pad[3], int(flip), float(gain),
-                                              oh, ow, _stream())
-        _native.check(st, 'upfirdn2d_nhwc')
-        ctx.save_for_backward(f)
-        ctx.cfg = (up, down, pad, flip, gain, (h, w))
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        (f,) = ctx.saved_tensors
-        up, down, pad, flip, gain, (ih, iw) = ctx.cfg
-        fh, fw = f.shape
-        _, _, oh, ow = dy.shape
-        p = (fw - pad[0] - 1, iw * up - ow * down + pad[0] - up + 1, fh - pad[2] - 1, ih * up - oh * down + pad[2] - up + 1)
-        return UpfirdnNhwcFn.apply(dy, f, down, up, p, not flip, gain), None, None, None, None, None, None
-
-
-def upfirdn2d_nhwc(x, f, up=1, down=1, padding=(0, 0, 0, 0), flip_filter=False, gain=1.0):
-    return UpfirdnNhwcFn.apply(x, f.to(torch.float32).contiguous(), int(up), int(down), tuple(padding), bool(flip_filter),
-                               float(gain))
-
-
-class MaxPool2x2Fn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        _require_gpu(x)
-        x = nhwc(x)
-        n, c, h, w = x.shape
-        y = empty_nhwc(n, c, h // 2, w // 2, x.dtype, x.device)
-        _native.check(_native.lib().vqk_maxpool2x2(dcode(x.dtype), x.data_ptr(), 0, y.data_ptr(), n, h, w, c, 0, _stream()), 'maxpool')
-        ctx.save_for_backward(x)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        n, c, h, w = x.shape
-        dx = torch.empty_like(x, memory_format=_CL)
-        _native.check(_native.lib().vqk_maxpool2x2(dcode(x.dtype), x.data_ptr(), nhwc(dy).data_ptr(), dx.data_ptr(), n, h, w, c,
-                                                   1, _stream()), 'maxpool_backward')
-        return dx
-
-
-class ChannelAffineFn(torch.autograd.Function):
-    """y = x * scale[c] + shift[c] (constants)"""
-
-    @staticmethod
-    def forward(ctx, x, scale, shift):
-        _require_gpu(x)
-        x = nhwc(x)
-        n, c, h, w = x.shape
-        y = torch.empty_like(x, memory_format=_CL)
-        _native.check(_native.lib().vqk_channel_affine(dcode(x.dtype), x.data_ptr(), scale.data_ptr(), _p(shift), y.data_ptr(),
-                                                       n * h * w, c, _stream()), 'channel_affine')
-        ctx.save_for_backward(scale)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        (scale,) = ctx.saved_tensors
-        dy = nhwc(dy)
-        n, c, h, w = dy.shape
-        dx = torch.empty_like(dy, memory_format=_CL)
-        _native.check(_native.lib().vqk_channel_affine(dcode(dy.dtype), dy.data_ptr(), scale.data_ptr(), 0, dx.data_ptr(),
-                                                       n * h * w, c, _stream()), 'channel_affine')
-        return dx, None, None
-
-
-class LpipsTapFn(torch.autograd.Function):
-    """per-image LPIPS contribution of one feature tap; gradient flows to ``fy`` (the reconstruction branch) only"""
-
-    @staticmethod
-    def forward(ctx, fx, fy, lin):
-        _require_gpu(fx)
-        fx, fy = nhwc(fx), nhwc(fy)
-        n, c, h, w = fx.shape
-        out = torch.zeros(n, dtype=torch.float32, device=fx.device)
-        _native.check(_native.lib().vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
-                                                  out.data_ptr(), 0, 1.0, 0, _stream()), 'lpips_tap')
-        ctx.save_for_backward(fx, fy, lin)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        fx, fy, lin = ctx.saved_tensors
-        n, c, h, w = fx.shape
-        # dout is [n]: the kernel scales every image by its own upstream gradient (no host-side test of the values, which
-        # would be a device -> host sync in the middle of the backward)
-        dfy = torch.empty_like(fy, memory_format=_CL)
-        _native.check(_native.lib().vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
-                                                  0, dout.contiguous().float().data_ptr(), 1.0, dfy.data_ptr(), _stream()),
-                      'lpips_tap_backward')
-        return None, dfy, None
-
-
-class LpipsTapsFn(torch.autograd.Function):
-    """sum over the feature taps of the per-image LPIPS contributions (lpips.py: the five taps' terms added up) as ONE node: the
-    tap kernels accumulate into one zero-filled [B] vector -- no fill and no add launch per tap; gradients to the ``fy`` only"""
-
-    @staticmethod
-    def forward(ctx, ntap: int, *args):
-        fxs, fys, lins = args[:ntap], args[ntap:2 * ntap], args[2 * ntap:3 * ntap]
-        _require_gpu(fxs[0])
-        fxs, fys = [nhwc(t) for t in fxs], [nhwc(t) for t in fys]
-        n = fxs[0].shape[0]
-        out = torch.zeros(n, dtype=torch.float32, device=fxs[0].device)
-        lib, st = _native.lib(), _stream()
-        for fx, fy, lin in zip(fxs, fys, lins):
-            _, c, h, w = fx.shape
-            _native.check(lib.vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
-                                            out.data_ptr(), 0, 1.0, 0, st), 'lpips_tap')
-        ctx.save_for_backward(*fxs, *fys, *lins)
-        ctx.ntap = ntap
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        k = ctx.ntap
-        saved = ctx.saved_tensors
-        fxs, fys, lins = saved[:k], saved[k:2 * k], saved[2 * k:]
-        d = dout.contiguous().float()
-        lib, st = _native.lib(), _stream()
-        grads = []
-        for fx, fy, lin in zip(fxs, fys, lins):
-            n, c, h, w = fx.shape
-            dfy = torch.empty_like(fy, memory_format=_CL)
-            _native.check(lib.vqk_lpips_tap(dcode(fx.dtype), fx.data_ptr(), fy.data_ptr(), lin.data_ptr(), n, h * w, c,
-                                            0, d.data_ptr(), 1.0, dfy.data_ptr(), st), 'lpips_tap_backward')
-            grads.append(dfy)
-        return (None,) + (None,) * k + tuple(grads) + (None,) * k
-
-
-class MbstdFn(torch.autograd.Function):
-    """minibatch-stddev feature appended as one extra channel (discriminator.py:277-293); output channels are
-    padded with zeros to a whole 16-byte chunk"""
-
-    @staticmethod
-    def forward(ctx, x, group: int):
-        _require_gpu(x)
-        x = nhwc(x)
-        n, c, h, w = x.shape
-        g = min(group, n)
-        cp = -(-(c + 1) // epc(x.dtype)) * epc(x.dtype)
-        y = empty_nhwc(n, cp, h, w, x.dtype, x.device)
-        stat = torch.empty(n // g, dtype=torch.float32, device=x.device)
-        _native.check(_native.lib().vqk_mbstd(dcode(x.dtype), x.data_ptr(), 0, y.data_ptr(), stat.data_ptr(), n, h * w, c, cp, g,
-                                              0, _stream()), 'mbstd')
-        ctx.save_for_backward(x)
-        ctx.cfg = (g, cp)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        g, cp = ctx.cfg
-        return MbstdBwdFn.apply(x, nhwc(dy), g, cp), None
-
-
-class MbstdBwdFn(torch.autograd.Function):
-    """first backward of the minibatch-stddev layer as a differentiable op (it is non-linear in x, and R1
-    differentiates the backward pass)"""
-
-    @staticmethod
-    def forward(ctx, x, dy, g: int, cp: int):
-        n, c, h, w = x.shape
-        dx = torch.empty_like(x, memory_format=_CL)
-        _native.check(_native.lib().vqk_mbstd(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, n, h * w, c, cp,
-                                              g, 1, _stream()), 'mbstd_backward')
-        ctx.save_for_backward(x, dy)
-        ctx.cfg = (g, cp)
-        return dx
-
-    @staticmethod
-    def backward(ctx, v):
-        x, dy = ctx.saved_tensors
-        g, cp = ctx.cfg
-        n, c, h, w = x.shape
-        v = nhwc(v)
-        ddy = torch.empty_like(dy, memory_format=_CL)
-        dxx = torch.empty_like(x, memory_format=_CL)
-        _native.check(_native.lib().vqk_mbstd_double_backward(dcode(x.dtype), x.data_ptr(), dy.data_ptr(), v.data_ptr(),
-                                                              ddy.data_ptr(), dxx.data_ptr(), n, h * w, c, cp, g, _stream()),
-                      'mbstd_double_backward')
-        return dxx, ddy, None, None
-
-
-class AddFn(torch.autograd.Function):
-    """a + b on the HIP axpby kernel (the resnet skip add of the discriminator, discriminator.py:259)"""
-
-    @staticmethod
-    def forward(ctx, a, b):
-        a, b = nhwc(a), nhwc(b)
-        y = torch.empty_like(a, memory_format=_CL)
-        _native.check(_native.lib().vqk_axpby(dcode(a.dtype), a.data_ptr(), b.data_ptr(), y.data_ptr(), 1.0, 1.0, a.numel(),
-                                              _stream()), 'axpby')
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        return dy, dy
-
-
 FUSE_DISC_BLOCK = _native.switch('VQK_FUSE_DISC_BLOCK', '1') != '0'
 DIRECT_LINEAR_WGRAD = _native.switch('VQK_DIRECT_LINEAR_WGRAD', '1') != '0'   # linear ConvActFn layers: scaled weight gradient straight into the arena
 DIRECT_BIAS_GRAD = _native.switch('VQK_DIRECT_BIAS_GRAD', '1') != '0'    # ConvActFn: bias gradient straight into the optimizer's arena
-
-
-def _conv_act_cfg(x, weight, k, stride, pad, act, wgain, out_gain):
-    """the ``ctx.cfg`` tuple ConvActFn.forward builds for this call (channel counts already whole 16-byte chunks)"""
-    o, i = weight.shape[0], weight.shape[1]
-    e = epc(x.dtype)
-    return (k, stride, pad, act, float(wgain), float(out_gain), o, i, x.shape[1], -(-o // e) * e, x.dtype)
-
-
-class DiscBlockFn(torch.autograd.Function):
-    """One resnet DiscriminatorBlock (discriminator.py:233-262: y = skip(x) * sqrt(1/2) + conv1(conv0(x)) * sqrt(1/2)) as ONE
-    autograd node.  Forward: the same five launches as the layer-by-layer form.  Backward, in an order autograd cannot choose:
-    (1) conv1 (activation gradient, stride-2 data gradient, weight gradient), (2) the skip branch down to the block input's
-    resolution, (3) conv0's activation gradient FUSED into the blur's adjoint (vqk_upfirdn2d_act_backward: blur^T(dB) is never
-    stored), (4) conv0's data gradient with the skip branch's gradient added IN ITS EPILOGUE (no accumulation pass).
-    First-order only: the R1 pass (autograd.grad(..., create_graph=True), loss.py:98-112) uses the layer-by-layer form."""
-
-    @staticmethod
-    def layers(x, w0, b0, w1, b1, ws, f, cfg):
-        """the block layer by layer (DiscriminatorBlock.forward's un-fused form); returns the intermediates as well"""
-        wg0, wg1, wgs, act, act_gain, gain, pad_blur, pad_skip = cfg
-        ys = UpfirdnNhwcFn.apply(x, f, 1, 2, pad_skip, False, 1.0)
-        ysk = ConvActFn.apply(ys, ws, None, 1, 1, 0, 0, wgs, gain, None)
-        y0 = ConvActFn.apply(x, w0, b0, 3, 1, 1, act, wg0, act_gain, None)
-        blur = UpfirdnNhwcFn.apply(y0, f, 1, 1, pad_blur, False, 1.0)
-        y1 = ConvActFn.apply(blur, w1, b1, 3, 2, 0, act, wg1, act_gain * gain, None)
-        return AddFn.apply(ysk, y1), ys, y0, blur, y1
-
-    @staticmethod
-    def forward(ctx, x, w0, b0, w1, b1, ws, f, cfg):
-        wg0, wg1, wgs, act, act_gain, gain, pad_blur, pad_skip = cfg
-        x_in, x = x, nhwc(x)
-        out, ys, y0, blur, y1 = DiscBlockFn.layers(x, w0, b0, w1, b1, ws, f, cfg)
-        ctx.block_cfg = cfg
-        ctx.save_for_backward(x_in, ys, y0, blur, y1, f)        # (the INPUT itself: a double backward differentiates through it)
-        ctx.refs = (w0, b0, w1, b1, ws)
-        ctx.cfgs = (_conv_act_cfg(x, w0, 3, 1, 1, act, wg0, act_gain), _conv_act_cfg(blur, w1, 3, 2, 0, act, wg1, act_gain * gain),
-                    _conv_act_cfg(ys, ws, 1, 1, 0, 0, wgs, gain), pad_blur, pad_skip)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        x, ys, y0, blur, y1, f = ctx.saved_tensors
-        w0, b0, w1, b1, ws = ctx.refs
-        cfg0, cfg1, cfgs, pad_blur, pad_skip = ctx.cfgs
-        need = ctx.needs_input_grad
-        if torch.is_grad_enabled():
-            # this backward is itself being differentiated (create_graph=True, e.g. R1 on a pass that was not announced with
-            # double_backward=True): the fused passes below record nothing, so the block is evaluated again layer by layer and
-            # ITS differentiable backward is used (costs one forward of the block)
-            with torch.enable_grad():
-                ins = [x, w0, b0, w1, b1, ws]
-                out = DiscBlockFn.layers(x, w0, b0, w1, b1, ws, f, ctx.block_cfg)[0]
-                idx = [i for i in range(6) if need[i] and ins[i] is not None]
-                got = torch.autograd.grad(out, [ins[i] for i in idx], g, create_graph=True, allow_unused=True)
-            res = [None] * 8
-            for i, v in zip(idx, got):
-                res[i] = v
-            return tuple(res)
-        x = nhwc(x)
-        g = nhwc(g)
-        n, c, h, w = x.shape
-        fh, fw = f.shape
-        # (1) conv1
-        d_blur, dw1, db1 = _conv_act_backward(blur, y1, (w1, b1), cfg1, (True, need[3], need[4]), g)
-        # (2) skip: 1x1 data gradient at half resolution, then the adjoint of blur + decimate (upfirdn2d.py:259-268)
-        g_lo, dws, _ = _conv_act_backward(ys, None, (ws, None), cfgs, (need[0], need[5], False), g)
-        u = None
-        if need[0]:
-            _, _, oh, ow = ys.shape
-            ps = (fw - pad_skip[0] - 1, w - ow * 2 + pad_skip[0], fh - pad_skip[2] - 1, h - oh * 2 + pad_skip[2])
-            u = UpfirdnNhwcFn.apply(g_lo, f, 2, 1, ps, True, 1.0)
-        # (3) + (4) conv0
-        _, _, bh, bw = blur.shape
-        pb = (fw - pad_blur[0] - 1, w - bw + pad_blur[0], fh - pad_blur[2] - 1, h - bh + pad_blur[2])
-        act = cfg0[3]
-
-        def make_t(scale, dbsum, db_scale=1.0):
-            t0 = torch.empty_like(y0, memory_format=_CL)
-            st = _native.lib().vqk_upfirdn2d_act_backward(dcode(x.dtype), d_blur.data_ptr(), f.data_ptr(), y0.data_ptr(), t0.data_ptr(),
-                                                          n, bh, bw, c, pb[0], pb[1], pb[2], pb[3], 1, float(scale), act, h, w,
-                                                          _stream()) if (act in (2, 3) and fh == 4 and fw == 4) else -1
-            if st not in (-1, _native.ERR_SHAPE):
-                _native.check(st, 'upfirdn2d_act_backward')
-            else:                                        # shapes outside the fused kernel: blur^T, then the activation gradient
-                t0 = ActBwdFn.apply(UpfirdnNhwcFn.apply(d_blur, f, 1, 1, pb, True, 1.0), y0, act, float(scale), None)
-            if dbsum is not None:
-                raw_colsum(n * h * w, c, t0, out=dbsum, scale=db_scale)
-            return t0
-
-        gx, dw0, db0 = _conv_act_backward(x, y0, (w0, b0), cfg0, (need[0], need[1], need[2]), None, make_t=make_t, dx_residual=u)
-        return gx, dw0, db0, dw1, db1, dws, None, None
-
-
-class ReconLossFn(torch.autograd.Function):
-    """(l1, l2) = (mean |t - r|, mean (t - r)^2) over the un-padded element count (loss.py:58-63,118-119)"""
-
-    @staticmethod
-    def forward(ctx, recon, target, denom: float):
-        _require_gpu(recon)
-        recon = nhwc(recon)
-        target = nhwc(target.to(torch.float32))
-        sums = torch.zeros(2, dtype=torch.float32, device=recon.device)
-        lib, st = _native.lib(), _stream()
-        _native.check(lib.vqk_l1_sum(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(), recon.numel(), sums[0:1].data_ptr(), st), 'l1')
-        _native.check(lib.vqk_sse(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(), recon.numel(), sums[1:2].data_ptr(), st), 'sse')
-        ctx.save_for_backward(recon, target)
-        ctx.denom = denom
-        return sums[0] / denom, sums[1] / denom
-
-    @staticmethod
-    def backward(ctx, d1, d2):
-        recon, target = ctx.saved_tensors
-        d = torch.empty_like(recon, memory_format=_CL)
-        lib, st = _native.lib(), _stream()
-        one = torch.ones((), dtype=torch.float32, device=recon.device)
-        g1 = (d1 if d1 is not None else one * 0).to(torch.float32).contiguous()
-        g2 = (d2 if d2 is not None else one * 0).to(torch.float32).contiguous()
-        _native.check(lib.vqk_l1l2_backward(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(), recon.numel(),
-                                            1.0 / ctx.denom, 0.0, g1.data_ptr(), d.data_ptr(), 0, st), 'l1_backward')
-        _native.check(lib.vqk_l1l2_backward(dcode(recon.dtype), recon.data_ptr(), target.data_ptr(), recon.numel(),
-                                            0.0, 1.0 / ctx.denom, g2.data_ptr(), d.data_ptr(), 1, st), 'l2_backward')
-        return d, None, None
-
-
-class GanLossFn(torch.autograd.Function):
-    """generator_loss / discriminator_loss of loss.py:11-51 on [B,1] logits"""
-
-    @staticmethod
-    def forward(ctx, logits_real, logits_fake, mode: int, which: int):
-        lf = logits_fake.to(torch.float32).contiguous()
-        lr = logits_real.to(torch.float32).contiguous() if logits_real is not None else None
-        _require_gpu(lf)
-        loss = torch.zeros((), dtype=torch.float32, device=lf.device)
-        _native.check(_native.lib().vqk_gan_loss(_p(lr), lf.data_ptr(), lf.numel(), mode, which, loss.data_ptr(), 0, 0, 0,
-                                                 _stream()), 'gan_loss')
-        ctx.save_for_backward(lr, lf)
-        ctx.cfg = (mode, which, logits_fake.shape)
-        return loss
-
-    @staticmethod
-    def backward(ctx, dloss):
-        lr, lf = ctx.saved_tensors
-        mode, which, shape = ctx.cfg
-        dfake = torch.empty_like(lf)
-        dreal = torch.empty_like(lr) if lr is not None else None
-        gs = dloss.to(torch.float32).contiguous()
-        _native.check(_native.lib().vqk_gan_loss(_p(lr), lf.data_ptr(), lf.numel(), mode, which, 0, _p(dreal), dfake.data_ptr(),
-                                                 gs.data_ptr(), _stream()), 'gan_loss_backward')
-        return (dreal.view(shape) if dreal is not None else None), dfake.view(shape), None, None
-
-
-class SumSqFn(torch.autograd.Function):
-    """sum(g^2) over all elements (R1 penalty, loss.py:108); backward 2 g * upstream"""
-
-    @staticmethod
-    def forward(ctx, gimg):
-        gimg = gimg.contiguous()
-        zero = torch.zeros(gimg.numel(), dtype=torch.float32, device=gimg.device)
-        out = torch.zeros((), dtype=torch.float32, device=gimg.device)
-        _native.check(_native.lib().vqk_sse(dcode(gimg.dtype), gimg.data_ptr(), zero.data_ptr(), gimg.numel(), out.data_ptr(),
-                                            _stream()), 'sse')
-        ctx.save_for_backward(gimg)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        (gimg,) = ctx.saved_tensors
-        zero = torch.zeros(gimg.numel(), dtype=torch.float32, device=gimg.device)
-        d = torch.empty_like(gimg)
-        _native.check(_native.lib().vqk_mse_tanh_backward(dcode(gimg.dtype), gimg.data_ptr(), zero.data_ptr(), gimg.numel(), 1.0,
-                                                          dout.to(torch.float32).contiguous().data_ptr(), 0, d.data_ptr(),
-                                                          _stream()), 'sumsq_backward')
-        return d
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -3043,3 +1860,10 @@ def install_tracing() -> int:
 
 if TRACE:
     install_tracing()
+
+
+# ------------------------------------------------------------------------------------------------------
+# operator families kept in their own files (this module stays the one import: `ops.VQLookupFn`, `ops.conv_act`, ...)
+# ------------------------------------------------------------------------------------------------------
+from ._ops_vq import *        # noqa: E402,F401,F403  quantizers
+from ._ops_gan import *       # noqa: E402,F401,F403  VQ-GAN loss path, the reference's two plugins
