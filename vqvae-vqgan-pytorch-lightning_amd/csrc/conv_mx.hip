@@ -56,6 +56,12 @@ using vqkd::xcd_remap;
 #ifndef VQK_MX_PRIO
 #define VQK_MX_PRIO 0        // s_setprio of the matrix waves
 #endif
+#ifndef VQK_MX_PACE
+#define VQK_MX_PACE 0        // 1: the drain of a parked tile is spread over the NEXT tile's units 0 .. nun-2 instead of bursting in unit 0 -- measured SLOWER (round 6, profiles/round6_mx_phase_attribution.txt: 598 vs 587 us at 128 -> 128 @256^2, the 1x1 form 104 vs 73 us, the step +0.57 ms): what the matrix waves lose is proportional to the auxiliary waves' work, not to its burstiness
+#endif
+#ifndef VQK_MX_WL
+#define VQK_MX_WL 0          // matrix-wave layout: 0 = 2 (pixels) x 2 (couts), a wave owns PIX/2 pixels x 64 couts; 1 = 1 x 4, PIX pixels x 32 couts:
+#endif                       // half the weight-fragment loads per MFMA (the CU's vector-memory path, profiles/round6_mx_phase_attribution.txt), twice the LDS fragment reads
 #ifndef VQK_MX_JOUTER
 #define VQK_MX_JOUTER 0      // MFMA order inside a phase: 0 pixel-fragment-major, 1 weight-fragment-major
 #endif
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     constexpr int BUF = PIECES * 1024, STG = NBUF * BUF, SPITCH = 272, SCR = STG + PIX * SPITCH;   // SCR: 1 KiB of statistics partials
     constexpr int TQR = SCR + 1024;                              // 8-entry ring of tile ids (dynamic tile queue)
     constexpr int TWD = TAPW ? TAPW : NTAP == 9 ? 3 : NTAP == 4 ? 2 : 1;      // taps per window row
-    constexpr int NI = PIX / 64, NJ = 2;                         // a matrix wave: NI x 32 pixels x 64 couts (PIX = 128: the half tile of the
+    constexpr int NI = VQK_MX_WL ? PIX / 32 : PIX / 64, NJ = VQK_MX_WL ? 1 : 2;                         // a matrix wave: NI x 32 pixels x 64 couts (PIX = 128: the half tile of the
                                                                  // 16x16 maps, twice as many blocks for a chip that their 256-pixel tiles leave half empty)
     constexpr int NQ = PIX / 16;                                 // 16-byte staging pieces per auxiliary thread and tile
     static_assert(PIX == 256 || ((PIX == 128 || PIX == 64) && !POOL && NTAP == 9), "256-pixel tiles, or plain 128- / 64-pixel part tiles");
@@ -145,11 +151,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         return tp;
     };
     auto unit_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // VQK_MXABL & 64 (instrumented build, tools/mx_phase_probe.py): g.gn_ws is NOT a statistics workspace but a debug buffer -- every
+    // matrix wave leaves {cycles in its unit loop, cycles parked in the unit barrier, cycles parking tiles, units} there (s_memtime)
+    double* const gnws = (VQK_MXABL & 64) ? nullptr : g.gn_ws;
+    unsigned long long* const dbg = (VQK_MXABL & 64) ? reinterpret_cast<unsigned long long*>(g.gn_ws) : nullptr;
 
     if (wave < 4) {
         // ================================================================= M waves: MFMA only
         if (VQK_MX_PRIO) __builtin_amdgcn_s_setprio(VQK_MX_PRIO);
-        const int wm = wave >> 1, wn = wave & 1;
+        const int wm = VQK_MX_WL ? 0 : wave >> 1, wn = VQK_MX_WL ? wave : wave & 1;
         const int p = lane & 31, kg = lane >> 5;
         unsigned abase[NI], sbase[NI];
 #pragma unroll
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             if (TWLOG == 5) { ty = wm * NI + i; tx = p; }
             else { ty = wm * 2 * NI + 2 * i + (p >> 4); tx = p & 15; }
             abase[i] = (unsigned)(((ty + (pmode ? 0 : g.tap_oy)) * HW2 + tx + (pmode ? 0 : g.tap_ox)) * RS + kg * 16);
-            sbase[i] = (unsigned)(STG + (ty * TW + tx) * SPITCH + (wn * 64 + 4 * kg) * 2);
+            sbase[i] = (unsigned)(STG + (ty * TW + tx) * SPITCH + (wn * (32 * NJ) + 4 * kg) * 2);
         }
         const int lane16 = lane * 16;
         const int phase_bytes = (g.cout >> 5) * nch * (NPH * 1024);
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         auto unit_w = [&](int key, int c, int j) -> int {
             const int ph = unit_ph(key, c), cc = pmode == 2 ? c - ph * nch : c;
             const int wph = (NTAP == 4 && g.phase_rev) ? 3 - ph : ph;      // (conv_geom.h: phase_rev -- the pooled data gradient)
-            return wph * phase_bytes + (((key & 0xffff) * 4 + wn * 2 + j) * nch + cc) * (NPH * 1024);
+            return wph * phase_bytes + (((key & 0xffff) * 4 + wn * NJ + j) * nch + cc) * (NPH * 1024);
         };
         // window offset of a phase inside the halo: forward (a, b), data gradient (1 - a, 1 - b) (vqk_conv2d_ups_phase)
         auto phase_off = [&](int ph) -> int {
@@ -201,7 +211,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         unit_barrier();                                          // the halo of unit 0 has landed
 
         int tj = 0, c = 0, bi = 0, t_next = 0;
+        unsigned long long t_bar = 0, t_park = 0, n_units = 0, t_c0 = 0, t_cl = 0, t_top = 0;     // (t_c0 / t_cl: MFMA sections of a tile's first / last unit)
+        const unsigned long long t_begin = (VQK_MXABL & 64) ? __builtin_amdgcn_s_memtime() : 0;
         for (;;) {
+            if (VQK_MXABL & 64) t_top = __builtin_amdgcn_s_memtime();
             // the id of the next tile is read one unit before it is needed (published two units earlier by the first X wave)
             if (c == nun - 2) t_next = next_id(tj + 1);
             const bool last_c = c == nun - 1, more = last_c && t_next < total_tiles;
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                         if (reads) {
 #pragma unroll
                             for (int i = 0; i < NI; ++i) { SGB(0x008, 1); SGB(0x100, 1); }
-                            SGB(0x008, NI * NJ - NI);
+                            if constexpr (NI * NJ - NI > 0) SGB(0x008, NI * NJ - NI);
                         } else {
                             SGB(0x008, NI * NJ);
                         }
@@ -279,6 +292,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            const unsigned long long t_a = (VQK_MXABL & 64) ? __builtin_amdgcn_s_memtime() : 0;
+            if (VQK_MXABL & 64) { if (c == 0) t_c0 += t_a - t_top; if (c == nun - 1) t_cl += t_a - t_top; }
             if (c == nun - 1 && !((VQK_MXABL & 4) && g.n > 0)) {
                 // park the tile: lane (pixel p, half kg) holds couts j*32 + 8*rq + 4*kg + e of its wave's 64 -> 8-byte pieces
 #pragma unroll
@@ -292,12 +307,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                             *reinterpret_cast<u32x2*>(smem + sbase[i] + (j * 32 + 8 * rq) * 2) = o;
                         }
             }
+            if (VQK_MXABL & 64) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the park's ds_writes are issued, not retired: count them as park)
+                const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+                unit_barrier();
+                const unsigned long long t_c = __builtin_amdgcn_s_memtime();
+                t_park += t_b - t_a; t_bar += t_c - t_b; ++n_units;
+            } else
             unit_barrier();
             if (last_c) { if (!more) break; ++tj; }
             cur_nt = nxt_nt; c = nc;
             bi = bi == NBUF - 1 ? 0 : bi + 1;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) wcur[j] = wnxt[j];
+        }
+        if ((VQK_MXABL & 64) && dbg && lane == 0) {
+            unsigned long long* o = dbg + ((int64_t)blockIdx.x * 4 + wave) * 8;
+            o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_bar; o[2] = t_park; o[3] = n_units;
+            o[4] = t_c0; o[5] = t_cl; o[6] = (unsigned long long)nun; o[7] = 0;
         }
         return;
     }
@@ -392,13 +419,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                 const int span = g.gn_cpg >> 3;
                 if (span >= 2) v += __shfl_xor(v, 1, 64);
                 if (span >= 4) v += __shfl_xor(v, 2, 64);
-                if (stat_idx >= 0 && (span < 2 || (lane & (span - 1)) == 0)) g.gn_ws[stat_idx] = (double)v;
+                if (stat_idx >= 0 && (span < 2 || (lane & (span - 1)) == 0)) gnws[stat_idx] = (double)v;
             } else if (stat_idx >= 0) {
-                atomicAdd(g.gn_ws + stat_idx, (double)v);
+                atomicAdd(gnws + stat_idx, (double)v);
             }
         }
     };
-    auto drain = [&](const OutPos& o, const u32x4 (&rv)[NR]) {
+    // k0 .. k1: the output pieces of this call (round 6: a tile's drain is PACED over the next tile's units -- measured with the
+    // instrumented build, tools/mx_phase_probe.py: the matrix waves' unit beside a whole-tile drain took 6993 cycles against 5222 for a
+    // unit with quiet auxiliary waves, 128 -> 128 @256^2); `first` clears the statistics accumulators, `last` folds them
+    float ga = 0.f, qa = 0.f, gb = 0.f, qb = 0.f;                // GroupNorm sums of the tile being drained: channels 0-3 / 4-7 of the thread's eight
+    auto drain = [&](const OutPos& o, const u32x4 (&rv)[NR], int k0, int k1, bool first, bool last) {
+        if (first) { ga = 0.f; qa = 0.f; gb = 0.f; qb = 0.f; }
         float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (bias) {
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + o.co), b1 = *reinterpret_cast<const f32x4*>(bias + o.co + 4);
@@ -406,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
         }
         // GroupNorm statistics of the stored output (wave-uniform switch): channel sums over this thread's pieces
-        const bool want_stats = g.gn_ws != nullptr;
+        const bool want_stats = gnws != nullptr;
         // (v_dot2c_f32_bf16 sums a packed pair -- against (1, 1) for the sum, against itself for the squares -- straight
         // from the stored bf16 words: 8 VALU per 16-byte piece instead of 24 for unpack / add / fma; every X-wave VALU
         // instruction competes with the matrix wave of its SIMD for the issue port)
@@ -416,7 +448,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         // products of a piece go out as ONE statement with the four accumulators interleaved, and `settle` closes the
         // chain before the sums are read; without it the last products of a tile were dropped now and then)
         const unsigned ones2 = 0x3f803f80u;
-        float ga = 0.f, qa = 0.f, gb = 0.f, qb = 0.f;            // channels 0-3 / 4-7 of the thread's eight
         auto tally = [&](const u32x4& o) {
             const unsigned d0 = o[0], d1 = o[1], d2 = o[2], d3 = o[3];
             asm("v_dot2c_f32_bf16 %0, %4, %8\n\tv_dot2c_f32_bf16 %1, %4, %4\n\tv_dot2c_f32_bf16 %2, %6, %8\n\t"
@@ -428,11 +459,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
         u32x4 t[NQ];                                             // the thread's staging pieces, all requested up front
         if constexpr (!POOL) {
 #pragma unroll
-            for (int k = 0; k < NQ; ++k)
+            for (int k = 0; k < NQ; ++k) {
+                if (k < k0 || k >= k1) continue;                 // (wave-uniform)
                 t[k] = *reinterpret_cast<const u32x4*>(smem + STG + (k * 16 + (xt >> 4)) * SPITCH + slot * 16);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < NQ; ++k) {
+                if ((k >> 2) < k0 || (k >> 2) >= k1) continue;
                 const int opp = (k >> 2) * 16 + (xt >> 4);
                 const int ty = 2 * (opp >> (TWLOG - 1)) + ((k >> 1) & 1), tx = 2 * (opp & (TW / 2 - 1)) + (k & 1);
                 t[k] = *reinterpret_cast<const u32x4*>(smem + STG + (ty * TW + tx) * SPITCH + slot * 16);
@@ -443,6 +477,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             if (!bias && !res && g.act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f) {     // plain copy (wave-uniform)
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
+                    if (k < k0 || k >= k1) continue;
                     __builtin_amdgcn_raw_buffer_store_b128(t[k], ysrd, res_off(o, k), 0, VQK_MX_NT);
                     if (want_stats) tally(t[k]);
                 }
@@ -451,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                 float abl_b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, abl_g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
+                    if (k < k0 || k >= k1) continue;
                     float f[8], r[8];
                     unpack8(t[k], f);
                     unpack8(rv[k], r);
@@ -494,6 +530,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             // y = pool_scale * sum over the 2x2 window of (conv + bias + residual), written at half resolution
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
+                if (k < k0 || k >= k1) continue;
                 const int opp = k * 16 + (xt >> 4);              // pooled pixel 0..63 of the (TH/2) x (TW/2) output patch
                 const int oty = opp >> (TWLOG - 1), otx = opp & (TW / 2 - 1);
                 float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -512,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
                 if (want_stats) tally(ov);
             }
         }
-        if (want_stats) {
+        if (want_stats && last) {
             // thread: 8 channels = two 4-channel halves (one group each when cpg == 4, the same group otherwise); the four
             // lanes l, l+16, l+32, l+48 of a wave own the same channels -> sum over them, then copy q = lane >> 4 of a slot
             // keeps ONE of the (up to) four values.  The four X waves' 64 values are parked in LDS and combined by the first
@@ -593,6 +630,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     OutPos done = out_pos(cur);
     int fu = 4 % nun, ford = 4 / nun;                            // (u + 4) % nun, (u + 4) / nun: the tile of unit u + 4
     bool pending = false, flush = false;
+    int dk = 0;                                                  // next piece of the tile being drained
     u32x4 rv[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) rv[k] = u32x4{0u, 0u, 0u, 0u};
@@ -618,11 +656,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
             bump();
         }
         if (flush) { flush_stats(); flush = false; }
-        if (pending && !((VQK_MXABL & 2) && g.n > 0)) { drain(done, rv); flush = g.gn_ws != nullptr; }   // tile parked during unit u-1
+        if (pending && !((VQK_MXABL & 2) && g.n > 0)) {          // a tile parked during unit u-1 (or earlier: paced) waits in the staging tile
+            // paced: ceil(NP / (nun - 1)) pieces per interval over the next tile's units 0 .. nun-2 -- it has to be gone before that
+            // tile is parked at the end of its unit nun-1 (the residual registers are reloaded in that interval, too)
+            const int per = (VQK_MX_PACE && nun > 2) ? (NP + nun - 2) / (nun - 1) : NP;
+            const int k1 = dk + per < NP ? dk + per : NP;
+            drain(done, rv, dk, k1, dk == 0, k1 == NP);
+            dk = k1;
+            if (dk == NP) { pending = false; dk = 0; flush = gnws != nullptr; }
+        }
         const bool last_c = c == nun - 1;
         int t_next = 0;
-        pending = last_c;                                        // unit u ends a tile: its residual is requested now,
-        if (pending) {                                           // the tile itself is drained in the next interval
+        if (last_c) {                                            // unit u ends a tile: its residual is requested now,
+            pending = true;                                      // the tile itself is drained from the next interval on
             done = out_pos(cur);
             if (res) load_res(done, rv);
             t_next = next_id(tj + 1);
@@ -645,8 +691,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx_kernel(const bf16_raw* __re
     if (flush) flush_stats();
     if (pending) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        drain(done, rv);
-        if (g.gn_ws) {
+        drain(done, rv, dk, NP, dk == 0, true);
+        if (gnws) {
             unit_barrier();                                      // the M waves have ended: this joins the X waves only
             flush_stats();
         }
