@@ -207,7 +207,7 @@ def other_configs(steps: int = 20, warmup: int = 5) -> dict:
                                       peak_tflops=sr['peak_tflops'], counted=sr['counted'])
                 if rl:
                     res[label].update(dominant_kernel=rl['kernel'], dominant_kernel_avg_launch_us=rl['avg_kernel_launch_us'],
-                                      dominant_kernel_frac=rl['frac'], dominant_kernel_ms_per_step=round(rl['kernel_time_frac_of_step'] * j['ms_per_step'], 3))
+                                      dominant_kernel_frac=rl['frac'], dominant_kernel_executed_frac=rl['executed_frac'], dominant_kernel_ms_per_step=round(rl['kernel_time_frac_of_step'] * j['ms_per_step'], 3))
         except Exception as exc:
             res[label] = dict(error=f'{type(exc).__name__}: {exc}')
     return res

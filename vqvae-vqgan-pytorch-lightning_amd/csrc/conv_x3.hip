@@ -72,9 +72,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
 
     const int wm = WL ? 0 : wave >> 1, wn = WL ? wave : wave & 1;
     const int p = lane & 31, kg = lane >> 5;
+    // 16-wide patches: an MFMA tile's 32 pixels are two patch rows.  ds_read_b128 serves a wave in the lane groups {0-3, 12-15, 20-27} and
+    // {4-11, 16-19, 28-31} (+32): with lanes 0-15 on one row and 16-31 on the next, each group straddles both rows and two of its
+    // sixteen 80-byte-pitch slots collide (measured: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).  Which lane holds which pixel
+    // is free -- the epilogue uses the same map -- so the first hardware group takes the 16 consecutive pixels of row 0, the second
+    // those of row 1: conflict-free.
+    const bool grp_b = (p >= 4 && p < 12) || (p >= 16 && p < 20) || p >= 28;
+    const int rank16 = p < 4 ? p : p < 12 ? p - 4 : p < 16 ? p - 8 : p < 20 ? p - 8 : p < 28 ? p - 12 : p - 16;
     auto pix_of = [&](int i, int& ty, int& tx) {                 // patch pixel of this lane in the wave's MFMA tile i
         if (TWLOG == 5) { ty = wm * NI + i; tx = p; }
-        else { ty = wm * 2 * NI + 2 * i + (p >> 4); tx = p & 15; }
+        else { ty = wm * 2 * NI + 2 * i + (grp_b ? 1 : 0); tx = rank16; }
     };
     unsigned abase[NI];                                          // LDS byte offset of tile i's pixel, tap (0,0), ks 0, hi plane
 #pragma unroll
@@ -338,8 +345,10 @@ __device__ __forceinline__ bf16x8_t x3_tr_frag2(const char* p) {
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                   float* __restrict__ dw, ConvGeom g, int patches_per_split) {
     constexpr int PWD = 8, PIX = 64, HWD = 10, HROWS = 100, X_ROWS = 112;
-    constexpr int DY_HALF = PIX * 64, X_HALF = X_ROWS * 64;      // bytes per 32-channel half tile (bf16)
-    constexpr int PLANE = 2 * DY_HALF + 2 * X_HALF;              // 22528: one of (hi, lo)
+    // bytes per 32-channel half tile (bf16), + 64: the two halves of a row are written by lanes 0-7 / 8-15 of ONE ds_write_b64 group --
+    // at a multiple of 128 B apart they would share their banks (measured 20 % conflict cycles)
+    constexpr int DY_HALF = PIX * 64 + 64, X_HALF = X_ROWS * 64 + 64;
+    constexpr int PLANE = 2 * DY_HALF + 2 * X_HALF;              // 22784: one of (hi, lo)
     constexpr int DY_UNITS = PIX * 16, UNITS = DY_UNITS + HROWS * 16, NSLOT = (UNITS + 255) / 256;      // 16-byte fp32 units: 2624 -> 11 slots
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -507,7 +516,7 @@ int launch_conv3x3_wgrad_x3(const void* x, const void* dy, float* dw, const Conv
     if (splits < 1) splits = 1;
     const int pps = (total_patches + splits - 1) / splits;
     splits = (total_patches + pps - 1) / pps;
-    constexpr int lds = 2 * 22528;
+    constexpr int lds = 2 * 22784;
     hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, (const float*)x,
                        (const float*)dy, dw, g, pps);
     return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
