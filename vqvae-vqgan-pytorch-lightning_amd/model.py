@@ -125,6 +125,12 @@ class VQVAE(BaseVQVAE, _LightningBase):
             self.quantizer.init_codebook()
         self.compute_dtype, self.conv_products = resolve_compute_dtype(compute_dtype)
         set_compute_dtype(self, compute_dtype)
+        if self.conv_products != 'fp32' and self.criterion is not None:
+            # the split-product mode is built and pinned for the AUTOENCODER's convs (tests/test_gpu_fullsize.py); the loss networks
+            # (LPIPS-VGG16, the StyleGAN2 discriminator) keep exact fp32 products in the fp32 storage modes
+            for m in self.criterion.modules():
+                if hasattr(m, 'conv_products'):
+                    m.conv_products = 'fp32'
 
     # ------------------------------------------------------------------ forward (model.py:151-161)
     def forward(self, x: torch.Tensor):
