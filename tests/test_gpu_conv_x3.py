@@ -180,3 +180,26 @@ def test_x3_mode_runs_a_resblock_like_the_exact_mode():
     for a, b in zip(res['fp32'], res['bf16x3']):
         assert float((a - b).abs().max()) / float(a.abs().max()) < 1e-4
     assert not torch.equal(res['fp32'][0], res['bf16x3'][0])      # (it did take the other kernel)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,hb,hr', [(2, 128, 256, 32, 32, 0, 0), (3, 512, 256, 16, 16, 1, 0), (1, 256, 128, 8, 48, 0, 1), (2, 64, 64, 24, 16, 1, 1)])
+def test_x3_1x1_forward_and_data_gradient(n, cin, cout, h, w, hb, hr):
+    """the NTAP = 1 form (ResBlock shortcuts, autoencoder.py:52-55; the latent's conv_out): forward, and the data gradient through the
+    transposed operand"""
+    g = torch.Generator(device=DEV).manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    wt = torch.randn(cout, 1, 1, cin, device=DEV, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, device=DEV, generator=g) if hb else None
+    res = torch.randn(n, cout, h, w, device=DEV, generator=g).contiguous(memory_format=CL) if hr else None
+    assert ops.weight_layout(F32, n, h, w, cin, cout, 1, False, x3=True) == 5
+    assert ops.weight_layout(F32, n, h, w, cin, cout, 1, False, x3=False) == 0
+    y = ops.raw_conv_fprop(x, ops.pack_weights(wt.reshape(-1), F32, cout, cin, 1, False, 5), bias, res, 1, False, 0, F32, cout, 5)
+    ref = F.conv2d(x.double(), wt.permute(0, 3, 1, 2).double(), bias.double() if hb else None)
+    if hr:
+        ref = ref + res.double()
+    dy = torch.randn(n, cout, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    dx = ops.raw_conv_fprop(dy, ops.pack_weights(wt.reshape(-1), F32, cout, cin, 1, True, 5), None, None, 1, False, 0, F32, cin, 5)
+    refd = F.conv_transpose2d(dy.double(), wt.permute(0, 3, 1, 2).double())
+    torch.cuda.synchronize()
+    assert float((y.double() - ref).abs().max()) / float(ref.abs().max()) < TOL
+    assert float((dx.double() - refd).abs().max()) / float(refd.abs().max()) < TOL

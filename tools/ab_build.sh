@@ -10,7 +10,7 @@ cd "$(dirname "$0")/../vqvae-vqgan-pytorch-lightning_amd/csrc"
 mkdir -p ../../ab_libs
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -c $src -o ../../ab_libs/${obj%.o}_$tag.o
 objs=""
-for o in vq.o vq_filter.o entropy.o conv.o conv_mx.o conv_wgmx.o conv_x3.o conv_thin_f32.o conv_edge.o norm.o pointwise.o optim.o stylegan_ops.o gan_ops.o calib.o api.o; do
+for o in vq.o vq_filter.o entropy.o conv.o conv_wgrad.o conv_mx.o conv_wgmx.o conv_x3.o conv_thin_f32.o conv_edge.o norm.o pointwise.o optim.o stylegan_ops.o gan_ops.o calib.o api.o; do
   if [ "$o" = "$obj" ]; then objs="$objs ../../ab_libs/${obj%.o}_$tag.o"; else objs="$objs $o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_libs/libvqk_$tag.so $objs

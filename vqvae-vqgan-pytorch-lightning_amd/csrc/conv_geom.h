@@ -86,6 +86,12 @@ int launch_conv3x3_mx(const void* x, const void* w, const float* bias, const voi
 // grid = tiles x splits blocks of 512 threads, `pps` 8x16-pixel patches per split
 // `part` (deterministic mode): workspace of splits * tiles * 64*9*64 floats -- the splits' partial tiles are stored there and
 // summed in split order by a second launch instead of being accumulated with fp32 atomics
+// conv.hip <-> conv_wgrad.hip: the geometry builder and the per-host-thread launch state (test hook vqk_conv_set_variant, the
+// weight-gradient grid cap of vqk_conv_set_block_caps)
+int conv_make_geom(ConvGeom& g, int dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups);
+int& conv_force_variant();
+int& conv_wgrad_blocks();
+
 // split-product 3x3 conv (conv_x3.hip): fp32 in / out, three bf16 products per multiply-add; weights in layout 5
 int launch_conv3x3_x3(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                       const ConvGeom& g, int act, int blocks_cap, hipStream_t st);

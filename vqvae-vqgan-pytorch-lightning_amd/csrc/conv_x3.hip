@@ -45,18 +45,21 @@ __device__ __forceinline__ float x3_act(float v, int act) {
 
 // WL 0: the four waves as 2 (pixels) x 2 (couts), wave tile 64 px x 64 couts; WL 1: 1 x 4, wave tile 128 px x 32 couts (half the
 // L2 -> register weight stream per MFMA, twice the LDS fragment reads)
-template <int TWLOG, int WL>
+// NTAP 9: 3x3, 'same' padding; NTAP 1: the 1x1 convs (ResBlock shortcuts, autoencoder.py:52-55; the latent's conv_out, :143) -- no halo, two
+// phases per unit, memory-bound (fp32 in + out at ~5 TB/s)
+template <int TWLOG, int WL, int NTAP = 9>
 __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restrict__ x, const bf16_raw* __restrict__ wp,
                                                             const float* __restrict__ bias, const float* __restrict__ res,
                                                             float* __restrict__ y, const char* __restrict__ zeros, ConvGeom g,
                                                             int act) {
-    constexpr int PIX = 128, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr int HM = NTAP == 9 ? 1 : 0;                        // halo margin
+    constexpr int PIX = 128, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2 * HM, HROWS = (TH + 2 * HM) * HW2;
     constexpr int RS = 80;                                       // padded LDS row stride per plane (64 B payload)
     constexpr int HALO_INSTR = (HROWS + 7) / 8;                  // register pieces: 8 rows x 128 B (32 fp32 channels) per wave load
     constexpr int PLANE = HALO_INSTR * 8 * RS, BUF = 2 * PLANE;  // hi plane, lo plane (whole pieces: the last piece's padding rows are written too)
     constexpr int NSLOT = (HALO_INSTR + 3) / 4;
     constexpr int NI = WL ? 4 : 2, NJ = WL ? 1 : 2;
-    constexpr int UNITW = 36 * 1024;                             // weight bytes of one (32-cout tile, chunk): 9 taps x 2 ks x (hi, lo)
+    constexpr int UNITW = NTAP * 4 * 1024;                       // weight bytes of one (32-cout tile, chunk): taps x 2 ks x (hi, lo)
     typedef bf16x8_t frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
         const float* ximg = x + (int64_t)tp.img * g.h_in * g.w_in * g.cin + c * 32 + lchan;
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
-            const int iy = tp.py0 + slot_hy[sl] - 1, ix = tp.px0 + slot_hx[sl] - 1;
+            const int iy = tp.py0 + slot_hy[sl] - HM, ix = tp.px0 + slot_hx[sl] - HM;
             const bool ok = slot_ok[sl] && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
             const float* src = ximg + ((int64_t)(iy >> g.ups) * g.w_in + (ix >> g.ups)) * g.cin;
             const void* sp = ok ? (const void*)src : (const void*)zeros;      // select, not branch
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
             a[0][i][1] = *reinterpret_cast<const frag_t*>(lbase[i] + PLANE);
         }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * HW2 + (tap % 3)) * RS;        // compile-time after unrolling
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int toff = ((tap / 3) * HW2 + (tap % 3)) * RS;        // compile-time after unrolling (NTAP 1: 0)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (ks == 0) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
                         a[1][i][1] = *reinterpret_cast<const frag_t*>(lbase[i] + PLANE + toff + 32);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 2 * NI, 0);
-                } else if (tap < 8) {
+                } else if (tap < NTAP - 1) {
                     const int toff1 = (((tap + 1) / 3) * HW2 + ((tap + 1) % 3)) * RS;
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int hl = 0; hl < 2; ++hl) {
-                        const char* src = (tap == 8) ? wnxt[j] + (ks * 2 + hl) * 1024 : wcur[j] + (((tap + 1) * 2 + ks) * 2 + hl) * 1024;
+                        const char* src = (tap == NTAP - 1) ? wnxt[j] + (ks * 2 + hl) * 1024 : wcur[j] + (((tap + 1) * 2 + ks) * 2 + hl) * 1024;
                         bw[j][ks][hl] = *reinterpret_cast<const frag_t*>(src + lane16);
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -483,11 +486,16 @@ namespace vqkd {
 // x fp32 [N, h_in, w_in, Cin], w: layout 5, y fp32 [N, h, w, Cout]; Cin % 32 == 0, h % 8 == 0, w % 16 == 0
 int launch_conv3x3_x3(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                       const ConvGeom& g, int act, int blocks_cap, hipStream_t st) {
-    if (g.ks != 3 || (g.cin & 31) || (g.h & 7) || (g.w & 15) || (g.cout & 3)) return VQK_ERR_SHAPE;
+    if ((g.ks != 3 && g.ks != 1) || (g.cin & 31) || (g.h & 7) || (g.w & 15) || (g.cout & 3) || (g.ks == 1 && g.ups)) return VQK_ERR_SHAPE;
     const int total = g.n * (g.h / 8) * (g.w / 16) * g.tiles_n;
     const int cap = blocks_cap > 0 ? blocks_cap : 512;
     const dim3 grid((unsigned)(total < cap ? total : cap));
     constexpr int lds = 2 * 2 * 184 * 80;                        // two buffers x (hi, lo) planes of the 10x18 halo (23 pieces of 8 rows)
+    if (g.ks == 1) {                                             // 1x1: the tile's own 128 pixels (16 pieces), one tap
+        hipLaunchKernelGGL((conv3x3_x3_kernel<4, 1, 1>), grid, dim3(256), 2 * 2 * 128 * 80, st, (const float*)x, (const bf16_raw*)w, bias,
+                           (const float*)res, (float*)y, (const char*)zeros, g, act);
+        return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
+    }
     const int wl = VQK_TUNE("X3_WL", 1);
     if (wl)
         hipLaunchKernelGGL((conv3x3_x3_kernel<4, 1>), grid, dim3(256), lds, st, (const float*)x, (const bf16_raw*)w, bias,

@@ -132,7 +132,7 @@ def set_conv_products(mode: str) -> None:
 
 def x3_serves(dtype, out_dtype, h_out: int, w_out: int, cin: int, cout: int, ksize: int) -> bool:
     """the split-product 3x3 kernel serves this problem (fp32 in / out, whole 32-channel chunks, 8x16-pixel tiles)"""
-    return (dtype == torch.float32 and out_dtype in (None, torch.float32) and ksize == 3 and cin % 32 == 0 and cout % 32 == 0
+    return (dtype == torch.float32 and out_dtype in (None, torch.float32) and ksize in (1, 3) and cin % 32 == 0 and cout % 32 == 0
             and h_out % 8 == 0 and w_out % 16 == 0)
 
 
@@ -246,10 +246,10 @@ def weight_layout(dtype, n, h_in, w_in, cin, cout, ksize, ups, out_dtype=None, x
     """operand layout the fprop launcher wants for this problem (include/vqk.h: 0 = [O][kh][kw][I], 1 = fragment-major,
     5 = fragment-major (hi | lo) bf16 pairs of the split-product mode; ``x3``: that mode on / off, None = the process setting);
     a 1x1 conv has a fragment-major form only on the bf16 -> bf16 matrix/auxiliary-wave kernel"""
+    if (X3 if x3 is None else x3) and not (ups and ksize == 1) and x3_serves(dtype, out_dtype, h_in << int(ups), w_in << int(ups), cin, cout, ksize):
+        return 5                                   # split products on the bf16 matrix pipe (csrc/conv_x3.hip)
     if ksize == 1 and (dtype != torch.bfloat16 or (out_dtype is not None and out_dtype != torch.bfloat16)):
         return 0
-    if (X3 if x3 is None else x3) and x3_serves(dtype, out_dtype, h_in << int(ups), w_in << int(ups), cin, cout, ksize):
-        return 5                                   # split products on the bf16 matrix pipe (csrc/conv_x3.hip)
     if (_THIN_OUT and ksize == 3 and not ups and dtype == torch.bfloat16 and out_dtype in (None, torch.bfloat16)
             and cin == 128 and cout == 8 and h_in % 8 == 0 and w_in % 32 == 0):
         return 0                                   # the decoder's last conv: plain weights for vqk_conv2d_thin_out
@@ -519,6 +519,9 @@ def raw_conv_fprop(x, wq, bias, residual, ksize: int, ups: bool, act: int, out_d
         # thin-input kernel -- it writes 2 * Cout bytes per pixel at memory speed: an HBM line, not an MFMA one
         kname, flops = kname.replace('conv_fprop_kernel<bf16>', 'conv3x3_thin_in_kernel<bf16> (HBM)'), 0.0
         nbytes = x.numel() * 2 + y.numel() * 2
+    if ksize == 1 and wlayout == 5:
+        # the NTAP = 1 form of the split-product kernel: fp32 in + out at memory speed -- an HBM line like the bf16 1x1 form
+        kname, flops = 'conv1x1_x3_kernel<f32 as 3 x bf16> (HBM)' + (f' {cin}->{cout}@{h}x{w}' if _EVENT_SHAPES else ''), 0.0
     if ksize == 1 and kname.startswith('conv3x3_mx_kernel'):
         # the NTAP = 1 instantiation (ResBlock shortcuts): memory-bound, reported with its bytes like the GroupNorm passes
         kname, flops = kname.replace('conv3x3_mx_kernel<bf16>', 'conv1x1_mx_kernel<bf16> (HBM)'), 0.0
