@@ -259,6 +259,11 @@ int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw
 /* vqk_conv2d_wgrad_x3_f32: the same gradient straight from the fp32 tensors x [n][h_in][w_in][cin], dy [n][h][w][cout] -- both are
  * split in registers on their way into LDS and all three products come from one staged patch (csrc/conv_x3.hip:
  * conv3x3_wgrad_x3_kernel; no pair tensors, no split passes).  cin % 64 == 0, cout % 64 == 0, h % 8 == 0, w % 8 == 0. */
+/* vqk_conv2d_fprop_x3_gnstats: the layout-5 3x3 conv with the GroupNorm sums of its OUTPUT (sum, sum of squares per (sample, group),
+ * fp64 atomics) left in gn_ws as vqk_conv2d_fprop_gnstats leaves them for the bf16 convs -- the consuming vqk_gn_forward_presummed
+ * skips its statistics pass.  Cout % 128 == 0, Cout / groups in {4, 8, 16}; VQK_ERR_SHAPE otherwise and in deterministic mode. */
+int vqk_conv2d_fprop_x3_gnstats(const float* x, const void* w5, const float* bias, const float* residual, float* y, int n, int h_in,
+                                int w_in, int cin, int cout, int ups, double* gn_ws, int groups, const void* zeros, void* stream);
 int vqk_split_pair_f32(const float* src, void* dst, int64_t rows, int c, void* stream);
 int vqk_conv2d_wgrad_x3_f32(const float* x, const float* dy, float* dw, int n, int h_in, int w_in, int cin, int cout, int ups,
                             float scale, void* stream);

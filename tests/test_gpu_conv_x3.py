@@ -203,3 +203,36 @@ def test_x3_1x1_forward_and_data_gradient(n, cin, cout, h, w, hb, hr):
     torch.cuda.synchronize()
     assert float((y.double() - ref).abs().max()) / float(ref.abs().max()) < TOL
     assert float((dx.double() - refd).abs().max()) / float(refd.abs().max()) < TOL
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,ups,hb,hr,groups', [(2, 128, 128, 64, 64, 0, 0, 1, 32), (3, 128, 256, 32, 64, 0, 1, 0, 32), (2, 256, 512, 16, 32, 1, 1, 0, 32),
+                                                           (1, 64, 128, 40, 48, 0, 0, 0, 8)])
+def test_x3_conv_leaves_groupnorm_sums(n, cin, cout, h, w, ups, hb, hr, groups):
+    """vqk_conv2d_fprop_x3_gnstats: the conv's epilogue leaves sum / sum of squares per (sample, group) of its fp32 output in the
+    stream's GroupNorm workspace (channels per group 4, 8, 16), and the GroupNorm that consumes them equals the unfused sequence"""
+    g = torch.Generator(device=DEV).manual_seed(cin + cout + h + groups)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    wt = torch.randn(cout, 3, 3, cin, device=DEV, generator=g) / (3 * cin ** 0.5)
+    s = 2 if ups else 1
+    bias = torch.randn(cout, device=DEV, generator=g) if hb else None
+    res = torch.randn(n, cout, h * s, w * s, device=DEV, generator=g).contiguous(memory_format=CL) if hr else None
+    w5 = ops.pack_weights(wt.reshape(-1), F32, cout, cin, 3, False, 5)
+    gw = torch.randn(cout, device=DEV, generator=g) * 0.1 + 1.0
+    gb = torch.randn(cout, device=DEV, generator=g) * 0.1
+    y = ops.raw_conv_fprop_gnstats(x, w5, bias, res, bool(ups), cout, groups, wlayout=5)
+    assert y is not None
+    ws = ops._gn_ws(x.device, n * groups * 2 + n)
+    torch.cuda.synchronize()
+    sums = ws[:n * groups * 2].view(n, groups, 2).clone()
+    yd = y.double().view(n, groups, cout // groups, -1)
+    ref = torch.stack([yd.sum(dim=(2, 3)), (yd * yd).sum(dim=(2, 3))], dim=-1)
+    assert float((sums - ref).abs().max() / ref.abs().max()) < 1e-6
+    a_fused, st_fused = ops.raw_gn_forward(y, gw, gb, groups, 1e-6, True, presummed=True)
+    torch.cuda.synchronize()
+    assert float(ws.abs().max()) == 0.0                                    # the apply pass left the workspace zero again
+    y_plain = ops.raw_conv_fprop(x, w5, bias, res, 3, bool(ups), 0, F32, cout, 5)
+    a_plain, st_plain = ops.raw_gn_forward(y_plain, gw, gb, groups, 1e-6, True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_plain)
+    assert float((a_fused - a_plain).abs().max()) < 2e-5 * float(a_plain.abs().max())
+    assert float((st_fused - st_plain).abs().max()) < 1e-5 * float(st_plain.abs().max())

@@ -83,6 +83,7 @@ _PROTOS = {
     'vqk_conv2d_wgrad_pooled_dy': [I, P, P, P, I, I, I, I, I, F, P, P],
     'vqk_conv2d_wgrad_ups_phase': [I, P, P, P, I, I, I, I, I, F, P, P],
     'vqk_split_pair_f32': [P, P, L, I, P],
+    'vqk_conv2d_fprop_x3_gnstats': [P, P, P, P, P, I, I, I, I, I, I, P, I, P, P],
     'vqk_conv2d_wgrad_x3': [P, P, P, I, I, I, I, I, I, F, P, P],
     'vqk_conv2d_wgrad_x3_f32': [P, P, P, I, I, I, I, I, I, F, P],
     'vqk_conv2d_wgrad_pooled_dy_phase': [I, P, P, P, I, I, I, I, I, F, P, P],

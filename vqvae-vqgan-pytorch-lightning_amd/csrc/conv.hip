@@ -1866,6 +1866,23 @@ int vqk_conv2d_fprop_gnstats(int dtype, const void* x, const void* w, const floa
     return launch_fprop<bf16_raw, bf16_raw>(x, w, bias, residual, y, zeros, g, 0, 1, vqk_stream(stream));
 }
 
+int vqk_conv2d_fprop_x3_gnstats(const float* x, const void* w5, const float* bias, const float* residual, float* y, int n, int h_in,
+                                int w_in, int cin, int cout, int ups, double* gn_ws, int groups, const void* zeros, void* stream) {
+    // the split-product 3x3 conv (wlayout 5) with the GroupNorm sums of its fp32 output left in gn_ws (csrc/conv_x3.hip)
+    VQK_REQUIRE(x && w5 && y && zeros && gn_ws, VQK_ERR_ARG);
+    VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w5) && vqk_aligned16(zeros) && vqk_aligned16(y) && (!residual || vqk_aligned16(residual)),
+                VQK_ERR_ALIGN);
+    VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(groups > 0 && cout % groups == 0 && (cout % 128) == 0, VQK_ERR_SHAPE);
+    const int cpg = cout / groups;
+    VQK_REQUIRE((cpg == 4 || cpg == 8 || cpg == 16) && !g_det, VQK_ERR_SHAPE);     // (atomics: the deterministic mode keeps its statistics pass)
+    ConvGeom g;
+    const int rc = make_geom(g, VQK_F32, n, h_in, w_in, cin, cout, 3, ups);
+    if (rc) return rc;
+    g.gn_ws = gn_ws; g.gn_cpg = cpg;
+    return vqkd::launch_conv3x3_x3(x, w5, bias, residual, y, zeros, g, 0, g_stream_blocks, vqk_stream(stream));
+}
+
 int vqk_conv2d_thin_in_gnstats(int dtype, const void* x, const void* w, const float* bias, void* y, int n, int h, int wd, int cout,
                                double* gn_ws, int groups, void* stream) {
     VQK_REQUIRE(x && w && y && gn_ws, VQK_ERR_ARG);

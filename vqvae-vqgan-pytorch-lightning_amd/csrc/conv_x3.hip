@@ -252,6 +252,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
             const int n0 = cur.nt * 128;
             const int cwave = WL ? wn * 32 : wn * 64;            // first cout of this wave inside the 128-cout tile
             const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
+            // GroupNorm statistics of the stored output (g.gn_ws: vqk_conv2d_fprop_x3_gnstats; the consumer's GroupNorm then skips its
+            // statistics pass over this tensor): per lane the sums of its 4-channel halves over the tile's pixels, folded over the 32
+            // pixel lanes at the end of the tile, one fp64 atomic per (group, sum | sum of squares) and wave
+            const bool want_stats = plain && g.gn_ws != nullptr;
+            float gs[NJ][2][2], gq[NJ][2][2];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) { gs[j][qp][hf] = 0.f; gq[j][qp][hf] = 0.f; }
             if (plain) {
                 // lanes l and l + 32 hold the two halves of every 8-cout run: one v_permlane32_swap per value pairs them up so
                 // that each lane owns 8 consecutive couts = 32 contiguous bytes
@@ -289,6 +300,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
                             const f32x4 s0 = {v[0], v[1], v[2], v[3]}, s1 = {v[4], v[5], v[6], v[7]};
                             *reinterpret_cast<f32x4*>(y + o0 + cw) = s0;
                             *reinterpret_cast<f32x4*>(y + o0 + cw + 4) = s1;
+                            if (want_stats) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    gs[j][qp][0] += v[e]; gq[j][qp][0] = __builtin_fmaf(v[e], v[e], gq[j][qp][0]);
+                                    gs[j][qp][1] += v[4 + e]; gq[j][qp][1] = __builtin_fmaf(v[4 + e], v[4 + e], gq[j][qp][1]);
+                                }
+                            }
+                        }
+                }
+                if (want_stats) {
+                    const int cpg = g.gn_cpg, ngroups = g.cout / cpg;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int qp = 0; qp < 2; ++qp) {
+                            float a[2] = {gs[j][qp][0], gs[j][qp][1]}, q[2] = {gq[j][qp][0], gq[j][qp][1]};
+#pragma unroll
+                            for (int off = 1; off < 32; off <<= 1) {             // the 32 pixel lanes of this k-half
+#pragma unroll
+                                for (int hf = 0; hf < 2; ++hf) { a[hf] += __shfl_xor(a[hf], off, 64); q[hf] += __shfl_xor(q[hf], off, 64); }
+                            }
+                            if (cpg >= 8) { a[0] += a[1]; q[0] += q[1]; }         // the lane's eight couts are one group (or half of one)
+                            if (cpg >= 16) { a[0] += __shfl_xor(a[0], 32, 64); q[0] += __shfl_xor(q[0], 32, 64); }     // + the other k-half's eight
+                            const int cb = n0 + cwave + j * 32 + 16 * qp + 8 * kg;          // first of this lane's eight couts
+                            if (p == 0 && (cpg < 16 || kg == 0)) {
+                                double* w0 = g.gn_ws + ((int64_t)cur.img * ngroups + cb / cpg) * 2;
+                                atomicAdd(w0, (double)a[0]); atomicAdd(w0 + 1, (double)q[0]);
+                                if (cpg == 4) { atomicAdd(w0 + 2, (double)a[1]); atomicAdd(w0 + 3, (double)q[1]); }
+                            }
                         }
                 }
             } else {

@@ -564,8 +564,11 @@ if _native.switch('VQK_DETERMINISTIC', '') == '1':          # same as set_determ
     DETERMINISTIC = True
 
 
+X3_GNSTATS = _native.switch('VQK_X3_GNSTATS', '1') != '0'
+
+
 def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: int, pool: bool = False,
-                           pool_scale: float = 0.25):
+                           pool_scale: float = 0.25, wlayout: int = 1):
     """3x3 conv (+ fused 2x2 pooling) whose drain also leaves the GroupNorm sums of its OUTPUT in the stream's GroupNorm
     workspace (vqk_conv2d_fprop_gnstats).  Returns y, or None when the problem is not served by the fused kernel
     (nothing launched): the caller runs the plain conv, and the next ``raw_gn_forward`` its own statistics pass."""
@@ -573,13 +576,27 @@ def raw_conv_fprop_gnstats(x, wq, bias, residual, ups: bool, cout: int, groups: 
     n, cin, h, w = x.shape
     s = 2 if ups else 1
     ho, wo = (h * s // 2, w * s // 2) if pool else (h * s, w * s)
-    if not FUSE_GN_STATS or x.dtype != torch.bfloat16 or ho * wo <= 1024:
+    x3 = wlayout == 5 and x.dtype == torch.float32
+    if x3 and (pool or DETERMINISTIC or not X3_GNSTATS or cout % 128 or (cout // groups) not in (4, 8, 16)):
+        return None
+    if not FUSE_GN_STATS or (x.dtype != torch.bfloat16 and not x3) or ho * wo <= 1024:
         return None
     if _HANDOFF.gn is not None:                                  # sums nobody claimed (the consumer was not a GroupNorm)
         _claim_presummed(x, -1)
     y = empty_nhwc(n, cout, ho, wo, x.dtype, x.device)
     ws = _gn_sum_target(x.device, n, groups, h * s * w * s)
     flops = 2.0 * n * h * s * w * s * cout * cin * 9
+    if x3:
+        # split-product mode: fp32 sums of the fp32 output from the accumulators (csrc/conv_x3.hip)
+        nbytes = x.numel() * 4 + y.numel() * 4 * (2 if residual is not None else 1) + cout * cin * 9 * 4
+        st = _timed(_fprop_kernel_name(x.dtype, 5), flops,
+                    lambda: _native.lib().vqk_conv2d_fprop_x3_gnstats(x.data_ptr(), wq.data_ptr(), _p(bias), _p(residual), y.data_ptr(), n, h, w,
+                                                                      cin, cout, int(ups), ws.data_ptr(), groups,
+                                                                      zero_page(x.device).data_ptr(), _stream()), nbytes, exec_flops=3.0 * flops)
+        if st == _native.ERR_SHAPE:
+            return None
+        _native.check(st, 'conv2d_fprop_x3_gnstats')
+        return y
     nbytes = (x.numel() * x.element_size() + y.numel() * y.element_size()
               + (residual.numel() * residual.element_size() if residual is not None else 0) + cout * cin * 9 * x.element_size())
     st = _timed(_fprop_kernel_name(x.dtype, 1, (n, h * s, w * s, cin, cout, 0, x.dtype)), flops,
@@ -1317,8 +1334,8 @@ class Conv2dFn(torch.autograd.Function):
             # nearest x2 + 3x3 as four 2x2-tap convs on the low-resolution input (pre-summed weights)
             y = raw_conv_ups_phase(x, packed_weight(weight, cin, cout_pad, dt, 3, False, 2), b32, cout_pad, False, next_gn)
             phase = y is not None
-        if y is None and next_gn and k == 3 and act == 0 and layout == 1 and out_dtype == dt and cout_pad % 128 == 0 and cout_pad == o:
-            y = raw_conv_fprop_gnstats(x, wq, b32, res, ups, cout_pad, next_gn)
+        if y is None and next_gn and k == 3 and act == 0 and layout in (1, 5) and out_dtype == dt and cout_pad % 128 == 0 and cout_pad == o:
+            y = raw_conv_fprop_gnstats(x, wq, b32, res, ups, cout_pad, next_gn, wlayout=layout)
             if y is not None:
                 _note_presummed(y, next_gn)
         if (y is None and next_gn and k == 3 and act == 0 and layout == 0 and cin == 8 and cout_pad == o and res is None and not ups
@@ -1528,7 +1545,7 @@ class ResBlockFn(torch.autograd.Function):
         l1 = weight_layout(dt, n, h, w, cin, cout, 3, False)
         wq1 = packed_weight(c1w, cin, cout, dt, 3, False, l1)
         # the first conv's drain also sums its output for the second GroupNorm (no statistics pass over r1)
-        r1 = raw_conv_fprop_gnstats(a1, wq1, None, None, False, cout, groups) if l1 == 1 and cout % 128 == 0 else None
+        r1 = raw_conv_fprop_gnstats(a1, wq1, None, None, False, cout, groups, wlayout=l1) if l1 in (1, 5) and cout % 128 == 0 else None
         fused = r1 is not None
         if not fused:
             r1 = raw_conv_fprop(a1, wq1, None, None, 3, False, 0, dt, cout, l1)
@@ -1547,8 +1564,8 @@ class ResBlockFn(torch.autograd.Function):
             out = raw_conv_pooled_fprop_phase(a2, c2w, raw_pool(skip, 0.25), 0.25, next_gn)
         if out is not None:
             pass
-        elif next_gn and l2 == 1 and cout % 128 == 0:            # the sums for the GroupNorm that reads `out` next
-            out = raw_conv_fprop_gnstats(a2, wq2, None, skip, False, cout, next_gn, pool=pool, pool_scale=0.25)
+        elif next_gn and l2 in (1, 5) and cout % 128 == 0:       # the sums for the GroupNorm that reads `out` next
+            out = raw_conv_fprop_gnstats(a2, wq2, None, skip, False, cout, next_gn, pool=pool, pool_scale=0.25, wlayout=l2)
             if out is not None:
                 _note_presummed(out, next_gn, conv_hw=h * w)
         if out is not None:
