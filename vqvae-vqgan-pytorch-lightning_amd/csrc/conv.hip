@@ -1556,7 +1556,7 @@ int launch_fprop(const void* x, const void* w, const float* bias, const void* re
                 return vqkd::launch_conv3x3_thin_out_f32((const float*)x, (const float*)w, bias, (const float*)res, (float*)y, g.n, g.h, g.w,
                                                          g.cin, act, g.acc_scale, g.out_gain, st);
             if (g.cin == 4 && (g.cout == 64 || g.cout == 128 || g.cout == 256) && !res && act == 0 && g.acc_scale == 1.0f &&
-                g.out_gain == 1.0f && g.w >= 2)
+                g.out_gain == 1.0f && g.w >= 4 && (g.w % 4) == 0 && (int64_t)(10) * (g.w + 2) * 16 <= 64 * 1024)
                 return vqkd::launch_conv3x3_thin_in_f32((const float*)x, (const float*)w, bias, (float*)y, g.n, g.h, g.w, g.cout, st);
         }
     }

@@ -4,10 +4,10 @@
 //   vqvae/modules/autoencoder.py:170  conv_out C -> 3   (the reconstruction, + bias + tanh)
 // One side of these GEMMs is 4 channels wide: on 32x32 MFMA tiles 7/8 of the matrix pipe multiplies padding (measured before this
 // file, bs 32 @256x256: conv_out forward 4.6 ms on the 128-cout-tile kernel, each weight gradient 5.7 ms on the general kernel at
-// 6.8 TF).  They are memory-bound problems -- the wide tensor (1.07 GB at bs 32) has to be read once -- with 36 multiply-adds per
-// wide element: plain v_fma_f32 with the THIN operand in SCALAR registers (a wave works on ONE pixel at a time, its 64 lanes are 64
-// wide channels; the 3x3x4 window of the thin tensor is wave-uniform: s_load_dwordx4 + a sliding window) or, for conv_out's forward,
-// with the WEIGHTS in scalar registers (a lane is a pixel, the halo comes from LDS).
+// 6.8 TF).  They are memory-bound problems -- the wide tensor (1.07 GB at bs 32) has to be read or written once -- with 36
+// multiply-adds per wide element: plain v_fma_f32.  A wave works on ONE pixel at a time, its 64 lanes are 64 wide channels, and the
+// 3x3x4 window of the thin tensor is the same for every lane (staged rows in LDS, broadcast reads); conv_out's forward has the
+// WEIGHTS wave-uniform instead (scalar registers; a lane is a pixel, the halo comes from LDS).  0.36-0.51 ms per launch = 2-3 TB/s.
 //
 //   conv3x3_thin_out_f32_kernel      y[p][0..3]   = act(sum_{tap,c} x[p + tap][c] w[co][tap][c] + b)          (C -> 4)
 //   conv3x3_wgrad_thin_f32_kernel<0> dW[co][tap][0..3] += sum_p dy[p][co] x[p + tap][0..3]                    (thin x, wide dy)
@@ -106,29 +106,46 @@ __global__ __launch_bounds__(256) void conv3x3_thin_out_f32_kernel(const float* 
     *reinterpret_cast<f32x4*>(y + o) = v;
 }
 
-// wave-uniform 16-byte load (the address is uniform by construction: readfirstlane'd wave id, block id, loop counters)
-__device__ __forceinline__ u32x4 uniform_load16(const float* p) {
-    return *reinterpret_cast<const u32x4*>(p);
+// ---------------------------------------------------------------------------------------------- the thin operand through LDS
+// Both kernels below walk image rows pixel by pixel with a wave = 64 wide channels; what they need of the THIN tensor is the 3x3x4
+// window around the pixel -- the same for every lane.  Round 6, first form: scalar loads (s_load_dwordx4) + a sliding window in
+// SGPRs: latency-bound (every pixel waited for a scalar-cache round trip: 0.5-0.8 ms per launch against ~0.25 at memory speed).  Now
+// the block stages the R + 2 thin rows it needs ONCE in LDS -- zero rows / columns beyond the image, so the inner loop has no bounds
+// test -- and a wave reads its window with same-address (broadcast) ds_read_b128, four pixels (twelve reads) ahead of the FMAs.
+constexpr int THIN_R = 8;                                         // output rows per block (h % 8 == 0; else 4 / 2 / 1)
+
+// rows y0 - 1 .. y0 + R of image `img` into smem [R + 2][w + 2] x 16 B (column 0 = image column -1)
+__device__ __forceinline__ void stage_thin_rows(const float* __restrict__ thin, char* smem, int img, int y0, int R, int h, int w, int tid) {
+    const int wp = w + 2, total = (R + 2) * wp;
+    for (int e = tid; e < total; e += 256) {
+        const int rr = e / wp, cc = e - rr * wp;
+        const int yy = y0 + rr - 1, xx = cc - 1;
+        const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(thin + (((int64_t)img * h + yy) * w + xx) * 4);
+        *reinterpret_cast<f32x4*>(smem + (int64_t)e * 16) = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradients
 // G[wc][kh][kw][tc] = sum over pixels q of wide[q][wc] * thin[q + S (kh - 1, kw - 1)][tc], S = +1 (MODE 0: wide = dy, thin = x)
 // or -1 (MODE 1: wide = x, thin = dy: dW[tc][kh][kw][wc] = sum_p dy[p][tc] x[p + tap][wc] re-indexed over q = p + tap).
-// A wave owns 64 wide channels (one per lane) and walks image rows pixel by pixel; the thin tensor's 3x3 window (9 x 4 floats) lives
-// in scalar registers and slides along the row (3 scalar 16-byte loads per pixel); 36 v_fma_f32 per pixel and lane.
+// A wave owns 64 wide channels (one per lane) and walks the block's rows pixel by pixel: 36 v_fma_f32 per pixel and lane.
 template <int MODE>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_thin_f32_kernel(const float* __restrict__ wide, const float* __restrict__ thin,
                                                                      float* __restrict__ dw, int n, int h, int w, int cw,
-                                                                     float scale, int rows_per_block) {
+                                                                     float scale, int R) {
     constexpr int S = MODE == 0 ? 1 : -1;
-    __shared__ float red[4 * 36 * 64];
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // thin rows, then reused for the block reduction
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ncg = cw >> 6, wpg = 4 / ncg;                      // channel groups of 64, waves per group
     const int cg = wave % ncg, wslot = wave / ncg;
-    const int total_rows = n * h;
-    const int row0 = blockIdx.x * rows_per_block;
-    const int row1 = min(total_rows, row0 + rows_per_block);
+    const int bpi = h / R;                                       // blocks per image
+    const int img = blockIdx.x / bpi, y0 = (blockIdx.x - img * bpi) * R;
+    const int wp = w + 2;
+    stage_thin_rows(thin, smem, img, y0, R, h, w, tid);
+    __syncthreads();
     float acc[3][3][4];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -137,56 +154,46 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_thin_f32_kernel(const float
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.0f;
 
-    for (int r = row0 + wslot; r < row1; r += wpg) {
-        const int img = r / h, yy = r - img * h;
-        const float* wrow = wide + (int64_t)r * w * cw + cg * 64 + lane;
-        const float* trow[3];
-        unsigned rmask[3];
+    for (int r = wslot; r < R; r += wpg) {
+        const float* wrow = wide + (((int64_t)img * h + y0 + r) * w) * cw + cg * 64 + lane;
+        const char* t0 = smem + (int64_t)r * wp * 16;            // staged row r = image row y0 + r - 1: the window's top row
+        f32x4 tw[3][6];                                          // window columns x - 1 .. x + 4 of the three rows
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-            const int ty = yy + rr - 1;
-            const bool okr = ty >= 0 && ty < h;
-            trow[rr] = thin + ((int64_t)img * h + (okr ? ty : yy)) * w * 4;
-            rmask[rr] = okr ? 0xffffffffu : 0u;
-        }
-        // window columns j = 0, 1, 2 <-> image columns x - 1, x, x + 1
-        u32x4 tw[3][3];
+        for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            tw[rr][0] = z;
-            tw[rr][1] = uniform_load16(trow[rr]) & rmask[rr];
-            tw[rr][2] = uniform_load16(trow[rr] + 4) & rmask[rr];
-        }
+            for (int j = 0; j < 2; ++j) tw[rr][j] = *reinterpret_cast<const f32x4*>(t0 + ((int64_t)rr * wp + j) * 16);
+        // the wide operand runs EIGHT pixels ahead in registers (a wave's load is 256 contiguous bytes per pixel, nothing else hides
+        // its HBM latency: three blocks of four waves per CU)
+        float wn[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wn[k] = wrow[(int64_t)min(k, w - 1) * cw];
         for (int x0 = 0; x0 < w; x0 += 4) {
             float wv[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wv[k] = wrow[(int64_t)(x0 + k) * cw];
+            for (int k = 0; k < 4; ++k) { wv[k] = wn[k]; wn[k] = wn[k + 4]; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int xx = x0 + k;
+            for (int k = 0; k < 4; ++k) wn[4 + k] = wrow[(int64_t)min(x0 + 8 + k, w - 1) * cw];     // (clamped: the loads stay unconditional)
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int j = 2; j < 6; ++j) tw[rr][j] = *reinterpret_cast<const f32x4*>(t0 + ((int64_t)rr * wp + x0 + j) * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        const u32x4 tv = tw[1 + S * (kh - 1)][1 + S * (kw - 1)];
+                        const f32x4 tv = tw[1 + S * (kh - 1)][k + 1 + S * (kw - 1)];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[kh][kw][c] = __builtin_fmaf(wv[k], __uint_as_float(tv[c]), acc[kh][kw][c]);
+                        for (int c = 0; c < 4; ++c) acc[kh][kw][c] = __builtin_fmaf(wv[k], tv[c], acc[kh][kw][c]);
                     }
-                // slide: column xx + 2 enters (zero beyond the image; the load address stays inside the row)
-                const bool okc = xx + 2 < w;
-                const unsigned cm = okc ? 0xffffffffu : 0u;
-                const int cx = okc ? xx + 2 : w - 1;
 #pragma unroll
-                for (int rr = 0; rr < 3; ++rr) {
-                    tw[rr][0] = tw[rr][1];
-                    tw[rr][1] = tw[rr][2];
-                    tw[rr][2] = uniform_load16(trow[rr] + cx * 4) & (rmask[rr] & cm);
-                }
-            }
+            for (int rr = 0; rr < 3; ++rr) { tw[rr][0] = tw[rr][4]; tw[rr][1] = tw[rr][5]; }
         }
     }
     // fold the waves of a channel group, then one atomic per element and block
+    __syncthreads();                                             // everyone is done with the staged rows
+    float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -194,32 +201,44 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_thin_f32_kernel(const float
 #pragma unroll
             for (int c = 0; c < 4; ++c) red[(wave * 36 + (kh * 3 + kw) * 4 + c) * 64 + lane] = acc[kh][kw][c];
     __syncthreads();
-    if (wslot == 0) {
+    if constexpr (MODE == 0) {
+        // dW[wc][tap][tc] is contiguous in (tap, tc): the block's threads walk the DESTINATION index so that a wave's atomics are
+        // 256 consecutive bytes (lanes = channels made them 144-byte-strided: 4.7 M scattered atomics per launch)
+        for (int d = tid; d < cw * 36; d += 256) {
+            const int wc = d / 36, k = d - wc * 36, g2 = wc >> 6, l2 = wc & 63;
+            float s = 0.0f;
+            for (int ws = 0; ws < wpg; ++ws) s += red[((ws * ncg + g2) * 36 + k) * 64 + l2];
+            atomicAdd(dw + d, s * scale);
+        }
+    } else if (wslot == 0) {
         const int wc = cg * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 36; ++k) {
             float s = 0.0f;
             for (int ws = 0; ws < wpg; ++ws) s += red[((ws * ncg + cg) * 36 + k) * 64 + lane];
             const int tap = k >> 2, tc = k & 3;
-            float* dst = MODE == 0 ? dw + ((int64_t)wc * 9 + tap) * 4 + tc : dw + ((int64_t)tc * 9 + tap) * cw + wc;
-            atomicAdd(dst, s * scale);
+            atomicAdd(dw + ((int64_t)tc * 9 + tap) * cw + wc, s * scale);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------- 4 -> C, forward / data gradient
 // y[p][co] = sum_{tap, c < 4} x[p + tap][c] * w[co][tap][c] (+ bias[co]): a lane is an output channel with its 36 weights in
-// registers, a wave walks image rows pixel by pixel with the thin 3x3x4 window in scalar registers and stores 256 contiguous bytes
-// per pixel.  conv_in's forward (autoencoder.py:132) and, with wt = the [C][3][3][4] transposed / flipped operand, conv_out's data
-// gradient (:170).
+// registers, a wave walks the block's rows pixel by pixel and stores 256 contiguous bytes per pixel.  conv_in's forward
+// (autoencoder.py:132) and, with wt = the [C][3][3][4] transposed / flipped operand, conv_out's data gradient (:170).
 __global__ __launch_bounds__(256) void conv3x3_thin_in_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, float* __restrict__ y, int n,
-                                                                  int h, int wd, int cout, int rows_per_block) {
+                                                                  int h, int wd, int cout, int R) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ncg = cout >> 6, wpg = 4 / ncg;
     const int cg = wave % ncg, wslot = wave / ncg;
     const int co = cg * 64 + lane;
+    const int bpi = h / R;
+    const int img = blockIdx.x / bpi, y0 = (blockIdx.x - img * bpi) * R;
+    const int wp = wd + 2;
+    stage_thin_rows(x, smem, img, y0, R, h, wd, tid);
     float wr[9][4];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -228,51 +247,37 @@ __global__ __launch_bounds__(256) void conv3x3_thin_in_f32_kernel(const float* _
         for (int c = 0; c < 4; ++c) wr[tap][c] = v[c];
     }
     const float b = bias ? bias[co] : 0.0f;
-    const int total_rows = n * h;
-    const int row0 = blockIdx.x * rows_per_block;
-    const int row1 = min(total_rows, row0 + rows_per_block);
-    for (int r = row0 + wslot; r < row1; r += wpg) {
-        const int img = r / h, yy = r - img * h;
-        float* yrow = y + (int64_t)r * wd * cout + co;
-        const float* trow[3];
-        unsigned rmask[3];
+    __syncthreads();
+    for (int r = wslot; r < R; r += wpg) {
+        float* yrow = y + (((int64_t)img * h + y0 + r) * wd) * cout + co;
+        const char* t0 = smem + (int64_t)r * wp * 16;
+        f32x4 tw[3][6];
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-            const int ty = yy + rr - 1;
-            const bool okr = ty >= 0 && ty < h;
-            trow[rr] = x + ((int64_t)img * h + (okr ? ty : yy)) * wd * 4;
-            rmask[rr] = okr ? 0xffffffffu : 0u;
-        }
-        u32x4 tw[3][3];
+        for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            tw[rr][0] = z;
-            tw[rr][1] = uniform_load16(trow[rr]) & rmask[rr];
-            tw[rr][2] = uniform_load16(trow[rr] + 4) & rmask[rr];
-        }
-        for (int xx = 0; xx < wd; ++xx) {
-            float a0 = b, a1 = 0.0f;                             // two chains: 36 dependent fmas would serialise on the 4-cycle latency
+            for (int j = 0; j < 2; ++j) tw[rr][j] = *reinterpret_cast<const f32x4*>(t0 + ((int64_t)rr * wp + j) * 16);
+        for (int x0 = 0; x0 < wd; x0 += 4) {
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+            for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const u32x4 tv = tw[kh][kw];
-                    a0 = __builtin_fmaf(wr[kh * 3 + kw][0], __uint_as_float(tv[0]), a0);
-                    a1 = __builtin_fmaf(wr[kh * 3 + kw][1], __uint_as_float(tv[1]), a1);
-                    a0 = __builtin_fmaf(wr[kh * 3 + kw][2], __uint_as_float(tv[2]), a0);
-                    a1 = __builtin_fmaf(wr[kh * 3 + kw][3], __uint_as_float(tv[3]), a1);
-                }
-            yrow[(int64_t)xx * cout] = a0 + a1;
-            const bool okc = xx + 2 < wd;
-            const unsigned cm = okc ? 0xffffffffu : 0u;
-            const int cx = okc ? xx + 2 : wd - 1;
+                for (int j = 2; j < 6; ++j) tw[rr][j] = *reinterpret_cast<const f32x4*>(t0 + ((int64_t)rr * wp + x0 + j) * 16);
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
-                tw[rr][0] = tw[rr][1];
-                tw[rr][1] = tw[rr][2];
-                tw[rr][2] = uniform_load16(trow[rr] + cx * 4) & (rmask[rr] & cm);
+            for (int k = 0; k < 4; ++k) {
+                float a0 = b, a1 = 0.0f;                         // two chains: 36 dependent fmas would serialise on their latency
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const f32x4 tv = tw[kh][k + kw];
+                        a0 = __builtin_fmaf(wr[kh * 3 + kw][0], tv[0], a0);
+                        a1 = __builtin_fmaf(wr[kh * 3 + kw][1], tv[1], a1);
+                        a0 = __builtin_fmaf(wr[kh * 3 + kw][2], tv[2], a0);
+                        a1 = __builtin_fmaf(wr[kh * 3 + kw][3], tv[3], a1);
+                    }
+                yrow[(int64_t)(x0 + k) * cout] = a0 + a1;
             }
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) { tw[rr][0] = tw[rr][4]; tw[rr][1] = tw[rr][5]; }
         }
     }
 }
@@ -292,33 +297,32 @@ int launch_conv3x3_thin_out_f32(const float* x, const float* w, const float* bia
     return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
 }
 
+static inline int thin_rows_per_block(int h) { return (h % 8) == 0 ? 8 : (h % 4) == 0 ? 4 : (h % 2) == 0 ? 2 : 1; }
+
 // mode 0: thin = x [n][h][w][4], wide = dy [n][h][w][cw], dw [cw][3][3][4]; mode 1: wide = x [..][cw], thin = dy [..][4], dw [4][3][3][cw]
 int launch_conv3x3_wgrad_thin_f32(int mode, const float* wide, const float* thin, float* dw, int n, int h, int w, int cw, float scale,
                                   hipStream_t st) {
     if ((cw != 64 && cw != 128 && cw != 256) || (w & 3) || w < 4) return VQK_ERR_SHAPE;
-    const int rows = n * h;
-    int rpb = (rows + 1023) / 1024;                              // ~4 blocks per CU
-    const int wpg = 4 / (cw >> 6);
-    rpb = ((rpb + wpg - 1) / wpg) * wpg;
-    if (rpb < wpg) rpb = wpg;
-    const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
+    const int R = thin_rows_per_block(h);
+    size_t lds = (size_t)(R + 2) * (w + 2) * 16;
+    if (lds < 4 * 36 * 64 * 4) lds = 4 * 36 * 64 * 4;            // the block reduction reuses the buffer
+    if (lds > 64 * 1024) return VQK_ERR_SHAPE;
+    const unsigned blocks = (unsigned)(n * (h / R));
     if (mode == 0)
-        hipLaunchKernelGGL(conv3x3_wgrad_thin_f32_kernel<0>, dim3(blocks), dim3(256), 0, st, wide, thin, dw, n, h, w, cw, scale, rpb);
+        hipLaunchKernelGGL(conv3x3_wgrad_thin_f32_kernel<0>, dim3(blocks), dim3(256), lds, st, wide, thin, dw, n, h, w, cw, scale, R);
     else
-        hipLaunchKernelGGL(conv3x3_wgrad_thin_f32_kernel<1>, dim3(blocks), dim3(256), 0, st, wide, thin, dw, n, h, w, cw, scale, rpb);
+        hipLaunchKernelGGL(conv3x3_wgrad_thin_f32_kernel<1>, dim3(blocks), dim3(256), lds, st, wide, thin, dw, n, h, w, cw, scale, R);
     return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
 }
 
 // x fp32 [n][h][w][4], w fp32 [cout][3][3][4], y fp32 [n][h][w][cout]
 int launch_conv3x3_thin_in_f32(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cout, hipStream_t st) {
-    if ((cout != 64 && cout != 128 && cout != 256) || wd < 2) return VQK_ERR_SHAPE;
-    const int rows = n * h;
-    int rpb = (rows + 2047) / 2048;
-    const int wpg = 4 / (cout >> 6);
-    rpb = ((rpb + wpg - 1) / wpg) * wpg;
-    if (rpb < wpg) rpb = wpg;
-    const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(conv3x3_thin_in_f32_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, y, n, h, wd, cout, rpb);
+    if ((cout != 64 && cout != 128 && cout != 256) || (wd & 3) || wd < 4) return VQK_ERR_SHAPE;
+    const int R = thin_rows_per_block(h);
+    const size_t lds = (size_t)(R + 2) * (wd + 2) * 16;
+    if (lds > 64 * 1024) return VQK_ERR_SHAPE;
+    const unsigned blocks = (unsigned)(n * (h / R));
+    hipLaunchKernelGGL(conv3x3_thin_in_f32_kernel, dim3(blocks), dim3(256), lds, st, x, w, bias, y, n, h, wd, cout, R);
     return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
 }
 
