@@ -299,7 +299,7 @@ int vqk_conv2d_s2_dgrad(int dtype, const void* dy, const void* w3, const void* w
  * i.e. Cin/Cout swapped and both taps flipped).  2: the upsample-phase operand of vqk_conv2d_ups_phase (bf16, 3x3): four
  * phases (a, b) of fragment-major blocks with FOUR taps each, tap (r, s) of a phase = the sum of the 3x3 taps that fall
  * on the same low-resolution pixel (rows {0},{1,2} for a = 0 and {0,1},{2} for a = 1; columns alike); transpose = 1:
- * channels swapped and the 2x2 taps mirrored.  5: the SPLIT-PRODUCT operand (csrc/conv_x3.hip; dtype VQK_F32, 3x3, Cin % 32 == 0):
+ * channels swapped and the 2x2 taps mirrored.  5: the SPLIT-PRODUCT operand (csrc/conv_x3.hip; dtype VQK_F32, 3x3 or 1x1, Cin % 32 == 0):
  * layout 1 in bf16 with every fragment twice, hi = bf16(w) then lo = bf16(w - hi) -- [Cout/32][32-channel chunk][tap][k-substep]
  * [hi | lo][lane][16 bytes], 4 bytes per weight like the fp32 operands.  vqk_conv2d_fprop(VQK_F32, ..., out VQK_F32, wlayout 5)
  * then evaluates every product as x_hi w_hi + x_lo w_hi + x_hi w_lo on the bf16 matrix pipe with fp32 accumulation (the fp32

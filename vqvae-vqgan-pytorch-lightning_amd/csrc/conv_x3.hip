@@ -19,9 +19,14 @@
 // L2 -> registers one tap ahead.  Per (tap, k-substep) and wave: NI x NJ x 3 MFMAs on NI x 2 pixel fragments + NJ x 2 weight
 // fragments.  fp32 epilogue straight from the accumulators (v_permlane32_swap pairs the half-wave runs: 32 B per lane).
 //
-// split_pair_kernel: fp32 [rows][C] -> bf16 [rows][2C] = (hi | lo): the operand form of the WEIGHT gradient in this mode
-// (conv_wgmx.hip, ConvGeom::fold): dW = dy_hi^T x_hi + dy_hi^T x_lo + dy_lo^T x_hi as three tile classes of ONE launch of the
-// bf16 matrix/auxiliary-wave weight-gradient kernel, folded onto the same dW tile by its final atomic pass.
+// The same kernel with NTAP = 1 serves the 1x1 convs (no halo, memory-bound); its epilogue can leave the GroupNorm sums of the output
+// in the consumer's workspace (ConvGeom::gn_ws).  conv3x3_wgrad_x3_kernel (below) is the weight gradient: both fp32 operands split
+// in registers, three products per staged fragment pair.
+//
+// split_pair_kernel: fp32 [rows][C] -> bf16 [rows][2C] = (hi | lo): the operand form of the FIRST weight-gradient design of this
+// mode, kept as an A/B option (conv_wgmx.hip, ConvGeom::fold; ops.X3_WGRAD_FOLD): dW = dy_hi^T x_hi + dy_hi^T x_lo + dy_lo^T x_hi as
+// three tile classes of ONE launch of the bf16 matrix/auxiliary-wave weight-gradient kernel, folded onto the same dW tile by its final
+// atomic pass -- 36.2 ms per step (two split passes per conv included) against 21.6 for the kernel below.
 // ------------------------------------------------------------------------------------------------
 #include "conv_geom.h"
 #include <type_traits>
@@ -369,12 +374,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // conv3x3_wgrad_x3_kernel: the weight gradient of the split-product mode WITHOUT pair tensors -- fp32 x and fp32 dy are loaded into
 // registers (16 B = 4 channels of one pixel per lane and slot), split into (hi, lo) bf16 there and written to the hi / lo planes of
-// ONE 44-KiB LDS stage; the matrix loop forms all three products from the staged data (3 MFMAs per fragment pair instead of three
+// ONE 44.5-KiB LDS stage; the matrix loop forms all three products from the staged data (3 MFMAs per fragment pair instead of three
 // passes over three pair tensors: 3x the arithmetic intensity of the bf16 kernel per staged byte, no split passes, no folded tile
 // classes).  Geometry of conv3x3_wgrad_halo_kernel<false> (conv.hip): block = 64 co x 64 ci x 9 taps over a range of 8x8-pixel
 // patches, wave (i, j) owns the 32 x 32 tile of all taps (144 accumulators), fragments by ds_read_b64_tr_b16 from [rows][64 B] half
 // tiles.  Pipeline: the loads of patch p + 1 are in flight during the MFMAs of patch p; store phase and matrix phase are separated
-// by two barriers, and the second resident block of the CU (2 x 44 KiB) computes while this one converts.
+// by two barriers, and the second resident block of the CU (2 x 44.5 KiB) computes while this one converts.
 // dW[co][tap][ci] += scale * sum_pix dy[pix][co] * x[pix (+) tap][ci]   (autoencoder.py:57-60, :102-105, :132, :153)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bf16x8_t x3_tr_frag2(const char* p) {
