@@ -199,7 +199,10 @@ int vqk_conv2d_thin_in_gnstats(int dtype, const void* x, const void* w, const fl
  * -> y [N][2h][2w][Cout] (+ bias; gn_ws as in vqk_conv2d_fprop_gnstats, or NULL)), transpose = 1 for backward = 1 (x = dy
  * [N][2h][2w][Cin := conv's Cout] -> y = dx [N][h][w][Cout := conv's Cin], the four phases accumulate in place).  bf16,
  * Cout % 128 == 0, Cin % 64 == 0; VQK_ERR_SHAPE when the matrix/auxiliary-wave kernel does not serve the problem (nothing
- * launched: callers use vqk_conv2d_fprop with ups = 1 / the pooled data gradient). */
+ * launched: callers use vqk_conv2d_fprop with ups = 1 / the pooled data gradient).
+ * dtype VQK_F32 (this entry and the two pooled forms below): the SPLIT-PRODUCT mode -- fp32 tensors, w4 in layout 6, every product as
+ * three bf16 products (csrc/conv_x3.hip, NTAP = 4), one launch for the four phases; Cout % 128 == 0, Cin % 32 == 0, h % 8 == 0,
+ * w % 16 == 0 (h, w: the LOW resolution); gn_ws: groups of 4 / 8 / 16 channels, not in deterministic mode. */
 int vqk_conv2d_ups_phase(int dtype, const void* x, const void* w4, const float* bias, void* y, int n, int h, int w,
                          int cin, int cout, int backward, double* gn_ws, int groups, const void* zeros, void* stream);
 /* Data gradient of a 3x3 conv that is FOLLOWED by a 2x2 average pool (the encoder's Downsample in a ResBlock's last conv,
@@ -304,7 +307,9 @@ int vqk_conv2d_s2_dgrad(int dtype, const void* dy, const void* w3, const void* w
  * [hi | lo][lane][16 bytes], 4 bytes per weight like the fp32 operands.  vqk_conv2d_fprop(VQK_F32, ..., out VQK_F32, wlayout 5)
  * then evaluates every product as x_hi w_hi + x_lo w_hi + x_hi w_lo on the bf16 matrix pipe with fp32 accumulation (the fp32
  * activations are split on the fly; ~2^-17 relative per product): H % 8 == 0, W % 16 == 0 at the OUTPUT resolution, Cout % 4 == 0;
- * callers choose it (vqk_conv_weight_layout never returns 5; layout 1 / dtype VQK_F32 stays the exact v_mfma_f32_32x32x2_f32 mode). */
+ * callers choose it (vqk_conv_weight_layout never returns 5; layout 1 / dtype VQK_F32 stays the exact v_mfma_f32_32x32x2_f32 mode).
+ * 6: layout 2's phase-summed four-tap operand (the sums taken in fp32) stored as layout 5's (hi | lo) fragment pairs -- the operand of the
+ * phase entry points with dtype VQK_F32: [phase][Cout/32][32-channel chunk][tap 0..3][k-substep][hi | lo][lane][16 bytes]. */
 int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int cout, int ksize, int ups);
 int64_t vqk_conv_packed_elems(int cout, int cin, int ksize, int layout);
 int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int cin, int ksize, int transpose,

@@ -266,3 +266,104 @@ def test_bf16x3_model_on_sizes_the_split_kernels_only_partly_serve(size):
     assert abs(l0 - l1) < 1e-5 * abs(l0)
     assert float((g0 - g1).norm() / g0.norm()) < 2e-4
     assert not torch.equal(g0, g1)                                # (some layers did take the split-product kernels)
+
+
+# ---- the 2x2-resampling convs in PHASE form (conv_x3.hip NTAP = 4, layout 6): 4/9 of the multiply-adds, same split products ----
+# n, cin, cout, h, w (LOW resolution), bias
+PHASE_CASES = [(2, 128, 128, 16, 32, 1), (1, 128, 256, 8, 32, 0), (3, 256, 128, 16, 16, 1), (2, 128, 128, 64, 64, 1), (1, 32, 128, 24, 16, 0)]
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,hb', PHASE_CASES)
+def test_x3_upsample_conv_phase_form(n, cin, cout, h, w, hb):
+    """nearest-x2 + 3x3 conv (autoencoder.py:102-105), forward and data gradient, against fp64 on the un-summed nine taps"""
+    g = torch.Generator(device=DEV).manual_seed(cin + cout + h + w + hb)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    wt = torch.randn(cout, 3, 3, cin, device=DEV, generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn(cout, device=DEV, generator=g) if hb else None
+    dy = torch.randn(n, cout, 2 * h, 2 * w, device=DEV, generator=g).contiguous(memory_format=CL)
+    w4 = ops.pack_weights(wt.reshape(-1), F32, cout, cin, 3, False, 6)
+    y = ops.raw_conv_ups_phase(x, w4, bias, cout, False)
+    assert y is not None, 'the split-product phase kernel must serve this shape'
+    ref = _ref64(x, wt, bias, None, 1)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape and y.dtype == F32
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < TOL
+    assert float((y.double() - ref).norm() / ref.norm()) < 1e-5
+    if cout % 32 == 0 and cin % 128 == 0:
+        w4t = ops.pack_weights(wt.reshape(-1), F32, cout, cin, 3, True, 6)
+        dx = ops.raw_conv_ups_phase(dy, w4t, None, cin, True)
+        assert dx is not None
+        xu = F.interpolate(x.double(), scale_factor=2, mode='nearest').requires_grad_(True)
+        (dxu,) = torch.autograd.grad(F.conv2d(xu, wt.permute(0, 3, 1, 2).double(), padding=1), xu, dy.double())
+        dref = F.avg_pool2d(dxu, 2) * 4.0
+        torch.cuda.synchronize()
+        assert float((dx.double() - dref).abs().max() / dref.abs().max()) < TOL
+        assert float((dx.double() - dref).norm() / dref.norm()) < 1e-5
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,gn', [(2, 128, 128, 32, 32, 0), (2, 128, 256, 128, 64, 32), (1, 256, 256, 16, 32, 0), (3, 128, 128, 48, 32, 32)])
+def test_x3_pooled_conv_phase_forms(n, cin, cout, h, w, gn):
+    """3x3 conv + 2x2 average pool (autoencoder.py:89-91): the forward as a 4x4 stride-2 conv (+ pooled skip, + GroupNorm sums of the
+    result) and the data gradient from the POOLED gradient, against fp64; h, w: the conv's (full) resolution"""
+    g = torch.Generator(device=DEV).manual_seed(cin + cout + h + gn)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    wgt = (torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (3 * cin ** 0.5)).contiguous(memory_format=CL)
+    skip_p = torch.randn(n, cout, h // 2, w // 2, device=DEV, generator=g).contiguous(memory_format=CL)
+    dyp = torch.randn(n, cout, h // 2, w // 2, device=DEV, generator=g).contiguous(memory_format=CL)
+    ops._claim_presummed(x, -1)
+    got = ops.raw_conv_pooled_fprop_phase(x, wgt, skip_p, 0.25, gn, x3=True)
+    assert got is not None, 'the split-product pooled forward must serve this shape'
+    xd = x.double().requires_grad_(True)
+    conv = F.conv2d(xd, wgt.double(), padding=1)
+    ref = F.avg_pool2d(conv, 2) + skip_p.double()
+    torch.cuda.synchronize()
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < TOL
+    if gn and (h // 2) * (w // 2) > 1024:
+        assert ops.pending_gn() is not None
+        cpg = cout // gn
+        sums = ops._gn_ws(x.device, n * gn * 2)[:n * gn * 2].clone().view(n, gn, 2)
+        gv = got.double().view(n, gn, cpg, -1)
+        sref = torch.stack([gv.sum(dim=(2, 3)), (gv * gv).sum(dim=(2, 3))], dim=-1)
+        assert float((sums - sref).abs().max() / sref.abs().max()) < 1e-6
+        ops._claim_presummed(got, -1)                                # give the workspace back
+    assert float(ops._gn_ws(x.device, n * max(gn, 1) * 2).abs().max()) == 0.0
+    dx = ops.raw_conv_pooled_dgrad_phase(dyp, wgt, 0.25, x3=True)
+    assert dx is not None, 'the split-product pooled data gradient must serve this shape'
+    (dref,) = torch.autograd.grad(F.avg_pool2d(conv, 2), xd, dyp.double())
+    torch.cuda.synchronize()
+    assert dx.shape == dref.shape
+    assert float((dx.double() - dref).abs().max() / dref.abs().max()) < TOL
+    assert float((dx.double() - dref).norm() / dref.norm()) < 1e-5
+
+
+def test_x3_phase_forms_inside_the_autograd_functions(monkeypatch):
+    """a pooled ResBlock and an Upsample conv in bf16x3 mode: with and without the phase forms the results agree to split-product
+    accuracy (same products, 4/9 of them pre-summed in the weights)"""
+    n, c, h, w = 2, 128, 64, 64
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x0 = torch.randn(n, c, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    mk = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    n1w, n1b, n2w, n2b = mk(c), mk(c), mk(c), mk(c)
+    c1w = (mk(c, c, 3, 3) / (3 * c ** 0.5)).contiguous(memory_format=CL)
+    c2w = (mk(c, c, 3, 3) / (3 * c ** 0.5)).contiguous(memory_format=CL)
+    uw = (mk(c, c, 3, 3) / (3 * c ** 0.5)).contiguous(memory_format=CL)
+    ub = mk(c)
+    dy = mk(n, c, h, w).contiguous(memory_format=CL)
+    saved = ops.X3
+    outs = []
+    try:
+        ops.set_conv_products('bf16x3')
+        for on in (True, False):
+            monkeypatch.setattr(ops, 'X3_PHASE', on)
+            ps = [t.clone().requires_grad_(True) for t in (x0, n1w, n1b, c1w, n2w, n2b, c2w, uw, ub)]
+            ps[3].data = ps[3].data.contiguous(memory_format=CL); ps[6].data = ps[6].data.contiguous(memory_format=CL)
+            ps[7].data = ps[7].data.contiguous(memory_format=CL)
+            y = ops.res_block(ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], None, 32, 1e-6, pool=True)      # -> h/2
+            y = ops.conv2d(y, ps[7], ps[8], ups=True)                                                          # -> h
+            grads = torch.autograd.grad(y, ps, dy)
+            torch.cuda.synchronize()
+            outs.append([y.detach()] + [t.detach() for t in grads])
+    finally:
+        ops.X3 = saved
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) / float(b.abs().max()) < 1e-4

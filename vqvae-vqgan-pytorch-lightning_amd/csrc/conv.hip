@@ -1373,11 +1373,66 @@ __device__ __forceinline__ void pack_x3(const float* __restrict__ w, bf16_raw* _
     }
 }
 
+// layout 6 (split-product mode, the 2x2-resampling convs in phase form: conv_x3.hip NTAP = 4): the phase-summed four-tap operand of
+// layout 2 -- same phase / tap algebra, the sums taken in fp32 -- stored as layout 5's (hi | lo) fragment pairs:
+// [phase][cot][chunk of 32 channels][tap 4][ks][hi | lo][kg][co32][8].  Byte size = layout 2's element count x 4.
+__device__ __forceinline__ void pack_x3_phase(const float* __restrict__ w, bf16_raw* __restrict__ out, int cout, int cin, int transpose) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    const int dcout = transpose ? cin : cout, dcin = transpose ? cout : cin;
+    const int cot_tiles = ((dcout + 127) / 128) * 4;
+    const int ncc = dcin / 32;
+    const int64_t per_phase = (int64_t)cot_tiles * ncc * 4 * 2 * 64;
+    for (int64_t o = tid; o < 4 * per_phase; o += nthr) {
+        int64_t r = o;
+        const int co32 = (int)(r & 31); r >>= 5;
+        const int kg = (int)(r & 1); r >>= 1;
+        const int ks = (int)(r & 1); r >>= 1;
+        const int tapd = (int)(r & 3); r >>= 2;
+        const int cc = (int)(r % ncc); r /= ncc;
+        const int cot = (int)(r % cot_tiles);
+        const int ph = (int)(r / cot_tiles), pa = ph >> 1, pb = ph & 1;
+        const int co = cot * 32 + co32;
+        const int ci = ((cc * 2 + ks) * 2 + kg) * 8;
+        const int tap = transpose ? 3 - tapd : tapd;
+        const int tr = tap >> 1, ts = tap & 1;
+        const int ky0 = pa == 0 ? (tr == 0 ? 0 : 1) : (tr == 0 ? 0 : 2), ky1 = pa == 0 ? (tr == 0 ? 0 : 2) : (tr == 0 ? 1 : 2);
+        const int kx0 = pb == 0 ? (ts == 0 ? 0 : 1) : (ts == 0 ? 0 : 2), kx1 = pb == 0 ? (ts == 0 ? 0 : 2) : (ts == 0 ? 1 : 2);
+        float v[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        if (co < dcout) {
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) {
+                    if (!transpose) {
+                        const float* src = w + ((int64_t)co * 9 + ky * 3 + kx) * cin + ci;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += src[e];
+                    } else {
+                        const float* src = w + ((int64_t)ci * 9 + ky * 3 + kx) * cin + co;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += src[(int64_t)e * 9 * cin];
+                    }
+                }
+        }
+        const vqk_u32x4 hi = vqk_pack_bf16x8(v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lo[2 * q] = v[2 * q] - __uint_as_float(hi[q] << 16);
+            lo[2 * q + 1] = v[2 * q + 1] - __uint_as_float(hi[q] & 0xffff0000u);
+        }
+        const int64_t frag = ((((int64_t)ph * cot_tiles + cot) * ncc + cc) * 4 + tapd) * 2 + ks;       // (hi, lo) fragment pair index
+        bf16_raw* dst = out + (frag * 2 * 64 + kg * 32 + co32) * 8;
+        *reinterpret_cast<vqk_u32x4*>(dst) = hi;
+        *reinterpret_cast<vqk_u32x4*>(dst + 64 * 8) = vqk_pack_bf16x8(lo);
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restrict__ descs) {
     const int64_t* d = descs + (int64_t)blockIdx.y * 8;
     const float* src = reinterpret_cast<const float*>(d[0]);
     const int dtype = (int)d[2], cout = (int)d[3], cin = (int)d[4], ks = (int)d[5], tr = (int)d[6], lay = (int)d[7];
     if (lay == 5) pack_x3(src, reinterpret_cast<bf16_raw*>(d[1]), cout, cin, ks * ks, tr);
+    else if (lay == 6) pack_x3_phase(src, reinterpret_cast<bf16_raw*>(d[1]), cout, cin, tr);
     else if (dtype == VQK_F32) pack_any<float>(src, reinterpret_cast<float*>(d[1]), cout, cin, ks * ks, tr, lay);
     else pack_any<bf16_raw>(src, reinterpret_cast<bf16_raw*>(d[1]), cout, cin, ks * ks, tr, lay);
 }
@@ -1386,6 +1441,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restri
 __global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__ src, void* __restrict__ dst, int dtype, int cout,
                                                        int cin, int ks, int tr, int lay) {
     if (lay == 5) pack_x3(src, reinterpret_cast<bf16_raw*>(dst), cout, cin, ks * ks, tr);
+    else if (lay == 6) pack_x3_phase(src, reinterpret_cast<bf16_raw*>(dst), cout, cin, tr);
     else if (dtype == VQK_F32) pack_any<float>(src, reinterpret_cast<float*>(dst), cout, cin, ks * ks, tr, lay);
     else pack_any<bf16_raw>(src, reinterpret_cast<bf16_raw*>(dst), cout, cin, ks * ks, tr, lay);
 }
@@ -1941,8 +1997,26 @@ static int ups_phase_impl(int dtype, const void* x, const void* w4, const float*
                           float acc_scale, const void* res) {
     VQK_REQUIRE(x && w4 && y && zeros, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(w4) && vqk_aligned16(y), VQK_ERR_ALIGN);
-    VQK_REQUIRE(dtype == VQK_BF16, VQK_ERR_DTYPE);
+    VQK_REQUIRE(dtype == VQK_BF16 || dtype == VQK_F32, VQK_ERR_DTYPE);
     VQK_REQUIRE(backward == 0 || backward == 1, VQK_ERR_ARG);
+    if (dtype == VQK_F32) {
+        // the split-product mode (conv_x3.hip NTAP = 4; w4 in layout 6): fp32 tensors, one launch for the four phases
+        VQK_REQUIRE(!gn_ws || ((!backward || phase_rev) && groups > 0 && cout % groups == 0), VQK_ERR_SHAPE);
+        const int cpg = gn_ws ? cout / groups : 0;
+        VQK_REQUIRE(!gn_ws || cpg == 4 || cpg == 8 || cpg == 16, VQK_ERR_SHAPE);
+        VQK_REQUIRE(!res || (backward && phase_rev && vqk_aligned16(res)), VQK_ERR_ARG);
+        VQK_REQUIRE(!g_det || !gn_ws, VQK_ERR_SHAPE);                        // (its GroupNorm sums are atomic)
+        ConvGeom gx;
+        const int rcx = make_geom(gx, dtype, n, h, w, cin, cout, 3, 0);      // tiles over the LOW-resolution h x w grid
+        if (rcx) return rcx;
+        VQK_REQUIRE((cin % 32) == 0 && (cout % 128) == 0 && (h % 8) == 0 && (w % 16) == 0 && VQK_TUNE("UPS_PHASE", 1), VQK_ERR_SHAPE);
+        gx.ntap = 4;
+        gx.phase_mode = backward ? 2 : 1;
+        if (backward) { gx.h_in = 2 * h; gx.w_in = 2 * w; }
+        gx.phase_rev = phase_rev; gx.acc_scale = acc_scale;
+        gx.gn_ws = gn_ws; gx.gn_cpg = cpg;
+        return vqkd::launch_conv3x3_x3(x, w4, backward ? nullptr : bias, res, y, zeros, gx, 0, 0, vqk_stream(stream));
+    }
     VQK_REQUIRE(!gn_ws || ((!backward || phase_rev) && groups > 0 && cout % groups == 0 && (cout / groups) % 4 == 0), VQK_ERR_SHAPE);
     VQK_REQUIRE(!res || (backward && phase_rev && vqk_aligned16(res)), VQK_ERR_ARG);
     ConvGeom g;
@@ -2107,7 +2181,7 @@ int vqk_conv_weight_layout(int dtype, int n, int h_in, int w_in, int cin, int co
 
 int64_t vqk_conv_packed_elems(int cout, int cin, int ksize, int layout) {
     if (layout == 0) return (int64_t)cout * cin * ksize * ksize;
-    if (layout == 2) return (int64_t)4 * ((cout + 127) / 128) * 128 * cin * 4;      // four phases x four taps
+    if (layout == 2 || layout == 6) return (int64_t)4 * ((cout + 127) / 128) * 128 * cin * 4;      // four phases x four taps (6: fp32-sized (hi, lo) pairs)
     if (layout == 3) return (int64_t)((cout + 127) / 128) * 128 * cin * 9;          // four phases, 4 + 2 + 2 + 1 taps
     return (int64_t)((cout + 127) / 128) * 128 * cin * ksize * ksize;
 }
@@ -2141,6 +2215,10 @@ int vqk_conv_pack_weights(const float* w, void* out, int dtype, int cout, int ci
     } else if (layout == 5) {
         const int dcin = transpose ? cout : cin;
         VQK_REQUIRE((ksize == 3 || ksize == 1) && dtype == VQK_F32 && dcin % 32 == 0, VQK_ERR_SHAPE);
+        hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, out, dtype, cout, cin, ksize, transpose, layout);
+    } else if (layout == 6) {
+        const int dcin = transpose ? cout : cin;
+        VQK_REQUIRE(ksize == 3 && dtype == VQK_F32 && dcin % 32 == 0, VQK_ERR_SHAPE);
         hipLaunchKernelGGL(pack_one_kernel, dim3(64), dim3(256), 0, st, w, out, dtype, cout, cin, ksize, transpose, layout);
     } else if (layout == 2 || layout == 3) {
         const int dcin = transpose ? cout : cin;

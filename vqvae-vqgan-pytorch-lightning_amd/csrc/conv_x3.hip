@@ -51,13 +51,22 @@ __device__ __forceinline__ float x3_act(float v, int act) {
 // WL 0: the four waves as 2 (pixels) x 2 (couts), wave tile 64 px x 64 couts; WL 1: 1 x 4, wave tile 128 px x 32 couts (half the
 // L2 -> register weight stream per MFMA, twice the LDS fragment reads)
 // NTAP 9: 3x3, 'same' padding; NTAP 1: the 1x1 convs (ResBlock shortcuts, autoencoder.py:52-55; the latent's conv_out, :143) -- no halo, two
-// phases per unit, memory-bound (fp32 in + out at ~5 TB/s)
+// phases per unit, memory-bound (fp32 in + out at ~5 TB/s).
+// NTAP 4: the 2x2-RESAMPLING convs in PHASE form (the algebra of conv_mx.hip's NTAP = 4, ConvGeom::phase_mode / phase_rev): a nearest-x2
+// upsample followed by a 3x3 conv (autoencoder.py:102-105), and a 3x3 conv followed by a 2x2 average pool (:89-91), collapse per
+// output / input phase (a, b) to a 2x2 window of low-resolution shifts with pre-summed weights (layout 6): 4/9 of the multiply-adds.
+//   phase_mode 1 (phase = a TILE dimension): y[2i+a][2j+b] = window of x at rows i+a-1.., columns j+b-1.. -- the Upsample conv's forward;
+//     with phase_rev and the conv's data-gradient operand: the data gradient of conv + AvgPool from the POOLED gradient.
+//   phase_mode 2 (phase = a UNIT dimension: the tile accumulates its four phases x chunks): dx[i][j] = sum over the phases of the mirrored
+//     windows of the phase (a, b) of a full-resolution tensor, gathered at stride 2 -- the Upsample conv's data gradient; with
+//     phase_rev and the forward operand: the FORWARD of conv + AvgPool = a 4x4 stride-2 conv (+ pooled skip, + GroupNorm sums).
 template <int TWLOG, int WL, int NTAP = 9>
 __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restrict__ x, const bf16_raw* __restrict__ wp,
                                                             const float* __restrict__ bias, const float* __restrict__ res,
                                                             float* __restrict__ y, const char* __restrict__ zeros, ConvGeom g,
                                                             int act) {
-    constexpr int HM = NTAP == 9 ? 1 : 0;                        // halo margin
+    constexpr int HM = NTAP == 1 ? 0 : 1;                        // halo margin
+    constexpr int TWD = NTAP == 4 ? 2 : 3;                       // taps per window row
     constexpr int PIX = 128, TW = 1 << TWLOG, TH = PIX / TW, HW2 = TW + 2 * HM, HROWS = (TH + 2 * HM) * HW2;
     constexpr int RS = 80;                                       // padded LDS row stride per plane (64 B payload)
     constexpr int HALO_INSTR = (HROWS + 7) / 8;                  // register pieces: 8 rows x 128 B (32 fp32 channels) per wave load
@@ -71,11 +80,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = g.w >> TWLOG, tiles_y = g.h / TH;
-    const int total_tiles = g.n * tiles_y * tiles_x * g.tiles_n;
+    const int pmode = NTAP == 4 ? g.phase_mode : 0;
+    const int total_tiles = g.n * tiles_y * tiles_x * g.tiles_n * (pmode == 1 ? 4 : 1);
     const int nch = g.cin >> 5;                                  // 32-channel chunks
+    const int nun = pmode == 2 ? 4 * nch : nch;                  // units per tile
     const int vbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int my_tiles = (total_tiles - vbid + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int units = my_tiles * nch;
+    const int units = my_tiles * nun;
     if (units <= 0) return;
 
     const int wm = WL ? 0 : wave >> 1, wn = WL ? wave : wave & 1;
@@ -112,24 +123,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
     }
     const int lchan = (lane & 7) * 4;
 
-    struct TilePos { int img, py0, px0, nt; };
+    struct TilePos { int img, py0, px0, nt, ph; };
     auto tile_pos = [&](int j) -> TilePos {
         int t = vbid + j * (int)gridDim.x;
         TilePos tp;
         tp.nt = t % g.tiles_n; t /= g.tiles_n;
+        tp.ph = 0;
+        if (pmode == 1) { tp.ph = t & 3; t >>= 2; }              // the four phases of a patch side by side: they share its halo in L2
         const int txi = t % tiles_x; t /= tiles_x;
         const int tyi = t % tiles_y;
         tp.img = t / tiles_y; tp.py0 = tyi * TH; tp.px0 = txi * TW;
         return tp;
     };
     u32x4 hreg[NSLOT];
-    auto load_halo = [&](const TilePos& tp, int c) {
+    auto load_halo = [&](const TilePos& tp, int cu) {
+        // phase_mode 2: unit cu = phase * nch + chunk reads the phase (a, b) of the full-resolution source at stride 2
+        const int uph = pmode == 2 ? cu / nch : 0, c = pmode == 2 ? cu - uph * nch : cu;
+        const int ss = pmode == 2 ? 2 : 1, sa = pmode == 2 ? (uph >> 1) : 0, sb = pmode == 2 ? (uph & 1) : 0;
         const float* ximg = x + (int64_t)tp.img * g.h_in * g.w_in * g.cin + c * 32 + lchan;
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
             const int iy = tp.py0 + slot_hy[sl] - HM, ix = tp.px0 + slot_hx[sl] - HM;
             const bool ok = slot_ok[sl] && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
-            const float* src = ximg + ((int64_t)(iy >> g.ups) * g.w_in + (ix >> g.ups)) * g.cin;
+            const float* src = ximg + ((int64_t)((iy * ss + sa) >> g.ups) * g.w_in + ((ix * ss + sb) >> g.ups)) * g.cin;
             const void* sp = ok ? (const void*)src : (const void*)zeros;      // select, not branch
             hreg[sl] = *reinterpret_cast<const u32x4*>(sp);
         }
@@ -151,9 +167,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
     };
     const unsigned lane16 = (unsigned)lane * 16;
     const char* wroot = reinterpret_cast<const char*>(wp);
-    auto unit_w = [&](int nt, int c, int j) -> const char* {
-        const int cot = nt * 4 + (WL ? wn : wn * 2 + j);
-        return wroot + ((int64_t)cot * nch + c) * UNITW;
+    // weights of unit cu of a tile: (phase block,) 32-cout tile, chunk.  Phase: the tile's (mode 1) or the unit's (mode 2)
+    const int64_t phase_bytes = (int64_t)(g.tiles_n * 4) * nch * UNITW;
+    auto unit_ph = [&](const TilePos& tp, int cu) -> int { return pmode == 2 ? cu / nch : tp.ph; };
+    auto unit_w = [&](const TilePos& tp, int cu, int j) -> const char* {
+        const int cot = tp.nt * 4 + (WL ? wn : wn * 2 + j);
+        const int ph = unit_ph(tp, cu), cc = pmode == 2 ? cu - ph * nch : cu;
+        const int wph = (NTAP == 4 && g.phase_rev) ? 3 - ph : ph;
+        return wroot + wph * phase_bytes + ((int64_t)cot * nch + cc) * UNITW;
+    };
+    // window offset of a phase inside the halo: mode 1 (a, b), mode 2 (1 - a, 1 - b)
+    auto phase_off = [&](int ph) -> unsigned {
+        const int a = ph >> 1, b = ph & 1;
+        return pmode == 1 ? (unsigned)((a * HW2 + b) * RS) : pmode == 2 ? (unsigned)(((1 - a) * HW2 + (1 - b)) * RS) : 0u;
     };
 
     f32x16 acc[NI][NJ];
@@ -163,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
     frag_t bw[NJ][2][2];                                         // [j][ks][hi / lo] of the current tap
     const char* wcur[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) wcur[j] = unit_w(cur.nt, 0, j);
+    for (int j = 0; j < NJ; ++j) wcur[j] = unit_w(cur, 0, j);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -177,17 +203,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
     for (int u = 0; u < units; ++u) {
         const unsigned boff = (unsigned)((u & 1) * BUF);
         int ntj = tj, nc = c + 1;
-        if (nc == nch) { nc = 0; ntj = tj + 1; }
+        if (nc == nun) { nc = 0; ntj = tj + 1; }
         const bool has_next = u + 1 < units;
         if (!has_next) { ntj = tj; nc = c; }                     // clamp: loads stay unconditional
         const TilePos nxt = (ntj == tj) ? cur : tile_pos(ntj);
         load_halo(nxt, nc);                                      // in flight during this unit's MFMAs
         const char* wnxt[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) wnxt[j] = unit_w(nxt.nt, nc, j);
+        for (int j = 0; j < NJ; ++j) wnxt[j] = unit_w(nxt, nc, j);
         const char* lbase[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) lbase[i] = smem + boff + abase[i];
+        for (int i = 0; i < NI; ++i) lbase[i] = smem + boff + abase[i] + (NTAP == 4 ? phase_off(unit_ph(cur, c)) : 0u);
 
         // pixel fragments (hi and lo plane) run one (tap, k-substep) phase ahead of the MFMAs that consume them
         frag_t a[2][NI][2];
@@ -198,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
         }
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
-            const int toff = ((tap / 3) * HW2 + (tap % 3)) * RS;        // compile-time after unrolling (NTAP 1: 0)
+            const int toff = ((tap / TWD) * HW2 + (tap % TWD)) * RS;    // compile-time after unrolling (NTAP 1: 0)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (ks == 0) {
@@ -209,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 2 * NI, 0);
                 } else if (tap < NTAP - 1) {
-                    const int toff1 = (((tap + 1) / 3) * HW2 + ((tap + 1) % 3)) * RS;
+                    const int toff1 = (((tap + 1) / TWD) * HW2 + ((tap + 1) % TWD)) * RS;
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
                         a[0][i][0] = *reinterpret_cast<const frag_t*>(lbase[i] + toff1);
@@ -253,10 +279,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (c == nch - 1) {                                      // tile finished: fp32 epilogue from the accumulators
+        if (c == nun - 1) {                                      // tile finished: fp32 epilogue from the accumulators
             const int n0 = cur.nt * 128;
             const int cwave = WL ? wn * 32 : wn * 64;            // first cout of this wave inside the 128-cout tile
-            const bool plain = act == 0 && g.acc_scale == 1.0f && g.out_gain == 1.0f && (g.cout & 127) == 0;
+            const bool plain = act == 0 && g.out_gain == 1.0f && (g.cout & 127) == 0;
+            const bool scaled = g.acc_scale != 1.0f;
+            // phase_mode 1: the tile's pixels are the phase (a, b) of a 2h x 2w output
+            const int ds = pmode == 1 ? 2 : 1, da = pmode == 1 ? (cur.ph >> 1) : 0, db = pmode == 1 ? (cur.ph & 1) : 0;
+            const int oh = g.h * ds, ow = g.w * ds;
             // GroupNorm statistics of the stored output (g.gn_ws: vqk_conv2d_fprop_x3_gnstats; the consumer's GroupNorm then skips its
             // statistics pass over this tensor): per lane the sums of its 4-channel halves over the tile's pixels, folded over the 32
             // pixel lanes at the end of the tile, one fp64 atomic per (group, sum | sum of squares) and wave
@@ -275,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
                 for (int i = 0; i < NI; ++i) {
                     int ty, tx;
                     pix_of(i, ty, tx);
-                    const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
+                    const int64_t pix = ((int64_t)cur.img * oh + (cur.py0 + ty) * ds + da) * ow + (cur.px0 + tx) * ds + db;
                     const int64_t o0 = pix * g.cout + n0 + cwave + 8 * kg;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
@@ -289,6 +319,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
                                 const unsigned hi = __float_as_uint(acc[i][j][8 * qp + 4 + e]);
                                 const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
                                 v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+                            }
+                            if (scaled) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] *= g.acc_scale;
                             }
                             if (bias) {
                                 const float* bp = bias + n0 + cwave + 8 * kg + cw;
@@ -341,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
                 for (int i = 0; i < NI; ++i) {
                     int ty, tx;
                     pix_of(i, ty, tx);
-                    const int64_t pix = ((int64_t)cur.img * g.h + cur.py0 + ty) * g.w + cur.px0 + tx;
+                    const int64_t pix = ((int64_t)cur.img * oh + (cur.py0 + ty) * ds + da) * ow + (cur.px0 + tx) * ds + db;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -532,10 +566,16 @@ namespace vqkd {
 int launch_conv3x3_x3(const void* x, const void* w, const float* bias, const void* res, void* y, const void* zeros,
                       const ConvGeom& g, int act, int blocks_cap, hipStream_t st) {
     if ((g.ks != 3 && g.ks != 1) || (g.cin & 31) || (g.h & 7) || (g.w & 15) || (g.cout & 3) || (g.ks == 1 && g.ups)) return VQK_ERR_SHAPE;
-    const int total = g.n * (g.h / 8) * (g.w / 16) * g.tiles_n;
+    const int total = g.n * (g.h / 8) * (g.w / 16) * g.tiles_n * ((g.ntap == 4 && g.phase_mode == 1) ? 4 : 1);
     const int cap = blocks_cap > 0 ? blocks_cap : 512;
     const dim3 grid((unsigned)(total < cap ? total : cap));
     constexpr int lds = 2 * 2 * 184 * 80;                        // two buffers x (hi, lo) planes of the 10x18 halo (23 pieces of 8 rows)
+    if (g.ntap == 4) {                                           // the 2x2-resampling convs in phase form (layout 6)
+        if (g.ks != 3 || g.ups || (g.phase_mode != 1 && g.phase_mode != 2)) return VQK_ERR_SHAPE;
+        hipLaunchKernelGGL((conv3x3_x3_kernel<4, 1, 4>), grid, dim3(256), lds, st, (const float*)x, (const bf16_raw*)w, bias,
+                           (const float*)res, (float*)y, (const char*)zeros, g, act);
+        return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
+    }
     if (g.ks == 1) {                                             // 1x1: the tile's own 128 pixels (16 pieces), one tap
         hipLaunchKernelGGL((conv3x3_x3_kernel<4, 1, 1>), grid, dim3(256), 2 * 2 * 128 * 80, st, (const float*)x, (const bf16_raw*)w, bias,
                            (const float*)res, (float*)y, (const char*)zeros, g, act);

@@ -639,31 +639,53 @@ UPS_PHASE = int(_native.switch('VQK_UPS_PHASE', '1'))      # 0 off, 1 forward + 
 UPS_PHASE_WGRAD = _native.switch('VQK_UPS_PHASE_WGRAD', '1') != '0'    # the upsample convs' WEIGHT gradient in phase form too (round 5)
 
 
+X3_PHASE = _native.switch('VQK_X3_PHASE', '1') != '0'         # the phase forms in the split-product mode too (conv_x3.hip NTAP = 4)
+
+
+def phase_layout(dtype, x3: bool) -> int:
+    """operand layout of the phase forms: 2 (bf16), 6 (fp32 tensors in the split-product mode), 0: no phase form in this mode"""
+    if dtype == torch.bfloat16:
+        return 2
+    return 6 if (dtype == torch.float32 and x3 and X3_PHASE) else 0
+
+
+def _phase_gn_ok(x, cout: int, gn_groups: int) -> bool:
+    """the fused GroupNorm sums of a phase launch (fp32: conv_x3.hip's atomic sums, groups of 4 / 8 / 16 channels)"""
+    if x.dtype == torch.bfloat16:
+        return True
+    return X3_GNSTATS and not DETERMINISTIC and (cout // gn_groups) in (4, 8, 16)
+
+
+def _phase_name(dtype) -> str:
+    return 'conv3x3_mx_kernel<bf16>' if dtype == torch.bfloat16 else _fprop_kernel_name(dtype, 5)
+
+
 def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int = 0):
     """The nearest-x2 upsample + 3x3 conv in phase form (vqk_conv2d_ups_phase: four 2x2-tap launches, 4/9 of the
     multiply-adds).  forward: x [N,Cin,h,w] -> [N,cout,2h,2w] (+ bias; gn_groups: also the GroupNorm sums of the result);
-    backward: x = dy [N,C,2h,2w] -> dx [N,cout,h,w].  wq4: ``packed_weight(..., layout=2)`` (transpose for backward).
+    backward: x = dy [N,C,2h,2w] -> dx [N,cout,h,w].  wq4: ``packed_weight(..., layout=phase_layout(...))`` (transpose for backward).
     Returns None when the kernel does not serve the problem (nothing launched)."""
     _require_gpu(x)
-    if not UPS_PHASE or x.dtype != torch.bfloat16:
+    if not UPS_PHASE or x.dtype not in (torch.bfloat16, torch.float32):      # (fp32 tensors: the split-product mode, layout 6)
         return None
     n, cin, hx, wx = x.shape
     h, w = (hx // 2, wx // 2) if backward else (hx, wx)
-    if cout % 128 or cin % 64 or (backward and (hx % 2 or wx % 2)):
+    if cout % 128 or cin % (64 if x.dtype == torch.bfloat16 else 32) or (backward and (hx % 2 or wx % 2)):
         return None
     y = empty_nhwc(n, cout, h if backward else 2 * h, w if backward else 2 * w, x.dtype, x.device)
     ws = None
-    if gn_groups and not backward and FUSE_GN_STATS and 4 * h * w > 1024:
+    if gn_groups and not backward and FUSE_GN_STATS and 4 * h * w > 1024 and _phase_gn_ok(x, cout, gn_groups):
         if _HANDOFF.gn is not None:
             _claim_presummed(x, -1)
         ws = _gn_sum_target(x.device, n, gn_groups, 4 * h * w)
     flops = 2.0 * n * 4 * h * w * cout * cin * 9                 # ALGORITHMIC: the 3x3 conv over the upsampled image
     nbytes = x.numel() * x.element_size() + y.numel() * y.element_size() + cout * cin * 9 * x.element_size()
-    st = _timed('conv3x3_mx_kernel<bf16>' + (f' {cin}->{cout}@{y.shape[2]}x{y.shape[3]} phase-{"dgrad" if backward else "fwd"}' if _EVENT_SHAPES else ''), flops,
+    f32 = x.dtype == torch.float32
+    st = _timed(_phase_name(x.dtype) + (f' {cin}->{cout}@{y.shape[2]}x{y.shape[3]} phase-{"dgrad" if backward else "fwd"}' if _EVENT_SHAPES else ''), flops,
                 lambda: _native.lib().vqk_conv2d_ups_phase(dcode(x.dtype), x.data_ptr(), wq4.data_ptr(), _p(bias), y.data_ptr(),
                                                            n, h, w, cin, cout, int(backward), _p(ws), gn_groups,
-                                                           zero_page(x.device).data_ptr(), _stream()), nbytes, launches=1 if _UPS_MERGE else 4,
-                exec_flops=flops * 4.0 / 9.0)
+                                                           zero_page(x.device).data_ptr(), _stream()), nbytes,
+                launches=1 if (_UPS_MERGE or f32) else 4, exec_flops=flops * (3.0 if f32 else 1.0) * 4.0 / 9.0)
     if st == _native.ERR_SHAPE:
         return None
     _native.check(st, 'conv2d_ups_phase')
@@ -675,26 +697,28 @@ def raw_conv_ups_phase(x, wq4, bias, cout: int, backward: bool, gn_groups: int =
 POOLED_DGRAD_PHASE = _native.switch('VQK_POOLED_DGRAD_PHASE', '1') != '0'
 
 
-def raw_conv_pooled_dgrad_phase(dy_pooled, weight, scale: float):
+def raw_conv_pooled_dgrad_phase(dy_pooled, weight, scale: float, x3: bool = False):
     """data gradient of a 3x3 conv followed by a 2x2 average pool from the POOLED gradient, in phase form
     (vqk_conv2d_pooled_dgrad_phase): dy_pooled [N, O, h, w] -> dx [N, I, 2h, 2w] = scale * (nearest-x2(dy_pooled) conv flip(W)^T),
     4/9 of the multiply-adds of the tap form.  None when the kernel does not serve the problem (nothing launched)."""
     _require_gpu(dy_pooled)
-    if not UPS_PHASE or dy_pooled.dtype != torch.bfloat16:
+    lay = phase_layout(dy_pooled.dtype, x3)
+    if not UPS_PHASE or not lay:
         return None
     o, i = weight.shape[0], weight.shape[1]
     n, c, h, w = dy_pooled.shape
-    if c != o or i % 128 or o % 64:
+    if c != o or i % 128 or o % (64 if lay == 2 else 32):
         return None
     dx = empty_nhwc(n, i, 2 * h, 2 * w, dy_pooled.dtype, dy_pooled.device)
-    w4t = packed_weight(weight, i, o, dy_pooled.dtype, 3, True, 2)
+    w4t = packed_weight(weight, i, o, dy_pooled.dtype, 3, True, lay)
     flops = 2.0 * n * 4 * h * w * o * i * 9                      # ALGORITHMIC: the 3x3 data gradient at full resolution
-    nbytes = dy_pooled.numel() * 2 + dx.numel() * 2 + o * i * 9 * 2
-    st = _timed('conv3x3_mx_kernel<bf16>' + (f' {o}->{i}@{2 * h}x{2 * w} pooled-dgrad phase' if _EVENT_SHAPES else ''), flops,
+    es = dy_pooled.element_size()
+    nbytes = dy_pooled.numel() * es + dx.numel() * es + o * i * 9 * es
+    st = _timed(_phase_name(dy_pooled.dtype) + (f' {o}->{i}@{2 * h}x{2 * w} pooled-dgrad phase' if _EVENT_SHAPES else ''), flops,
                 lambda: _native.lib().vqk_conv2d_pooled_dgrad_phase(dcode(dy_pooled.dtype), dy_pooled.data_ptr(), w4t.data_ptr(),
                                                                     dx.data_ptr(), n, h, w, o, i, float(scale),
                                                                     zero_page(dy_pooled.device).data_ptr(), _stream()), nbytes,
-                exec_flops=flops * 4.0 / 9.0)
+                exec_flops=flops * (3.0 if lay == 6 else 1.0) * 4.0 / 9.0)
     if st == _native.ERR_SHAPE:
         return None
     _native.check(st, 'conv2d_pooled_dgrad_phase')
@@ -706,31 +730,33 @@ POOLED_WGRAD_PHASE = _native.switch('VQK_POOLED_WGRAD_PHASE', '0') != '0'      #
 POOLED_FPROP_MIN_HW = int(_native.switch('VQK_POOLED_FPROP_MIN_HW', '4096'))      # full-resolution pixels per image from which it is used
 
 
-def raw_conv_pooled_fprop_phase(x, weight, res_pooled, scale: float, gn_groups: int = 0):
+def raw_conv_pooled_fprop_phase(x, weight, res_pooled, scale: float, gn_groups: int = 0, x3: bool = False):
     """scale * sumpool2x2(conv3x3(x, W)) + res_pooled as ONE 4x4 stride-2 launch (vqk_conv2d_pooled_fprop_phase): x [N, I, 2h, 2w]
     -> [N, O, h, w]; gn_groups: the GroupNorm sums of the result go to the stream's workspace.  None when not served."""
     _require_gpu(x)
-    if not UPS_PHASE or x.dtype != torch.bfloat16:
+    lay = phase_layout(x.dtype, x3)
+    if not UPS_PHASE or not lay:
         return None
     o, i = weight.shape[0], weight.shape[1]
     n, c, hx, wx = x.shape
-    if c != i or o % 128 or i % 64 or hx % 2 or wx % 2:
+    if c != i or o % 128 or i % (64 if lay == 2 else 32) or hx % 2 or wx % 2:
         return None
     h, w = hx // 2, wx // 2
     y = empty_nhwc(n, o, h, w, x.dtype, x.device)
     ws = None
-    if gn_groups and FUSE_GN_STATS and h * w > 1024:
+    if gn_groups and FUSE_GN_STATS and h * w > 1024 and _phase_gn_ok(x, o, gn_groups):
         if _HANDOFF.gn is not None:
             _claim_presummed(x, -1)
         ws = _gn_sum_target(x.device, n, gn_groups, h * w)
-    w4 = packed_weight(weight, i, o, x.dtype, 3, False, 2)
+    w4 = packed_weight(weight, i, o, x.dtype, 3, False, lay)
     flops = 2.0 * n * hx * wx * o * i * 9                        # ALGORITHMIC: the 3x3 conv at full resolution
-    nbytes = x.numel() * 2 + y.numel() * 2 * (2 if res_pooled is not None else 1) + o * i * 9 * 2
-    st = _timed('conv3x3_mx_kernel<bf16>' + (f' {i}->{o}@{hx}x{wx} pooled-fprop phase' if _EVENT_SHAPES else ''), flops,
+    es = x.element_size()
+    nbytes = x.numel() * es + y.numel() * es * (2 if res_pooled is not None else 1) + o * i * 9 * es
+    st = _timed(_phase_name(x.dtype) + (f' {i}->{o}@{hx}x{wx} pooled-fprop phase' if _EVENT_SHAPES else ''), flops,
                 lambda: _native.lib().vqk_conv2d_pooled_fprop_phase(dcode(x.dtype), x.data_ptr(), w4.data_ptr(), _p(res_pooled), y.data_ptr(),
                                                                     n, h, w, i, o, float(scale), _p(ws), gn_groups,
                                                                     zero_page(x.device).data_ptr(), _stream()), nbytes,
-                exec_flops=flops * 4.0 / 9.0)
+                exec_flops=flops * (3.0 if lay == 6 else 1.0) * 4.0 / 9.0)
     if st == _native.ERR_SHAPE:
         return None
     _native.check(st, 'conv2d_pooled_fprop_phase')
@@ -1328,11 +1354,12 @@ class Conv2dFn(torch.autograd.Function):
         res = nhwc(residual) if residual is not None else None
         y = None
         phase = False
+        play = phase_layout(dt, X3)
         if (ups and k == 3 and act == 0 and res is None and out_dtype == dt and cout_pad == o and cin == i and UPS_PHASE
-                and dt == torch.bfloat16 and o % 128 == 0 and i % 128 == 0
-                and weight_layout(dt, n_img, h_in, w_in, cin, cout_pad, 3, False) == 1):
+                and play and o % 128 == 0 and i % 128 == 0
+                and weight_layout(dt, n_img, h_in, w_in, cin, cout_pad, 3, False) == (1 if play == 2 else 5)):
             # nearest x2 + 3x3 as four 2x2-tap convs on the low-resolution input (pre-summed weights)
-            y = raw_conv_ups_phase(x, packed_weight(weight, cin, cout_pad, dt, 3, False, 2), b32, cout_pad, False, next_gn)
+            y = raw_conv_ups_phase(x, packed_weight(weight, cin, cout_pad, dt, 3, False, play), b32, cout_pad, False, next_gn)
             phase = y is not None
         if y is None and next_gn and k == 3 and act == 0 and layout in (1, 5) and out_dtype == dt and cout_pad % 128 == 0 and cout_pad == o:
             y = raw_conv_fprop_gnstats(x, wq, b32, res, ups, cout_pad, next_gn, wlayout=layout)
@@ -1372,7 +1399,7 @@ class Conv2dFn(torch.autograd.Function):
             n_img, _, h_out, w_out = dyc.shape
             layout = weight_layout(dt, n_img, h_out, w_out, cout_pad, cin, k, False, x3=ctx.x3)
             if ups and ctx.phase and UPS_PHASE == 1:             # data gradient in phase form: four 2x2-tap launches
-                dx = raw_conv_ups_phase(dyc, packed_weight(weight, cin, cout_pad, dt, k, True, 2), None, cin, True)
+                dx = raw_conv_ups_phase(dyc, packed_weight(weight, cin, cout_pad, dt, k, True, phase_layout(dt, ctx.x3)), None, cin, True)
             if dx is not None:
                 pass
             elif ups and can_pool_epilogue(dt, cin, layout):
@@ -1558,10 +1585,11 @@ class ResBlockFn(torch.autograd.Function):
         l2 = weight_layout(dt, n, h, w, cout, cout, 3, False)
         wq2 = packed_weight(c2w, cout, cout, dt, 3, False, l2)
         out = None
-        if pool and POOLED_FPROP_PHASE and dt == torch.bfloat16 and l2 == 1 and cout % 128 == 0 and h * w >= POOLED_FPROP_MIN_HW:
+        if (pool and POOLED_FPROP_PHASE and cout % 128 == 0 and h * w >= POOLED_FPROP_MIN_HW
+                and ((dt == torch.bfloat16 and l2 == 1) or (l2 == 5 and phase_layout(dt, X3) and h % 16 == 0 and w % 32 == 0))):
             # conv2 + the level's average pool as the 4x4 stride-2 conv it is (4/9 of the multiply-adds); the skip is pooled by its
             # own memory-bound pass (the launch adds a residual at its OUTPUT resolution)
-            out = raw_conv_pooled_fprop_phase(a2, c2w, raw_pool(skip, 0.25), 0.25, next_gn)
+            out = raw_conv_pooled_fprop_phase(a2, c2w, raw_pool(skip, 0.25), 0.25, next_gn, x3=X3)
         if out is not None:
             pass
         elif next_gn and l2 in (1, 5) and cout % 128 == 0:       # the sums for the GroupNorm that reads `out` next
@@ -1638,7 +1666,12 @@ class ResBlockFn(torch.autograd.Function):
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)
             return dx, None, None, None, None, None, None, None, None, None, None, None
+        d_a2_pre = None
         if pool:
+            if x3 and POOLED_DGRAD_PHASE and h % 16 == 0 and w % 32 == 0:
+                # split-product mode: conv2's data gradient from the POOLED gradient in phase form (4/9 of the multiply-adds); its
+                # weight gradient and the skip still read the un-pooled gradient
+                d_a2_pre = raw_conv_pooled_dgrad_phase(dout, c2w, 0.25, x3=True)
             dout = raw_unpool(dout, 0.25)                   # backward of the fused avg-pool
 
         def conv_bwd(inp, dy, wparam, k, ci, co, need_dx=True, need_dw=True):
@@ -1678,9 +1711,9 @@ class ResBlockFn(torch.autograd.Function):
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         raw_conv_wgrad(a2, dout, 3, False, out=t2, x3=x3)
-                    d_a2, _ = conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)
+                    d_a2 = d_a2_pre if d_a2_pre is not None else conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)[0]
                 else:                                    # wgrad starts behind the dgrad: it overlaps GroupNorm only
-                    d_a2, _ = conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)
+                    d_a2 = d_a2_pre if d_a2_pre is not None else conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)[0]
                     fork = _fork_point(main)
                     if not CHAIN_FIRST:
                         _side_after(side, fork)
@@ -1737,7 +1770,9 @@ class ResBlockFn(torch.autograd.Function):
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)
             return dx, dn1w, dn1b, None, dn2w, dn2b, None, dwsc, None, None, None, None
-        d_a2, dw2 = conv_bwd(a2, dout, c2w, 3, cout, cout)
+        d_a2, dw2 = conv_bwd(a2, dout, c2w, 3, cout, cout, need_dx=d_a2_pre is None)
+        if d_a2_pre is not None:
+            d_a2 = d_a2_pre
         d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
         d_a1, dw1 = conv_bwd(a1, d_r1, c1w, 3, cin, cout)
         dskip, dwsc = dout, None
