@@ -414,6 +414,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
 // patches, wave (i, j) owns the 32 x 32 tile of all taps (144 accumulators), fragments by ds_read_b64_tr_b16 from [rows][64 B] half
 // tiles.  Pipeline: the loads of patch p + 1 are in flight during the MFMAs of patch p; store phase and matrix phase are separated
 // by two barriers, and the second resident block of the CU (2 x 44.5 KiB) computes while this one converts.
+// What bounds it (timing-only ablations VQK_X3ABL, profiles/round6_x3_wgrad_ablation.txt; 256 -> 256 @128^2, 32 images, 1509 us): one
+// product instead of three 812 us, half the x-fragment LDS reads -3 %, no split arithmetic -7 %, a sixteenth of the final atomics
+// +-0 (small maps -15 us); a role-split form (4 matrix + 4 staging waves, two stages, one block per CU) ran the large maps at the
+// same rate and cost the step 2.7 ms of overlap with the GroupNorm backward -- not kept.  1855 GFLOP of bf16 MFMAs in 1453 us =
+// 1277 TF: the rate at which the bf16 role-split kernels sit too (the power wall of DESIGN.md section 3).
 // dW[co][tap][ci] += scale * sum_pix dy[pix][co] * x[pix (+) tap][ci]   (autoencoder.py:57-60, :102-105, :132, :153)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bf16x8_t x3_tr_frag2(const char* p) {
@@ -424,6 +429,9 @@ __device__ __forceinline__ bf16x8_t x3_tr_frag2(const char* p) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+#ifndef VQK_X3ABL
+#define VQK_X3ABL 0          // timing-only ablations of conv3x3_wgrad_x3_kernel (tools/x3_wgrad_abl.sh): 1 one product, 2 half the x-fragment reads, 4 no split arithmetic in the stage, 8 no final atomics
+#endif
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                   float* __restrict__ dw, ConvGeom g, int patches_per_split) {
     constexpr int PWD = 8, PIX = 64, HWD = 10, HROWS = 100, X_ROWS = 112;
@@ -462,6 +470,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
     const unsigned dst0 = (unsigned)((c4 >> 3) * DY_HALF + trow * 64 + (c4 & 7) * 8);                  // + sl * 1024
     const unsigned dst1 = (unsigned)(2 * DY_HALF + (c4 >> 3) * X_HALF + trow * 64 + (c4 & 7) * 8);     // + (sl - 4) * 1024
     u32x4 stage[NSLOT];
+    unsigned okm = 0;                                            // bit sl: slot sl holds a pixel inside the image (applied at store time: a select on
+                                                                 // the loaded value here made the wave wait for the loads before its MFMAs)
     auto load_patch = [&](int patch) {
         const int img = patch / (ph * pw), rem = patch - img * (ph * pw);
         const int pyi = rem / pw, pxi = rem - pyi * pw;
@@ -478,21 +488,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
             const int iy = py0 + hy - 1, ix = px0 + hx - 1;
             const bool ok = row < HROWS && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
             const int cy = ok ? iy >> g.ups : 0, cx = ok ? ix >> g.ups : 0;            // clamped address: the load stays unconditional
-            const u32x4 v = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)cy * g.w_in + cx) * g.cin);
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            stage[sl] = ok ? v : z;
+            stage[sl] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)cy * g.w_in + cx) * g.cin);
+            okm = (okm & ~(1u << sl)) | (ok ? 1u << sl : 0u);
         }
     };
     auto store_patch = [&]() {
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
             if (sl == NSLOT - 1 && trow >= HROWS - 16 * (NSLOT - 5)) continue;       // halo rows 100..111 do not exist
-            const float f0 = __uint_as_float(stage[sl][0]), f1 = __uint_as_float(stage[sl][1]);
-            const float f2 = __uint_as_float(stage[sl][2]), f3 = __uint_as_float(stage[sl][3]);
+            const bool ok = sl < 4 || ((okm >> sl) & 1u);
+            const float f0 = ok ? __uint_as_float(stage[sl][0]) : 0.f, f1 = ok ? __uint_as_float(stage[sl][1]) : 0.f;
+            const float f2 = ok ? __uint_as_float(stage[sl][2]) : 0.f, f3 = ok ? __uint_as_float(stage[sl][3]) : 0.f;
+#if VQK_X3ABL & 4          // TIMING ONLY: raw words instead of the (hi, lo) split
+            const u32x2 hi = {stage[sl][0], stage[sl][1]}, lo = {stage[sl][2], stage[sl][3]};
+#else
             const unsigned h01 = pack_bf16x2(f0, f1), h23 = pack_bf16x2(f2, f3);
             const float l0 = f0 - __uint_as_float(h01 << 16), l1 = f1 - __uint_as_float(h01 & 0xffff0000u);
             const float l2 = f2 - __uint_as_float(h23 << 16), l3 = f3 - __uint_as_float(h23 & 0xffff0000u);
             const u32x2 hi = {h01, h23}, lo = {pack_bf16x2(l0, l1), pack_bf16x2(l2, l3)};
+#endif
             const unsigned d = sl < 4 ? dst0 + sl * 1024 : dst1 + (sl - 4) * 1024;
             *reinterpret_cast<u32x2*>(smem + d) = hi;
             *reinterpret_cast<u32x2*>(smem + PLANE + d) = lo;
@@ -518,10 +532,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int off = ((2 * gk + t / 3) * HWD + (t % 3)) * 64;
+#if VQK_X3ABL & 2          // TIMING ONLY: half the x-fragment reads
+                const bf16x8_t bh = x3_tr_frag2(pb + off), bl = bh;
+#else
                 const bf16x8_t bh = x3_tr_frag2(pb + off), bl = x3_tr_frag2(pb + PLANE + off);
+#endif
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+#if !(VQK_X3ABL & 1)       // TIMING ONLY (1): one product instead of three
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+#endif
             }
         }
         __syncthreads();                                         // everyone left the stage before it is rewritten
@@ -532,6 +552,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+#if VQK_X3ABL & 8          // TIMING ONLY: one atomic per tap instead of sixteen
+            if (r == 0 || acc[t][r] == 123.456f)
+#endif
             atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r] * g.acc_scale);
         }
 }
