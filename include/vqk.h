@@ -261,7 +261,11 @@ int vqk_conv2d_wgrad_general(int dtype, const void* x, const void* dy, float* dw
  * nothing launched, callers use the exact-fp32 vqk_conv2d_wgrad). */
 /* vqk_conv2d_wgrad_x3_f32: the same gradient straight from the fp32 tensors x [n][h_in][w_in][cin], dy [n][h][w][cout] -- both are
  * split in registers on their way into LDS and all three products come from one staged patch (csrc/conv_x3.hip:
- * conv3x3_wgrad_x3_kernel; no pair tensors, no split passes).  cin % 64 == 0, cout % 64 == 0, h % 8 == 0, w % 8 == 0. */
+ * conv3x3_wgrad_x3_kernel; no pair tensors, no split passes).  cin % 64 == 0, cout % 64 == 0, h % 8 == 0, w % 8 == 0.
+ * ups = 1 with h_in % 8 == 0, w_in % 8 == 0 runs in PHASE form (four 2x2-window launches' worth of blocks on the low-resolution grid,
+ * 4/9 of the MFMAs; tuning slot X3_WGRAD_PHASE = 0: the tap form).  ups = 2: the gradient of a conv that is FOLLOWED by a 2x2 average
+ * pool, from the POOLED gradient -- dy [n][h_in / 2][w_in / 2][cout], x [n][h_in][w_in][cin], scale = the pool's 0.25: phase form only
+ * (h_in % 16 == 0, w_in % 16 == 0; VQK_ERR_SHAPE otherwise, nothing launched). */
 /* vqk_conv2d_fprop_x3_gnstats: the layout-5 3x3 conv with the GroupNorm sums of its OUTPUT (sum, sum of squares per (sample, group),
  * fp64 atomics) left in gn_ws as vqk_conv2d_fprop_gnstats leaves them for the bf16 convs -- the consuming vqk_gn_forward_presummed
  * skips its statistics pass.  Cout % 128 == 0, Cout / groups in {4, 8, 16}; VQK_ERR_SHAPE otherwise and in deterministic mode. */

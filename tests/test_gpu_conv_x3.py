@@ -367,3 +367,51 @@ def test_x3_phase_forms_inside_the_autograd_functions(monkeypatch):
         ops.X3 = saved
     for a, b in zip(*outs):
         assert float((a - b).abs().max()) / float(b.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('phase', [1, 0])
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 128, 128, 16, 32), (1, 64, 256, 8, 8), (3, 256, 64, 24, 16), (2, 128, 128, 64, 64), (5, 64, 64, 8, 24)])
+def test_x3_upsample_conv_weight_gradient_phase_form(n, cin, cout, h, w, phase):
+    """dW of nearest-x2 + 3x3 conv (autoencoder.py:102-105): four 2x2-window phases on the low-resolution grid (tuning slot
+    X3_WGRAD_PHASE = 1, the default) and the tap form (0) against fp64; the target ACCUMULATES"""
+    g = torch.Generator(device=DEV).manual_seed(n + cin + cout + h)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    dy = torch.randn(n, cout, 2 * h, 2 * w, device=DEV, generator=g).contiguous(memory_format=CL)
+    pre = torch.randn(cout, 3, 3, cin, device=DEV, generator=g).permute(0, 3, 1, 2)
+    dw = pre.clone(memory_format=torch.preserve_format)
+    lib = native.lib()
+    try:
+        native.check(lib.vqk_set_tuning(b'X3_WGRAD_PHASE', phase), 'set_tuning')
+        ops.raw_conv_wgrad(x, dy, 3, True, out=dw, x3=True)
+    finally:
+        native.check(lib.vqk_set_tuning(b'X3_WGRAD_PHASE', 1), 'set_tuning')
+    xu = F.interpolate(x.double(), scale_factor=2, mode='nearest')
+    wd = torch.zeros(cout, cin, 3, 3, device=DEV, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xu, wd, None, padding=1) * dy.double()).sum().backward()
+    ref = wd.grad + pre.double()
+    torch.cuda.synchronize()
+    assert float((dw.double() - ref).abs().max()) / float(ref.abs().max()) < TOL
+    assert float((dw.double() - ref).norm() / ref.norm()) < 1e-5
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 128, 128, 32, 32), (1, 64, 256, 16, 48), (3, 256, 64, 48, 16), (2, 128, 128, 128, 128)])
+def test_x3_pooled_conv_weight_gradient_phase_form(n, cin, cout, h, w):
+    """dW of 3x3 conv + 2x2 average pool (autoencoder.py:89-91) from the POOLED gradient: the 16 taps of the 4x4 stride-2 window at pooled
+    resolution folded onto the 3x3 taps (vqk_conv2d_wgrad_x3_f32, ups = 2), against fp64 autograd; h, w: the conv's resolution"""
+    g = torch.Generator(device=DEV).manual_seed(n + cin + cout + w)
+    x = torch.randn(n, cin, h, w, device=DEV, generator=g).contiguous(memory_format=CL)
+    dyp = torch.randn(n, cout, h // 2, w // 2, device=DEV, generator=g).contiguous(memory_format=CL)
+    pre = torch.randn(cout, 3, 3, cin, device=DEV, generator=g).permute(0, 3, 1, 2)
+    dw = pre.clone(memory_format=torch.preserve_format)
+    assert ops.raw_conv_wgrad_pooled_x3(x, dyp, 0.25, dw), 'the pooled phase form must serve this shape'
+    wd = torch.zeros(cout, cin, 3, 3, device=DEV, dtype=torch.float64, requires_grad=True)
+    (F.avg_pool2d(F.conv2d(x.double(), wd, None, padding=1), 2) * dyp.double()).sum().backward()
+    ref = wd.grad + pre.double()
+    torch.cuda.synchronize()
+    assert float((dw.double() - ref).abs().max()) / float(ref.abs().max()) < TOL
+    assert float((dw.double() - ref).norm() / ref.norm()) < 1e-5
+    # not served: odd pooled sizes fall back (nothing launched, target untouched)
+    x2 = torch.randn(1, 64, 24, 24, device=DEV, generator=g).contiguous(memory_format=CL)
+    d2 = torch.randn(1, 64, 12, 12, device=DEV, generator=g).contiguous(memory_format=CL)
+    t2 = torch.zeros(64, 3, 3, 64, device=DEV).permute(0, 3, 1, 2)
+    assert not ops.raw_conv_wgrad_pooled_x3(x2, d2, 0.25, t2) and float(t2.abs().max()) == 0.0

@@ -832,11 +832,22 @@ int vqk_conv2d_wgrad_x3_f32(const float* x, const float* dy, float* dw, int n, i
     // split-product weight gradient straight from the fp32 tensors (csrc/conv_x3.hip: conv3x3_wgrad_x3_kernel)
     VQK_REQUIRE(x && dy && dw, VQK_ERR_ARG);
     VQK_REQUIRE(vqk_aligned16(x) && vqk_aligned16(dy), VQK_ERR_ALIGN);
-    VQK_REQUIRE(ups == 0 || ups == 1, VQK_ERR_ARG);
+    VQK_REQUIRE(ups == 0 || ups == 1 || ups == 2, VQK_ERR_ARG);
+    VQK_REQUIRE(!g_det && g_force_variant != 0, VQK_ERR_SHAPE);      // atomics only: deterministic mode keeps the exact-fp32 kernel
     ConvGeom g;
+    if (ups == 2 || (ups == 1 && VQK_TUNE("X3_WGRAD_PHASE", 1) && (h_in % 8) == 0 && (w_in % 8) == 0)) {
+        // the 2x2-resampling convs in phase form (4/9 of the MFMAs): patches over the LOW-resolution grid.  ups = 1: x [n][h_in][w_in] is
+        // that grid, dy [n][2 h_in][2 w_in]; ups = 2: dy = the pooled gradient [n][h_in / 2][w_in / 2] of a conv over x [n][h_in][w_in]
+        VQK_REQUIRE(ups == 1 || ((h_in % 16) == 0 && (w_in % 16) == 0), VQK_ERR_SHAPE);
+        const int hl = ups == 2 ? h_in / 2 : h_in, wl = ups == 2 ? w_in / 2 : w_in;
+        const int rcp = make_geom(g, VQK_F32, n, hl, wl, cin, cout, 3, 0);
+        if (rcp) return rcp;
+        g.ntap = 4; g.phase_mode = ups == 2 ? 2 : 1;
+        g.acc_scale = scale;
+        return vqkd::launch_conv3x3_wgrad_x3(x, dy, dw, g, g_wgrad_blocks, vqk_stream(stream));
+    }
     const int rc = make_geom(g, VQK_F32, n, h_in, w_in, cin, cout, 3, ups);
     if (rc) return rc;
-    VQK_REQUIRE(!g_det && g_force_variant != 0, VQK_ERR_SHAPE);      // atomics only: deterministic mode keeps the exact-fp32 kernel
     g.acc_scale = scale;
     return vqkd::launch_conv3x3_wgrad_x3(x, dy, dw, g, g_wgrad_blocks, vqk_stream(stream));
 }

@@ -432,6 +432,15 @@ __device__ __forceinline__ bf16x8_t x3_tr_frag2(const char* p) {
 #ifndef VQK_X3ABL
 #define VQK_X3ABL 0          // timing-only ablations of conv3x3_wgrad_x3_kernel (tools/x3_wgrad_abl.sh): 1 one product, 2 half the x-fragment reads, 4 no split arithmetic in the stage, 8 no final atomics
 #endif
+// NTAP = 4: the weight gradient of the 2x2-RESAMPLING convs in phase form -- 4/9 of the MFMAs for the same staged bytes.  Patches walk the
+// LOW-resolution grid (g.h x g.w), blockIdx.y = split * 4 + phase (a, b); per phase a 2x2 window of the low-resolution halo:
+//   g.phase_mode 1 (nearest-x2 upsample + conv, autoencoder.py:102-105): dy [n][2h][2w] is gathered at stride 2, offset (a, b); window
+//     offset (a, b); S_ab[r][s] = sum_pix dy_ab[pix] x[pix + (a + r - 1, b + s - 1)] is the gradient of every 3x3 tap that lands on that
+//     low-resolution pixel: rows {0} | {1, 2} for a = 0, {0, 1} | {2} for a = 1 (the phase sums of layout 2 / 6, transposed);
+//   g.phase_mode 2 (conv + 2x2 average pool, :89-91, dy = the POOLED gradient [n][h][w], x [n][2h][2w]): the 4x4 stride-2 window
+//     G[u][v] = sum_pix dy[pix] x[2 pix + (u - 1, v - 1)], u = 2 r + 1 - a: x gathered at stride 2, offset (a, b), window offset
+//     (1 - a, 1 - b); dW[ky][kx] = scale * sum_{a', b'} G[ky + a'][kx + b'] -- the same row sets with a := 1 - a.
+template <int NTAP>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                   float* __restrict__ dw, ConvGeom g, int patches_per_split) {
     constexpr int PWD = 8, PIX = 64, HWD = 10, HROWS = 100, X_ROWS = 112;
@@ -450,14 +459,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
     const int co0 = tco * 64, ci0 = tci * 64;
     const int pw = g.w >> 3, ph = g.h >> 3;
     const int total_patches = g.n * ph * pw;
-    const int p_begin = by * patches_per_split;
+    const int phase = NTAP == 4 ? (by & 3) : 0, split = NTAP == 4 ? (by >> 2) : by;
+    const int p_begin = split * patches_per_split;
     const int p_end = min(total_patches, p_begin + patches_per_split);
     if (p_begin >= p_end) return;
+    // phase forms: pixel stride / offset of the gathered operand, window offset inside the halo
+    const int pa_ = phase >> 1, pb_ = phase & 1;
+    const int dsy = (NTAP == 4 && g.phase_mode == 1) ? 2 : 1, xsx = (NTAP == 4 && g.phase_mode == 2) ? 2 : 1;
+    const int dya = dsy == 2 ? pa_ : 0, dyb = dsy == 2 ? pb_ : 0, xa = xsx == 2 ? pa_ : 0, xb = xsx == 2 ? pb_ : 0;
+    const int oa = NTAP == 4 ? (g.phase_mode == 1 ? pa_ : 1 - pa_) : 0, ob = NTAP == 4 ? (g.phase_mode == 1 ? pb_ : 1 - pb_) : 0;
 
     const int wi = wave >> 1, wj = wave & 1;
-    f32x16 acc[9];
+    f32x16 acc[NTAP];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
@@ -476,19 +491,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
         const int img = patch / (ph * pw), rem = patch - img * (ph * pw);
         const int pyi = rem / pw, pxi = rem - pyi * pw;
         const int py0 = pyi * 8, px0 = pxi * PWD;
-        const float* dyp = dy + (((int64_t)img * g.h + py0 + (trow >> 3)) * g.w + px0 + (trow & 7)) * g.cout + co0 + ch;
+        const int dyw = g.w * dsy;
+        const float* dyp = dy + (((int64_t)img * g.h * dsy + (py0 + (trow >> 3)) * dsy + dya) * dyw + (px0 + (trow & 7)) * dsy + dyb) * g.cout + co0 + ch;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl)                           // patch rows (trow >> 3) + 2 sl
-            stage[sl] = *reinterpret_cast<const u32x4*>(dyp + (int64_t)(2 * sl) * g.w * g.cout);
-        const float* ximg = x + (int64_t)img * g.h_in * g.w_in * g.cin + ci0 + ch;
+            stage[sl] = *reinterpret_cast<const u32x4*>(dyp + (int64_t)(2 * sl * dsy) * dyw * g.cout);
+        const int xh = NTAP == 4 ? g.h * xsx : g.h_in, xw = NTAP == 4 ? g.w * xsx : g.w_in;
+        const float* ximg = x + (int64_t)img * xh * xw * g.cin + ci0 + ch;
 #pragma unroll
         for (int sl = 4; sl < NSLOT; ++sl) {
             const int row = trow + 16 * (sl - 4);
             const int hy = row / HWD, hx = row - hy * HWD;
             const int iy = py0 + hy - 1, ix = px0 + hx - 1;
             const bool ok = row < HROWS && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
-            const int cy = ok ? iy >> g.ups : 0, cx = ok ? ix >> g.ups : 0;            // clamped address: the load stays unconditional
-            stage[sl] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)cy * g.w_in + cx) * g.cin);
+            const int cy = !ok ? 0 : NTAP == 4 ? iy * xsx + xa : iy >> g.ups;          // clamped address: the load stays unconditional
+            const int cx = !ok ? 0 : NTAP == 4 ? ix * xsx + xb : ix >> g.ups;
+            stage[sl] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)cy * xw + cx) * g.cin);
             okm = (okm & ~(1u << sl)) | (ok ? 1u << sl : 0u);
         }
     };
@@ -530,8 +548,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
         for (int gk = 0; gk < PIX / 16; ++gk) {                  // 16 pixels = patch rows 2 gk, 2 gk + 1
             const bf16x8_t ah = x3_tr_frag2(pa + gk * 16 * 64), al = x3_tr_frag2(pa + PLANE + gk * 16 * 64);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int off = ((2 * gk + t / 3) * HWD + (t % 3)) * 64;
+            for (int t = 0; t < NTAP; ++t) {
+                const int off = NTAP == 4 ? ((2 * gk + oa + t / 2) * HWD + ob + (t % 2)) * 64 : ((2 * gk + t / 3) * HWD + (t % 3)) * 64;
 #if VQK_X3ABL & 2          // TIMING ONLY: half the x-fragment reads
                 const bf16x8_t bh = x3_tr_frag2(pb + off), bl = bh;
 #else
@@ -547,16 +565,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
         __syncthreads();                                         // everyone left the stage before it is rewritten
     }
     const int ci = ci0 + wj * 32 + (lane & 31);
+    if constexpr (NTAP == 4) {
+        // window tap (r, s) of this phase -> every 3x3 tap it stands for (1, 2 or 4 of them: nine tile additions per block, as in the tap form)
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 4; ++t) {
+            const int r_ = t >> 1, s_ = t & 1;
+            const int ky0 = r_ == 0 ? 0 : (oa ? 2 : 1), ky1 = r_ == 0 ? (oa ? 1 : 0) : 2;
+            const int kx0 = s_ == 0 ? 0 : (ob ? 2 : 1), kx1 = s_ == 0 ? (ob ? 1 : 0) : 2;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
-#if VQK_X3ABL & 8          // TIMING ONLY: one atomic per tap instead of sixteen
-            if (r == 0 || acc[t][r] == 123.456f)
-#endif
-            atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r] * g.acc_scale);
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+                        atomicAdd(dw + ((int64_t)co * 9 + ky * 3 + kx) * g.cin + ci, acc[t][r] * g.acc_scale);
+                    }
+                }
         }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+#if VQK_X3ABL & 8          // TIMING ONLY: one atomic per tap instead of sixteen
+                if (r == 0 || acc[t][r] == 123.456f)
+#endif
+                atomicAdd(dw + ((int64_t)co * 9 + t) * g.cin + ci, acc[t][r] * g.acc_scale);
+            }
+    }
 }
 
 // fp32 [rows][c] -> bf16 [rows][2c]: (hi | lo) per row; a thread owns 8 consecutive channels (two 16-byte loads, two 16-byte stores)
@@ -617,24 +653,32 @@ int launch_conv3x3_x3(const void* x, const void* w, const float* bias, const voi
 }  // namespace vqkd
 
 namespace vqkd {
-// x fp32 [n][h_in][w_in][cin], dy fp32 [n][h][w][cout], dw fp32 [cout][3][3][cin] +=; cin % 64 == 0, cout % 64 == 0, h % 8 == 0, w % 8 == 0
+// x fp32 [n][h_in][w_in][cin], dy fp32 [n][h][w][cout], dw fp32 [cout][3][3][cin] +=; cin % 64 == 0, cout % 64 == 0, h % 8 == 0, w % 8 == 0.
+// g.ntap == 4 (g.phase_mode 1 | 2): the phase forms -- g.h x g.w is the LOW-resolution grid, see the kernel
 int launch_conv3x3_wgrad_x3(const void* x, const void* dy, float* dw, const ConvGeom& g, int blocks_cap, hipStream_t st) {
     if ((g.cin & 63) || (g.cout & 63) || (g.h & 7) || (g.w & 7) || g.ks != 3) return VQK_ERR_SHAPE;
+    const int phases = g.ntap == 4 ? 4 : 1;
+    if (phases == 4 && (g.ups || (g.phase_mode != 1 && g.phase_mode != 2))) return VQK_ERR_SHAPE;
     const int tiles = (g.cout >> 6) * (g.cin >> 6);
     const int total_patches = g.n * (g.h >> 3) * (g.w >> 3);
     // split-K over pixel patches: the cost model of the bf16 kernels (conv.hip::wgrad_general) with a third of their atomic passes
     // per multiply-add -- s* = sqrt(c * pixels / tiles) under the block cap (two blocks per CU)
     const int cap = blocks_cap > 0 ? blocks_cap : 512;
     const double coef = VQK_TUNE("X3_WGRAD_COEF_E4", 3200) * 1e-4;
-    int splits = (int)(sqrt(coef * (double)g.m / tiles) + 0.5);
-    if (splits > (cap + tiles - 1) / tiles) splits = (cap + tiles - 1) / tiles;
+    // (phase forms: the four phases are four times the blocks -- a quarter of the splits each, the same number of atomic passes)
+    int splits = (int)(sqrt(coef * (double)g.m * phases / tiles) / phases + 0.5);
+    if (splits > (cap + tiles * phases - 1) / (tiles * phases)) splits = (cap + tiles * phases - 1) / (tiles * phases);
     if (splits > (total_patches + 3) / 4) splits = (total_patches + 3) / 4;          // >= 256 pixels per block
     if (splits < 1) splits = 1;
     const int pps = (total_patches + splits - 1) / splits;
     splits = (total_patches + pps - 1) / pps;
     constexpr int lds = 2 * 22784;
-    hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, (const float*)x,
-                       (const float*)dy, dw, g, pps);
+    if (phases == 4)
+        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<4>, dim3((unsigned)tiles, (unsigned)(splits * 4)), dim3(256), lds, st, (const float*)x,
+                           (const float*)dy, dw, g, pps);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<9>, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, (const float*)x,
+                           (const float*)dy, dw, g, pps);
     return hipGetLastError() == hipSuccess ? VQK_OK : VQK_ERR_LAUNCH;
 }
 }  // namespace vqkd

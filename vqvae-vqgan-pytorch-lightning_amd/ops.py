@@ -928,9 +928,10 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8, x
             and cout % 64 == 0 and dy.shape[3] % 8 == 0 and dy.shape[2] % 8 == 0 and not DETERMINISTIC):
         # split-product mode: both fp32 operands split in registers on their way into LDS, three products per staged fragment pair
         # (csrc/conv_x3.hip: conv3x3_wgrad_x3_kernel)
-        st = _timed('conv3x3_wgrad_x3_kernel<f32 as 3 x bf16>' + (f' {cin}->{cout}@{dy.shape[2]}x{dy.shape[3]} k3' if _EVENT_SHAPES else ''), flops,
+        phase = bool(ups) and X3_WGRAD_PHASE and h % 8 == 0 and w % 8 == 0      # (the library's own rule: include/vqk.h)
+        st = _timed('conv3x3_wgrad_x3_kernel<f32 as 3 x bf16>' + (f' {cin}->{cout}@{dy.shape[2]}x{dy.shape[3]} k3{" phase" if phase else ""}' if _EVENT_SHAPES else ''), flops,
                     lambda: _native.lib().vqk_conv2d_wgrad_x3_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, cin, cout, int(ups),
-                                                                  1.0, _stream()), exec_flops=3.0 * flops)
+                                                                  1.0, _stream()), exec_flops=3.0 * flops * (4.0 / 9.0 if phase else 1.0))
         if st != _native.ERR_SHAPE:
             _native.check(st, 'conv2d_wgrad_x3_f32')
             return dw
@@ -967,6 +968,28 @@ def raw_conv_wgrad(x, dy, ksize: int, ups: bool, out=None, thin_true: int = 8, x
                                                        zero_page(x.device).data_ptr(), _stream()))
     _native.check(st, 'conv2d_wgrad')
     return dw
+
+
+X3_WGRAD_PHASE = _native.switch('VQK_X3_WGRAD_PHASE', '1') != '0'     # (also a tuning slot of the library: the upsample conv's weight gradient in phase form)
+
+
+def raw_conv_wgrad_pooled_x3(x, dy_pooled, scale: float, out) -> bool:
+    """split-product mode: out += the weight gradient of a 3x3 conv FOLLOWED by a 2x2 average pool, from the pooled gradient, in phase
+    form (vqk_conv2d_wgrad_x3_f32 with ups = 2: the 16 taps of the 4x4 stride-2 window at pooled resolution, 4/9 of the MFMAs).
+    False: not served, nothing launched."""
+    n, cin, h, w = x.shape
+    cout = dy_pooled.shape[1]
+    if (not X3_WGRAD_PHASE or x.dtype != torch.float32 or dy_pooled.dtype != torch.float32 or cin % 64 or cout % 64 or h % 16 or w % 16
+            or DETERMINISTIC or tuple(dy_pooled.shape[2:]) != (h // 2, w // 2)):
+        return False
+    flops = 2.0 * n * h * w * cout * cin * 9
+    st = _timed('conv3x3_wgrad_x3_kernel<f32 as 3 x bf16>' + (f' {cin}->{cout}@{h}x{w} k3 pooled-dy phase' if _EVENT_SHAPES else ''), flops,
+                lambda: _native.lib().vqk_conv2d_wgrad_x3_f32(x.data_ptr(), dy_pooled.data_ptr(), out.data_ptr(), n, h, w, cin, cout, 2,
+                                                              float(scale), _stream()), exec_flops=3.0 * flops * 4.0 / 9.0)
+    if st == _native.ERR_SHAPE:
+        return False
+    _native.check(st, 'conv2d_wgrad_x3_f32')
+    return True
 
 
 def raw_conv_wgrad_pooled_dy(x, dy_pooled, scale: float, out) -> bool:
@@ -1666,13 +1689,19 @@ class ResBlockFn(torch.autograd.Function):
             finally:
                 lib.vqk_conv_set_block_caps(0, 0)
             return dx, None, None, None, None, None, None, None, None, None, None, None
-        d_a2_pre = None
+        d_a2_pre = dout_p = None
         if pool:
             if x3 and POOLED_DGRAD_PHASE and h % 16 == 0 and w % 32 == 0:
-                # split-product mode: conv2's data gradient from the POOLED gradient in phase form (4/9 of the multiply-adds); its
-                # weight gradient and the skip still read the un-pooled gradient
+                # split-product mode: conv2's data gradient from the POOLED gradient in phase form (4/9 of the multiply-adds); so is its
+                # weight gradient (wgrad_c2 below); the skip still reads the un-pooled gradient
                 d_a2_pre = raw_conv_pooled_dgrad_phase(dout, c2w, 0.25, x3=True)
+            dout_p = dout if x3 else None
             dout = raw_unpool(dout, 0.25)                   # backward of the fused avg-pool
+
+        def wgrad_c2(tgt):
+            if dout_p is not None and raw_conv_wgrad_pooled_x3(a2, dout_p, 0.25, tgt):
+                return
+            raw_conv_wgrad(a2, dout, 3, False, out=tgt, x3=x3)
 
         def conv_bwd(inp, dy, wparam, k, ci, co, need_dx=True, need_dw=True):
             dx = None
@@ -1710,7 +1739,7 @@ class ResBlockFn(torch.autograd.Function):
                 if OVERLAP_MODE == 1:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        raw_conv_wgrad(a2, dout, 3, False, out=t2, x3=x3)
+                        wgrad_c2(t2)
                     d_a2 = d_a2_pre if d_a2_pre is not None else conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)[0]
                 else:                                    # wgrad starts behind the dgrad: it overlaps GroupNorm only
                     d_a2 = d_a2_pre if d_a2_pre is not None else conv_bwd(a2, dout, c2w, 3, cout, cout, need_dw=False)[0]
@@ -1718,12 +1747,12 @@ class ResBlockFn(torch.autograd.Function):
                     if not CHAIN_FIRST:
                         _side_after(side, fork)
                         with torch.cuda.stream(side):
-                            raw_conv_wgrad(a2, dout, 3, False, out=t2, x3=x3)
+                            wgrad_c2(t2)
                 d_r1, dn2w, dn2b = gn_bwd(r1, st2, w2, b2, d_a2, n2w, n2b)
                 if OVERLAP_MODE != 1 and CHAIN_FIRST:
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
-                        raw_conv_wgrad(a2, dout, 3, False, out=t2, x3=x3)
+                        wgrad_c2(t2)
                 if OVERLAP_MODE == 1:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
@@ -1763,7 +1792,7 @@ class ResBlockFn(torch.autograd.Function):
                     # they are joined at the end of the backward (join_side_streams) instead of at the end of the block and run
                     # beside the next blocks' kernels, which leave CUs free on these maps
                     _SIDE_PENDING.add(x.device)
-                    for t in (a1, a2, dout, d_r1):
+                    for t in (a1, a2, dout, d_r1) + ((dout_p,) if dout_p is not None else ()):
                         t.record_stream(side)
                 else:
                     main.wait_stream(side)
