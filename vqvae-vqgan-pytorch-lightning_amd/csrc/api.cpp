@@ -139,7 +139,9 @@ static TuneSlot g_tune[] = {
     {"X3_WL", 0, 0},
     {"X3_WGRAD_COEF_E4", 0, 0},
     {"X3_WGRAD_FOLD", 0, 0},
-    {"X3_WGRAD_PHASE", 0, 0}
+    {"X3_WGRAD_PHASE", 0, 0},
+    {"X3_WGRAD_PHASE_CAP_PCT", 0, 0},
+    {"X3_WGRAD_PHASE_COEF_E4", 0, 0}
 };
 static constexpr int kTune = (int)(sizeof(g_tune) / sizeof(g_tune[0]));
 TuneSlot* tune_slot(const char* name) {

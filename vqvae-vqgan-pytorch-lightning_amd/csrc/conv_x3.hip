@@ -663,8 +663,9 @@ int launch_conv3x3_wgrad_x3(const void* x, const void* dy, float* dw, const Conv
     const int total_patches = g.n * (g.h >> 3) * (g.w >> 3);
     // split-K over pixel patches: the cost model of the bf16 kernels (conv.hip::wgrad_general) with a third of their atomic passes
     // per multiply-add -- s* = sqrt(c * pixels / tiles) under the block cap (two blocks per CU)
-    const int cap = blocks_cap > 0 ? blocks_cap : 512;
-    const double coef = VQK_TUNE("X3_WGRAD_COEF_E4", 3200) * 1e-4;
+    int cap = blocks_cap > 0 ? blocks_cap : 512;
+    if (phases == 4) cap = cap * VQK_TUNE("X3_WGRAD_PHASE_CAP_PCT", 150) / 100;      // 166 VGPRs: a third block fits a CU (step 70.39 -> 69.89 ms)
+    const double coef = (phases == 4 ? VQK_TUNE("X3_WGRAD_PHASE_COEF_E4", 3200) : VQK_TUNE("X3_WGRAD_COEF_E4", 3200)) * 1e-4;
     // (phase forms: the four phases are four times the blocks -- a quarter of the splits each, the same number of atomic passes)
     int splits = (int)(sqrt(coef * (double)g.m * phases / tiles) / phases + 0.5);
     if (splits > (cap + tiles * phases - 1) / (tiles * phases)) splits = (cap + tiles * phases - 1) / (tiles * phases);
