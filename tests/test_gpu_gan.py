@@ -300,7 +300,11 @@ def test_vqgan_graphs_follow_adversarial_start_epoch():
     graph, moved_g = run(True)
     assert moved_e and moved_g                                        # epoch 1 stepped the discriminator in both modes
     assert graph[0][1] == 0.0 and graph[2][1] != 0.0 and graph[2][2] != 0.0      # generator / discriminator loss appear at epoch 1
-    np.testing.assert_allclose(np.array(graph), np.array(eager), rtol=2e-2, atol=1e-4)
+    # steps 1-2 (no adversarial term) repeat bit for bit; from epoch 1 on the discriminator's atomic sums make two EAGER runs differ by
+    # up to 2.1e-3 in the O(0.1) generator / O(1) discriminator loss of step 4 (scratch probe, 8 runs each: eager-vs-eager spread ==
+    # graph-vs-eager spread) -- an absolute 1e-2 on quantities whose scale is the logits', 5x that noise
+    np.testing.assert_allclose(np.array(graph)[:2], np.array(eager)[:2], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.array(graph), np.array(eager), rtol=2e-2, atol=1e-2)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
