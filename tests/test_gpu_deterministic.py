@@ -47,7 +47,7 @@ def _grads(qtype, dtype, size, batch, deterministic, graphed=False, ae=AE_FULL, 
     return opt.flat_g.clone()
 
 
-@pytest.mark.parametrize('dtype,size,batch', [(torch.bfloat16, 64, 8), (torch.float32, 64, 2), (torch.bfloat16, 128, 4)])
+@pytest.mark.parametrize('dtype,size,batch', [(torch.bfloat16, 64, 8), (torch.float32, 64, 2), (torch.bfloat16, 128, 4), ('bf16x3', 128, 2)])
 def test_two_runs_bit_identical_gradients(dtype, size, batch):
     g1 = _grads('standard', dtype, size, batch, True)
     g2 = _grads('standard', dtype, size, batch, True)
