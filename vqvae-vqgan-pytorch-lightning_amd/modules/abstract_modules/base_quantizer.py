@@ -58,5 +58,6 @@ class BaseVectorQuantizer(ABC, nn.Module):
             return
         picks = torch.multinomial(codebook_usage.float(), unused.numel(), replacement=True)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.broadcast(picks, src=0)
+            from ...optim import broadcast_
+            broadcast_(picks, src=0)                 # async + wait: no event on a stream that may capture next (optim.all_reduce_sum)
         self.codebook.weight[unused] = self.codebook.weight[picks]

@@ -24,7 +24,8 @@ def reduce_ema_stats(stats: torch.Tensor, local_batch: int, force_collective: bo
     on the rank-concatenated batch.  Host logic only (no kernel): callable on CPU tensors under gloo."""
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if world > 1 or (force_collective and dist.is_available() and dist.is_initialized()):
-        work = dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)     # async + wait: see optim.all_reduce_sum
+        from ..optim import _track
+        work = _track(dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True))     # async + wait: see optim.all_reduce_sum
         if work is not None:
             work.wait()
         EMA_COLLECTIVES[0] += 1

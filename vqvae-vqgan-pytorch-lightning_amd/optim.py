@@ -23,9 +23,48 @@ def all_reduce_sum(t: torch.Tensor) -> None:
     the watchdog terminates the process (seen 1 run in 3 with the full-size VQ-GAN step, where a capture takes seconds)."""
     from . import ops
     with ops.trace_range('vqk::all_reduce_sum'):
-        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+        work = _track(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
         if work is not None:
             work.wait()
+
+
+_PENDING: list = []          # Work handles of the collectives issued through this module's helpers since the last quiesce
+
+
+def _track(work):
+    if work is not None:
+        _PENDING.append(work)
+        del _PENDING[:-64]                                   # (completed long ago: only the recent ones can still be in flight)
+    return work
+
+
+def broadcast_(t: torch.Tensor, src: int = 0) -> None:
+    """``dist.broadcast`` as async + stream-side wait (see :func:`all_reduce_sum`: no event is recorded on the CURRENT stream)"""
+    work = _track(dist.broadcast(t, src=src, async_op=True))
+    if work is not None:
+        work.wait()
+
+
+def barrier() -> None:
+    """``dist.barrier`` as async + wait, for the same reason"""
+    work = _track(dist.barrier(async_op=True))
+    if work is not None:
+        work.wait()
+
+
+def quiesce_collectives(timeout_s: float = 30.0) -> None:
+    """before a hipGraph capture: every collective issued through the helpers above has COMPLETED (polled on its Work handle, not
+    assumed from a sleep) -- with async collectives the process group records its events on its own stream, so its watchdog never
+    meets an event 'last recorded in a capturing stream'"""
+    import time
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for w in _PENDING:
+        while not w.is_completed():
+            if time.time() - t0 > timeout_s:
+                raise RuntimeError('vqk: a collective issued before the capture has not completed')
+            time.sleep(0.001)
+    _PENDING.clear()
 
 
 def _is_channels_last_param(p: torch.Tensor) -> bool:
@@ -204,7 +243,8 @@ class FlatAdamW(torch.optim.Optimizer):
         if self.mute_collectives:
             return None
         self._count(hi - lo)
-        return dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
+        work = dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
+        return _track(work) if async_op else work
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -45,10 +45,11 @@ def _quiesce_collectives() -> None:
     """before a hipGraph capture: every collective issued so far has completed on the device AND the process group's watchdog
     thread (polls every 100 ms) has retired it -- the watchdog must not query RCCL events while this thread captures (HIP
     rejects a query of an event whose stream is capturing: the watchdog would terminate the process)"""
-    torch.cuda.synchronize()
+    from .optim import quiesce_collectives
+    quiesce_collectives()                                    # device idle + every tracked Work handle reports completion
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
         import time
-        time.sleep(0.3)
+        time.sleep(0.3)                                      # (three watchdog polls: belt and braces for collectives issued around the helpers)
 
 
 class MiniTrainer:
@@ -438,7 +439,8 @@ class MiniTrainer:
                         'state_dict': sd, 'optimizer_states': opts}, tmp)
             os.replace(tmp, path)
         if distributed:
-            dist.barrier()
+            from .optim import barrier
+            barrier()
 
     def load_checkpoint(self, model, path: str, strict: bool = True) -> dict:
         """resume: weights, optimizer moments / step counts, epoch and global step (call after ``attach``)"""
