@@ -446,6 +446,11 @@ def main():
     if one_gpu:
         os.environ['LOCAL_RANK'] = '0'
     rank, local, world = trainer_mod.init_distributed('gloo' if one_gpu else 'nccl')
+    if one_gpu:
+        # ranks as PROCESSES on one GPU: no cluster form of the GroupNorm backward (its waiting blocks can be starved by the other
+        # rank's launch: 602 / 868 timed-out blocks in a dry run, caught by check_kernel_health) -- ops.py: cluster_owner_ok
+        native0 = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
+        native0.check(native0.lib().vqk_set_tuning(b'GN_CLUSTER_MAX_HW', 0), 'set_tuning')
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (the launcher started {world} ranks); '
                          f'pass --gpus {world} or launch --nproc-per-node {args.gpus}')

@@ -471,7 +471,12 @@ int vqk_gn_backward_ws(int dtype, const void* x, const float* stats, const float
  * progress assumes that each XCD dispatches its share of a grid in block-index order (then the lowest waiting block's partners are
  * always resident or done -- csrc/norm.hip); the wait is BOUNDED (~0.2 s): a block that gives up is counted and falls through with
  * incomplete sums.  vqk_gn_cluster_timeouts reports the count (0 in a healthy run; synchronises the device).  A kernel killed
- * mid-way leaves sums / tickets dirty: re-zero the workspace. */
+ * mid-way leaves sums / tickets dirty: re-zero the workspace.
+ * CONCURRENCY RULE: the progress argument covers ONE cluster launch at a time per GPU.  Two of them in flight together (two streams, or
+ * two processes sharing the device) can each occupy the slots the other's waiting blocks need -- measured: two ranks on one GPU, 600-870
+ * timed-out blocks.  A caller that may run a second GroupNorm backward concurrently states a workspace WITHOUT the ticket region for it
+ * (ws_doubles = N*G*2 + N: the two-kernel passes); the Python host gives the form to one host thread's models (ops.cluster_owner_ok);
+ * processes that share a GPU set the GN_CLUSTER_MAX_HW slot to 0. */
 int vqk_gn_cluster_timeouts(int* count);
 /* vqk_gn_backward_ws (same-resolution addend) that also accumulates the per-channel sums of the dx it writes into
  * dx_colsum[C] (fp32): when x is the output of a conv with a bias, that is the conv's bias gradient -- no column-sum pass over

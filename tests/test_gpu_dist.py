@@ -450,6 +450,10 @@ def _gloo_one_gpu_worker(rank, port, kind, steps, out):
     r, local, world = trainer_mod.init_distributed('gloo')
     assert dist.is_initialized() and dist.get_backend() == 'gloo' and world == 2 and local == 0
     torch.cuda.set_device(0)
+    # two PROCESSES on one GPU: the cluster form of the GroupNorm backward (blocks of a launch wait for each other) is for one such
+    # kernel at a time -- two ranks' launches can starve each other's waiting blocks (ops.py: cluster_owner_ok)
+    native = importlib.import_module(PKG + '._native')
+    native.check(native.lib().vqk_set_tuning(b'GN_CLUSTER_MAX_HW', 0), 'set_tuning')
     parts = _one_gpu_images(kind)
     losses, state, (ncoll, graphs) = _graphed_run(kind, parts[rank].to('cuda:0'), steps, 2)
     dist.barrier()

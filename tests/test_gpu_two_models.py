@@ -162,3 +162,37 @@ def test_two_vqgan_models_on_two_threads():
             dk = [k for k in got if k.startswith('criterion.discriminator') and k.endswith('weight')]
             assert dk and all(not torch.equal(got[k], s0[k]) for k in dk)          # every discriminator weight moved
     assert not ops._TASK_MODES                                  # every tagged graph task was untagged again
+
+
+def test_cluster_groupnorm_backward_belongs_to_one_host_thread():
+    """two launches of the cluster form (blocks of a launch wait for each other, csrc/norm.hip) must never run concurrently: the
+    form is handed to the first host thread whose forward reaches a GroupNorm; a second thread's models get the two-kernel passes
+    (same result to rounding), and no block ever times out"""
+    import ctypes
+    import threading
+    native = importlib.import_module('vqvae-vqgan-pytorch-lightning_amd._native')
+    n, c, h = 4, 128, 32                                           # 32 x 32 map: cluster-eligible
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(n, c, h, h, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, c, h, h, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w, b = torch.randn(c, device=DEV, generator=g), torch.randn(c, device=DEV, generator=g)
+    assert ops.cluster_owner_ok()                                  # this (the main) thread owns the form
+    _, st = ops.raw_gn_forward(x, w, b, 32, 1e-6, True)
+    res = {}
+
+    def other():
+        res['owner'] = ops.cluster_owner_ok()
+        with torch.cuda.stream(torch.cuda.Stream()):
+            res['dx'] = ops.raw_gn_backward(x, st, w, b, dy, 32, True)[0].float()
+            torch.cuda.current_stream().synchronize()
+
+    t = threading.Thread(target=other); t.start(); t.join()
+    assert res['owner'] is False and ops.cluster_owner_ok()
+    dx_cluster = ops.raw_gn_backward(x, st, w, b, dy, 32, True)[0].float()
+    dx_two = ops.raw_gn_backward(x, st, w, b, dy, 32, True, cluster_ok=False)[0].float()
+    torch.cuda.synchronize()
+    assert float((res['dx'] - dx_two).abs().max()) <= 1e-5 * float(dx_two.abs().max())      # the other thread: same passes (fp64 sums in arrival order)
+    assert float((dx_cluster - dx_two).abs().max()) <= 2e-2 * float(dx_two.abs().max())
+    cnt = ctypes.c_int(-1)
+    native.check(native.lib().vqk_gn_cluster_timeouts(ctypes.byref(cnt)), 'gn_cluster_timeouts')
+    assert cnt.value == 0

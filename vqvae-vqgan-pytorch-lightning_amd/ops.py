@@ -1049,6 +1049,37 @@ def _gn_ws_doubles(n: int, c: int, groups: int) -> int:
     return n * groups * 2 + n + n * (c // 32)
 
 
+# The single-kernel CLUSTER form of the GroupNorm backward (csrc/norm.hip: gn_cluster_bwd_kernel) makes blocks wait for each other
+# inside a launch.  Its progress argument (blocks dispatched in index order, a cluster = consecutive indices) holds for ONE such
+# kernel at a time: two of them running concurrently -- two models stepped from two host threads, or two PROCESSES sharing a GPU --
+# can each fill the slots the other's waiting blocks need; the bounded spin then gives up (vqk_gn_cluster_timeouts: wrong
+# gradients, caught by check_kernel_health -- seen for real with two ranks on one GPU).  So the form belongs to ONE host thread's
+# models per process: the first thread whose forward reaches a GroupNorm; every other thread's models take the two-kernel passes
+# (the library takes the cluster form only when the workspace it is handed carries the ticket region).  Processes that share a
+# GPU on purpose (bench.py's one-GPU dry run, the gloo two-rank test) set the tuning slot GN_CLUSTER_MAX_HW to 0.
+_CLUSTER_OWNER = [None]
+_CLUSTER_LOCK = threading.Lock()
+
+
+def cluster_owner_ok() -> bool:
+    """does the calling host thread own the cluster form of the GroupNorm backward?  (read at FORWARD time: the backward runs on the
+    autograd engine's thread)"""
+    me = threading.get_ident()
+    own = _CLUSTER_OWNER[0]
+    if own == me:
+        return True
+    with _CLUSTER_LOCK:
+        own = _CLUSTER_OWNER[0]
+        if own is None or not any(t.ident == own for t in threading.enumerate()):      # nobody yet / the owner thread is gone
+            _CLUSTER_OWNER[0] = own = me
+    return own == me
+
+
+def _gn_red_size(red, n: int, c: int, groups: int, cluster_ok: bool) -> int:
+    """the workspace size handed to the library: without the ticket region it takes the two-kernel passes (include/vqk.h)"""
+    return red.numel() if cluster_ok else min(red.numel(), n * groups * 2 + n)
+
+
 def _gn_cluster(dtype, hw: int, c: int, groups: int) -> bool:
     """does vqk_gn_backward_ws take its single-kernel cluster form for this map?  (bench statistics: 3 tensor passes, not 5)"""
     v = 4 if dtype == torch.float32 else 8
@@ -1202,7 +1233,8 @@ def raw_gn_forward(x, w, b, groups: int, eps: float, silu: bool, presummed: bool
     return y, stats
 
 
-def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None, add=None, dx_colsum=None, out=None):
+def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=None, add=None, dx_colsum=None, out=None,
+                    cluster_ok: bool | None = None):
     """``dx_colsum``: fp32 [C] buffer that also receives the per-channel sums of the dx written (the bias gradient of the conv
     that produced x: vqk_gn_backward_colsum); the caller checks :func:`gn_colsum_ok` first.  ``out``: dx goes here (batch slice)."""
     n, c, h, wd = x.shape
@@ -1212,7 +1244,10 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
     _claim_presummed(x, -1)                                      # (clears a stale note + workspace; never matches)
     red = _gn_ws(x.device, _gn_ws_doubles(n, c, groups))
     nb = x.numel() * x.element_size()
-    one_pass = h * wd <= 512 or _gn_cluster(x.dtype, h * wd, c, groups)
+    if cluster_ok is None:
+        cluster_ok = cluster_owner_ok()                          # (direct callers: tests, tools)
+    red_n = _gn_red_size(red, n, c, groups, cluster_ok)
+    one_pass = h * wd <= 512 or (cluster_ok and _gn_cluster(x.dtype, h * wd, c, groups))
     passes = (3 if one_pass else 5) + (1 if add is not None else 0)     # x, dy (twice on the two-kernel path), dx, skip
     if dx_colsum is not None:
         st = _timed('group_norm_bwd (HBM)' + (f' {c}@{h}x{wd} +bias-grad' if _EVENT_SHAPES else ''), 0.0,
@@ -1226,7 +1261,7 @@ def raw_gn_backward(x, stats, w, b, dy, groups: int, silu: bool, dw=None, db=Non
     st = _timed('group_norm_bwd (HBM)' + (f' {c}@{h}x{wd}' if _EVENT_SHAPES else ''), 0.0,
                 lambda: _native.lib().vqk_gn_backward_ws(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
                                                          b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-                                                         db.data_ptr(), red.data_ptr(), red.numel(), n, h, wd, c, groups,
+                                                         db.data_ptr(), red.data_ptr(), red_n, n, h, wd, c, groups,
                                                          int(silu), 0, _p(add), 0, 1.0, _stream()), passes * nb)
     _native.check(st, 'gn_backward')
     return dx, dw, db
@@ -1256,18 +1291,22 @@ def _claim_bias_colsum(x):
     return None
 
 
-def raw_gn_backward_pooled_add(x, stats, w, b, dy, groups: int, silu: bool, dw, db, add_pooled, add_scale: float):
+def raw_gn_backward_pooled_add(x, stats, w, b, dy, groups: int, silu: bool, dw, db, add_pooled, add_scale: float,
+                               cluster_ok: bool | None = None):
     """raw_gn_backward whose skip-branch addend is still at half resolution (vqk_gn_backward_pooled_add)"""
     n, c, h, wd = x.shape
     dx = torch.empty_like(x, memory_format=_CL)
     _claim_presummed(x, -1)
     red = _gn_ws(x.device, _gn_ws_doubles(n, c, groups))
     nb = x.numel() * x.element_size()
-    passes = 3.25 if _gn_cluster(x.dtype, h * wd, c, groups) else 5.25
+    if cluster_ok is None:
+        cluster_ok = cluster_owner_ok()
+    red_n = _gn_red_size(red, n, c, groups, cluster_ok)
+    passes = 3.25 if (cluster_ok and _gn_cluster(x.dtype, h * wd, c, groups)) else 5.25
     st = _timed('group_norm_bwd (HBM)' + (f' {c}@{h}x{wd} pooled-add' if _EVENT_SHAPES else ''), 0.0,
                 lambda: _native.lib().vqk_gn_backward_ws(dcode(x.dtype), x.data_ptr(), stats.data_ptr(), w.data_ptr(),
                                                          b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-                                                         db.data_ptr(), red.data_ptr(), red.numel(), n, h, wd, c, groups,
+                                                         db.data_ptr(), red.data_ptr(), red_n, n, h, wd, c, groups,
                                                          int(silu), 1, 0, add_pooled.data_ptr(), float(add_scale), _stream()),
                 passes * nb)
     _native.check(st, 'gn_backward_pooled_add')
@@ -1486,6 +1525,7 @@ class GroupNormSiLUFn(torch.autograd.Function):
         ctx.save_for_backward(x, stats, w, b)
         ctx.params = (weight, bias)
         ctx.cfg = (groups, silu, weight.shape, bias.shape)
+        ctx.cluster_ok = cluster_owner_ok()
         return y
 
     @staticmethod
@@ -1495,7 +1535,7 @@ class GroupNormSiLUFn(torch.autograd.Function):
         tw, tb = direct_grad(ctx.params[0]), direct_grad(ctx.params[1])
         direct = tw is not None and tb is not None
         dx, dw, db = raw_gn_backward(x, stats, w, b, nhwc(dy), groups, silu, tw if direct else None,
-                                     tb if direct else None)
+                                     tb if direct else None, cluster_ok=ctx.cluster_ok)
         if direct:
             return dx, None, None, None, None, None
         return dx, dw.view(wshape), db.view(bshape), None, None, None
@@ -1631,6 +1671,7 @@ class ResBlockFn(torch.autograd.Function):
         ctx.params = (n1w, n1b, c1w, n2w, n2b, c2w, scw)
         ctx.cfg = (groups, cin, cout, pool)
         ctx.x3 = X3
+        ctx.cluster_ok = cluster_owner_ok()
         return out
 
     @staticmethod
@@ -1665,7 +1706,7 @@ class ResBlockFn(torch.autograd.Function):
                     with torch.cuda.stream(side):
                         if not raw_conv_wgrad_pooled_dy(a2, dout, 0.25, t2):
                             raise RuntimeError('vqk: pooled weight gradient not served for an eligible shape')
-                d_r1, _, _ = raw_gn_backward(r1, st2, w2, b2, d_a2, groups, True, tw2, tb2)
+                d_r1, _, _ = raw_gn_backward(r1, st2, w2, b2, d_a2, groups, True, tw2, tb2, cluster_ok=ctx.cluster_ok)
                 if CHAIN_FIRST:
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
@@ -1680,7 +1721,7 @@ class ResBlockFn(torch.autograd.Function):
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
                         raw_conv_wgrad(a1, d_r1, 3, False, out=t1, x3=x3)
-                dx = raw_gn_backward_pooled_add(x, st1, w1, b1, d_a1, groups, True, tw1, tb1, dout, 0.25)
+                dx = raw_gn_backward_pooled_add(x, st1, w1, b1, d_a1, groups, True, tw1, tb1, dout, 0.25, cluster_ok=ctx.cluster_ok)
                 if CHAIN_FIRST:
                     _side_after(side, fork)
                     with torch.cuda.stream(side):
@@ -1724,7 +1765,7 @@ class ResBlockFn(torch.autograd.Function):
                 if cs is not None:
                     _DB_DONE.add(id(colsum_of))
             dx, dw, db = raw_gn_backward(inp, st, wv, bv, dy, groups, True, tw if direct else None,
-                                         tb if direct else None, add=add, dx_colsum=cs)
+                                         tb if direct else None, add=add, dx_colsum=cs, cluster_ok=ctx.cluster_ok)
             if direct:
                 return dx, None, None
             return dx, dw.view(wparam.shape), db.view(bparam.shape)
